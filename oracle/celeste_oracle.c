@@ -1,0 +1,469 @@
+/*
+ * celeste_oracle.c -- CPU restatement of CelestePy's render + Poisson log-lik path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle: only tests/,
+ * __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load it.  The
+ * product (desi-mcmc_amd/) never links, imports or calls anything in oracle/.
+ *
+ * Parity status: PINNED.  Every function below is checked in tests/test_oracle.py
+ * against fixtures produced by running the reference's own Python in the build
+ * container (tests/golden/make_golden.py), including the reference's own
+ * known-answer test (CelestePy/test/test_gmm.py:63-105, seed 41, K=42).
+ *
+ * Each function cites the reference file:line (relative to /root/reference) it
+ * restates.  All arithmetic is IEEE double, in the reference's operation order
+ * where that order is observable (box edges, log-domain mixture sum).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -fopenmp -shared).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* One band image's parameters: the FitsImage fields the path reads
+ * (CelestePy/fits_image.py:85-155).  Plain doubles, 37 of them, no padding. */
+typedef struct {
+    double eps;          /* epsilon = SKY*GAIN            fits_image.py:113 */
+    double kappa;        /* GAIN                          fits_image.py:112 */
+    double calib;        /* CALIB (nmgy per count)        fits_image.py:116 */
+    double w[3];         /* PSF weights                   fits_image.py:129 */
+    double mu[3][2];     /* PSF means (x, y)              fits_image.py:130 */
+    double cov[3][2][2]; /* PSF covariances               fits_image.py:135-137 */
+    double rho[2];       /* CRPIX - 1                     fits_image.py:99  */
+    double phi[2];       /* CRVAL                         fits_image.py:100 */
+    double ups[2][2];    /* CD                            fits_image.py:101 */
+    double ups_inv[2][2];/* inv(CD)                       fits_image.py:103 */
+    double R;            /* star bounding radius, eps=1e-3 fits_image.py:151-155 */
+} orc_band;
+
+int orc_band_doubles(void) { return (int)(sizeof(orc_band) / sizeof(double)); }
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* exp / dev galaxy profile mixtures: Hogg & Lang amplitudes and variances
+ * (CelestePy/mixture_profiles.py:9-19; amplitudes are normalised at :13,:19). */
+static const double EXP_AMP_RAW[6] = {2.34853813e-03, 3.07995260e-02, 2.23364214e-01,
+                                      1.17949102e+00, 4.33873750e+00, 5.99820770e+00};
+static const double EXP_VAR[6] = {1.20078965e-03, 8.84526493e-03, 3.91463084e-02,
+                                  1.39976817e-01, 4.60962500e-01, 1.50159566e+00};
+static const double DEV_AMP_RAW[8] = {4.26347652e-02, 2.40127183e-01, 6.85907632e-01, 1.51937350e+00,
+                                      2.83627243e+00, 4.46467501e+00, 5.72440830e+00, 5.60989349e+00};
+static const double DEV_VAR[8] = {2.23759216e-04, 1.00220099e-03, 4.18731126e-03, 1.69432589e-02,
+                                  6.84850479e-02, 2.87207080e-01, 1.33320254e+00, 8.40215071e+00};
+
+#define K_PSF 3
+#define K_EXP 6
+#define K_DEV 8
+#define K_PROF (K_EXP + K_DEV)
+#define K_GAL (K_PROF * K_PSF)
+
+/* numpy's pairwise-free np.sum over 6 / 8 elements is a plain left-to-right sum */
+void orc_profile_tables(double *exp_amp, double *exp_var, double *dev_amp, double *dev_var) {
+    double s = 0.0;
+    for (int i = 0; i < K_EXP; i++) s += EXP_AMP_RAW[i];
+    for (int i = 0; i < K_EXP; i++) { exp_amp[i] = EXP_AMP_RAW[i] / s; exp_var[i] = EXP_VAR[i]; }
+    s = 0.0;
+    for (int i = 0; i < K_DEV; i++) s += DEV_AMP_RAW[i];
+    for (int i = 0; i < K_DEV; i++) { dev_amp[i] = DEV_AMP_RAW[i] / s; dev_var[i] = DEV_VAR[i]; }
+}
+
+/* ------------------------------------------------------------------ WCS -- */
+
+/* fits_image.py:166-174 equa2pixel (linear WCS; returns [x, y]) */
+void orc_equa2pixel(const orc_band *b, const double u[2], double v[2]) {
+    double phi1rad = b->phi[1] / 180.0 * M_PI;
+    double s0 = (u[0] - b->phi[0]) * cos(phi1rad);
+    double s1 = (u[1] - b->phi[1]);
+    v[0] = (b->ups_inv[0][0] * s0 + b->ups_inv[0][1] * s1) + b->rho[0];
+    v[1] = (b->ups_inv[1][0] * s0 + b->ups_inv[1][1] * s1) + b->rho[1];
+}
+
+/* fits_image.py:176-181 pixel2equa */
+void orc_pixel2equa(const orc_band *b, const double p[2], double u[2]) {
+    double phi1rad = b->phi[1] / 180.0 * M_PI;
+    double d0 = p[0] - b->rho[0], d1 = p[1] - b->rho[1];
+    double i0 = b->ups[0][0] * d0 + b->ups[0][1] * d1;
+    double i1 = b->ups[1][0] * d0 + b->ups[1][1] * d1;
+    u[0] = i0 / cos(phi1rad) + b->phi[0];
+    u[1] = i1 + b->phi[1];
+}
+
+/* fits_image.py:196-216 cd_at_pixel: 10-px finite difference of pixel2equa */
+void orc_cd_at_pixel(const orc_band *b, double x, double y, double cd[4]) {
+    const double step = 10.0;
+    double p[2], e0[2], ex[2], ey[2];
+    p[0] = x; p[1] = y; orc_pixel2equa(b, p, e0);
+    p[0] = x + step; p[1] = y; orc_pixel2equa(b, p, ex);
+    p[0] = x; p[1] = y + step; orc_pixel2equa(b, p, ey);
+    double cosd = cos(e0[1] * (M_PI / 180.0));
+    cd[0] = (ex[0] - e0[0]) / step * cosd;
+    cd[1] = (ey[0] - e0[0]) / step * cosd;
+    cd[2] = (ex[1] - e0[1]) / step;
+    cd[3] = (ey[1] - e0[1]) / step;
+}
+
+/* ------------------------------------------------------ bounding radius -- */
+
+/* util/bound/bounding_box.py:9-31 calc_bounding_radius.
+ * scipy.stats.chi2.ppf(1 - error, 2) has the closed form -2 ln(error) for 2 dof;
+ * `rsq` is passed in so that tests can hand over scipy's own value. */
+double orc_bounding_radius_rsq(const double *w, const double *mu, const double *cov, int K,
+                               double rsq, const double center[2]) {
+    double minbound = -INFINITY;
+    (void)w;
+    for (int i = 0; i < K; i++) {
+        const double *c = cov + 4 * i;
+        double sigma1 = sqrt(c[0]);
+        double sigma2 = sqrt(c[3]);
+        double rho = c[1] / (sigma1 * sigma2);
+        double A11 = sigma1;
+        double A21 = rho * sigma2;
+        double A22 = sigma2 * sqrt(1.0 - rho * rho);
+        double An = 1.0 / rsq * (1.0 / (A11 * A11) + (A21 * A21) / (A22 * A22));
+        double Bn = 1.0 / rsq * (-2.0 * A21 / (A11 * (A22 * A22)));
+        double Cn = 1.0 / rsq * 1.0 / (A22 * A22);
+        double majaxis = pow(0.5 * (An + Cn - sqrt(Bn * Bn + (An - Cn) * (An - Cn))), -0.5);
+        double d0 = mu[2 * i] - center[0], d1 = mu[2 * i + 1] - center[1];
+        double dist = sqrt(d0 * d0 + d1 * d1);
+        double cand = majaxis + dist;
+        if (cand > minbound) minbound = cand;
+    }
+    return minbound;
+}
+
+double orc_bounding_radius(const double *w, const double *mu, const double *cov, int K,
+                           double error, const double center[2]) {
+    /* chi2.ppf(1-error, 2) = -2 log(1 - (1 - error)); scipy evaluates it from q = 1 - error */
+    double q = 1.0 - error;
+    double rsq = -2.0 * log1p(-q);
+    return orc_bounding_radius_rsq(w, mu, cov, K, rsq, center);
+}
+
+/* ------------------------------------------------------------ evaluators -- */
+
+/* util/like/gmm_like_fast.pyx:130-176 gmm_like_2d: component-outer, pixel-inner
+ * (prange) direct sum; in-loop 2x2 inverse; exp(-log2pi - .5 log det - .5 q) * w. */
+void orc_gmm_like_2d(double *probs, const double *x, int64_t N, const double *ws, const double *mus,
+                     const double *sigs, int K) {
+    const double log2pi = log(2.0 * M_PI);
+    int64_t n;
+#pragma omp parallel for schedule(static)
+    for (n = 0; n < N; n++) probs[n] = 0.0;
+    for (int k = 0; k < K; k++) {
+        const double *s = sigs + 4 * k;
+        double detk = s[0] * s[3] - s[1] * s[2];
+        double invk_00 = s[3] / detk;
+        double invk_11 = s[0] / detk;
+        double invk_01 = -1 * s[1] / detk;
+        double m0 = mus[2 * k], m1 = mus[2 * k + 1], wk = ws[k];
+#pragma omp parallel for schedule(static)
+        for (n = 0; n < N; n++) {
+            double x0 = x[2 * n] - m0;
+            double x1 = x[2 * n + 1] - m1;
+            double quad = x0 * x0 * invk_00 + x1 * x1 * invk_11 + 2. * x0 * x1 * invk_01;
+            probs[n] += exp(-log2pi - .5 * log(detk) - .5 * quad) * wk;
+        }
+    }
+}
+
+/* util/dists/mog.py:5-21 mog_loglike: log sum_k pi_k N(x; mu_k, C_k) via logsumexp.
+ * icovs are full 2x2 (the einsum 'ijk,lji->lki' contracts solved = icov . centered). */
+static inline double mog_loglike_pt(double px, double py, const double *means, const double *icovs,
+                                    const double *dets, const double *pis, int K, double *scratch) {
+    const double log2pi = log(2 * M_PI);
+    double mx = -INFINITY;
+    for (int k = 0; k < K; k++) {
+        double c0 = px - means[2 * k], c1 = py - means[2 * k + 1];
+        const double *ic = icovs + 4 * k;
+        double s0 = ic[0] * c0 + ic[1] * c1;
+        double s1 = ic[2] * c0 + ic[3] * c1;
+        double lp = -0.5 * (s0 * c0 + s1 * c1) - log2pi - 0.5 * log(dets[k]) + log(pis[k]);
+        scratch[k] = lp;
+        if (lp > mx) mx = lp;
+    }
+    if (!isfinite(mx)) mx = 0.0; /* scipy.special.logsumexp guards a non-finite max */
+    double s = 0.0;
+    for (int k = 0; k < K; k++) s += exp(scratch[k] - mx);
+    return log(s) + mx;
+}
+
+void orc_mog_loglike(double *out, const double *x, int64_t N, const double *means, const double *icovs,
+                     const double *dets, const double *pis, int K) {
+    int64_t n;
+#pragma omp parallel
+    {
+        double *scratch = (double *)malloc(sizeof(double) * (size_t)(K > 0 ? K : 1));
+#pragma omp for schedule(static)
+        for (n = 0; n < N; n++)
+            out[n] = mog_loglike_pt(x[2 * n], x[2 * n + 1], means, icovs, dets, pis, K, scratch);
+        free(scratch);
+    }
+}
+
+/* exp(mog_loglike) on the integer grid [x0,x1) x [y0,y1), row-major [y][x]
+ * (celeste.py:141-144 / mog.py:102-112: meshgrid 'xy', ravel C). Serial: callers
+ * parallelise over sources. */
+static void eval_grid(double *patch, int x0, int x1, int y0, int y1, const double *means,
+                      const double *icovs, const double *dets, const double *pis, int K) {
+    double scratch[K_GAL];
+    int nx = x1 - x0;
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++)
+            patch[(int64_t)(y - y0) * nx + (x - x0)] =
+                exp(mog_loglike_pt((double)x, (double)y, means, icovs, dets, pis, K, scratch));
+}
+
+static inline void inv2(const double c[4], double ic[4], double *det) {
+    double d = c[0] * c[3] - c[1] * c[2];
+    ic[0] = c[3] / d; ic[1] = -c[1] / d; ic[2] = -c[2] / d; ic[3] = c[0] / d;
+    *det = d;
+}
+
+/* ------------------------------------------------------------ star stamp -- */
+
+/* celeste.py:114-140: pixel location, overlap test (Q1, reproduced with its axis mix-up)
+ * and the int()-truncated box.  Returns 0 when the reference returns (None, None, None),
+ * 1 otherwise; box = {y0, y1, x0, x1} (may be empty/negative-width: Q1). */
+int orc_star_box(const orc_band *b, int H, int W, const double u[2], double v[2], int box[4]) {
+    orc_equa2pixel(b, u, v);
+    int miss = (v[0] < -50 || v[0] > 2 * H || v[1] < -50 || v[0] > 2 * W); /* celeste.py:130-132 */
+    if (miss) return 0;
+    double bound = b->R;
+    int lx = (int)(v[0] - bound), hx = (int)(v[0] + bound + 1);   /* int(): truncation toward 0 */
+    int ly = (int)(v[1] - bound), hy = (int)(v[1] + bound + 1);
+    box[2] = lx > 0 ? lx : 0; box[3] = hx < W ? hx : W;
+    box[0] = ly > 0 ? ly : 0; box[1] = hy < H ? hy : H;
+    return 1;
+}
+
+/* celeste.py:153-162: unit-flux PSF stamp on a given box (means = psf.mu + v,
+ * icovs = inv(covars), dets = exp(logdets), pis = weights). */
+void orc_star_patch(const orc_band *b, const double v[2], const int box[4], double *patch) {
+    double means[2 * K_PSF], icovs[4 * K_PSF], dets[K_PSF];
+    for (int k = 0; k < K_PSF; k++) {
+        means[2 * k] = b->mu[k][0] + v[0];
+        means[2 * k + 1] = b->mu[k][1] + v[1];
+        double d;
+        inv2(&b->cov[k][0][0], icovs + 4 * k, &d);
+        dets[k] = exp(log(d)); /* logdets via slogdet, then np.exp(logdets): celeste.py:160 */
+    }
+    eval_grid(patch, box[2], box[3], box[0], box[1], means, icovs, dets, b->w, K_PSF);
+}
+
+/* ---------------------------------------------------------- galaxy stamp -- */
+
+/* celeste_galaxy_conditionals.py:90-125: gen_galaxy_ra_dec_basis + gen_galaxy_transformation.
+ * phi_s is in DEGREES (Q7).  Returns Tinv (pixels per r_e), row-major. */
+void orc_galaxy_tinv(double sig_s, double rho_s, double phi_s, const double cd[4], double Tinv[4]) {
+    double phi = (90. - phi_s) * M_PI / 180.;
+    double re_deg = fmax(1. / 30, sig_s) / 3600.;
+    double cp = cos(phi), sp = sin(phi);
+    double G[4] = {re_deg * cp, re_deg * (sp * rho_s), re_deg * (-sp), re_deg * (cp * rho_s)};
+    double Gi[4], T[4], d;
+    inv2(G, Gi, &d);
+    T[0] = Gi[0] * cd[0] + Gi[1] * cd[2];
+    T[1] = Gi[0] * cd[1] + Gi[1] * cd[3];
+    T[2] = Gi[2] * cd[0] + Gi[3] * cd[2];
+    T[3] = Gi[2] * cd[1] + Gi[3] * cd[3];
+    inv2(T, Tinv, &d);
+}
+
+/* celeste_galaxy_conditionals.py:193-203 + util/dists/mog.py:75-100:
+ * convex_combine([exp, dev], [theta, 1-theta]) -> apply_affine(Tinv, [px,py]) -> convolve(psf).
+ * Output order is galaxy-major: idx = j*3 + k (Q10).  th = {theta, sigma, phi, rho}. */
+void orc_galaxy_table(const orc_band *b, const double th[4], const double u[2], double *pis,
+                      double *means, double *covs, double pxy[2], double Tinv[4]) {
+    double ea[K_EXP], ev[K_EXP], da[K_DEV], dv[K_DEV];
+    orc_profile_tables(ea, ev, da, dv);
+    orc_equa2pixel(b, u, pxy);
+    double cd[4];
+    orc_cd_at_pixel(b, pxy[0], pxy[1], cd);
+    orc_galaxy_tinv(th[1], th[3], th[2], cd, Tinv);
+    for (int j = 0; j < K_PROF; j++) {
+        double pj = (j < K_EXP) ? th[0] * ea[j] : (1. - th[0]) * da[j - K_EXP];
+        double var = (j < K_EXP) ? ev[j] : dv[j - K_EXP];
+        /* apply_affine: A . (var I) . A^T, evaluated as dot(dot(A, c), A.T) */
+        double Ac[4] = {Tinv[0] * var, Tinv[1] * var, Tinv[2] * var, Tinv[3] * var};
+        double C[4] = {Ac[0] * Tinv[0] + Ac[1] * Tinv[1], Ac[0] * Tinv[2] + Ac[1] * Tinv[3],
+                       Ac[2] * Tinv[0] + Ac[3] * Tinv[1], Ac[2] * Tinv[2] + Ac[3] * Tinv[3]};
+        for (int k = 0; k < K_PSF; k++) {
+            int i = j * K_PSF + k;
+            pis[i] = pj * b->w[k];
+            means[2 * i] = pxy[0] + b->mu[k][0];
+            means[2 * i + 1] = pxy[1] + b->mu[k][1];
+            covs[4 * i + 0] = C[0] + b->cov[k][0][0];
+            covs[4 * i + 1] = C[1] + b->cov[k][0][1];
+            covs[4 * i + 2] = C[2] + b->cov[k][1][0];
+            covs[4 * i + 3] = C[3] + b->cov[k][1][1];
+        }
+    }
+}
+
+/* celeste_galaxy_conditionals.py:205-211: bound (error 1e-5, centre (px,py)) and the
+ * floor/ceil box (Q6); box = {y0, y1, x0, x1}. Returns the bound. */
+double orc_galaxy_box(int H, int W, const double *pis, const double *means, const double *covs,
+                      const double pxy[2], int box[4]) {
+    double bound = orc_bounding_radius(pis, means, covs, K_GAL, 1e-5, pxy);
+    double xl = fmax(0.0, floor(pxy[0] - bound)), xh = fmin((double)W, ceil(pxy[0] + bound));
+    double yl = fmax(0.0, floor(pxy[1] - bound)), yh = fmin((double)H, ceil(pxy[1] + bound));
+    box[0] = (int)yl; box[1] = (int)yh; box[2] = (int)xl; box[3] = (int)xh;
+    return bound;
+}
+
+/* mog.py:102-112 evaluate_grid on the box, with dets/icovs from update_params (:55-56). */
+void orc_galaxy_patch(const double *pis, const double *means, const double *covs, const int box[4],
+                      double *patch) {
+    double icovs[4 * K_GAL], dets[K_GAL];
+    for (int i = 0; i < K_GAL; i++) inv2(covs + 4 * i, icovs + 4 * i, dets + i);
+    eval_grid(patch, box[2], box[3], box[0], box[1], means, icovs, dets, pis, K_GAL);
+}
+
+/* -------------------------------------------------- one source, one band -- */
+
+/* Unit-flux patch of one source in one band: A8 (type 0) or A17 (type 1).
+ * Returns the number of patch pixels written (0 => no contribution); box = {y0,y1,x0,x1}.
+ * `patch` may be NULL to query the box only. */
+int64_t orc_source_patch(const orc_band *b, int H, int W, int type, const double u[2],
+                         const double shape[4], int box[4], double *patch) {
+    if (type == 0) {
+        double v[2];
+        if (!orc_star_box(b, H, W, u, v, box)) { box[0] = box[1] = box[2] = box[3] = 0; return 0; }
+        if (box[1] <= box[0] || box[3] <= box[2]) return 0;
+        if (patch) orc_star_patch(b, v, box, patch);
+    } else {
+        double pis[K_GAL], means[2 * K_GAL], covs[4 * K_GAL], pxy[2], Tinv[4];
+        orc_galaxy_table(b, shape, u, pis, means, covs, pxy, Tinv);
+        orc_galaxy_box(H, W, pis, means, covs, pxy, box);
+        if (box[1] <= box[0] || box[3] <= box[2]) return 0;
+        if (patch) orc_galaxy_patch(pis, means, covs, box, patch);
+    }
+    return (int64_t)(box[1] - box[0]) * (box[3] - box[2]);
+}
+
+/* ----------------------------------------------------------- full field -- */
+
+/* celeste.py:203-219 gen_model_image + :237-252 celeste_likelihood[_multi_image], with the
+ * patch-accumulating extension for galaxies (models.py:88-108 semantics):
+ *   lambda[b] = eps_b + sum_s counts[s][b] * unit_patch(s, b) placed at its own box
+ *   ll_band[b] = sum_{y,x} nelec * log(lambda) - lambda
+ * counts[s*B + b] is the expected-photon multiplier (the three flux conventions of
+ * celeste.py:35-62 are applied by the caller).  Sources are accumulated in index order.
+ * lambda (B*H*W) and ll_band (B) are outputs; nelec may be NULL (then ll_band is not written).
+ * stats (may be NULL): {n_srcpix, n_gauss} summed over bands.
+ * Parallelism: chunks of sources rendered in parallel into private patches, added serially. */
+void orc_render_field(const orc_band *bands, int B, int H, int W, int64_t S, const int32_t *type,
+                      const double *radec, const double *counts, const double *shape,
+                      const double *nelec, double *lambda, double *ll_band, double *stats) {
+    enum { CHUNK = 64 };
+    double n_srcpix = 0.0, n_gauss = 0.0;
+    int64_t maxpix = (int64_t)H * W;
+    for (int b = 0; b < B; b++) {
+        double *lam = lambda + (int64_t)b * H * W;
+        for (int64_t i = 0; i < (int64_t)H * W; i++) lam[i] = 0.0;
+        for (int64_t s0 = 0; s0 < S; s0 += CHUNK) {
+            int64_t ns = (S - s0 < CHUNK) ? (S - s0) : CHUNK;
+            double *patches[CHUNK];
+            int boxes[CHUNK][4];
+            int64_t npix[CHUNK];
+            int64_t c;
+#pragma omp parallel for schedule(dynamic, 1)
+            for (c = 0; c < ns; c++) {
+                int64_t s = s0 + c;
+                npix[c] = orc_source_patch(&bands[b], H, W, type[s], radec + 2 * s, shape + 4 * s,
+                                           boxes[c], NULL);
+                patches[c] = NULL;
+                if (npix[c] > 0 && npix[c] <= maxpix) {
+                    patches[c] = (double *)malloc(sizeof(double) * (size_t)npix[c]);
+                    orc_source_patch(&bands[b], H, W, type[s], radec + 2 * s, shape + 4 * s, boxes[c],
+                                     patches[c]);
+                }
+            }
+            for (c = 0; c < ns; c++) {
+                if (!patches[c]) continue;
+                int64_t s = s0 + c;
+                double cnt = counts[s * B + b];
+                int y0 = boxes[c][0], y1 = boxes[c][1], x0 = boxes[c][2], x1 = boxes[c][3];
+                int nx = x1 - x0;
+                for (int y = y0; y < y1; y++)
+                    for (int x = x0; x < x1; x++)
+                        lam[(int64_t)y * W + x] += patches[c][(int64_t)(y - y0) * nx + (x - x0)] * cnt;
+                n_srcpix += (double)npix[c];
+                n_gauss += (double)npix[c] * (type[s] == 0 ? K_PSF : K_GAL);
+                free(patches[c]);
+            }
+        }
+        double eps = bands[b].eps;
+        for (int64_t i = 0; i < (int64_t)H * W; i++) lam[i] = eps + lam[i];
+        if (nelec && ll_band) {
+            const double *ne = nelec + (int64_t)b * H * W;
+            /* np.sum is pairwise; at 1e-6 relative the order is immaterial, but long double
+             * keeps the oracle's own error far below the tolerance */
+            long double acc = 0.0L;
+            for (int64_t i = 0; i < (int64_t)H * W; i++) acc += (long double)(ne[i] * log(lam[i]) - lam[i]);
+            ll_band[b] = (double)acc;
+        }
+    }
+    if (stats) { stats[0] = n_srcpix; stats[1] = n_gauss; }
+}
+
+/* Reference-faithful variant of gen_model_image for STARS (celeste.py:203-219): every source
+ * allocates a zeroed full frame, embeds its patch, scales the whole frame and adds it.
+ * Timed on a stated subsample to document the reference's O(S*H*W) behaviour. */
+void orc_gen_model_image_fullframe(const orc_band *band, int H, int W, int64_t S, const double *radec,
+                                   const double *counts_b, double *lambda) {
+    int64_t n = (int64_t)H * W;
+    double *f_s = (double *)calloc((size_t)n, sizeof(double));
+    for (int64_t s = 0; s < S; s++) {
+        double *grid = (double *)calloc((size_t)n, sizeof(double));  /* celeste.py:170-171 */
+        int box[4];
+        double v[2];
+        if (orc_star_box(band, H, W, radec + 2 * s, v, box) && box[1] > box[0] && box[3] > box[2]) {
+            int nx = box[3] - box[2];
+            double *patch = (double *)malloc(sizeof(double) * (size_t)nx * (size_t)(box[1] - box[0]));
+            orc_star_patch(band, v, box, patch);
+            for (int y = box[0]; y < box[1]; y++)
+                memcpy(grid + (int64_t)y * W + box[2], patch + (int64_t)(y - box[0]) * nx,
+                       sizeof(double) * (size_t)nx);
+            free(patch);
+        }
+        double c = counts_b[s];
+        for (int64_t i = 0; i < n; i++) f_s[i] += grid[i] * c;            /* celeste.py:45,217 */
+        free(grid);
+    }
+    for (int64_t i = 0; i < n; i++) lambda[i] = band->eps + f_s[i];       /* celeste.py:219 */
+    free(f_s);
+}
+
+/* sources.py:6-12 poisson_loglike on a patch with mask (mask may be NULL). */
+double orc_poisson_loglike(const double *data, const double *model, const uint8_t *mask, int64_t n) {
+    long double a = 0.0L, bsum = 0.0L;
+    for (int64_t i = 0; i < n; i++) {
+        if (model[i] > 0. && (!mask || mask[i])) {
+            a += (long double)(log(model[i]) * data[i]);
+            bsum += (long double)model[i];
+        }
+    }
+    return (double)(a - bsum);
+}
