@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline metric of BASELINE.json on MI355X.
+
+Workload (config.workload): BASELINE.json configs[2], the configuration the metric is quoted
+on -- 10 000 mixed star/galaxy sources x 5 bands x 2048^2, synthetic (data "synthetic").
+One step = one full-field log-likelihood evaluation with everything resident in HBM:
+    k_prep (WCS, galaxy shape matrix, bounding box per source x band) -> k_bin (tile lists)
+    -> k_render (model images + fused Poisson term) -> k_reduce -> 5 doubles to the host
+    [-> one all-reduce of the 5 doubles across ranks when N > 1].
+value = source-pixel evaluations per second, whole job (sum over ranks / max-over-ranks time);
+ms_per_step = full-field log-lik latency.  N > 1: one field per rank ("weak"), launched by
+torchrun, one collective per step (RCCL).
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--kernel direct|recurrence]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TF = 78.6     # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+FLOP_PER_GAUSS = 35.0        # SURVEY 8d accounting: 10 arithmetic + exp counted as 25
+
+
+def cpu_baseline(field, nsample, orc):
+    """The CPU oracle timed on a bounded sample of the SAME workload (first `nsample` sources,
+    all bands, full frame), all host threads.  Reported beside the GPU number; not the target."""
+    sl = slice(0, nsample)
+    bands = field.bands.copy()
+    for b in range(field.B):
+        bands[b, 36] = field.images.band(b)[36]
+    t0 = time.perf_counter()
+    lam, ll, st = orc.render_field(bands, field.H, field.W, field.src["type"][sl], field.src["radec"][sl],
+                                   field.src["counts"][sl], field.src["shape"][sl], field.nelec)
+    dt = time.perf_counter() - t0
+    return dict(value=st["n_srcpix"] / dt, unit="source-pixel evals/s", cores=orc.max_threads(), kind="port",
+                sample="first %d of %d sources, %d bands, %dx%d frame, %.2e source-px in %.2f s wall "
+                       "(oracle/celeste_oracle.c, OpenMP over sources)"
+                       % (nsample, field.S, field.B, field.H, field.W, st["n_srcpix"], dt),
+                gauss_evals_per_s=st["n_gauss"] / dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="mixed10k_2048")
+    ap.add_argument("--kernel", default="recurrence", choices=["direct", "recurrence"])
+    ap.add_argument("--tail-log", type=float, default=60.0)
+    ap.add_argument("--cpu-sample", type=int, default=400, help="sources in the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+
+    import desi_mcmc_amd as cel
+    from desi_mcmc_amd import dist, synth
+
+    rank, world, local = dist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    ctx = cel.Context(local)
+    ctx.set_kernel(args.kernel)
+    ctx.set_tail_log(args.tail_log)
+
+    # one field per rank (weak scaling): same population, different seed
+    field = synth.SyntheticField.from_config(ctx, args.workload, seed=42 + 1000 * rank)
+    stats = None
+
+    def step():
+        ll, llb = field.images.render(field.sources, loglik=True)
+        if world > 1:
+            llb = dist.allreduce_loglik(llb, device=local)
+        return llb
+
+    for _ in range(args.warmup):
+        step()
+    stats = field.images.stats()
+    ctx.profile(True)
+
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        llb = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+
+    t_render, n_render = ctx.profile_get("render")
+    t_bin, _ = ctx.profile_get("bin")
+    t_prep, _ = ctx.profile_get("prep")
+    t_red, _ = ctx.profile_get("reduce")
+    ctx.profile(False)
+
+    # max over ranks of the elapsed time, sum over ranks of the work
+    agg = torch.tensor([dt, stats["n_srcpix"], stats["n_gauss"]], dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as td
+        agg = agg.cuda(local)
+        tmax = agg[:1].clone()
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        tsum = agg[1:].clone()
+        td.all_reduce(tsum, op=td.ReduceOp.SUM)
+        dt_max, n_srcpix_all, n_gauss_all = tmax.item(), tsum[0].item(), tsum[1].item()
+    else:
+        dt_max, n_srcpix_all, n_gauss_all = dt, stats["n_srcpix"], stats["n_gauss"]
+
+    if rank == 0:
+        S, B, H, W, fg = synth.CONFIGS[args.workload]
+        n_imgpix = B * H * W
+        # algorithmic HBM bytes of one k_render launch (DESIGN.md "Measurement"):
+        #   read nelec 8 B + write lambda 8 B per image pixel, + one 128-B record per (source, band)
+        alg_bytes = 16.0 * n_imgpix + 128.0 * S * B
+        achieved = alg_bytes / (t_render * 1e-3) / 1e9 if t_render > 0 else 0.0
+        out = {
+            "metric": "source-pixel evals/sec (full-field Poisson log-lik, %d sources x %d bands x %dx%d)" % (S, B, H, W),
+            "value": n_srcpix_all * args.steps / dt_max,
+            "unit": "source-pixel evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "sources": S, "bands": B, "frame": [H, W],
+                       "galaxy_fraction": fg, "kernel": args.kernel, "tail_log": args.tail_log,
+                       "parallelism": "1 field per GPU, %d GPU(s), 1 all-reduce of %d doubles per step" % (world, B)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_render", "kernel_ms": t_render, "launches": n_render,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            # the roof that actually binds this kernel: fp64 vector ALU
+            "fp64_valu": {"achieved": FLOP_PER_GAUSS * stats["n_gauss"] / (t_render * 1e-3) / 1e12 if t_render > 0 else 0.0,
+                          "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s (35 flop per Gaussian-eval accounting)"},
+            "work": {"n_srcpix_per_step": n_srcpix_all, "n_gauss_per_step": n_gauss_all,
+                     "gauss_evals_per_s": n_gauss_all * args.steps / dt_max,
+                     "n_tile_entries": stats["n_tile_entries"]},
+            "kernels_ms": {"k_prep": t_prep, "k_bin": t_bin, "k_render": t_render, "k_reduce": t_red},
+            "loglik": float(np.sum(llb)),
+        }
+        out["fp64_valu"]["frac"] = out["fp64_valu"]["achieved"] / FP64_VALU_PEAK_TF
+        if world == 1 and args.cpu_sample > 0:
+            from oracle import oracle as orc      # cpu_baseline leg only
+            out["cpu_baseline"] = cpu_baseline(field, min(args.cpu_sample, S), orc)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as td
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+"""ctypes binding of libceleste_hip.so (the C ABI declared in include/celeste_hip.h).
+
+There is no fallback: if the HIP library is missing or no GPU is visible, every entry point
+raises.  Nothing here imports torch or the oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libceleste_hip.so")
+
+CEL_OK, CEL_ERR_INVALID, CEL_ERR_HIP, CEL_ERR_NOMEM, CEL_ERR_NO_DEVICE = 0, 1, 2, 3, 4
+CEL_HOST, CEL_DEVICE = 0, 1
+CEL_RENDER_LOGLIK, CEL_RENDER_NO_STORE = 1, 2
+CEL_OPT_KERNEL, CEL_OPT_TAIL_LOG, CEL_OPT_PROFILE = 1, 2, 3
+KERNELS = {"prep": 0, "bin": 1, "render": 2, "reduce": 3, "stamps": 4, "gmm": 5}
+BAND_DOUBLES = 37
+MAX_BANDS = 16
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_void_pp = C.POINTER(C.c_void_p)
+
+# every symbol include/celeste_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("cel_abi_version", C.c_int, []),
+    ("cel_last_error", C.c_char_p, []),
+    ("cel_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("cel_ctx_create", C.c_int, [C.c_int, C.c_void_p, c_void_pp]),
+    ("cel_ctx_destroy", C.c_int, [C.c_void_p]),
+    ("cel_ctx_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("cel_ctx_synchronize", C.c_int, [C.c_void_p]),
+    ("cel_ctx_set_option", C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    ("cel_ctx_get_option", C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+    ("cel_images_create", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, c_void_pp]),
+    ("cel_images_destroy", C.c_int, [C.c_void_p]),
+    ("cel_images_set_nelec", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    ("cel_images_set_epsilon", C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    ("cel_images_set_window", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    ("cel_images_get_band", C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+    ("cel_images_get_lambda", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    ("cel_images_device_ptrs", C.c_int, [C.c_void_p, c_void_pp, c_void_pp]),
+    ("cel_sources_create", C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_void_pp]),
+    ("cel_sources_destroy", C.c_int, [C.c_void_p]),
+    ("cel_sources_set", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    ("cel_render_field", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_double_p, c_double_p]),
+    ("cel_field_stats", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
+    ("cel_stamp_boxes", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_int32_p, c_int32_p]),
+    ("cel_render_stamps", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_int32_p, c_int64_p, C.c_void_p, C.c_int]),
+    ("cel_gmm_like_2d", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p, C.c_int,
+                                  C.c_void_p, C.c_int]),
+    ("cel_bounding_radius", C.c_int, [c_double_p, c_double_p, c_double_p, C.c_int, C.c_double, c_double_p, c_double_p]),
+    ("cel_profile_reset", C.c_int, [C.c_void_p]),
+    ("cel_profile_get", C.c_int, [C.c_void_p, C.c_int, c_double_p, c_int64_p]),
+]
+
+
+class CelesteHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library.  Loud failure when it has not been built (no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CelesteHipError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C desi-mcmc_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)   # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        if L.cel_abi_version() != 1:
+            raise CelesteHipError("ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status == CEL_OK:
+        return
+    msg = lib().cel_last_error().decode("utf-8", "replace")
+    if status == CEL_ERR_INVALID:
+        raise ValueError(msg)               # gmm_like_fast.pyx:146-149 raises ValueError
+    if status == CEL_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise CelesteHipError(msg)
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().cel_device_count(C.byref(n)))
+    return n.value

@@ -1,0 +1,249 @@
+"""Drop-in mirror of the render + likelihood API of CelestePy/celeste.py (reference lines cited
+per function).  Same names, argument order and return tuples; the arithmetic runs in the HIP
+kernels behind the C ABI (include/celeste_hip.h).  No CPU fallback exists: without the built
+library and a GPU these functions raise.
+
+Divergences from the reference, all documented in DESIGN.md "Quirks":
+  Q1  a star that fails the reference's overlap test contributes nothing to gen_model_image
+      (the reference multiplies None and raises TypeError);
+  Q3  galaxies are accepted by gen_model_image / celeste_likelihood: each source's own patch is
+      accumulated (the reference's gen_galaxy_psf_image ignores return_patch and breaks there);
+  planck  stars given by temperature (`src.t`) need a hook: set `photons_expected_brightness`.
+"""
+import weakref
+
+import numpy as np
+
+from . import field as _field
+from .fits_image import FitsImage  # noqa: F401  (re-exported like the reference does)
+
+BANDS = np.array(['u', 'g', 'r', 'i', 'z'], dtype=object)
+
+#: optional hook with the signature of planck.photons_expected_brightness(t, b, band)
+#: (CelestePy/planck.py:155); black-body photometry itself is outside this path.
+photons_expected_brightness = None
+
+_DEVICE = 0
+
+
+def set_device(device):
+    global _DEVICE
+    _DEVICE = int(device)
+    _SETS.clear()
+
+
+# ---- device-resident image sets, cached per python image object ---------------------------
+_SETS = {}
+
+
+def _image_set(images):
+    """ImageSet for a tuple of same-shape FitsImage objects (uploaded once, nelec is immutable)."""
+    key = tuple(id(im) for im in images)
+    hit = _SETS.get(key)
+    if hit is not None and all(r() is im for r, im in zip(hit[0], images)):
+        iset, eps = hit[1], hit[2]
+        for b, im in enumerate(images):          # epsilon is resampled by Gibbs (models.py:156-160)
+            if im.epsilon != eps[b]:
+                iset.set_epsilon(b, im.epsilon)
+                eps[b] = im.epsilon
+        return iset
+    H, W = images[0].nelec.shape
+    ctx = _field.default_context(_DEVICE)
+    bands = np.stack([im.band_record() for im in images])
+    iset = _field.ImageSet(ctx, bands, H, W, nelec=np.stack([im.nelec for im in images]))
+    if len(_SETS) > 64:
+        _SETS.clear()
+    try:
+        refs = [weakref.ref(im) for im in images]
+    except TypeError:
+        return iset
+    _SETS[key] = (refs, iset, [im.epsilon for im in images])
+    return iset
+
+
+def _flux(src, band):
+    f = src.fluxes
+    if isinstance(f, dict):
+        return f[band]
+    return f[list(BANDS).index(band)]
+
+
+def expected_photons(src, image):
+    """The multiplier of gen_src_image: three flux conventions (celeste.py:35-62)."""
+    if src.a == 0:
+        if src.t:
+            if photons_expected_brightness is None:
+                raise NotImplementedError("star given by temperature: set celeste.photons_expected_brightness "
+                                          "to a planck.photons_expected_brightness(t, b, band) callable")
+            return photons_expected_brightness(src.t, src.b, image.band)
+        return image.nmgy2counts(_flux(src, image.band))
+    elif src.a == 1:
+        return image.nmgy2counts(_flux(src, image.band))
+    elif src.a is None and src.fluxes is not None:
+        return image.kappa * _flux(src, image.band)
+    raise Exception("No way to compute expected photons without at least fluxes or brightness")
+
+
+def _source_arrays(srcs, images, counts_fn=expected_photons):
+    S = len(srcs)
+    typ = np.zeros(S, dtype=np.int32)
+    radec = np.zeros((S, 2))
+    shape = np.zeros((S, 4))
+    counts = np.zeros((S, len(images)))
+    for s, src in enumerate(srcs):
+        radec[s] = src.u
+        if src.a == 1:
+            typ[s] = 1
+            shape[s] = [src.theta, src.sigma, src.phi, src.rho]
+        for b, im in enumerate(images):
+            counts[s, b] = counts_fn(src, im)
+    return typ, radec, counts, shape
+
+
+def _one_stamp(image, typ, u, shape, xlim=None, ylim=None, scale=1.0):
+    """(patch or None, (y0,y1), (x0,x1)) for one source on one image."""
+    iset = _image_set((image,))
+    srcs = iset._sources(np.array([typ], dtype=np.int32), np.asarray(u, dtype=np.float64)[None, :],
+                         np.array([[scale]]), np.asarray(shape, dtype=np.float64)[None, :])
+    boxes_in = None
+    if xlim is not None and ylim is not None:
+        boxes_in = np.array([[int(ylim[0]), int(ylim[1]), int(xlim[0]), int(xlim[1])]], dtype=np.int32)
+    patches, boxes = iset.stamps(srcs, 0, scaled=(scale != 1.0), boxes_in=boxes_in)
+    y0, y1, x0, x1 = (int(v) for v in boxes[0])
+    return patches[0], (y0, y1), (x0, x1)
+
+
+# ---- celeste.py:114-176 -----------------------------------------------------------------------
+def gen_point_source_psf_image(u, image, xlim=None, ylim=None, check_overlap=True, return_patch=True,
+                               psf_grid=None, pixel_grid=None):
+    """generates a PSF image (assigns density values to pixels)  -- celeste.py:114-176"""
+    zeros4 = (0.0, 0.0, 0.0, 0.0)
+    if pixel_grid is not None and xlim is not None and ylim is not None:
+        # caller-supplied N x 2 points (celeste.py:145-152): generic evaluator
+        v_s = image.equa2pixel(u)
+        ctx = _field.default_context(_DEVICE)
+        vals = ctx.gmm_like_2d(pixel_grid, image.weights, image.means + v_s, image.covars)
+        (miny_b, maxy_b), (minx_b, maxx_b) = ylim, xlim
+        patch = vals.reshape((int(maxy_b - miny_b), int(maxx_b - minx_b)), order='C')
+    else:
+        patch, (miny_b, maxy_b), (minx_b, maxx_b) = _one_stamp(image, 0, u, zeros4, xlim, ylim)
+        if patch is None and xlim is None and ylim is None and not check_overlap:
+            # overlap test disabled: redo the reference's box on the host (celeste.py:137-140)
+            v_s = image.equa2pixel(u)
+            bound = image.R
+            minx_b, maxx_b = max(0, int(v_s[0] - bound)), min(int(v_s[0] + bound + 1), image.nelec.shape[1])
+            miny_b, maxy_b = max(0, int(v_s[1] - bound)), min(int(v_s[1] + bound + 1), image.nelec.shape[0])
+            if maxx_b > minx_b and maxy_b > miny_b:
+                patch, _, _ = _one_stamp(image, 0, u, zeros4, (minx_b, maxx_b), (miny_b, maxy_b))
+        if patch is None:
+            return None, None, None
+        if xlim is not None and ylim is not None:
+            (miny_b, maxy_b), (minx_b, maxx_b) = ylim, xlim
+    if return_patch:
+        return patch, (miny_b, maxy_b), (minx_b, maxx_b)
+    if psf_grid is None:
+        psf_grid = np.zeros(image.nelec.shape, dtype=float)
+    psf_grid[int(miny_b):int(maxy_b), int(minx_b):int(maxx_b)] = patch
+    return psf_grid, (0, psf_grid.shape[0]), (0, psf_grid.shape[1])
+
+
+# ---- celeste.py:99-111 ------------------------------------------------------------------------
+def gen_galaxy_psf_image(src, image, return_patch=True, check_overlap=True):
+    """unit-flux galaxy stamp for a SrcParams galaxy  -- celeste.py:99-111"""
+    assert src.a == 1, "generating glaxay psf image for non galaxy."
+    from . import celeste_galaxy_conditionals as gal_funs
+    th = np.array([src.theta, src.sigma, src.phi, src.rho])
+    return gal_funs.gen_galaxy_psf_image(th, src.u, image, check_overlap=check_overlap,
+                                         unconstrained=False, return_patch=return_patch)
+
+
+# ---- celeste.py:26-62 -------------------------------------------------------------------------
+def gen_src_image(src, image, return_patch=True):
+    """expected photon image of a single source: unit stamp x expected photons  -- celeste.py:26-62"""
+    if src.a == 1:
+        f_s, _, _ = gen_galaxy_psf_image(src, image, return_patch=return_patch)
+    else:
+        f_s, _, _ = gen_point_source_psf_image(src.u, image, return_patch=return_patch)
+    return f_s * expected_photons(src, image)    # TypeError on None, like the reference (Q1)
+
+
+def gen_src_psf_image(src, image):
+    if src.a == 0:
+        return gen_point_source_psf_image(src.u, image)
+    elif src.a == 1:
+        return gen_galaxy_psf_image(src, image)
+    raise NotImplementedError("not implemented!")
+
+
+# ---- celeste.py:72-96 -------------------------------------------------------------------------
+def gen_point_source_psf_image_with_fluxes(src_params, fits_image, return_patch=True, psf_grid=None):
+    src_img, ylim, xlim = gen_point_source_psf_image(src_params.u, fits_image, return_patch=True,
+                                                     psf_grid=psf_grid)
+    flux = src_params.flux_dict[fits_image.band]
+    src_img = src_img * ((flux / fits_image.calib) * fits_image.kappa)
+    return src_img, ylim, xlim
+
+
+def gen_src_image_with_fluxes(src, img):
+    """counts-scaled patch, star or galaxy, flux_dict convention  -- celeste.py:84-96"""
+    scale = (src.flux_dict[img.band] / img.calib) * img.kappa
+    if src.a == 1:
+        patch, (y0, y1), (x0, x1) = _one_stamp(img, 1, src.u, [src.theta, src.sigma, src.phi, src.rho],
+                                               scale=scale)
+        return patch, (float(y0), float(y1)), (float(x0), float(x1))
+    return _one_stamp(img, 0, src.u, (0.0, 0.0, 0.0, 0.0), scale=scale)
+
+
+# ---- celeste.py:203-219 -----------------------------------------------------------------------
+def gen_model_image(srcs, image):
+    """pixel-wise mean counts: epsilon + sum of source images  -- celeste.py:203-219"""
+    iset = _image_set((image,))
+    typ, radec, counts, shape = _source_arrays(srcs, (image,))
+    iset.render(iset._sources(typ, radec, counts, shape), loglik=False)
+    return iset.model_images()[0]
+
+
+# ---- celeste.py:222-234 -----------------------------------------------------------------------
+def gen_src_prob_layers(srcs, img):
+    """(S+1, H, W) responsibilities: epsilon/lambda, F_s/lambda  -- celeste.py:222-234"""
+    iset = _image_set((img,))
+    typ, radec, counts, shape = _source_arrays(srcs, (img,))
+    sset = iset._sources(typ, radec, counts, shape)
+    iset.render(sset, loglik=False)
+    lam = iset.model_images()[0]
+    patches, boxes = iset.stamps(sset, 0, scaled=True)
+    probs = np.zeros((len(srcs) + 1,) + lam.shape)
+    probs[0] = img.epsilon / lam
+    for s, p in enumerate(patches):
+        if p is not None:
+            y0, y1, x0, x1 = boxes[s]
+            probs[s + 1, y0:y1, x0:x1] = p / lam[y0:y1, x0:x1]
+    return probs
+
+
+# ---- celeste.py:237-252 -----------------------------------------------------------------------
+def celeste_likelihood(srcs, image):
+    """Poisson log-likelihood sum(nelec*log(lambda) - lambda)  -- celeste.py:237-240"""
+    iset = _image_set((image,))
+    typ, radec, counts, shape = _source_arrays(srcs, (image,))
+    total, _ = iset.render(iset._sources(typ, radec, counts, shape), loglik=True)
+    return total
+
+
+def celeste_likelihood_multi_image(srcs, images):
+    """sum of celeste_likelihood over images  -- celeste.py:243-252"""
+    ll = 0
+    images = list(images)
+    i = 0
+    while i < len(images):
+        # consecutive images of one shape share a device image set (<= 16 per set)
+        j = i + 1
+        while j < len(images) and j - i < 16 and images[j].nelec.shape == images[i].nelec.shape:
+            j += 1
+        group = tuple(images[i:j])
+        iset = _image_set(group)
+        typ, radec, counts, shape = _source_arrays(srcs, group)
+        total, _ = iset.render(iset._sources(typ, radec, counts, shape), loglik=True)
+        ll += total
+        i = j
+    return ll

@@ -1,0 +1,84 @@
+"""Multi-GPU layer: one process per GPU, partition by pixels, ONE scalar-sized collective.
+
+log lambda is non-linear in the per-pixel sum over sources, so every pixel's lambda has to be
+complete on one GPU before the log.  Two partitions satisfy that without any
+data-path exchange:
+
+  fields  independent fields (or exposures) are dealt to ranks; each rank renders and scores its
+          own fields                                                   -> weak scaling
+  strips  one field is cut into row strips aligned to the 32-row tile; a source is replicated to
+          every strip its box touches (the k_bin pass does that implicitly: every rank holds the
+          catalogue, bins only its rows)                               -> strong scaling
+
+Either way the only communication is the sum of B per-band log-likelihood doubles: one
+all-reduce over RCCL/xGMI on GPUs (backend "nccl" is RCCL on ROCm), gloo on CPU test rigs.
+"""
+import os
+
+import numpy as np
+
+TILE_ROWS = 32
+
+
+def strip_rows(H, world, rank, align=TILE_ROWS):
+    """Rows [y0, y1) of rank's strip: contiguous, tile-aligned, covering [0, H) exactly once."""
+    tiles = (H + align - 1) // align
+    lo = (tiles * rank) // world
+    hi = (tiles * (rank + 1)) // world
+    return min(lo * align, H), min(hi * align, H)
+
+
+def field_shard(n_fields, world, rank):
+    """Indices of the fields rank owns (round-robin: equal counts when world divides n_fields)."""
+    return list(range(rank, n_fields, world))
+
+
+def init_from_env(backend=None):
+    """torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun's contract).
+    -> (rank, world, local_rank).  No-op (0, 1, 0) when WORLD_SIZE is unset or 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world <= 1:
+        return 0, 1, local
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def allreduce_loglik(ll_band, device=None, deterministic=False):
+    """Sum per-band log-likelihoods over ranks.  ll_band: (B,) float64 numpy -> (B,) numpy.
+
+    deterministic=False: one all-reduce (sum) of B doubles -- the collective north_star names.
+    deterministic=True : all-gather + fixed rank-order sum on the host, bitwise reproducible for
+                         any topology."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return np.asarray(ll_band, dtype=np.float64).copy()
+    t = torch.from_numpy(np.ascontiguousarray(ll_band, dtype=np.float64).copy())
+    if dist.get_backend() == "nccl":
+        t = t.cuda(device if device is not None else torch.cuda.current_device())
+    if deterministic:
+        parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, t)
+        out = np.zeros(t.numel())
+        for p in parts:            # rank order
+            out += p.cpu().numpy()
+        return out
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

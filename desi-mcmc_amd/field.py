@@ -1,0 +1,241 @@
+"""Device-resident handles over the C ABI: a context, a set of band images, a set of sources.
+
+This is the host-side "fast lane" the reference-API mirror (celeste.py) is built on, and what
+bulk callers (MCMC sweeps, bench.py) use directly so that nothing is re-uploaded per call.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib as L
+
+BAND_KEYS = ("eps", "kappa", "calib", "weights", "means", "covars", "rho", "phi", "ups", "ups_inv", "R")
+
+
+def pack_band(eps, kappa, calib, weights, means, covars, rho, phi, ups, ups_inv, R=0.0):
+    """-> 37 doubles in cel_band order (include/celeste_hip.h)."""
+    out = np.zeros(L.BAND_DOUBLES)
+    out[0:3] = [eps, kappa, calib]
+    out[3:6] = np.asarray(weights, dtype=np.float64).ravel()
+    out[6:12] = np.asarray(means, dtype=np.float64).ravel()
+    out[12:24] = np.asarray(covars, dtype=np.float64).ravel()
+    out[24:26] = np.asarray(rho, dtype=np.float64).ravel()
+    out[26:28] = np.asarray(phi, dtype=np.float64).ravel()
+    out[28:32] = np.asarray(ups, dtype=np.float64).ravel()
+    out[32:36] = np.asarray(ups_inv, dtype=np.float64).ravel()
+    out[36] = R
+    return out
+
+
+def pack_bands(rec):
+    """dict of per-band stacked arrays (keys BAND_KEYS) -> (B, 37)."""
+    B = len(np.atleast_1d(rec["eps"]))
+    return np.stack([pack_band(*[np.asarray(rec[k])[b] for k in BAND_KEYS]) for b in range(B)])
+
+
+class Context(object):
+    """One HIP device + stream.  `stream` is a raw hipStream_t (int), e.g.
+    torch.cuda.current_stream().cuda_stream; None lets the library create its own."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        L.check(L.lib().cel_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = int(device)
+        self._finalizer = weakref.finalize(self, L.lib().cel_ctx_destroy, self._h)
+
+    def set_stream(self, stream):
+        L.check(L.lib().cel_ctx_set_stream(self._h, C.c_void_p(stream) if stream else None))
+
+    def synchronize(self):
+        L.check(L.lib().cel_ctx_synchronize(self._h))
+
+    def set_option(self, key, value):
+        L.check(L.lib().cel_ctx_set_option(self._h, int(key), float(value)))
+
+    def get_option(self, key):
+        v = C.c_double(0.0)
+        L.check(L.lib().cel_ctx_get_option(self._h, int(key), C.byref(v)))
+        return v.value
+
+    # convenience
+    def set_kernel(self, name):
+        self.set_option(L.CEL_OPT_KERNEL, {"direct": 0, "recurrence": 1}[name])
+
+    def set_tail_log(self, T):
+        self.set_option(L.CEL_OPT_TAIL_LOG, T)
+
+    def profile(self, on=True):
+        self.set_option(L.CEL_OPT_PROFILE, 1.0 if on else 0.0)
+        L.check(L.lib().cel_profile_reset(self._h))
+
+    def profile_get(self, kernel):
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        L.check(L.lib().cel_profile_get(self._h, L.KERNELS[kernel], C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def gmm_like_2d(self, x, ws, mus, sigs, probs=None):
+        """probs[n] = sum_k ws[k] N(x[n]; mus[k], sigs[k])  (gmm_like_fast.pyx:130-176)."""
+        x, ws, mus, sigs = L.f64(x), L.f64(ws), L.f64(mus), L.f64(sigs)
+        if x.ndim != 2 or x.shape[1] != 2:
+            raise ValueError("x must be N x 2")
+        if mus.shape[0] != sigs.shape[0] or mus.shape[0] != ws.shape[0]:
+            raise ValueError("Means, covariances and weights must have same first dimension!")
+        if mus.ndim != 2 or sigs.ndim != 3 or mus.shape[1] != sigs.shape[1] or mus.shape[1] != sigs.shape[2] \
+                or mus.shape[1] != 2:
+            raise ValueError("Means and inverse covariance shapes don't jive!")
+        if probs is None:
+            probs = np.zeros(x.shape[0], dtype=np.float64)
+        if probs.dtype != np.float64 or not probs.flags.c_contiguous or probs.shape != (x.shape[0],):
+            raise ValueError("probs must be a C-contiguous float64 buffer of length N")
+        L.check(L.lib().cel_gmm_like_2d(self._h, x.ctypes.data, x.shape[0], L.dptr(ws), L.dptr(mus), L.dptr(sigs),
+                                        int(ws.shape[0]), probs.ctypes.data, L.CEL_HOST))
+        return probs
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class SourceSet(object):
+    """S sources on the device: type, (ra,dec), counts[S,B], shape[S,4]."""
+
+    def __init__(self, ctx, capacity, B):
+        self.ctx, self.B, self.capacity = ctx, int(B), int(capacity)
+        self._h = C.c_void_p()
+        L.check(L.lib().cel_sources_create(ctx._h, int(capacity), int(B), C.byref(self._h)))
+        self._finalizer = weakref.finalize(self, L.lib().cel_sources_destroy, self._h)
+        self.S = 0
+
+    def set(self, typ, radec, counts, shape=None):
+        typ = np.ascontiguousarray(typ, dtype=np.int32)
+        S = typ.shape[0]
+        radec, counts = L.f64(radec).reshape(S, 2), L.f64(counts).reshape(S, self.B)
+        shape = np.zeros((S, 4)) if shape is None else L.f64(shape).reshape(S, 4)
+        L.check(L.lib().cel_sources_set(self._h, S, typ.ctypes.data, radec.ctypes.data, counts.ctypes.data,
+                                        shape.ctypes.data, L.CEL_HOST))
+        self.S = S
+        return self
+
+    def set_device(self, S, typ_ptr, radec_ptr, counts_ptr, shape_ptr):
+        """Same, from raw device pointers (e.g. torch tensors' data_ptr())."""
+        L.check(L.lib().cel_sources_set(self._h, int(S), C.c_void_p(typ_ptr), C.c_void_p(radec_ptr),
+                                        C.c_void_p(counts_ptr), C.c_void_p(shape_ptr), L.CEL_DEVICE))
+        self.S = int(S)
+        return self
+
+
+class ImageSet(object):
+    """B band images of one H x W field, resident on the device."""
+
+    def __init__(self, ctx, bands, H, W, nelec=None):
+        bands = L.f64(bands).reshape(-1, L.BAND_DOUBLES)
+        self.ctx, self.B, self.H, self.W = ctx, bands.shape[0], int(H), int(W)
+        self._h = C.c_void_p()
+        L.check(L.lib().cel_images_create(ctx._h, self.B, self.H, self.W, L.dptr(bands), C.byref(self._h)))
+        self._finalizer = weakref.finalize(self, L.lib().cel_images_destroy, self._h)
+        self._srcs = None
+        if nelec is not None:
+            self.set_nelec(nelec)
+
+    def set_nelec(self, nelec):
+        nelec = L.f64(nelec)
+        if nelec.size != self.B * self.H * self.W:
+            raise ValueError("nelec must have B*H*W = %d elements" % (self.B * self.H * self.W))
+        L.check(L.lib().cel_images_set_nelec(self._h, nelec.ctypes.data, L.CEL_HOST))
+
+    def set_nelec_device(self, ptr):
+        L.check(L.lib().cel_images_set_nelec(self._h, C.c_void_p(ptr), L.CEL_DEVICE))
+
+    def set_window(self, y0, full_H):
+        """This set holds rows [y0, y0+H) of a full_H-row frame (row-strip partition, dist.py)."""
+        L.check(L.lib().cel_images_set_window(self._h, int(y0), int(full_H)))
+
+    def set_epsilon(self, band, eps):
+        L.check(L.lib().cel_images_set_epsilon(self._h, int(band), float(eps)))
+
+    def band(self, b):
+        out = np.zeros(L.BAND_DOUBLES)
+        L.check(L.lib().cel_images_get_band(self._h, int(b), L.dptr(out)))
+        return out
+
+    def device_ptrs(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        L.check(L.lib().cel_images_device_ptrs(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # ---- the hot path ----
+    def _sources(self, typ, radec, counts, shape):
+        S = len(typ)
+        if self._srcs is None or self._srcs.capacity < S:
+            self._srcs = SourceSet(self.ctx, max(S, 16), self.B)
+        return self._srcs.set(typ, radec, counts, shape)
+
+    def render(self, sources, loglik=False, store=True):
+        """gen_model_image for all bands (+ fused celeste_likelihood).
+        -> (ll_total, ll_band[B]) when loglik else None.  Model images stay on the device;
+        fetch with .model_images()."""
+        flags = (L.CEL_RENDER_LOGLIK if loglik else 0) | (0 if store else L.CEL_RENDER_NO_STORE)
+        if loglik:
+            llb = np.zeros(self.B)
+            tot = C.c_double(0.0)
+            L.check(L.lib().cel_render_field(self._h, sources._h, flags, L.dptr(llb), C.byref(tot)))
+            return tot.value, llb
+        L.check(L.lib().cel_render_field(self._h, sources._h, flags, None, None))
+        return None
+
+    def model_images(self):
+        out = np.empty((self.B, self.H, self.W))
+        L.check(L.lib().cel_images_get_lambda(self._h, out.ctypes.data, L.CEL_HOST))
+        return out
+
+    def stats(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        L.check(L.lib().cel_field_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(n_srcpix=a.value, n_gauss=b.value, n_tile_entries=c.value)
+
+    def stamp_boxes(self, sources, band):
+        S = sources.S
+        boxes = np.zeros((S, 4), dtype=np.int32)
+        status = np.zeros(S, dtype=np.int32)
+        L.check(L.lib().cel_stamp_boxes(self._h, sources._h, int(band),
+                                        boxes.ctypes.data_as(L.c_int32_p), status.ctypes.data_as(L.c_int32_p)))
+        return boxes, status
+
+    def stamps(self, sources, band, scaled=False, boxes_in=None):
+        """Per-source stamps in one band -> (list of 2-D arrays or None, boxes[S,4] = y0,y1,x0,x1)."""
+        S = sources.S
+        if boxes_in is None:
+            boxes, status = self.stamp_boxes(sources, band)
+        else:
+            boxes = np.ascontiguousarray(boxes_in, dtype=np.int32).reshape(S, 4)
+            status = ((boxes[:, 1] > boxes[:, 0]) & (boxes[:, 3] > boxes[:, 2])).astype(np.int32)
+        area = np.where(status > 0, (boxes[:, 1] - boxes[:, 0]).astype(np.int64) * (boxes[:, 3] - boxes[:, 2]), 0)
+        offs = np.zeros(S + 1, dtype=np.int64)
+        np.cumsum(area, out=offs[1:])
+        flat = np.zeros(max(int(offs[-1]), 1))
+        L.check(L.lib().cel_render_stamps(
+            self._h, sources._h, int(band), 1 if scaled else 0,
+            boxes.ctypes.data_as(L.c_int32_p) if boxes_in is not None else None,
+            offs.ctypes.data_as(L.c_int64_p), flat.ctypes.data, L.CEL_HOST))
+        out = []
+        for s in range(S):
+            if status[s] > 0:
+                out.append(flat[offs[s]:offs[s + 1]].reshape(boxes[s, 1] - boxes[s, 0], boxes[s, 3] - boxes[s, 2]))
+            else:
+                out.append(None)
+        return out, boxes
+
+
+def bounding_radius(weights, means, covars, error, center=(0.0, 0.0)):
+    """calc_bounding_radius (util/bound/bounding_box.py:9-31) through the C ABI (host arithmetic)."""
+    w, mu, cov, c = L.f64(weights), L.f64(means), L.f64(covars), L.f64(center)
+    out = C.c_double(0.0)
+    L.check(L.lib().cel_bounding_radius(L.dptr(w), L.dptr(mu), L.dptr(cov), int(w.shape[0]), float(error),
+                                        L.dptr(c), C.byref(out)))
+    return out.value

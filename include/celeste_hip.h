@@ -1,0 +1,180 @@
+/*
+ * celeste_hip.h -- C ABI of the MI355X (gfx950) render + Poisson log-likelihood path.
+ *
+ * The reference (HIPS/DESI-MCMC, CelestePy) has no FFI layer for this path: the boundary
+ * is the module-function API of CelestePy/celeste.py and celeste_galaxy_conditionals.py,
+ * plus one native seam (CelestePy/util/like/__init__.py:5-14, which swaps the Cython
+ * gmm_like_2d in for the numpy gmm_prob).  Each entry point below names the reference
+ * interface it replaces (file:line relative to the reference root).  The Python mirror in
+ * desi-mcmc_amd/ binds exactly these symbols with ctypes; INTEGRATION.md shows the stub a
+ * CelestePy maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only; no C++/torch/numpy types cross this boundary;
+ *   - every function returns a cel_status; nothing throws across the ABI;
+ *     cel_last_error() gives the message of the calling thread's last failure;
+ *   - all arithmetic and all image / parameter buffers are IEEE fp64, images row-major [y][x];
+ *   - `mem` says where a caller buffer lives: CEL_HOST (pageable or pinned host memory) or
+ *     CEL_DEVICE (a HIP device pointer on the context's device, e.g. torch.Tensor.data_ptr());
+ *   - device memory for images, sources, bins and partial sums is owned by the library;
+ *   - work is enqueued on the context's HIP stream; calls that return values to the host
+ *     synchronise that stream, the *_async forms do not;
+ *   - there is NO CPU fallback: without a HIP device cel_ctx_create fails with
+ *     CEL_ERR_NO_DEVICE.
+ */
+#ifndef CELESTE_HIP_H
+#define CELESTE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CEL_ABI_VERSION 1
+
+typedef enum {
+    CEL_OK = 0,
+    CEL_ERR_INVALID = 1,   /* bad argument / shape mismatch: the Python mirror raises ValueError
+                              (gmm_like_fast.pyx:146-149) */
+    CEL_ERR_HIP = 2,       /* a HIP runtime call failed */
+    CEL_ERR_NOMEM = 3,
+    CEL_ERR_NO_DEVICE = 4  /* no usable gfx950 device */
+} cel_status;
+
+enum { CEL_HOST = 0, CEL_DEVICE = 1 };
+
+/* cel_render_field flags */
+enum {
+    CEL_RENDER_LOGLIK = 1,   /* also reduce sum(nelec*log(lambda) - lambda) per band */
+    CEL_RENDER_NO_STORE = 2  /* do not write the model images (log-lik only)        */
+};
+
+/* cel_ctx_set_option keys */
+enum {
+    CEL_OPT_KERNEL = 1,    /* 0 = direct exp per Gaussian-pixel, 1 = row-recurrence (default) */
+    CEL_OPT_TAIL_LOG = 2,  /* T >= 0: drop a component on a tile where its exponent is < -T
+                              everywhere (0 = never drop). default 60 (e^-60 = 8.8e-27)       */
+    CEL_OPT_PROFILE = 3    /* 1 = bracket every kernel launch with HIP events              */
+};
+
+/* kernels reported by cel_profile_get */
+enum {
+    CEL_K_PREP = 0, CEL_K_BIN = 1, CEL_K_RENDER = 2, CEL_K_REDUCE = 3, CEL_K_STAMPS = 4,
+    CEL_K_GMM = 5, CEL_K_COUNT = 6
+};
+
+typedef struct cel_ctx cel_ctx;
+typedef struct cel_images cel_images;
+typedef struct cel_sources cel_sources;
+
+/* One band image's parameters = the FitsImage fields the path reads
+ * (CelestePy/fits_image.py:85-155).  37 doubles, no padding. */
+typedef struct {
+    double eps;        /* epsilon = SKY*GAIN                     fits_image.py:113 */
+    double kappa;      /* GAIN                                   fits_image.py:112 */
+    double calib;      /* CALIB, nmgy per count                  fits_image.py:116 */
+    double w[3];       /* PSF mixture weights                    fits_image.py:129 */
+    double mu[6];      /* PSF means, (x,y) per component         fits_image.py:130 */
+    double cov[12];    /* PSF covariances, 2x2 per component     fits_image.py:135-137 */
+    double rho[2];     /* CRPIX - 1                              fits_image.py:99  */
+    double phi[2];     /* CRVAL                                  fits_image.py:100 */
+    double ups[4];     /* CD matrix                              fits_image.py:101 */
+    double ups_inv[4]; /* inv(CD)                                fits_image.py:103 */
+    double R;          /* star bounding radius (error 1e-3)      fits_image.py:151-155;
+                          <= 0: computed by the library with cel_bounding_radius */
+} cel_band;
+
+/* ---- library / context ------------------------------------------------------------- */
+int cel_abi_version(void);
+const char *cel_last_error(void);
+int cel_device_count(int *n);
+
+/* device: HIP ordinal.  stream: a hipStream_t to enqueue on (NULL = the library creates one). */
+int cel_ctx_create(int device, void *stream, cel_ctx **out);
+int cel_ctx_destroy(cel_ctx *ctx);
+int cel_ctx_set_stream(cel_ctx *ctx, void *stream);
+int cel_ctx_synchronize(cel_ctx *ctx);
+int cel_ctx_set_option(cel_ctx *ctx, int key, double value);
+int cel_ctx_get_option(cel_ctx *ctx, int key, double *value);
+
+/* ---- images: B bands of one H x W field -------------------------------------------- */
+/* Replaces constructing B FitsImage objects (fits_image.py:48-155) as far as the path reads them. */
+int cel_images_create(cel_ctx *ctx, int B, int H, int W, const cel_band *bands, cel_images **out);
+int cel_images_destroy(cel_images *img);
+/* nelec: B*H*W observed electron counts, FitsImage.nelec (fits_image.py:86-93); stays on device */
+int cel_images_set_nelec(cel_images *img, const double *nelec, int mem);
+/* Gibbs resamples the sky level (models.py:156-160) */
+int cel_images_set_epsilon(cel_images *img, int band, double eps);
+/* Declare that this image set holds rows [y0, y0 + H) of a full_H-row frame (row-strip partition
+ * of one field across GPUs).  Source boxes and the overlap test are formed against
+ * the full frame (celeste.py:130-140) and then cut to the window, so the strips tile the frame's
+ * model image exactly.  WCS (rho) stays that of the full frame. */
+int cel_images_set_window(cel_images *img, int y0, int full_H);
+int cel_images_get_band(cel_images *img, int band, cel_band *out);
+/* copy the last rendered model images (B*H*W) out */
+int cel_images_get_lambda(cel_images *img, double *out, int mem);
+/* raw device pointers of the library-owned B*H*W buffers (for zero-copy consumers) */
+int cel_images_device_ptrs(cel_images *img, void **nelec, void **lambda);
+
+/* ---- sources ------------------------------------------------------------------------ */
+/* Replaces a python list of SrcParams (celeste_src.py:57-94) as far as the path reads them:
+ *   type[s]   0 star, 1 galaxy (SrcParams.a)
+ *   radec[s]  (ra, dec) degrees (SrcParams.u)
+ *   counts[s*B + b] expected photons of source s in band b -- the multiplier that
+ *             gen_src_image applies (celeste.py:35-62; the caller picks the flux convention)
+ *   shape[s]  theta, sigma (arcsec), phi (DEGREES, celeste_galaxy_conditionals.py:97), rho */
+int cel_sources_create(cel_ctx *ctx, int64_t capacity, int B, cel_sources **out);
+int cel_sources_destroy(cel_sources *src);
+int cel_sources_set(cel_sources *src, int64_t S, const int32_t *type, const double *radec,
+                    const double *counts, const double *shape, int mem);
+
+/* ---- the hot path --------------------------------------------------------------------- */
+/* gen_model_image (celeste.py:203-219) for every band + celeste_likelihood /
+ * celeste_likelihood_multi_image (celeste.py:237-252), fused.  Galaxies are accumulated by
+ * their own patches (models.py:88-108 semantics).
+ *   lambda[b] = eps_b + sum_s counts[s][b] * unit_stamp(s, b)     (kept on device)
+ *   ll_band[b] = sum_{y,x} nelec*log(lambda) - lambda              (host, B doubles, may be NULL)
+ *   ll_total   = sum_b ll_band[b]                                  (host, may be NULL)
+ * Synchronises the stream when ll_band or ll_total is non-NULL. */
+int cel_render_field(cel_images *img, cel_sources *src, int flags, double *ll_band, double *ll_total);
+/* work counters of the last cel_render_field: n_srcpix = sum of box areas (source-pixel
+ * evaluations), n_gauss = sum of K*area, n_tile_entries = length of the tile lists */
+int cel_field_stats(cel_images *img, double *n_srcpix, double *n_gauss, double *n_tile_entries);
+
+/* ---- stamps --------------------------------------------------------------------------- */
+/* gen_point_source_psf_image (celeste.py:114-176) / gen_galaxy_psf_image
+ * (celeste_galaxy_conditionals.py:185-214) for every source of `src` in one band.
+ * Step 1: boxes[s*4..] = y0, y1, x0, x1 and status[s] (1 = has a stamp, 0 = the reference
+ *         returns (None, None, None) or the box is empty).  Host arrays.
+ * Step 2: the caller sizes a packed buffer (offsets[s+1]-offsets[s] = box area, or the area of
+ *         the caller-imposed box in boxes_in) and the stamps are written into it, row-major.
+ *   scaled: 0 = unit flux, 1 = multiplied by counts[s][band] (gen_src_image_with_fluxes,
+ *           celeste.py:84-96)
+ *   boxes_in: NULL = each source's own box; else S*4 caller limits (xlim/ylim arguments of
+ *           celeste.py:145-152); a source with an empty box is skipped. */
+int cel_stamp_boxes(cel_images *img, cel_sources *src, int band, int32_t *boxes, int32_t *status);
+int cel_render_stamps(cel_images *img, cel_sources *src, int band, int scaled, const int32_t *boxes_in,
+                      const int64_t *offsets, double *out, int mem);
+
+/* ---- generic evaluator ------------------------------------------------------------------ */
+/* gmm_like_2d (util/like/gmm_like_fast.pyx:130-176; wrapper util/like/__init__.py:7-11):
+ * probs[n] = sum_k ws[k] N(x[n]; mus[k], sigs[k]).  x: N*2, mus: K*2, sigs: K*4 covariances.
+ * x and probs follow `mem`; ws/mus/sigs are host arrays. */
+int cel_gmm_like_2d(cel_ctx *ctx, const double *x, int64_t N, const double *ws, const double *mus,
+                    const double *sigs, int K, double *probs, int mem);
+
+/* calc_bounding_radius (util/bound/bounding_box.py:9-31); host arithmetic, no device needed */
+int cel_bounding_radius(const double *w, const double *mu, const double *cov, int K, double error,
+                        const double *center, double *out);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* With CEL_OPT_PROFILE = 1 every launch of kernel `k` is bracketed by HIP events on the
+ * context's stream; cel_profile_get synchronises and returns the mean duration. */
+int cel_profile_reset(cel_ctx *ctx);
+int cel_profile_get(cel_ctx *ctx, int kernel, double *mean_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CELESTE_HIP_H */

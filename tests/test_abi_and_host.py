@@ -1,0 +1,189 @@
+"""CPU-only checks: the C-ABI library loads and exports every declared symbol, fails loudly
+without a GPU (no CPU fallback), and the host-side mirror logic matches the goldens.
+No compute call reaches a device here."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+BANDS = ["u", "g", "r", "i", "z"]
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    import desi_mcmc_amd
+    return desi_mcmc_amd
+
+
+def test_library_exports_every_declared_symbol(built):
+    from desi_mcmc_amd import _lib
+    header = open(os.path.join(ROOT, "include", "celeste_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char \*)\s*\*?(cel_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 27
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    lib = _lib.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (cel_\w+)", out))
+    assert declared <= exported
+    assert lib.cel_abi_version() == 1
+
+
+def test_code_object_is_gfx950_only(built):
+    from desi_mcmc_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not present")
+    out = subprocess.run([objdump, "--offloading", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    archs = set(re.findall(r"gfx\w+", out))
+    assert archs == {"gfx950"}, archs
+
+
+def test_no_gpu_means_loud_failure_not_fallback(built):
+    from desi_mcmc_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.CelesteHipError, match="no CPU fallback"):
+        built.Context(0)
+    from desi_mcmc_amd.util.like import gmm_like_2d
+    with pytest.raises(_lib.CelesteHipError):
+        gmm_like_2d(np.zeros((4, 2)), np.ones(1), np.zeros((1, 2)), np.eye(2)[None])
+
+
+def test_product_never_touches_oracle_or_reference():
+    """the product path must not import, link or read oracle/ or /root/reference"""
+    pkg = os.path.join(ROOT, "desi-mcmc_amd")
+    bad = []
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")) or fn == "Makefile":
+                txt = open(os.path.join(dp, fn)).read()
+                if re.search(r"(import\s+oracle|from\s+oracle|oracle[/.]\w|libceleste_oracle|/root/reference)", txt):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+
+
+def test_bounding_radius_host_entry(built):
+    from desi_mcmc_amd.util.bound.bounding_box import calc_bounding_radius, get_bounding_boxes_idx
+    rec = load_golden("bands_253.npz")
+    g = load_golden("radius.npz")
+    for b in range(5):
+        r = calc_bounding_radius(rec["weights"][b], rec["means"][b], rec["covars"][b], 0.001)
+        np.testing.assert_allclose(r, g["psf_R_1e3"][b], rtol=1e-13)
+        r5 = calc_bounding_radius(rec["weights"][b], rec["means"][b], rec["covars"][b], 1e-5,
+                                  center=np.array([0.3, -0.2]))
+        np.testing.assert_allclose(r5, g["psf_R_1e5_c"][b], rtol=1e-13)
+    gs = load_golden("galaxy_stamps.npz")
+    for i in (0, 5, 17):
+        r = calc_bounding_radius(gs["s_cw"][i], gs["s_cm"][i], gs["s_cc"][i], 1e-5, center=gs["s_pix"][i])
+        np.testing.assert_allclose(r, gs["s_bound"][i], rtol=1e-12)
+    with pytest.raises(ValueError):
+        calc_bounding_radius(rec["weights"][0], rec["means"][0], rec["covars"][0], 1.5)
+    boxes = np.array([[0, 10, 0, 10], [5, 15, 5, 15], [20, 30, 20, 30]])
+    assert list(get_bounding_boxes_idx(np.array([7, 7]), boxes)) == [0, 1]
+
+
+def test_fitsimage_mirror_host_logic(built):
+    rec = load_golden("bands_253.npz")
+    g = load_golden("wcs_points.npz")
+    for b in (0, 2):
+        im = built.FitsImage.from_record(BANDS[b], rec, b, rec["nelec"][b])
+        np.testing.assert_allclose(im.R, rec["R"][b], rtol=1e-13)
+        np.testing.assert_allclose(im.Ups_n_inv, rec["ups_inv"][b], rtol=1e-14)
+        for p, e, pb, cd in zip(g["pix"], g["equa_b%d" % b], g["pix_back_b%d" % b], g["cd_b%d" % b]):
+            np.testing.assert_allclose(im.pixel2equa(p), e, rtol=1e-15)
+            np.testing.assert_allclose(im.equa2pixel(e), pb, rtol=1e-12, atol=1e-10)
+            np.testing.assert_allclose(im.cd_at_pixel(p[0], p[1]), cd, rtol=1e-9, atol=1e-18)
+        assert not im.nelec.flags.writeable
+        np.testing.assert_allclose(im.nmgy2counts(3.0), 3.0 / rec["calib"][b] * rec["kappa"][b])
+        assert im.band_record().shape == (37,)
+    # from_header reproduces the reference's header arithmetic (fits_image.py:85-147)
+    hdr = {"CALIB": rec["calib"][2], "SKY": rec["eps"][2] / rec["kappa"][2], "GAIN": rec["kappa"][2],
+           "CRPIX1": 26.0, "CRPIX2": 26.0, "CRVAL1": rec["phi"][2][0], "CRVAL2": rec["phi"][2][1],
+           "CD1_1": rec["ups"][2][0, 0], "CD1_2": 0.0, "CD2_1": 0.0, "CD2_2": rec["ups"][2][1, 1]}
+    psf = list(rec["weights"][2]) + list(rec["means"][2].ravel())
+    for k in range(3):
+        c = rec["covars"][2][k]
+        psf += [c[0, 0], c[1, 1], c[0, 1]]
+    hdr.update({"PSF_P%d" % i: v for i, v in enumerate(psf)})
+    pix = (rec["nelec"][2] / hdr["GAIN"] - hdr["SKY"]) * hdr["CALIB"]
+    im = built.FitsImage.from_header("r", hdr, pix)
+    assert np.array_equal(im.nelec, rec["nelec"][2])
+    np.testing.assert_allclose(im.epsilon, rec["eps"][2], rtol=1e-15)
+    np.testing.assert_allclose(im.covars, rec["covars"][2], rtol=1e-15)
+
+
+def test_flux_conventions_q2(built):
+    from desi_mcmc_amd import celeste
+    rec = load_golden("bands_253.npz")
+    im = built.FitsImage.from_record("r", rec, 2, rec["nelec"][2])
+    fl = dict(zip(BANDS, [1., 2., 3., 4., 5.]))
+    star = built.SrcParams(u=np.zeros(2), a=0, fluxes=fl)
+    gal = built.SrcParams(u=np.zeros(2), a=1, fluxes=np.array([1., 2., 3., 4., 5.]), theta=.5, sigma=1., phi=0., rho=.5)
+    cat = built.SrcParams(u=np.zeros(2), fluxes=fl)
+    assert celeste.expected_photons(star, im) == 3.0 / im.calib * im.kappa          # celeste.py:41
+    assert celeste.expected_photons(gal, im) == 3.0 / im.calib * im.kappa           # celeste.py:50
+    assert celeste.expected_photons(cat, im) == im.kappa * 3.0                       # celeste.py:55
+    with pytest.raises(Exception):
+        celeste.expected_photons(built.SrcParams(u=np.zeros(2)), im)                 # celeste.py:57-58
+    with pytest.raises(NotImplementedError):
+        celeste.expected_photons(built.SrcParams(u=np.zeros(2), a=0, t=5000., b=1.), im)
+    celeste.photons_expected_brightness = lambda t, b, band: 42.0
+    try:
+        assert celeste.expected_photons(built.SrcParams(u=np.zeros(2), a=0, t=5000., b=1.), im) == 42.0
+    finally:
+        celeste.photons_expected_brightness = None
+    assert gal.flux_dict["r"] == 3.0 and np.allclose(gal.shape, [.5, 1., 0., .5])
+
+
+def test_galaxy_mixture_host_helper(built):
+    from desi_mcmc_amd import celeste_galaxy_conditionals as gal
+    rec = load_golden("bands_253.npz")
+    g = load_golden("galaxy_stamps.npz")
+    imgs = {b: built.FitsImage.from_record(BANDS[b], rec, b, rec["nelec"][b]) for b in (1, 2, 3)}
+    for i in range(0, len(g["s_th"]), 5):
+        img = imgs[int(g["s_band"][i])]
+        pis, means, covs, pxy = gal.galaxy_mixture(g["s_th"][i], g["s_u"][i], img)
+        np.testing.assert_allclose(pis, g["s_cw"][i], rtol=1e-13)
+        np.testing.assert_allclose(means, g["s_cm"][i], rtol=1e-13)
+        np.testing.assert_allclose(covs, g["s_cc"][i], rtol=1e-9)
+        th = g["s_th"][i]
+        np.testing.assert_allclose(gal.gen_galaxy_transformation(th[1], th[3], th[2], img.cd_at_pixel(*pxy)),
+                                   g["s_tinv"][i], rtol=1e-9)
+        src = built.SrcParams(u=g["s_u"][i], a=1, theta=th[0], sigma=th[1], phi=th[2], rho=th[3])
+        np.testing.assert_allclose(gal.gen_galaxy_psf_image_bound(src, img), g["s_bound"][i], rtol=1e-9)
+
+
+def test_synth_sources_deterministic(built):
+    from desi_mcmc_amd import synth
+    bands = synth.make_bands(2048, 2048, 5)
+    a = synth.make_sources(100, 2048, 2048, bands, 0.5, 42)
+    b = synth.make_sources(100, 2048, 2048, bands, 0.5, 42)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert bands.shape == (5, 37) and np.all(bands[:, 24] == 1024.0)
+    # pixel2equa round trip against the FitsImage mirror
+    rec = load_golden("bands_253.npz")
+    im = built.FitsImage.from_record("r", rec, 2, rec["nelec"][2])
+    np.testing.assert_allclose(synth.pixel2equa(im.band_record(), np.array([[3.5, 40.25]]))[0],
+                               im.pixel2equa(np.array([3.5, 40.25])), rtol=1e-15)
+
+
+def test_strip_partition_covers_frame_once(built):
+    from desi_mcmc_amd import dist
+    for H in (1, 31, 32, 80, 2048, 1489):
+        for world in (1, 2, 3, 4, 8):
+            rows = [dist.strip_rows(H, world, r) for r in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == H
+            for (a0, a1), (b0, b1) in zip(rows[:-1], rows[1:]):
+                assert a1 == b0 and a0 <= a1
+                assert a1 % 32 == 0 or a1 == H
+    assert dist.field_shard(8, 4, 1) == [1, 5]

@@ -1,0 +1,69 @@
+"""N > 1 path on CPU: world_size-2 gloo.  The per-rank compute is stood in by the CPU oracle
+(tests may use it); what is under test is the partition arithmetic and the one collective of
+desi-mcmc_amd/dist.py -- the same code bench.py runs over RCCL on GPUs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from desi_mcmc_amd import dist
+    from oracle import oracle as orc
+    r, w, _ = dist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    g = load_golden("mini_field.npz")
+    B = orc.pack_bands(g)
+    H, W = int(g["H"]), int(g["W"])
+    counts = g["flux"] / g["calib"][None, :] * g["kappa"][None, :]
+    lam, _, _ = orc.render_field(B, H, W, g["is_gal"], g["radec"], counts, g["shape"], None)
+    if mode == "strips":
+        y0, y1 = dist.strip_rows(H, world, rank)
+        part = np.array([orc.poisson_loglike(g["nelec"][b, y0:y1], lam[b, y0:y1]) for b in range(5)])
+    else:  # fields: rank r owns field r (field 1 = the same sky observed with +1 electron per pixel)
+        mine = dist.field_shard(world, world, rank)
+        part = np.zeros(5)
+        for f in mine:
+            part += np.array([orc.poisson_loglike(g["nelec"][b] + f, lam[b]) for b in range(5)])
+    tot = dist.allreduce_loglik(part)
+    tot_det = dist.allreduce_loglik(part, deterministic=True)
+    dist.barrier()
+    np.save(os.path.join(out_dir, "%s_%d.npy" % (mode, rank)), np.stack([tot, tot_det, part]))
+    import torch.distributed as td
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["strips", "fields"])
+def test_world2_gloo_loglik_allreduce(tmp_path, mode):
+    import torch.multiprocessing as mp
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), "%s_%d.npy" % (mode, r))) for r in range(world)]
+    g = load_golden("mini_field.npz")
+    if mode == "strips":
+        expect = g["ll_band"]
+    else:
+        from oracle import oracle as orc
+        expect = g["ll_band"] + np.array([orc.poisson_loglike(g["nelec"][b] + 1, g["lam"][b]) for b in range(5)])
+    for r in range(world):
+        np.testing.assert_allclose(res[r][0], expect, rtol=1e-12)      # all-reduce
+        np.testing.assert_allclose(res[r][1], expect, rtol=1e-12)      # all-gather + ordered sum
+        assert np.array_equal(res[r][1], res[0][1])                     # identical on every rank
+    assert not np.allclose(res[0][2], res[1][2])                        # the ranks did different work

@@ -1,0 +1,398 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the goldens and the CPU oracle.
+
+Tolerances.  north_star: 1e-6 relative for fp64 model pixels and log-lik.  The tests assert
+tighter bounds that the design guarantees:
+  RT_STAMP 1e-10  unit-flux stamps (direct evaluator) against goldens / oracle
+  RT_LAM   1e-10  model pixels lambda (both evaluators; dropped tails are < e^-60 of a component peak)
+  RT_LL    1e-11  log-likelihoods
+Boxes (integer work) are compared bit-exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, unpack_ragged
+
+pytestmark = pytest.mark.gpu
+
+RT_STAMP, RT_LAM, RT_LL = 1e-10, 1e-10, 1e-11
+BANDS = ["u", "g", "r", "i", "z"]
+
+
+@pytest.fixture(scope="module")
+def cel():
+    import desi_mcmc_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(cel):
+    return cel.default_context(0)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def stamp_images(cel):
+    rec = load_golden("bands_253.npz")
+    return rec, [cel.FitsImage.from_record(BANDS[b], rec, b, rec["nelec"][b]) for b in range(5)]
+
+
+def frame_images(cel, rec, H, W, nelec=None):
+    """FitsImage objects of a synthetic H x W frame whose band constants come from `rec`."""
+    out = []
+    for b in range(len(rec["eps"])):
+        r = {k: np.array(v, copy=True) for k, v in rec.items() if k in
+             ("eps", "kappa", "calib", "weights", "means", "covars", "rho", "phi", "ups")}
+        r["rho"][b] = [W / 2.0, H / 2.0]
+        out.append(cel.FitsImage.from_record(BANDS[b % 5], r, b, np.zeros((H, W)) if nelec is None else nelec[b]))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+def test_fitsimage_radius_matches_reference(stamp_images):
+    rec, imgs = stamp_images
+    for b, im in enumerate(imgs):
+        np.testing.assert_allclose(im.R, rec["R"][b], rtol=1e-13)
+        np.testing.assert_allclose(im.invcovars, rec["invcovars"][b], rtol=1e-12)
+        np.testing.assert_allclose(im.logdets, rec["logdets"][b], rtol=1e-12)
+
+
+def test_gmm_like_2d_reference_seed41(cel):
+    """the reference's own test (CelestePy/test/test_gmm.py:63-105) against the HIP evaluator"""
+    from desi_mcmc_amd.util.like import gmm_like_2d
+    g = load_golden("evaluator.npz")
+    got = gmm_like_2d(g["X"], g["ws"], g["means"], g["covs"])
+    np.testing.assert_allclose(got, g["gmm_prob"], rtol=1e-10, atol=1e-300)
+    assert np.allclose(got, g["gmm_prob"])            # the reference's own criterion
+    buf = np.zeros(g["X"].shape[0])
+    out = gmm_like_2d(g["X"], g["ws"], g["means"], g["covs"], probs=buf)
+    assert out is buf and np.array_equal(buf, got)    # caller buffer is filled in place
+
+
+def test_gmm_like_2d_edge_cases(cel, orc):
+    from desi_mcmc_amd.util.like import gmm_like_2d
+    rs = np.random.RandomState(3)
+    for N, K in ((1, 1), (63, 3), (257, 64), (1000, 65), (4097, 130)):
+        x = rs.randn(N, 2) * 3
+        ws = rs.rand(K) - 0.2          # negative weights are legal on this route (Q8)
+        mus = rs.randn(K, 2)
+        A = rs.randn(K, 2, 2)
+        sigs = A @ A.transpose(0, 2, 1) + 0.05 * np.eye(2)
+        got = gmm_like_2d(x, ws, mus, sigs)
+        np.testing.assert_allclose(got, orc.gmm_like_2d(x, ws, mus, sigs), rtol=1e-10, atol=1e-280)
+    assert gmm_like_2d(np.zeros((0, 2)), np.ones(1), np.zeros((1, 2)), np.eye(2)[None]).shape == (0,)
+    with pytest.raises(ValueError):
+        gmm_like_2d(np.zeros((4, 2)), np.ones(3), np.zeros((2, 2)), np.zeros((3, 2, 2)))
+    with pytest.raises(ValueError):
+        gmm_like_2d(np.zeros((4, 2)), np.ones(3), np.zeros((3, 2)), np.zeros((3, 2, 3)))
+
+
+def test_star_stamps_golden_boxes_edges_q1(cel, stamp_images):
+    from desi_mcmc_amd import celeste
+    rec, imgs = stamp_images
+    g = load_golden("star_stamps.npz")
+    patches = unpack_ragged(g["flat"], g["offs"], g["shapes"])
+    for i, (bi, u, box, none) in enumerate(zip(g["band"], g["u"], g["box"], g["is_none"])):
+        patch, yl, xl = celeste.gen_point_source_psf_image(u, imgs[bi])
+        if none:
+            assert patch is None and yl is None and xl is None        # Q1: (None, None, None)
+            continue
+        if patches[i].size == 0:
+            assert patch is None
+            continue
+        assert (yl[0], yl[1], xl[0], xl[1]) == tuple(int(t) for t in box)
+        np.testing.assert_allclose(patch, patches[i], rtol=RT_STAMP, atol=1e-300)
+    # caller limits and full-frame embedding (celeste.py:145-152,169-176)
+    p, yl, xl = celeste.gen_point_source_psf_image(g["lim_u"], imgs[2], xlim=tuple(g["lim_xlim"]),
+                                                   ylim=tuple(g["lim_ylim"]))
+    np.testing.assert_allclose(p, g["lim_patch"], rtol=RT_STAMP)
+    full, yl, xl = celeste.gen_point_source_psf_image(g["lim_u"], imgs[2], return_patch=False)
+    assert yl == (0, 51) and xl == (0, 51)
+    np.testing.assert_allclose(full, g["full_image"], rtol=RT_STAMP)
+    grid = np.ones((51, 51))
+    out, _, _ = celeste.gen_point_source_psf_image(g["lim_u"], imgs[2], return_patch=False, psf_grid=grid)
+    assert out is grid                                                # written in place
+    # pixel_grid route (generic points)
+    xx, yy = np.meshgrid(np.arange(5., 40.), np.arange(12., 51.), indexing="xy")
+    pg = np.column_stack((xx.ravel(), yy.ravel()))
+    p2, _, _ = celeste.gen_point_source_psf_image(g["lim_u"], imgs[2], xlim=(5, 40), ylim=(12, 51), pixel_grid=pg)
+    np.testing.assert_allclose(p2, g["lim_patch"], rtol=RT_STAMP)
+
+
+@pytest.mark.parametrize("tag", ["s", "b"])
+def test_galaxy_stamps_golden(cel, stamp_images, tag):
+    from desi_mcmc_amd import celeste_galaxy_conditionals as gal
+    rec, imgs = stamp_images
+    g = load_golden("galaxy_stamps.npz")
+    if tag == "b":
+        imgs = frame_images(cel, rec, int(g["big_H"]), int(g["big_W"]))
+    stride = int(g[tag + "_stride"])
+    patches = unpack_ragged(g[tag + "_flat"], g[tag + "_offs"], g[tag + "_shapes"])
+    for i in range(len(patches)):
+        img = imgs[g[tag + "_band"][i]]
+        th, u = g[tag + "_th"][i], g[tag + "_u"][i]
+        patch, yl, xl = gal.gen_galaxy_psf_image(th, u, img)
+        assert (yl[0], yl[1], xl[0], xl[1]) == tuple(g[tag + "_box"][i])
+        assert isinstance(yl[0], float)                               # Q5: float limits
+        np.testing.assert_allclose(patch.sum(), g[tag + "_sum"][i], rtol=1e-10)
+        np.testing.assert_allclose(patch[::stride, ::stride], patches[i], rtol=RT_STAMP, atol=1e-300)
+        np.testing.assert_allclose(gal.gen_galaxy_transformation(th[1], th[3], th[2], img.cd_at_pixel(*g[tag + "_pix"][i])),
+                                   g[tag + "_tinv"][i], rtol=1e-9)
+        pis, means, covs, _ = gal.galaxy_mixture(th, u, img)
+        np.testing.assert_allclose(pis, g[tag + "_cw"][i], rtol=1e-13)
+        np.testing.assert_allclose(covs, g[tag + "_cc"][i], rtol=1e-9)
+
+
+@pytest.mark.parametrize("kernel,tail", [("direct", 60.0), ("recurrence", 60.0), ("recurrence", 0.0),
+                                         ("recurrence", 30.0)])
+def test_mini_field_golden(cel, ctx, kernel, tail):
+    """mixed star/galaxy 96x80 field, 5 bands: lambda, per-band ll, per-source patches"""
+    g = load_golden("mini_field.npz")
+    H, W = int(g["H"]), int(g["W"])
+    ctx.set_kernel(kernel)
+    ctx.set_tail_log(tail)
+    try:
+        from desi_mcmc_amd import field
+        bands = field.pack_bands(g)
+        iset = cel.ImageSet(ctx, bands, H, W, nelec=g["nelec"])
+        counts = g["flux"] / g["calib"][None, :] * g["kappa"][None, :]
+        sset = cel.SourceSet(ctx, 12, 5).set(g["is_gal"], g["radec"], counts, g["shape"])
+        ll, llb = iset.render(sset, loglik=True)
+        lam = iset.model_images()
+        rt = RT_LAM if tail != 30.0 else 1e-9
+        np.testing.assert_allclose(lam, g["lam"], rtol=rt)
+        np.testing.assert_allclose(llb, g["ll_band"], rtol=RT_LL)
+        np.testing.assert_allclose(ll, g["ll"], rtol=RT_LL)
+        st = iset.stats()
+        assert st["n_srcpix"] == sum(int(np.prod(s)) for s in g["patch_shapes"])
+        # scaled per-source patches (gen_src_image_with_fluxes)
+        patches = unpack_ragged(g["patch_flat"], g["patch_offs"], g["patch_shapes"])
+        for b in (0, 2, 4):
+            got, boxes = iset.stamps(sset, b, scaled=True)
+            for s in range(12):
+                i = b * 12 + s
+                assert tuple(boxes[s]) == tuple(g["patch_box"][i])
+                np.testing.assert_allclose(got[s], patches[i], rtol=RT_STAMP, atol=1e-300)
+    finally:
+        ctx.set_kernel("recurrence")
+        ctx.set_tail_log(60.0)
+
+
+def test_reference_api_on_mini_field(cel, stamp_images):
+    """gen_model_image / celeste_likelihood[_multi_image] / gen_src_image with SrcParams lists"""
+    from desi_mcmc_amd import celeste
+    rec, _ = stamp_images
+    g = load_golden("mini_field.npz")
+    H, W = int(g["H"]), int(g["W"])
+    imgs = frame_images(cel, {k: g[k] for k in g}, H, W, nelec=g["nelec"])
+    idx = g["star_idx"]
+    stars = [cel.SrcParams(u=g["radec"][s], a=0, fluxes=dict(zip(BANDS, g["flux"][s]))) for s in idx]
+    for b in (0, 3):
+        np.testing.assert_allclose(celeste.gen_model_image(stars, imgs[b]), g["star_lam"][b], rtol=RT_LAM)
+    np.testing.assert_allclose(celeste.celeste_likelihood_multi_image(stars, imgs), g["star_ll"], rtol=RT_LL)
+    # mixed list through the extended gen_model_image (Q3)
+    srcs = [cel.SrcParams(u=g["radec"][s], a=int(g["is_gal"][s]), fluxes=g["flux"][s], theta=g["shape"][s, 0],
+                          sigma=g["shape"][s, 1], phi=g["shape"][s, 2], rho=g["shape"][s, 3]) for s in range(12)]
+    np.testing.assert_allclose(celeste.gen_model_image(srcs, imgs[2]), g["lam"][2], rtol=RT_LAM)
+    np.testing.assert_allclose(celeste.celeste_likelihood(srcs, imgs[1]), g["ll_band"][1], rtol=RT_LL)
+    np.testing.assert_allclose(celeste.celeste_likelihood_multi_image(srcs, imgs), g["ll"], rtol=RT_LL)
+    # per-source images
+    patches = unpack_ragged(g["patch_flat"], g["patch_offs"], g["patch_shapes"])
+    for s in (0, 1, 4, 7):
+        p, yl, xl = celeste.gen_src_image_with_fluxes(srcs[s], imgs[2])
+        i = 2 * 12 + s
+        assert (int(yl[0]), int(yl[1]), int(xl[0]), int(xl[1])) == tuple(g["patch_box"][i])
+        np.testing.assert_allclose(p, patches[i], rtol=RT_STAMP, atol=1e-300)
+    # responsibilities sum to one (celeste.py:222-234)
+    layers = celeste.gen_src_prob_layers(srcs, imgs[2])
+    assert layers.shape == (13, H, W)
+    np.testing.assert_allclose(layers.sum(axis=0), 1.0, rtol=1e-12)
+    # epsilon is updatable without re-upload (models.py:156-160)
+    old = imgs[1].epsilon
+    imgs[1].epsilon = old * 1.5
+    lam = celeste.gen_model_image(srcs, imgs[1])
+    np.testing.assert_allclose(lam, g["lam"][1] + 0.5 * old, rtol=1e-12)
+    imgs[1].epsilon = old
+
+
+def test_config1_real_stamps(cel, stamp_images):
+    from desi_mcmc_amd import celeste
+    rec, imgs = stamp_images
+    g = load_golden("config1.npz")
+    srcs = [cel.SrcParams(u=row[:2], fluxes=dict(zip(BANDS, row[2:]))) for row in g["cat"]]   # a=None (Q2)
+    for b in range(5):
+        np.testing.assert_allclose(celeste.gen_model_image(srcs, imgs[b]), g["lam"][b], rtol=RT_LAM)
+        np.testing.assert_allclose(celeste.celeste_likelihood(srcs, imgs[b]), g["ll_band"][b], rtol=RT_LL)
+    np.testing.assert_allclose(celeste.celeste_likelihood_multi_image(srcs, imgs), g["ll"], rtol=RT_LL)
+    star = cel.SrcParams(u=g["one_u"], a=0, fluxes=dict(zip(BANDS, g["one_flux"])))
+    np.testing.assert_allclose(celeste.gen_src_image(star, imgs[2]), g["one_patch"], rtol=RT_STAMP)
+    np.testing.assert_allclose(celeste.gen_model_image([star], imgs[2]), g["one_lam"], rtol=RT_LAM)
+    np.testing.assert_allclose(celeste.celeste_likelihood([star], imgs[2]), g["one_ll"], rtol=RT_LL)
+
+
+# ------------------------------------------------------------------------------------------
+# seeded synthetic fields against the CPU oracle
+# ------------------------------------------------------------------------------------------
+def oracle_bands(field):
+    b = field.bands.copy()
+    for i in range(b.shape[0]):
+        b[i, 36] = field.images.band(i)[36]      # the radius the library computed
+    return b
+
+
+@pytest.mark.parametrize("kernel", ["direct", "recurrence"])
+def test_config2_stars_512_vs_oracle(cel, ctx, orc, kernel):
+    from desi_mcmc_amd import synth
+    ctx.set_kernel(kernel)
+    try:
+        f = synth.SyntheticField.from_config(ctx, "stars1k_512")
+        ll, llb = f.images.render(f.sources, loglik=True)
+        lam = f.images.model_images()
+        o_lam, o_ll, o_st = orc.render_field(oracle_bands(f), f.H, f.W, f.src["type"], f.src["radec"],
+                                             f.src["counts"], f.src["shape"], f.nelec)
+        np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM)
+        np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
+        st = f.images.stats()
+        assert st["n_srcpix"] == o_st["n_srcpix"] and st["n_gauss"] == o_st["n_gauss"]
+    finally:
+        ctx.set_kernel("recurrence")
+
+
+@pytest.mark.parametrize("kernel", ["direct", "recurrence"])
+def test_mixed_field_vs_oracle(cel, ctx, orc, kernel):
+    """config 3's source population at a size the oracle finishes in seconds: 400 sources, 3 bands,
+    non-multiple-of-tile frame 500 x 333"""
+    from desi_mcmc_amd import synth
+    ctx.set_kernel(kernel)
+    try:
+        f = synth.SyntheticField(ctx, 400, 3, 333, 500, frac_gal=0.5, seed=7)
+        ll, llb = f.images.render(f.sources, loglik=True)
+        lam = f.images.model_images()
+        o_lam, o_ll, o_st = orc.render_field(oracle_bands(f), f.H, f.W, f.src["type"], f.src["radec"],
+                                             f.src["counts"], f.src["shape"], f.nelec)
+        np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM)
+        np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
+        assert f.images.stats()["n_srcpix"] == o_st["n_srcpix"]
+    finally:
+        ctx.set_kernel("recurrence")
+
+
+def test_edge_cases_empty_ragged_offimage(cel, ctx, orc):
+    from desi_mcmc_amd import synth
+    # no sources at all: lambda == epsilon, ll = sum(n log eps - eps)
+    for H, W in ((1, 1), (31, 65), (33, 64), (64, 63)):
+        bands = synth.make_bands(H, W, 2)
+        iset = cel.ImageSet(ctx, bands, H, W, nelec=np.full((2, H, W), 3.0))
+        sset = cel.SourceSet(ctx, 4, 2).set(np.zeros(0, np.int32), np.zeros((0, 2)), np.zeros((0, 2)), np.zeros((0, 4)))
+        ll, llb = iset.render(sset, loglik=True)
+        lam = iset.model_images()
+        for b in range(2):
+            assert np.all(lam[b] == bands[b, 0])
+            np.testing.assert_allclose(llb[b], H * W * (3.0 * np.log(bands[b, 0]) - bands[b, 0]), rtol=1e-13)
+    # sources off-image / on the border / failing the Q1 test / degenerate galaxy sizes
+    H, W = 70, 130
+    bands = synth.make_bands(H, W, 2)
+    pix = np.array([[-30., 10.], [-60., 10.], [129.9, 69.9], [0., 0.], [500., 500.], [65., -20.], [64.5, 35.2],
+                    [-200., 35.]])
+    typ = np.array([0, 0, 1, 1, 1, 0, 1, 1], np.int32)
+    radec = synth.pixel2equa(bands[0], pix)
+    shape = np.tile([0.5, 2.0, 30.0, 0.5], (8, 1))
+    shape[6, 1] = 1e-4          # below the 1/30 arcsec floor
+    counts = np.full((8, 2), 1000.0)
+    nelec = np.random.RandomState(1).poisson(300.0, size=(2, H, W)).astype(float)
+    iset = cel.ImageSet(ctx, bands, H, W, nelec=nelec)
+    sset = cel.SourceSet(ctx, 8, 2).set(typ, radec, counts, shape)
+    ll, llb = iset.render(sset, loglik=True)
+    ob = bands.copy()
+    ob[:, 36] = [iset.band(0)[36], iset.band(1)[36]]
+    o_lam, o_ll, _ = orc.render_field(ob, H, W, typ, radec, counts, shape, nelec)
+    np.testing.assert_allclose(iset.model_images(), o_lam, rtol=RT_LAM)
+    np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
+    boxes, status = iset.stamp_boxes(sset, 0)
+    assert status[1] == 0 and status[4] == 0 and status[7] == 0        # Q1 miss, far galaxy boxes empty
+
+
+def test_sharp_psf_forces_direct_fallback_and_short_segments(cel, ctx, orc):
+    """very narrow components (var 0.02..0.3 px^2): the recurrence must re-seed often or fall back"""
+    from desi_mcmc_amd import synth
+    H, W = 96, 128
+    bands = synth.make_bands(H, W, 1)
+    for scale in (0.15, 0.02):
+        b = bands.copy()
+        b[0, 12:24] *= scale
+        b[0, 36] = 0.0
+        typ = np.array([0, 1, 0], np.int32)
+        radec = synth.pixel2equa(b[0], np.array([[40.3, 50.7], [90.2, 30.1], [64.0, 64.0]]))
+        shape = np.tile([0.4, 1.0, 20.0, 0.7], (3, 1))
+        counts = np.full((3, 1), 5e4)
+        nelec = np.random.RandomState(2).poisson(500.0, size=(1, H, W)).astype(float)
+        iset = cel.ImageSet(ctx, b, H, W, nelec=nelec)
+        sset = cel.SourceSet(ctx, 3, 1).set(typ, radec, counts, shape)
+        ll, llb = iset.render(sset, loglik=True)
+        b[0, 36] = iset.band(0)[36]
+        o_lam, o_ll, _ = orc.render_field(b, H, W, typ, radec, counts, shape, nelec)
+        np.testing.assert_allclose(iset.model_images(), o_lam, rtol=RT_LAM)
+        np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE-size field: size-independent properties
+# ------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big_field(cel, ctx):
+    from desi_mcmc_amd import synth
+    return synth.SyntheticField.from_config(ctx, "mixed10k_2048")
+
+
+def test_full_size_properties(cel, ctx, big_field):
+    f = big_field
+    ll1, llb1 = f.images.render(f.sources, loglik=True)
+    lam1 = f.images.model_images()
+    # (1) the fused reduction equals a host recomputation from the stored model pixels
+    host = np.array([np.sum(f.nelec[b] * np.log(lam1[b]) - lam1[b]) for b in range(f.B)])
+    np.testing.assert_allclose(llb1, host, rtol=1e-12)
+    # (2) bitwise reproducible run to run (fixed-order lists and reduction)
+    ll2, llb2 = f.images.render(f.sources, loglik=True)
+    assert ll1 == ll2 and np.array_equal(llb1, llb2)
+    assert np.array_equal(lam1, f.images.model_images())
+    # (3) direct and recurrence evaluators agree
+    ctx.set_kernel("direct")
+    try:
+        ll3, llb3 = f.images.render(f.sources, loglik=True)
+        lam3 = f.images.model_images()
+    finally:
+        ctx.set_kernel("recurrence")
+    np.testing.assert_allclose(lam1, lam3, rtol=1e-11)
+    np.testing.assert_allclose(llb1, llb3, rtol=1e-12)
+    # (4) linearity in the source set: (lam(A) - eps) + (lam(B) - eps) == lam(A u B) - eps
+    half = f.S // 2
+    eps = f.bands[:, 0][:, None, None]
+    parts = []
+    for sl in (slice(0, half), slice(half, f.S)):
+        ss = cel.SourceSet(ctx, f.S, f.B).set(f.src["type"][sl], f.src["radec"][sl], f.src["counts"][sl],
+                                              f.src["shape"][sl])
+        f.images.render(ss)
+        parts.append(f.images.model_images() - eps)
+    np.testing.assert_allclose(parts[0] + parts[1], lam1 - eps, rtol=1e-9, atol=1e-9)
+    # (5) flux conservation: the total model flux is the sum of counts x stamp mass inside the frame
+    st = f.images.stats()
+    assert st["n_srcpix"] > 1e8 and st["n_gauss"] > st["n_srcpix"]
+
+
+def test_full_size_spot_check_vs_oracle(cel, ctx, orc, big_field):
+    """a 256 x 192 window of the 2048^2 field against the oracle: only sources near the window"""
+    f = big_field
+    f.images.render(f.sources, loglik=False)
+    lam = f.images.model_images()
+    ob = oracle_bands(f)
+    x0, y0, w, h = 900, 1100, 256, 192
+    near = np.where((np.abs(f.src["pix"][:, 0] - (x0 + w / 2)) < w / 2 + 330) &
+                    (np.abs(f.src["pix"][:, 1] - (y0 + h / 2)) < h / 2 + 330))[0]
+    for b in (0, 2):
+        o_lam, _, _ = orc.render_field(ob[b:b + 1], f.H, f.W, f.src["type"][near], f.src["radec"][near],
+                                       f.src["counts"][near][:, b:b + 1], f.src["shape"][near])
+        np.testing.assert_allclose(lam[b, y0:y0 + h, x0:x0 + w], o_lam[0, y0:y0 + h, x0:x0 + w], rtol=RT_LAM)
