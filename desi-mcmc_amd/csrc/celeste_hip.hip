@@ -43,13 +43,6 @@
 
 #include "../../include/celeste_hip.h"
 
-#define K_PSF 3
-#define K_EXP 6
-#define K_PROF 14
-#define K_GAL 42
-#define TILE_W 64
-#define MAX_BANDS 16
-
 // ------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------
@@ -71,542 +64,10 @@ static int fail(int code, const char *fmt, ...) {
                         #expr, hipGetErrorString(e_), __FILE__, __LINE__);                    \
     } while (0)
 
-// ------------------------------------------------------------------------------------------
-// device-side data
-// ------------------------------------------------------------------------------------------
-struct BandDev {        // per band, SoA-friendly PSF so that lane k can index component k
-    double eps;
-    double w[K_PSF], mux[K_PSF], muy[K_PSF], cxx[K_PSF], cxy[K_PSF], cyy[K_PSF];
-    double rho[2], phi[2], ups[4], ups_inv[4];
-    double R;
-};
-
-struct alignas(16) SrcRec {   // one per (band, source); 128 bytes
-    double px, py;            // pixel position (x = column, y = row)
-    double scale;             // expected photons of this source in this band
-    double w00, w01, w11;     // galaxy: Tinv Tinv^T (cov_j = var_j * W + psf_cov_k)
-    double theta;             // exp-profile fraction
-    int x0, x1, y0, y1;       // clipped box [x0,x1) x [y0,y1); empty when x1<=x0 or y1<=y0
-    int type;                 // 0 star, 1 galaxy, -1 no contribution
-    int pad[3];
-    double rsv[5];
-};
-static_assert(sizeof(SrcRec) == 128, "SrcRec must be 128 bytes");
-
-// exp/dev profile mixtures (Hogg & Lang; CelestePy/mixture_profiles.py:9-19), amplitudes
-// normalised on the host exactly as the reference does (:13,:19) and uploaded once.
-__constant__ double c_prof_amp[K_PROF];
-__constant__ double c_prof_var[K_PROF];
-
-static const double H_EXP_AMP[6] = {2.34853813e-03, 3.07995260e-02, 2.23364214e-01,
-                                    1.17949102e+00, 4.33873750e+00, 5.99820770e+00};
-static const double H_EXP_VAR[6] = {1.20078965e-03, 8.84526493e-03, 3.91463084e-02,
-                                    1.39976817e-01, 4.60962500e-01, 1.50159566e+00};
-static const double H_DEV_AMP[8] = {4.26347652e-02, 2.40127183e-01, 6.85907632e-01, 1.51937350e+00,
-                                    2.83627243e+00, 4.46467501e+00, 5.72440830e+00, 5.60989349e+00};
-static const double H_DEV_VAR[8] = {2.23759216e-04, 1.00220099e-03, 4.18731126e-03, 1.69432589e-02,
-                                    6.84850479e-02, 2.87207080e-01, 1.33320254e+00, 8.40215071e+00};
-
-#define PI_D 3.14159265358979323846
-
-// ------------------------------------------------------------------------------------------
-// k_prep: (band, source) -> record + box
-// ------------------------------------------------------------------------------------------
-__device__ inline void dev_pixel2equa(const BandDev &b, double x, double y, double cphi, double &ra,
-                                      double &dec) {
-    double d0 = x - b.rho[0], d1 = y - b.rho[1];
-    double i0 = b.ups[0] * d0 + b.ups[1] * d1;
-    double i1 = b.ups[2] * d0 + b.ups[3] * d1;
-    ra = i0 / cphi + b.phi[0];
-    dec = i1 + b.phi[1];
-}
-
-__device__ inline double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
-
-// calc_bounding_radius for one component (bounding_box.py:13-27)
-__device__ inline double comp_radius(double cxx, double cxy, double cyy, double rsq_inv, double dist) {
-    double s1 = sqrt(cxx), s2 = sqrt(cyy);
-    double rho = cxy / (s1 * s2);
-    double A11 = s1, A21 = rho * s2, A22 = s2 * sqrt(1.0 - rho * rho);
-    double An = rsq_inv * (1.0 / (A11 * A11) + (A21 * A21) / (A22 * A22));
-    double Bn = rsq_inv * (-2.0 * A21 / (A11 * (A22 * A22)));
-    double Cn = rsq_inv * 1.0 / (A22 * A22);
-    double maj = 1.0 / sqrt(0.5 * (An + Cn - sqrt(Bn * Bn + (An - Cn) * (An - Cn))));
-    return maj + dist;
-}
-
-__global__ void __launch_bounds__(256)
-k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int win_h, int64_t S,
-       const int *__restrict__ type, const double *__restrict__ radec,
-       const double *__restrict__ counts, const double *__restrict__ shape, double rsq_gal,
-       SrcRec *__restrict__ recs, int4 *__restrict__ boxes) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= S * B) return;
-    int b = (int)(i / S);
-    int64_t s = i - (int64_t)b * S;
-    const BandDev &bd = bands[b];
-    SrcRec r;
-    memset(&r, 0, sizeof(r));
-    int t = type[s];
-    double ra = radec[2 * s], dec = radec[2 * s + 1];
-    // equa2pixel (fits_image.py:166-174)
-    double cphi = cos(bd.phi[1] / 180.0 * PI_D);
-    double s0 = (ra - bd.phi[0]) * cphi, s1 = dec - bd.phi[1];
-    double px = (bd.ups_inv[0] * s0 + bd.ups_inv[1] * s1) + bd.rho[0];
-    double py = (bd.ups_inv[2] * s0 + bd.ups_inv[3] * s1) + bd.rho[1];
-    r.px = px; r.py = py;
-    r.scale = counts[s * B + b];
-    r.type = t;
-    const double BIG = 1073741824.0;
-    if (t == 0) {
-        // celeste.py:130-140: overlap test (with the reference's axis mix-up, Q1) + int() box
-        bool miss = (px < -50 || px > 2.0 * H || py < -50 || px > 2.0 * W);
-        if (miss || !(px == px) || !(py == py)) {
-            r.type = -1;
-        } else {
-            double bound = bd.R;
-            int lx = (int)clampd(px - bound, -BIG, BIG), hx = (int)clampd(px + bound + 1, -BIG, BIG);
-            int ly = (int)clampd(py - bound, -BIG, BIG), hy = (int)clampd(py + bound + 1, -BIG, BIG);
-            r.x0 = max(0, lx); r.x1 = min(hx, W);
-            r.y0 = max(0, ly); r.y1 = min(hy, H);
-        }
-    } else if (t == 1) {
-        double theta = shape[4 * s], sig = shape[4 * s + 1], phi_s = shape[4 * s + 2], rho_s = shape[4 * s + 3];
-        // cd_at_pixel (fits_image.py:196-216): 10-px finite difference of pixel2equa
-        double ra0, dec0, rax, decx, ray, decy;
-        dev_pixel2equa(bd, px, py, cphi, ra0, dec0);
-        dev_pixel2equa(bd, px + 10.0, py, cphi, rax, decx);
-        dev_pixel2equa(bd, px, py + 10.0, cphi, ray, decy);
-        double cosd = cos(dec0 * (PI_D / 180.0));
-        double cd0 = (rax - ra0) / 10.0 * cosd, cd1 = (ray - ra0) / 10.0 * cosd;
-        double cd2 = (decx - dec0) / 10.0, cd3 = (decy - dec0) / 10.0;
-        // gen_galaxy_transformation (celeste_galaxy_conditionals.py:90-125); phi in degrees (Q7)
-        double phi = (90.0 - phi_s) * PI_D / 180.0;
-        double re_deg = fmax(1.0 / 30, sig) / 3600.0;
-        double cp = cos(phi), sp = sin(phi);
-        double g0 = re_deg * cp, g1 = re_deg * (sp * rho_s), g2 = re_deg * (-sp), g3 = re_deg * (cp * rho_s);
-        double gd = g0 * g3 - g1 * g2;
-        double gi0 = g3 / gd, gi1 = -g1 / gd, gi2 = -g2 / gd, gi3 = g0 / gd;
-        double t0 = gi0 * cd0 + gi1 * cd2, t1 = gi0 * cd1 + gi1 * cd3;
-        double t2 = gi2 * cd0 + gi3 * cd2, t3 = gi2 * cd1 + gi3 * cd3;
-        double td = t0 * t3 - t1 * t2;
-        double ti0 = t3 / td, ti1 = -t1 / td, ti2 = -t2 / td, ti3 = t0 / td;   // Tinv
-        double w00 = ti0 * ti0 + ti1 * ti1, w01 = ti0 * ti2 + ti1 * ti3, w11 = ti2 * ti2 + ti3 * ti3;
-        r.w00 = w00; r.w01 = w01; r.w11 = w11; r.theta = theta;
-        // calc_bounding_radius over the 42 convolved components, error 1e-5, centre (px, py)
-        double rsq_inv = 1.0 / rsq_gal;
-        double bound = -INFINITY;
-        for (int k = 0; k < K_PSF; k++) {
-            double mx = (px + bd.mux[k]) - px, my = (py + bd.muy[k]) - py;
-            double dist = sqrt(mx * mx + my * my);
-            for (int j = 0; j < K_PROF; j++) {
-                double v = c_prof_var[j];
-                double rr = comp_radius(v * w00 + bd.cxx[k], v * w01 + bd.cxy[k], v * w11 + bd.cyy[k],
-                                        rsq_inv, dist);
-                bound = fmax(bound, rr);
-            }
-        }
-        if (!(bound == bound) || !(px == px) || !(py == py)) {
-            r.type = -1;
-        } else {
-            // celeste_galaxy_conditionals.py:208-211: floor/ceil box (Q6)
-            r.x0 = (int)clampd(fmax(0.0, floor(px - bound)), -BIG, BIG);
-            r.x1 = (int)clampd(fmin((double)W, ceil(px + bound)), -BIG, BIG);
-            r.y0 = (int)clampd(fmax(0.0, floor(py - bound)), -BIG, BIG);
-            r.y1 = (int)clampd(fmin((double)H, ceil(py + bound)), -BIG, BIG);
-        }
-    } else {
-        r.type = -1;
-    }
-    // row window [win_y0, win_y0 + win_h) of the H-row frame (strip partition across GPUs):
-    // boxes are formed against the FULL frame exactly as above, then cut to the window and
-    // re-based, so a strip renders the same pixels the whole frame would.
-    r.y0 = max(r.y0, win_y0) - win_y0;
-    r.y1 = min(r.y1, win_y0 + win_h) - win_y0;
-    r.py = py - (double)win_y0;
-    if (r.type < 0 || r.x1 <= r.x0 || r.y1 <= r.y0) {
-        r.x0 = r.x1 = r.y0 = r.y1 = 0;
-        if (r.type >= 0) r.type = -1 - r.type;   // remember the kind, mark "no contribution"
-    }
-    recs[i] = r;
-    boxes[i] = make_int4(r.x0, r.x1, r.y0, r.y1);
-}
-
-// work counters of one render: sum of box areas and K-weighted areas (on demand, not timed)
-__global__ void k_stats(const SrcRec *__restrict__ recs, int64_t n, double *out) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    double a = 0.0, g = 0.0;
-    if (i < n) {
-        const SrcRec &r = recs[i];
-        if (r.type >= 0) {
-            a = (double)(r.x1 - r.x0) * (double)(r.y1 - r.y0);
-            g = a * (r.type == 0 ? K_PSF : K_GAL);
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); g += __shfl_down(g, o); }
-    if ((threadIdx.x & 63) == 0 && a != 0.0) { atomicAdd(out, a); atomicAdd(out + 1, g); }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_bin: per-tile source lists, in source order
-// ------------------------------------------------------------------------------------------
-// pass 0 (lists == nullptr): count; the last lane-0 of each tile reserves its segment with one
-// atomicAdd on `cursor` (segment ORDER in the buffer is arbitrary, list CONTENT is not).
-// pass 1: fill.  One wave per tile.
-__global__ void __launch_bounds__(64)
-k_bin(const int4 *__restrict__ boxes, int64_t S, int ntx, int nty, int TH, int pass,
-      int *__restrict__ tile_cnt, int64_t *__restrict__ tile_off, unsigned long long *cursor,
-      int *__restrict__ lists, int64_t capacity, int *overflow) {
-    int tile = blockIdx.x;
-    int lane = threadIdx.x;
-    int per_band = ntx * nty;
-    int b = tile / per_band;
-    int t = tile - b * per_band;
-    int ty = t / ntx, tx = t - ty * ntx;
-    int X0 = tx * TILE_W, X1 = X0 + TILE_W, Y0 = ty * TH, Y1 = Y0 + TH;
-    const int4 *bx = boxes + (int64_t)b * S;
-    int64_t base = 0;
-    if (pass == 1) base = tile_off[tile];
-    int count = 0;
-    for (int64_t s0 = 0; s0 < S; s0 += 64) {
-        int64_t s = s0 + lane;
-        bool hit = false;
-        if (s < S) {
-            int4 q = bx[s];
-            hit = (q.x < X1) && (q.y > X0) && (q.z < Y1) && (q.w > Y0) && (q.y > q.x) && (q.w > q.z);
-        }
-        unsigned long long m = __ballot(hit);
-        if (pass == 1 && hit) {
-            int pos = __popcll(m & ((1ull << lane) - 1ull));
-            int64_t at = base + count + pos;
-            if (at < capacity) lists[at] = (int)s; else *overflow = 1;
-        }
-        count += __popcll(m);
-    }
-    if (pass == 0 && lane == 0) {
-        tile_cnt[tile] = count;
-        tile_off[tile] = (int64_t)atomicAdd(cursor, (unsigned long long)count);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// component tables in LDS
-// ------------------------------------------------------------------------------------------
-// Per component, 8 doubles, SoA over k (reads in the evaluators are wave-uniform broadcasts):
-//   A   = scale * weight / (2 pi sqrt(det))     mx, my = mean
-//   qa, qb, qc = inverse covariance [[qa, qb], [qb, qc]]
-//   ixx = qa - qb^2/qc = 1/Sigma_xx,  iyy = qc - qb^2/qa = 1/Sigma_yy   (marginal bounds)
-struct CompTab {
-    double A[K_GAL + 6], mx[K_GAL + 6], my[K_GAL + 6], qa[K_GAL + 6], qb[K_GAL + 6], qc[K_GAL + 6],
-        ixx[K_GAL + 6], iyy[K_GAL + 6], eq[K_GAL + 6];   // eq = exp(-qc): the row-to-row ratio of r
-};
-
-__device__ inline void build_comp(CompTab &T, int k, int type, double px, double py, double scale,
-                                  double w00, double w01, double w11, double theta,
-                                  const BandDev *__restrict__ bd) {
-    int kk = (type == 0) ? k : (k % K_PSF);
-    int j = k / K_PSF;
-    double cxx = bd->cxx[kk], cxy = bd->cxy[kk], cyy = bd->cyy[kk], wt = bd->w[kk];
-    if (type == 1) {
-        double var = c_prof_var[j];
-        double amp = (j < K_EXP) ? theta * c_prof_amp[j] : (1.0 - theta) * c_prof_amp[j];
-        cxx += var * w00; cxy += var * w01; cyy += var * w11;
-        wt *= amp;
-    }
-    double det = cxx * cyy - cxy * cxy;
-    double inv = 1.0 / det;
-    double qa = cyy * inv, qb = -cxy * inv, qc = cxx * inv;
-    T.A[k] = scale * wt / (2.0 * PI_D * sqrt(det));
-    T.mx[k] = px + bd->mux[kk];
-    T.my[k] = py + bd->muy[kk];
-    T.qa[k] = qa; T.qb[k] = qb; T.qc[k] = qc;
-    T.ixx[k] = 1.0 / cxx;   // = qa - qb^2/qc
-    T.iyy[k] = 1.0 / cyy;
-    T.eq[k] = exp(-qc);
-}
-
-__device__ inline double wave_sum(double v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    return v;
-}
-
-// distance from m to the closed interval [lo, hi]
-__device__ inline double dist_to_interval(double m, double lo, double hi) {
-    return fmax(fmax(lo - m, m - hi), 0.0);
-}
-
-// ---- direct evaluator: sum over components of A exp(-q/2) at (x, y) -------------------------
-__device__ inline double eval_direct(const CompTab &T, int K, double x, double y) {
-    double s = 0.0;
-    for (int k = 0; k < K; k++) {
-        double dx = x - T.mx[k], dy = y - T.my[k];
-        double q = T.qa[k] * dx * dx + 2.0 * T.qb[k] * dx * dy + T.qc[k] * dy * dy;
-        s += T.A[k] * exp(-0.5 * q);
-    }
-    return s;
-}
-
-// ---- recurrence evaluator -------------------------------------------------------------------
-// For a fixed column x the exponent of component k is a parabola in the row y:
-//   E(y) = -1/2 (qa dx^2 + 2 qb dx dy + qc dy^2),  g(y) = A exp(E(y))
-//   g(y+1) = g(y) r(y),  r(y) = exp(-(qb dx + qc dy + qc/2)),  r(y+1) = r(y) exp(-qc)
-// A segment of L rows is seeded with two exp() and then costs 2 mul + 1 add per row.
-// Underflow safety: a lane whose value matters anywhere in the segment (E >= -T there) has
-// E >= -T - L sqrt(2 T qc) - qc L^2/2 at the seed row; L is chosen so that this stays above
-// -680 (fp64 exp underflows gradually below -708), so a significant lane never starts from a
-// flushed seed.  Insignificant lanes may start from 0 and stay 0: they are below e^-T anyway.
-// r's exponent is clamped to +-680: it can only exceed that on lanes whose g is exactly 0.
-#define REC_G 6           // components advanced together (independent chains = ILP)
-#define REC_EMAX 680.0
-
-__device__ inline int seg_len(double qc, double T) {
-    // largest L with (L sqrt(qc/2) + sqrt(T))^2 <= REC_EMAX
-    double u = sqrt(REC_EMAX) - sqrt(T);
-    double L = u / sqrt(0.5 * qc);
-    return (int)fmin(L, 4096.0);
-}
-
-// Accumulate source components [k0, k0+REC_G) over rows [ra, rb) of column x into acc (LDS
-// column of this lane, stride TILE_W doubles).  `on` masks lanes outside the source box.
-template <int G>
-__device__ inline void rec_group(const CompTab &T, int k0, int kn, double x, int Y0, int ra, int rb,
-                                 int L, bool on, double *__restrict__ acc_col) {
-    double g[G], r[G], q[G];
-    for (int sa = ra; sa < rb; sa += L) {
-        int sb = min(sa + L, rb);
-        double y0 = (double)(Y0 + sa);
-#pragma unroll
-        for (int i = 0; i < G; i++) {
-            int k = k0 + i;
-            if (i < kn) {
-                double dx = x - T.mx[k], dy = y0 - T.my[k];
-                double qa = T.qa[k], qb = T.qb[k], qc = T.qc[k];
-                double e = -0.5 * (qa * dx * dx + 2.0 * qb * dx * dy + qc * dy * dy);
-                double er = -(qb * dx + qc * dy + 0.5 * qc);
-                er = fmin(fmax(er, -REC_EMAX), REC_EMAX);
-                g[i] = on ? T.A[k] * exp(e) : 0.0;
-                r[i] = exp(er);
-                q[i] = T.eq[k];
-            } else {
-                g[i] = 0.0; r[i] = 0.0; q[i] = 0.0;
-            }
-        }
-        for (int row = sa; row < sb; row++) {
-            double s = 0.0;
-#pragma unroll
-            for (int i = 0; i < G; i++) {
-                s += g[i];
-                g[i] *= r[i];
-                r[i] *= q[i];
-            }
-            acc_col[row * TILE_W] += s;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_render: one wave per (band, tile)
-// ------------------------------------------------------------------------------------------
-struct RenderArgs {
-    const BandDev *bands;
-    const SrcRec *recs;
-    const int *lists;
-    const int *tile_cnt;
-    const int64_t *tile_off;
-    const double *nelec;
-    double *lambda;
-    double *partials;
-    int64_t S, capacity;
-    int B, H, W, ntx, nty;
-    int flags;        // CEL_RENDER_*
-    int variant;      // 0 direct, 1 recurrence
-    double tail_T;    // drop threshold (0 = never)
-};
-
-template <int TH>
-__global__ void __launch_bounds__(64)
-k_render(RenderArgs a) {
-    __shared__ double acc[TH * TILE_W];
-    __shared__ CompTab T;
-    const int lane = threadIdx.x;
-    const int tile = blockIdx.x;
-    const int per_band = a.ntx * a.nty;
-    const int b = tile / per_band;
-    const int t = tile - b * per_band;
-    const int ty = t / a.ntx, tx = t - ty * a.ntx;
-    const int X0 = tx * TILE_W, Y0 = ty * TH;
-    const int xi = X0 + lane;
-    const double x = (double)xi;
-    const BandDev *bd = a.bands + b;
-
-#pragma unroll
-    for (int r = 0; r < TH; r++) acc[r * TILE_W + lane] = 0.0;
-
-    const int cnt = a.tile_cnt[tile];
-    const int64_t off = a.tile_off[tile];
-    const SrcRec *recs = a.recs + (int64_t)b * a.S;
-    const double Tdrop = a.tail_T;
-
-    for (int e = 0; e < cnt; e++) {
-        int64_t at = off + e;
-        if (at >= a.capacity) break;
-        const int s = __builtin_amdgcn_readfirstlane(a.lists[at]);
-        const SrcRec *rp = recs + s;
-        const int type = rp->type;
-        const int K = (type == 0) ? K_PSF : K_GAL;
-        const int bx0 = rp->x0, bx1 = rp->x1, by0 = rp->y0, by1 = rp->y1;
-        __syncthreads();   // previous source's table reads are done
-        if (lane < K)
-            build_comp(T, lane, type, rp->px, rp->py, rp->scale, rp->w00, rp->w01, rp->w11, rp->theta, bd);
-        __syncthreads();
-        const int ra = max(by0, Y0) - Y0, rb = min(by1, Y0 + TH) - Y0;
-        const bool on = (xi >= bx0) && (xi < bx1);
-        if (a.variant == 0) {
-            for (int row = ra; row < rb; row++) {
-                double v = eval_direct(T, K, x, (double)(Y0 + row));
-                if (on) acc[row * TILE_W + lane] += v;
-            }
-        } else {
-            // the part of this tile the source's box covers, for the drop test
-            const double xa = (double)max(bx0, X0), xb = (double)(min(bx1, X0 + TILE_W) - 1);
-            const double ya = (double)(Y0 + ra), yb = (double)(Y0 + rb - 1);
-            for (int k0 = 0; k0 < K; k0 += REC_G) {
-                const int kn = min(REC_G, K - k0);
-                // group-uniform segment length and drop decision
-                int L = 1 << 20;
-                bool any = false;
-                double qcmax = 0.0;
-                for (int i = 0; i < kn; i++) {
-                    int k = k0 + i;
-                    double ddx = dist_to_interval(T.mx[k], xa, xb), ddy = dist_to_interval(T.my[k], ya, yb);
-                    double qmin = fmax(ddx * ddx * T.ixx[k], ddy * ddy * T.iyy[k]);
-                    bool keep = (Tdrop <= 0.0) || (0.5 * qmin <= Tdrop);
-                    any = any || keep;
-                    qcmax = fmax(qcmax, T.qc[k]);
-                }
-                if (!any) continue;
-                L = seg_len(qcmax, Tdrop > 0.0 ? Tdrop : 100.0);
-                if (L < 4) {
-                    // pathologically sharp component: evaluate this group directly
-                    for (int row = ra; row < rb; row++) {
-                        double sum = 0.0;
-                        for (int i = 0; i < kn; i++) {
-                            int k = k0 + i;
-                            double dx = x - T.mx[k], dy = (double)(Y0 + row) - T.my[k];
-                            double q = T.qa[k] * dx * dx + 2.0 * T.qb[k] * dx * dy + T.qc[k] * dy * dy;
-                            sum += T.A[k] * exp(-0.5 * q);
-                        }
-                        if (on) acc[row * TILE_W + lane] += sum;
-                    }
-                } else {
-                    rec_group<REC_G>(T, k0, kn, x, Y0, ra, rb, L, on, acc + lane);
-                }
-            }
-        }
-    }
-
-    // epilogue: lambda = eps + acc, written once (512-B coalesced rows); fused Poisson term
-    const double eps = bd->eps;
-    const bool store = !(a.flags & CEL_RENDER_NO_STORE);
-    const bool ll = (a.flags & CEL_RENDER_LOGLIK) != 0;
-    double part = 0.0;
-    const int64_t plane = (int64_t)b * a.H * a.W;
-    if (xi < a.W) {
-#pragma unroll 4
-        for (int r = 0; r < TH; r++) {
-            int y = Y0 + r;
-            if (y < a.H) {
-                double lam = eps + acc[r * TILE_W + lane];
-                int64_t idx = plane + (int64_t)y * a.W + xi;
-                if (store) a.lambda[idx] = lam;
-                if (ll) part += a.nelec[idx] * log(lam) - lam;
-            }
-        }
-    }
-    if (ll) {
-        part = wave_sum(part);
-        if (lane == 0) a.partials[tile] = part;
-    }
-}
-
-// fixed-order reduction of the per-tile partials: one block per band
-__global__ void __launch_bounds__(256)
-k_reduce(const double *__restrict__ partials, int per_band, double *__restrict__ ll_band) {
-    __shared__ double sm[256];
-    int b = blockIdx.x;
-    const double *p = partials + (int64_t)b * per_band;
-    double s = 0.0, c = 0.0;   // Kahan per thread, fixed stride
-    for (int i = threadIdx.x; i < per_band; i += 256) {
-        double y = p[i] - c;
-        double tsum = s + y;
-        c = (tsum - s) - y;
-        s = tsum;
-    }
-    sm[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) ll_band[b] = sm[0];
-}
-
-// ------------------------------------------------------------------------------------------
-// k_stamps: one wave per (source, 64-column strip, row chunk) job
-// ------------------------------------------------------------------------------------------
-struct StampJob { int src; int x0; int y0; int y1; };   // strip starts at column x0; rows [y0,y1)
-
-__global__ void __launch_bounds__(64)
-k_stamps(const BandDev *__restrict__ bands, int band, const SrcRec *__restrict__ recs,
-         const StampJob *__restrict__ jobs, const int4 *__restrict__ obox,
-         const int64_t *__restrict__ offsets, int scaled, double *__restrict__ out) {
-    __shared__ CompTab T;
-    const int lane = threadIdx.x;
-    const StampJob jb = jobs[blockIdx.x];
-    const SrcRec *rp = recs + jb.src;
-    const int4 ob = obox[jb.src];           // output box: x0, x1, y0, y1
-    int type = rp->type;
-    if (type < 0) type = -1 - type;         // caller-imposed limits: still a valid source kind
-    const int K = (type == 0) ? K_PSF : K_GAL;
-    const BandDev *bd = bands + band;
-    if (lane < K)
-        build_comp(T, lane, type, rp->px, rp->py, scaled ? rp->scale : 1.0, rp->w00, rp->w01, rp->w11,
-                   rp->theta, bd);
-    __syncthreads();
-    const int xi = jb.x0 + lane;
-    if (xi >= ob.y) return;
-    const int nx = ob.y - ob.x;
-    double *o = out + offsets[jb.src];
-    for (int y = jb.y0; y < jb.y1; y++) {
-        double v = eval_direct(T, K, (double)xi, (double)y);
-        o[(int64_t)(y - ob.z) * nx + (xi - ob.x)] = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_gmm: generic evaluator, one thread per point, components staged through LDS
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_gmm(const double *__restrict__ x, int64_t N, const double *__restrict__ comp /* K*6: A,mx,my,qa,qb,qc */,
-      int K, double *__restrict__ probs) {
-    __shared__ double sc[64 * 6];
-    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    double px = 0.0, py = 0.0;
-    if (n < N) { px = x[2 * n]; py = x[2 * n + 1]; }
-    double s = 0.0;
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        int kn = min(64, K - k0);
-        __syncthreads();
-        for (int i = threadIdx.x; i < kn * 6; i += blockDim.x) sc[i] = comp[(int64_t)k0 * 6 + i];
-        __syncthreads();
-        for (int k = 0; k < kn; k++) {
-            double dx = px - sc[k * 6 + 1], dy = py - sc[k * 6 + 2];
-            double q = sc[k * 6 + 3] * dx * dx + 2.0 * sc[k * 6 + 4] * dx * dy + sc[k * 6 + 5] * dy * dy;
-            s += sc[k * 6 + 0] * exp(-0.5 * q);
-        }
-    }
-    if (n < N) probs[n] = s;
-}
+#include "device_common.h"
+#include "k_prep_bin.h"
+#include "k_render.h"
+#include "k_misc.h"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -1094,7 +555,7 @@ int cel_render_field(cel_images *im, cel_sources *src, int flags, double *ll_ban
         a.bands = im->d_bands; a.recs = im->d_recs; a.lists = im->d_lists; a.tile_cnt = im->d_tile_cnt;
         a.tile_off = im->d_tile_off; a.nelec = im->d_nelec; a.lambda = im->d_lambda; a.partials = im->d_partials;
         a.S = S; a.capacity = im->lists_cap; a.B = im->B; a.H = im->H; a.W = im->W; a.ntx = im->ntx; a.nty = im->nty;
-        a.flags = flags; a.variant = c->variant; a.tail_T = c->tail_T;
+        a.flags = flags; a.variant = c->variant; a.tail_T = c->tail_T; a.order = nullptr;
         pi = prof_begin(c, CEL_K_RENDER);
         hipLaunchKernelGGL((k_render<32>), dim3(T), dim3(64), 0, st, a);
         prof_end(c, pi);

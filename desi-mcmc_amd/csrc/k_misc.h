@@ -1,0 +1,64 @@
+// k_misc.h -- stamp and generic-evaluator kernels
+#pragma once
+#include "k_render.h"
+// ------------------------------------------------------------------------------------------
+// k_stamps: one wave per (source, 64-column strip, row chunk) job
+// ------------------------------------------------------------------------------------------
+struct StampJob { int src; int x0; int y0; int y1; };   // strip starts at column x0; rows [y0,y1)
+
+__global__ void __launch_bounds__(64)
+k_stamps(const BandDev *__restrict__ bands, int band, const SrcRec *__restrict__ recs,
+         const StampJob *__restrict__ jobs, const int4 *__restrict__ obox,
+         const int64_t *__restrict__ offsets, int scaled, double *__restrict__ out) {
+    __shared__ CompTab T;
+    const int lane = threadIdx.x;
+    const StampJob jb = jobs[blockIdx.x];
+    const SrcRec *rp = recs + jb.src;
+    const int4 ob = obox[jb.src];           // output box: x0, x1, y0, y1
+    int type = rp->type;
+    if (type < 0) type = -1 - type;         // caller-imposed limits: still a valid source kind
+    const int K = (type == 0) ? K_PSF : K_GAL;
+    const BandDev *bd = bands + band;
+    if (lane < K)
+    {
+        Comp c = make_comp(lane, type, rp->px, rp->py, scaled ? rp->scale : 1.0, rp->w00, rp->w01, rp->w11,
+                           rp->theta, bd);
+        T.A[lane] = c.A; T.mx[lane] = c.mx; T.my[lane] = c.my;
+        T.qa[lane] = c.qa; T.qb[lane] = c.qb; T.qc[lane] = c.qc;
+    }
+    __syncthreads();
+    const int xi = jb.x0 + lane;
+    if (xi >= ob.y) return;
+    const int nx = ob.y - ob.x;
+    double *o = out + offsets[jb.src];
+    for (int y = jb.y0; y < jb.y1; y++) {
+        double v = eval_direct(T, 0, K, (double)xi, (double)y);
+        o[(int64_t)(y - ob.z) * nx + (xi - ob.x)] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_gmm: generic evaluator, one thread per point, components staged through LDS
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_gmm(const double *__restrict__ x, int64_t N, const double *__restrict__ comp /* K*6: A,mx,my,qa,qb,qc */,
+      int K, double *__restrict__ probs) {
+    __shared__ double sc[64 * 6];
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double px = 0.0, py = 0.0;
+    if (n < N) { px = x[2 * n]; py = x[2 * n + 1]; }
+    double s = 0.0;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        int kn = min(64, K - k0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < kn * 6; i += blockDim.x) sc[i] = comp[(int64_t)k0 * 6 + i];
+        __syncthreads();
+        for (int k = 0; k < kn; k++) {
+            double dx = px - sc[k * 6 + 1], dy = py - sc[k * 6 + 2];
+            double q = sc[k * 6 + 3] * dx * dx + 2.0 * sc[k * 6 + 4] * dx * dy + sc[k * 6 + 5] * dy * dy;
+            s += sc[k * 6 + 0] * exp(-0.5 * q);
+        }
+    }
+    if (n < N) probs[n] = s;
+}
+

@@ -1,0 +1,183 @@
+// k_prep_bin.h -- source preparation and tile binning kernels
+#pragma once
+#include "device_common.h"
+// ------------------------------------------------------------------------------------------
+// k_prep: (band, source) -> record + box
+// ------------------------------------------------------------------------------------------
+__device__ inline void dev_pixel2equa(const BandDev &b, double x, double y, double cphi, double &ra,
+                                      double &dec) {
+    double d0 = x - b.rho[0], d1 = y - b.rho[1];
+    double i0 = b.ups[0] * d0 + b.ups[1] * d1;
+    double i1 = b.ups[2] * d0 + b.ups[3] * d1;
+    ra = i0 / cphi + b.phi[0];
+    dec = i1 + b.phi[1];
+}
+
+__device__ inline double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+// calc_bounding_radius for one component (bounding_box.py:13-27)
+__device__ inline double comp_radius(double cxx, double cxy, double cyy, double rsq_inv, double dist) {
+    double s1 = sqrt(cxx), s2 = sqrt(cyy);
+    double rho = cxy / (s1 * s2);
+    double A11 = s1, A21 = rho * s2, A22 = s2 * sqrt(1.0 - rho * rho);
+    double An = rsq_inv * (1.0 / (A11 * A11) + (A21 * A21) / (A22 * A22));
+    double Bn = rsq_inv * (-2.0 * A21 / (A11 * (A22 * A22)));
+    double Cn = rsq_inv * 1.0 / (A22 * A22);
+    double maj = 1.0 / sqrt(0.5 * (An + Cn - sqrt(Bn * Bn + (An - Cn) * (An - Cn))));
+    return maj + dist;
+}
+
+__global__ void __launch_bounds__(256)
+k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int win_h, int64_t S,
+       const int *__restrict__ type, const double *__restrict__ radec,
+       const double *__restrict__ counts, const double *__restrict__ shape, double rsq_gal,
+       SrcRec *__restrict__ recs, int4 *__restrict__ boxes) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * B) return;
+    int b = (int)(i / S);
+    int64_t s = i - (int64_t)b * S;
+    const BandDev &bd = bands[b];
+    SrcRec r;
+    memset(&r, 0, sizeof(r));
+    int t = type[s];
+    double ra = radec[2 * s], dec = radec[2 * s + 1];
+    // equa2pixel (fits_image.py:166-174)
+    double cphi = cos(bd.phi[1] / 180.0 * PI_D);
+    double s0 = (ra - bd.phi[0]) * cphi, s1 = dec - bd.phi[1];
+    double px = (bd.ups_inv[0] * s0 + bd.ups_inv[1] * s1) + bd.rho[0];
+    double py = (bd.ups_inv[2] * s0 + bd.ups_inv[3] * s1) + bd.rho[1];
+    r.px = px; r.py = py;
+    r.scale = counts[s * B + b];
+    r.type = t;
+    const double BIG = 1073741824.0;
+    if (t == 0) {
+        // celeste.py:130-140: overlap test (with the reference's axis mix-up, Q1) + int() box
+        bool miss = (px < -50 || px > 2.0 * H || py < -50 || px > 2.0 * W);
+        if (miss || !(px == px) || !(py == py)) {
+            r.type = -1;
+        } else {
+            double bound = bd.R;
+            int lx = (int)clampd(px - bound, -BIG, BIG), hx = (int)clampd(px + bound + 1, -BIG, BIG);
+            int ly = (int)clampd(py - bound, -BIG, BIG), hy = (int)clampd(py + bound + 1, -BIG, BIG);
+            r.x0 = max(0, lx); r.x1 = min(hx, W);
+            r.y0 = max(0, ly); r.y1 = min(hy, H);
+        }
+    } else if (t == 1) {
+        double theta = shape[4 * s], sig = shape[4 * s + 1], phi_s = shape[4 * s + 2], rho_s = shape[4 * s + 3];
+        // cd_at_pixel (fits_image.py:196-216): 10-px finite difference of pixel2equa
+        double ra0, dec0, rax, decx, ray, decy;
+        dev_pixel2equa(bd, px, py, cphi, ra0, dec0);
+        dev_pixel2equa(bd, px + 10.0, py, cphi, rax, decx);
+        dev_pixel2equa(bd, px, py + 10.0, cphi, ray, decy);
+        double cosd = cos(dec0 * (PI_D / 180.0));
+        double cd0 = (rax - ra0) / 10.0 * cosd, cd1 = (ray - ra0) / 10.0 * cosd;
+        double cd2 = (decx - dec0) / 10.0, cd3 = (decy - dec0) / 10.0;
+        // gen_galaxy_transformation (celeste_galaxy_conditionals.py:90-125); phi in degrees (Q7)
+        double phi = (90.0 - phi_s) * PI_D / 180.0;
+        double re_deg = fmax(1.0 / 30, sig) / 3600.0;
+        double cp = cos(phi), sp = sin(phi);
+        double g0 = re_deg * cp, g1 = re_deg * (sp * rho_s), g2 = re_deg * (-sp), g3 = re_deg * (cp * rho_s);
+        double gd = g0 * g3 - g1 * g2;
+        double gi0 = g3 / gd, gi1 = -g1 / gd, gi2 = -g2 / gd, gi3 = g0 / gd;
+        double t0 = gi0 * cd0 + gi1 * cd2, t1 = gi0 * cd1 + gi1 * cd3;
+        double t2 = gi2 * cd0 + gi3 * cd2, t3 = gi2 * cd1 + gi3 * cd3;
+        double td = t0 * t3 - t1 * t2;
+        double ti0 = t3 / td, ti1 = -t1 / td, ti2 = -t2 / td, ti3 = t0 / td;   // Tinv
+        double w00 = ti0 * ti0 + ti1 * ti1, w01 = ti0 * ti2 + ti1 * ti3, w11 = ti2 * ti2 + ti3 * ti3;
+        r.w00 = w00; r.w01 = w01; r.w11 = w11; r.theta = theta;
+        // calc_bounding_radius over the 42 convolved components, error 1e-5, centre (px, py)
+        double rsq_inv = 1.0 / rsq_gal;
+        double bound = -INFINITY;
+        for (int k = 0; k < K_PSF; k++) {
+            double mx = (px + bd.mux[k]) - px, my = (py + bd.muy[k]) - py;
+            double dist = sqrt(mx * mx + my * my);
+            for (int j = 0; j < K_PROF; j++) {
+                double v = c_prof_var[j];
+                double rr = comp_radius(v * w00 + bd.cxx[k], v * w01 + bd.cxy[k], v * w11 + bd.cyy[k],
+                                        rsq_inv, dist);
+                bound = fmax(bound, rr);
+            }
+        }
+        if (!(bound == bound) || !(px == px) || !(py == py)) {
+            r.type = -1;
+        } else {
+            // celeste_galaxy_conditionals.py:208-211: floor/ceil box (Q6)
+            r.x0 = (int)clampd(fmax(0.0, floor(px - bound)), -BIG, BIG);
+            r.x1 = (int)clampd(fmin((double)W, ceil(px + bound)), -BIG, BIG);
+            r.y0 = (int)clampd(fmax(0.0, floor(py - bound)), -BIG, BIG);
+            r.y1 = (int)clampd(fmin((double)H, ceil(py + bound)), -BIG, BIG);
+        }
+    } else {
+        r.type = -1;
+    }
+    // row window [win_y0, win_y0 + win_h) of the H-row frame (strip partition across GPUs):
+    // boxes are formed against the FULL frame exactly as above, then cut to the window and
+    // re-based, so a strip renders the same pixels the whole frame would.
+    r.y0 = max(r.y0, win_y0) - win_y0;
+    r.y1 = min(r.y1, win_y0 + win_h) - win_y0;
+    r.py = py - (double)win_y0;
+    if (r.type < 0 || r.x1 <= r.x0 || r.y1 <= r.y0) {
+        r.x0 = r.x1 = r.y0 = r.y1 = 0;
+        if (r.type >= 0) r.type = -1 - r.type;   // remember the kind, mark "no contribution"
+    }
+    recs[i] = r;
+    boxes[i] = make_int4(r.x0, r.x1, r.y0, r.y1);
+}
+
+// work counters of one render: sum of box areas and K-weighted areas (on demand, not timed)
+__global__ void k_stats(const SrcRec *__restrict__ recs, int64_t n, double *out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double a = 0.0, g = 0.0;
+    if (i < n) {
+        const SrcRec &r = recs[i];
+        if (r.type >= 0) {
+            a = (double)(r.x1 - r.x0) * (double)(r.y1 - r.y0);
+            g = a * (r.type == 0 ? K_PSF : K_GAL);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); g += __shfl_down(g, o); }
+    if ((threadIdx.x & 63) == 0 && a != 0.0) { atomicAdd(out, a); atomicAdd(out + 1, g); }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_bin: per-tile source lists, in source order
+// ------------------------------------------------------------------------------------------
+// pass 0 (lists == nullptr): count; the last lane-0 of each tile reserves its segment with one
+// atomicAdd on `cursor` (segment ORDER in the buffer is arbitrary, list CONTENT is not).
+// pass 1: fill.  One wave per tile.
+__global__ void __launch_bounds__(64)
+k_bin(const int4 *__restrict__ boxes, int64_t S, int ntx, int nty, int TH, int pass,
+      int *__restrict__ tile_cnt, int64_t *__restrict__ tile_off, unsigned long long *cursor,
+      int *__restrict__ lists, int64_t capacity, int *overflow) {
+    int tile = blockIdx.x;
+    int lane = threadIdx.x;
+    int per_band = ntx * nty;
+    int b = tile / per_band;
+    int t = tile - b * per_band;
+    int ty = t / ntx, tx = t - ty * ntx;
+    int X0 = tx * TILE_W, X1 = X0 + TILE_W, Y0 = ty * TH, Y1 = Y0 + TH;
+    const int4 *bx = boxes + (int64_t)b * S;
+    int64_t base = 0;
+    if (pass == 1) base = tile_off[tile];
+    int count = 0;
+    for (int64_t s0 = 0; s0 < S; s0 += 64) {
+        int64_t s = s0 + lane;
+        bool hit = false;
+        if (s < S) {
+            int4 q = bx[s];
+            hit = (q.x < X1) && (q.y > X0) && (q.z < Y1) && (q.w > Y0) && (q.y > q.x) && (q.w > q.z);
+        }
+        unsigned long long m = __ballot(hit);
+        if (pass == 1 && hit) {
+            int pos = __popcll(m & ((1ull << lane) - 1ull));
+            int64_t at = base + count + pos;
+            if (at < capacity) lists[at] = (int)s; else *overflow = 1;
+        }
+        count += __popcll(m);
+    }
+    if (pass == 0 && lane == 0) {
+        tile_cnt[tile] = count;
+        tile_off[tile] = (int64_t)atomicAdd(cursor, (unsigned long long)count);
+    }
+}
+

@@ -1,0 +1,310 @@
+// k_render.h -- component tables, evaluators, the tile render kernel, the ll reduction
+#pragma once
+#include "device_common.h"
+
+// ------------------------------------------------------------------------------------------
+// component tables in LDS
+// ------------------------------------------------------------------------------------------
+// Per component (SoA over k; reads in the evaluators are wave-uniform LDS broadcasts):
+//   A   = scale * weight / (2 pi sqrt(det))     mx, my = mean
+//   qa, qb, qc = inverse covariance [[qa, qb], [qb, qc]]
+//   eq  = exp(-qc): the row-to-row ratio of the recurrence's r
+//   L   = longest underflow-safe recurrence segment for this component (rows)
+#define CT_N (K_GAL + 6)
+struct CompTab {
+    double A[CT_N], mx[CT_N], my[CT_N], qa[CT_N], qb[CT_N], qc[CT_N], eq[CT_N];
+    int L[CT_N];
+};
+
+struct Comp {   // one component in registers
+    double A, mx, my, qa, qb, qc, ixx, iyy;   // ixx = 1/Sigma_xx, iyy = 1/Sigma_yy (marginals)
+};
+
+// Galaxy components are enumerated PSF-major and, inside one PSF component, by increasing
+// profile variance, so that neighbouring k have similar widths: groups of the recurrence then
+// share a segment length and are dropped together far from the centre.  (The reference's order
+// is galaxy-major, mog.py:75-81; only the fp summation order differs, ~1e-16)
+//   index into [exp0..exp5, dev0..dev7] sorted by variance:
+__constant__ int c_prof_order[K_PROF] = {6, 7, 0, 8, 1, 9, 2, 10, 3, 11, 4, 12, 5, 13};
+
+__device__ inline Comp make_comp(int k, int type, double px, double py, double scale, double w00,
+                                 double w01, double w11, double theta, const BandDev *__restrict__ bd) {
+    int kk = (type == 0) ? k : (k / K_PROF);
+    double cxx = bd->cxx[kk], cxy = bd->cxy[kk], cyy = bd->cyy[kk], wt = bd->w[kk];
+    if (type == 1) {
+        int j = c_prof_order[k - kk * K_PROF];
+        double var = c_prof_var[j];
+        double amp = (j < K_EXP) ? theta * c_prof_amp[j] : (1.0 - theta) * c_prof_amp[j];
+        cxx += var * w00; cxy += var * w01; cyy += var * w11;
+        wt *= amp;
+    }
+    double det = cxx * cyy - cxy * cxy;
+    double inv = 1.0 / det;
+    Comp c;
+    c.qa = cyy * inv; c.qb = -cxy * inv; c.qc = cxx * inv;
+    c.A = scale * wt / (2.0 * PI_D * sqrt(det));
+    c.mx = px + bd->mux[kk];
+    c.my = py + bd->muy[kk];
+    c.ixx = 1.0 / cxx;
+    c.iyy = 1.0 / cyy;
+    return c;
+}
+
+__device__ inline double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+// distance from m to the closed interval [lo, hi]
+__device__ inline double dist_to_interval(double m, double lo, double hi) {
+    return fmax(fmax(lo - m, m - hi), 0.0);
+}
+
+// ---- exp() for the recurrence seeds -----------------------------------------------------------
+// exp(x) = 2^e * 2^(j/64) * exp(r), x = (64 e + j) ln2/64 + r, |r| <= ln2/128:
+// a 64-entry table of 2^(j/64) in LDS and a degree-5 polynomial (truncation r^6/720 < 4e-17).
+// ~11 fp64 ops against ~17 + range checks for the library exp; error <= ~2 ulp.  Inputs are
+// finite and <= 709 here; large negative inputs flush to 0 through ldexp.
+__device__ inline double exp_tab(double x, const double *__restrict__ et) {
+    const double INV = 92.332482616893656758;        // 64 / ln 2
+    const double LN2_64_HI = 0x1.62e42fee00000p-7;         // ln2/64, upper 32 bits (n * HI is exact)
+    const double LN2_64_LO = 2.9815858269852933e-12;       // ln2/64 - HI
+    double n = rint(x * INV);
+    double r = fma(n, -LN2_64_HI, x);
+    r = fma(n, -LN2_64_LO, r);
+    int ni = (int)n;
+    double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(et[ni & 63] * p, ni >> 6);
+}
+
+// ---- direct evaluator: sum over components of A exp(-q/2) at (x, y) -------------------------
+__device__ inline double eval_direct(const CompTab &T, int k0, int k1, double x, double y) {
+    double s = 0.0;
+    for (int k = k0; k < k1; k++) {
+        double dx = x - T.mx[k], dy = y - T.my[k];
+        double q = T.qa[k] * dx * dx + 2.0 * T.qb[k] * dx * dy + T.qc[k] * dy * dy;
+        s += T.A[k] * exp(-0.5 * q);
+    }
+    return s;
+}
+
+// ---- recurrence evaluator -------------------------------------------------------------------
+// For a fixed column x the exponent of component k is a parabola in the row y:
+//   E(y) = -1/2 (qa dx^2 + 2 qb dx dy + qc dy^2),  g(y) = A exp(E(y))
+//   g(y+1) = g(y) r(y),  r(y) = exp(-(qb dx + qc dy + qc/2)),  r(y+1) = r(y) exp(-qc)
+// A segment of L rows is seeded with two exp() and then costs 2 mul + 1 add per row.
+// Underflow safety: a lane whose value matters anywhere in the segment (E >= -T there) has
+// E >= -T - L sqrt(2 T qc) - qc L^2/2 at the seed row; L is chosen so that this stays above
+// -680 (fp64 exp underflows gradually below -708), so a significant lane never starts from a
+// flushed seed.  Insignificant lanes may start from 0 and stay 0: they are below e^-T anyway.
+// r's exponent is clamped to +-680: it can only exceed that on lanes whose g is exactly 0.
+#define REC_G 6           // components advanced together (independent chains = ILP)
+#define REC_EMAX 680.0
+
+__device__ inline int seg_len(double qc, double T) {
+    // largest L with (L sqrt(qc/2) + sqrt(T))^2 <= REC_EMAX
+    double u = sqrt(REC_EMAX) - sqrt(T);
+    double L = u / sqrt(0.5 * qc);
+    return (int)fmin(L, 4096.0);
+}
+
+// Accumulate components [k0, k0+G) over rows [ra, rb) of column x into acc_col (the LDS column of
+// this lane, stride TILE_W doubles).  `on` masks lanes outside the source box.
+template <int G>
+__device__ inline void rec_group(const CompTab &T, const double *__restrict__ et, int k0, double x,
+                                 int Y0, int ra, int rb, int L, bool on, double *__restrict__ acc_col) {
+    double g[G], r[G], q[G];
+    for (int sa = ra; sa < rb; sa += L) {
+        const int sb = min(sa + L, rb);
+        const double y0 = (double)(Y0 + sa);
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const int k = k0 + i;
+            double dx = x - T.mx[k], dy = y0 - T.my[k];
+            double qb = T.qb[k], qc = T.qc[k];
+            double hx = qb * dx + qc * dy;                      // = -dE/dy
+            double e = -0.5 * (T.qa[k] * dx * dx + (qb * dx + hx) * dy);
+            double er = fmin(fmax(-(hx + 0.5 * qc), -REC_EMAX), REC_EMAX);
+            g[i] = on ? T.A[k] * exp_tab(e, et) : 0.0;
+            r[i] = exp_tab(er, et);
+            q[i] = T.eq[k];
+        }
+        for (int row = sa; row < sb; row++) {
+            double s = g[0];
+#pragma unroll
+            for (int i = 1; i < G; i++) s += g[i];
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                g[i] *= r[i];
+                r[i] *= q[i];
+            }
+            acc_col[row * TILE_W] += s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_render: one wave per (band, tile)
+// ------------------------------------------------------------------------------------------
+struct RenderArgs {
+    const BandDev *bands;
+    const SrcRec *recs;
+    const int *lists;
+    const int *tile_cnt;
+    const int64_t *tile_off;
+    const int *order;     // tile launch order (heaviest first) or nullptr
+    const double *nelec;
+    double *lambda;
+    double *partials;
+    int64_t S, capacity;
+    int B, H, W, ntx, nty;
+    int flags;        // CEL_RENDER_*
+    int variant;      // 0 direct, 1 recurrence
+    double tail_T;    // drop threshold (0 = never)
+};
+
+template <int TH>
+__global__ void __launch_bounds__(64)
+k_render(RenderArgs a) {
+    __shared__ double acc[TH * TILE_W];
+    __shared__ CompTab T;
+    __shared__ double et[64];
+    const int lane = threadIdx.x;
+    const int tile = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const int per_band = a.ntx * a.nty;
+    const int b = tile / per_band;
+    const int t = tile - b * per_band;
+    const int ty = t / a.ntx, tx = t - ty * a.ntx;
+    const int X0 = tx * TILE_W, Y0 = ty * TH;
+    const int xi = X0 + lane;
+    const double x = (double)xi;
+    const BandDev *bd = a.bands + b;
+
+    et[lane] = exp2((double)lane * (1.0 / 64.0));
+#pragma unroll
+    for (int r = 0; r < TH; r++) acc[r * TILE_W + lane] = 0.0;
+
+    const int cnt = a.tile_cnt[tile];
+    const int64_t off = a.tile_off[tile];
+    const SrcRec *recs = a.recs + (int64_t)b * a.S;
+    const double Tdrop = a.tail_T;
+    const double Tseg = Tdrop > 0.0 ? Tdrop : 100.0;
+
+    for (int e = 0; e < cnt; e++) {
+        int64_t at = off + e;
+        if (at >= a.capacity) break;
+        const int s = __builtin_amdgcn_readfirstlane(a.lists[at]);
+        const SrcRec *rp = recs + s;
+        const int type = rp->type;
+        const int K = (type == 0) ? K_PSF : K_GAL;
+        const int bx0 = rp->x0, bx1 = rp->x1, by0 = rp->y0, by1 = rp->y1;
+        const int ra = max(by0, Y0) - Y0, rb = min(by1, Y0 + TH) - Y0;
+        const bool on = (xi >= bx0) && (xi < bx1);
+        // the part of this tile the source's box covers, for the drop test
+        const double xa = (double)max(bx0, X0), xb = (double)(min(bx1, X0 + TILE_W) - 1);
+        const double ya = (double)(Y0 + ra), yb = (double)(Y0 + rb - 1);
+
+        // lane k builds component k, decides whether it can matter on this tile, and the kept
+        // components are compacted into the LDS table in k order
+        bool keep = false;
+        Comp c;
+        int Lk = 0;
+        if (lane < K) {
+            c = make_comp(lane, type, rp->px, rp->py, rp->scale, rp->w00, rp->w01, rp->w11, rp->theta, bd);
+            double ddx = dist_to_interval(c.mx, xa, xb), ddy = dist_to_interval(c.my, ya, yb);
+            double qmin = fmax(ddx * ddx * c.ixx, ddy * ddy * c.iyy);   // lower bound of q on the rect
+            keep = (a.variant == 0) || (Tdrop <= 0.0) || (0.5 * qmin <= Tdrop);
+            Lk = seg_len(c.qc, Tseg);
+        }
+        const unsigned long long km = __ballot(keep);
+        const int Kk = __popcll(km);
+        __syncthreads();   // previous source's table reads are done
+        if (keep) {
+            int p = __popcll(km & ((1ull << lane) - 1ull));
+            T.A[p] = c.A; T.mx[p] = c.mx; T.my[p] = c.my;
+            T.qa[p] = c.qa; T.qb[p] = c.qb; T.qc[p] = c.qc;
+            T.eq[p] = exp(-c.qc);
+            T.L[p] = Lk;
+        }
+        __syncthreads();
+        if (a.variant == 0) {
+            for (int row = ra; row < rb; row++) {
+                double v = eval_direct(T, 0, Kk, x, (double)(Y0 + row));
+                if (on) acc[row * TILE_W + lane] += v;
+            }
+            continue;
+        }
+        for (int k0 = 0; k0 < Kk; k0 += REC_G) {
+            const int kn = min(REC_G, Kk - k0);
+            int L = T.L[k0];
+            for (int i = 1; i < kn; i++) L = min(L, T.L[k0 + i]);
+            L = __builtin_amdgcn_readfirstlane(L);
+            if (L < 4) {
+                // pathologically sharp component: evaluate this group directly
+                for (int row = ra; row < rb; row++) {
+                    double v = eval_direct(T, k0, k0 + kn, x, (double)(Y0 + row));
+                    if (on) acc[row * TILE_W + lane] += v;
+                }
+                continue;
+            }
+            double *col = acc + lane;
+            switch (kn) {
+            case 6: rec_group<6>(T, et, k0, x, Y0, ra, rb, L, on, col); break;
+            case 5: rec_group<5>(T, et, k0, x, Y0, ra, rb, L, on, col); break;
+            case 4: rec_group<4>(T, et, k0, x, Y0, ra, rb, L, on, col); break;
+            case 3: rec_group<3>(T, et, k0, x, Y0, ra, rb, L, on, col); break;
+            case 2: rec_group<2>(T, et, k0, x, Y0, ra, rb, L, on, col); break;
+            default: rec_group<1>(T, et, k0, x, Y0, ra, rb, L, on, col); break;
+            }
+        }
+    }
+
+    // epilogue: lambda = eps + acc, written once (512-B coalesced rows); fused Poisson term
+    const double eps = bd->eps;
+    const bool store = !(a.flags & CEL_RENDER_NO_STORE);
+    const bool ll = (a.flags & CEL_RENDER_LOGLIK) != 0;
+    double part = 0.0;
+    const int64_t plane = (int64_t)b * a.H * a.W;
+    if (xi < a.W) {
+#pragma unroll 4
+        for (int r = 0; r < TH; r++) {
+            int y = Y0 + r;
+            if (y < a.H) {
+                double lam = eps + acc[r * TILE_W + lane];
+                int64_t idx = plane + (int64_t)y * a.W + xi;
+                if (store) a.lambda[idx] = lam;
+                if (ll) part += a.nelec[idx] * log(lam) - lam;
+            }
+        }
+    }
+    if (ll) {
+        part = wave_sum(part);
+        if (lane == 0) a.partials[tile] = part;
+    }
+}
+
+// fixed-order reduction of the per-tile partials: one block per band
+__global__ void __launch_bounds__(256)
+k_reduce(const double *__restrict__ partials, int per_band, double *__restrict__ ll_band) {
+    __shared__ double sm[256];
+    int b = blockIdx.x;
+    const double *p = partials + (int64_t)b * per_band;
+    double s = 0.0, c = 0.0;   // Kahan per thread, fixed stride
+    for (int i = threadIdx.x; i < per_band; i += 256) {
+        double y = p[i] - c;
+        double tsum = s + y;
+        c = (tsum - s) - y;
+        s = tsum;
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ll_band[b] = sm[0];
+}
