@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--workload", default="mixed10k_2048")
     ap.add_argument("--kernel", default="recurrence", choices=["direct", "recurrence"])
     ap.add_argument("--tail-log", type=float, default=60.0)
+    ap.add_argument("--tile-rows", type=int, default=32, choices=[32, 64])
+    ap.add_argument("--tile-order", type=int, default=1, choices=[0, 1])
     ap.add_argument("--cpu-sample", type=int, default=400, help="sources in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -73,6 +75,9 @@ def main():
     ctx = cel.Context(local)
     ctx.set_kernel(args.kernel)
     ctx.set_tail_log(args.tail_log)
+    from desi_mcmc_amd import _lib
+    ctx.set_option(_lib.CEL_OPT_TILE_ROWS, args.tile_rows)
+    ctx.set_option(_lib.CEL_OPT_TILE_ORDER, args.tile_order)
 
     # one field per rank (weak scaling): same population, different seed
     field = synth.SyntheticField.from_config(ctx, args.workload, seed=42 + 1000 * rank)
@@ -139,6 +144,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "sources": S, "bands": B, "frame": [H, W],
                        "galaxy_fraction": fg, "kernel": args.kernel, "tail_log": args.tail_log,
+                       "tile_rows": args.tile_rows, "tile_order": args.tile_order,
                        "parallelism": "1 field per GPU, %d GPU(s), 1 all-reduce of %d doubles per step" % (world, B)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

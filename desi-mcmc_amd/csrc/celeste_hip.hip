@@ -87,6 +87,8 @@ struct cel_ctx {
     int variant = 1;
     double tail_T = 60.0;
     bool profile = false;
+    bool tile_order = true;   // launch k_render tiles heaviest-first
+    int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created
     Prof prof;
     double *pinned = nullptr;   // MAX_BANDS + 8 doubles of pinned host memory for readbacks
 };
@@ -103,8 +105,9 @@ struct cel_images {
     // per-render scratch, grown on demand
     SrcRec *d_recs = nullptr;
     int4 *d_boxes = nullptr;
+    int *d_kind = nullptr;
     int64_t recs_cap = 0;
-    int *d_tile_cnt = nullptr;
+    int *d_tile_cnt = nullptr, *d_tile_work = nullptr, *d_order = nullptr;
     int64_t *d_tile_off = nullptr;
     unsigned long long *d_cursor = nullptr;   // [0] cursor, [1] overflow flag (as int)
     int *d_lists = nullptr;
@@ -297,6 +300,13 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
     case CEL_OPT_PROFILE:
         c->profile = (v != 0.0);
         return CEL_OK;
+    case CEL_OPT_TILE_ORDER:
+        c->tile_order = (v != 0.0);
+        return CEL_OK;
+    case CEL_OPT_TILE_ROWS:
+        if (v != 32.0 && v != 64.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TILE_ROWS must be 32 or 64");
+        c->tile_rows = (int)v;
+        return CEL_OK;
     }
     return fail(CEL_ERR_INVALID, "unknown option %d", key);
 }
@@ -307,6 +317,8 @@ int cel_ctx_get_option(cel_ctx *c, int key, double *v) {
     case CEL_OPT_KERNEL: *v = c->variant; return CEL_OK;
     case CEL_OPT_TAIL_LOG: *v = c->tail_T; return CEL_OK;
     case CEL_OPT_PROFILE: *v = c->profile ? 1.0 : 0.0; return CEL_OK;
+    case CEL_OPT_TILE_ORDER: *v = c->tile_order ? 1.0 : 0.0; return CEL_OK;
+    case CEL_OPT_TILE_ROWS: *v = c->tile_rows; return CEL_OK;
     }
     return fail(CEL_ERR_INVALID, "unknown option %d", key);
 }
@@ -317,7 +329,7 @@ int cel_images_destroy(cel_images *im) {
     (void)hipSetDevice(im->ctx->device);
     (void)hipStreamSynchronize(im->ctx->stream);
     void *ptrs[] = {im->d_bands, im->d_nelec, im->d_lambda, im->d_partials, im->d_llband, im->d_recs,
-                    im->d_boxes, im->d_tile_cnt, im->d_tile_off, im->d_cursor, im->d_lists, im->d_stats};
+                    im->d_boxes, im->d_kind, im->d_tile_cnt, im->d_tile_work, im->d_order, im->d_tile_off, im->d_cursor, im->d_lists, im->d_stats};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete im;
@@ -333,7 +345,7 @@ int cel_images_create(cel_ctx *c, int B, int H, int W, const cel_band *bands, ce
     if (!im) return fail(CEL_ERR_NOMEM, "out of host memory");
     im->ctx = c; im->B = B; im->H = H; im->W = W;
     im->full_H = H; im->win_y0 = 0;
-    im->TH = 32;
+    im->TH = c->tile_rows;
     im->ntx = (W + TILE_W - 1) / TILE_W;
     im->nty = (H + im->TH - 1) / im->TH;
     BandDev hb[MAX_BANDS];
@@ -370,6 +382,8 @@ int cel_images_create(cel_ctx *c, int B, int H, int W, const cel_band *bands, ce
     IM_TRY(hipMalloc((void **)&im->d_partials, sizeof(double) * T));
     IM_TRY(hipMalloc((void **)&im->d_llband, sizeof(double) * MAX_BANDS));
     IM_TRY(hipMalloc((void **)&im->d_tile_cnt, sizeof(int) * T));
+    IM_TRY(hipMalloc((void **)&im->d_tile_work, sizeof(int) * T));
+    IM_TRY(hipMalloc((void **)&im->d_order, sizeof(int) * T));
     IM_TRY(hipMalloc((void **)&im->d_tile_off, sizeof(int64_t) * T));
     IM_TRY(hipMalloc((void **)&im->d_cursor, sizeof(unsigned long long) * 2));
     IM_TRY(hipMalloc((void **)&im->d_stats, sizeof(double) * 2));
@@ -483,10 +497,12 @@ static int ensure_recs(cel_images *im, int64_t n) {
     HIP_TRY(hipStreamSynchronize(im->ctx->stream));
     if (im->d_recs) (void)hipFree(im->d_recs);
     if (im->d_boxes) (void)hipFree(im->d_boxes);
-    im->d_recs = nullptr; im->d_boxes = nullptr; im->recs_cap = 0;
+    if (im->d_kind) (void)hipFree(im->d_kind);
+    im->d_recs = nullptr; im->d_boxes = nullptr; im->d_kind = nullptr; im->recs_cap = 0;
     int64_t cap = n + n / 4 + 64;
     HIP_TRY(hipMalloc((void **)&im->d_recs, sizeof(SrcRec) * cap));
     HIP_TRY(hipMalloc((void **)&im->d_boxes, sizeof(int4) * cap));
+    HIP_TRY(hipMalloc((void **)&im->d_kind, sizeof(int) * cap));
     im->recs_cap = cap;
     return CEL_OK;
 }
@@ -515,7 +531,7 @@ static int run_prep(cel_images *im, cel_sources *src) {
     int pi = prof_begin(c, CEL_K_PREP);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, im->d_bands, im->B,
                        im->full_H, im->W, im->win_y0, im->H, src->S, src->d_type, src->d_radec, src->d_counts, src->d_shape,
-                       rsq_galaxy(), im->d_recs, im->d_boxes);
+                       rsq_galaxy(), im->d_recs, im->d_boxes, im->d_kind);
     prof_end(c, pi);
     HIP_TRY(hipGetLastError());
     return CEL_OK;
@@ -544,20 +560,25 @@ int cel_render_field(cel_images *im, cel_sources *src, int flags, double *ll_ban
     for (int attempt = 0; attempt < 8; attempt++) {
         HIP_TRY(hipMemsetAsync(im->d_cursor, 0, sizeof(unsigned long long) * 2, st));
         int pi = prof_begin(c, CEL_K_BIN);
-        hipLaunchKernelGGL(k_bin, dim3(T), dim3(64), 0, st, im->d_boxes, S, im->ntx, im->nty, im->TH, 0,
-                           im->d_tile_cnt, im->d_tile_off, im->d_cursor, (int *)nullptr, im->lists_cap,
-                           (int *)(im->d_cursor + 1));
-        hipLaunchKernelGGL(k_bin, dim3(T), dim3(64), 0, st, im->d_boxes, S, im->ntx, im->nty, im->TH, 1,
-                           im->d_tile_cnt, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
-                           (int *)(im->d_cursor + 1));
+        hipLaunchKernelGGL(k_bin, dim3(T), dim3(64), 0, st, im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, 0,
+                           im->d_tile_cnt, im->d_tile_work, im->d_tile_off, im->d_cursor, (int *)nullptr,
+                           im->lists_cap, (int *)(im->d_cursor + 1));
+        hipLaunchKernelGGL(k_bin, dim3(T), dim3(64), 0, st, im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, 1,
+                           im->d_tile_cnt, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists,
+                           im->lists_cap, (int *)(im->d_cursor + 1));
+        if (c->tile_order)
+            hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, im->d_tile_work, T, im->d_order);
         prof_end(c, pi);
         RenderArgs a;
         a.bands = im->d_bands; a.recs = im->d_recs; a.lists = im->d_lists; a.tile_cnt = im->d_tile_cnt;
         a.tile_off = im->d_tile_off; a.nelec = im->d_nelec; a.lambda = im->d_lambda; a.partials = im->d_partials;
         a.S = S; a.capacity = im->lists_cap; a.B = im->B; a.H = im->H; a.W = im->W; a.ntx = im->ntx; a.nty = im->nty;
-        a.flags = flags; a.variant = c->variant; a.tail_T = c->tail_T; a.order = nullptr;
+        a.flags = flags; a.variant = c->variant; a.tail_T = c->tail_T; a.order = c->tile_order ? im->d_order : nullptr;
         pi = prof_begin(c, CEL_K_RENDER);
-        hipLaunchKernelGGL((k_render<32>), dim3(T), dim3(64), 0, st, a);
+        if (im->TH == 64)
+            hipLaunchKernelGGL((k_render<64>), dim3(T), dim3(64), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_render<32>), dim3(T), dim3(64), 0, st, a);
         prof_end(c, pi);
         if (flags & CEL_RENDER_LOGLIK) {
             pi = prof_begin(c, CEL_K_REDUCE);

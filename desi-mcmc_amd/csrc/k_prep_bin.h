@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256)
 k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int win_h, int64_t S,
        const int *__restrict__ type, const double *__restrict__ radec,
        const double *__restrict__ counts, const double *__restrict__ shape, double rsq_gal,
-       SrcRec *__restrict__ recs, int4 *__restrict__ boxes) {
+       SrcRec *__restrict__ recs, int4 *__restrict__ boxes, int *__restrict__ kind) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S * B) return;
     int b = (int)(i / S);
@@ -122,6 +122,7 @@ k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int w
     }
     recs[i] = r;
     boxes[i] = make_int4(r.x0, r.x1, r.y0, r.y1);
+    kind[i] = r.type < 0 ? 0 : (r.type == 0 ? K_PSF : K_GAL);
 }
 
 // work counters of one render: sum of box areas and K-weighted areas (on demand, not timed)
@@ -144,10 +145,12 @@ __global__ void k_stats(const SrcRec *__restrict__ recs, int64_t n, double *out)
 // ------------------------------------------------------------------------------------------
 // pass 0 (lists == nullptr): count; the last lane-0 of each tile reserves its segment with one
 // atomicAdd on `cursor` (segment ORDER in the buffer is arbitrary, list CONTENT is not).
+// Pass 0 also writes a work estimate per tile (sum over its sources of K * (rows + seed cost)),
+// which k_order turns into a heaviest-first launch order for k_render.
 // pass 1: fill.  One wave per tile.
 __global__ void __launch_bounds__(64)
-k_bin(const int4 *__restrict__ boxes, int64_t S, int ntx, int nty, int TH, int pass,
-      int *__restrict__ tile_cnt, int64_t *__restrict__ tile_off, unsigned long long *cursor,
+k_bin(const int4 *__restrict__ boxes, const int *__restrict__ kind, int64_t S, int ntx, int nty, int TH,
+      int pass, int *__restrict__ tile_cnt, int *__restrict__ tile_work, int64_t *__restrict__ tile_off, unsigned long long *cursor,
       int *__restrict__ lists, int64_t capacity, int *overflow) {
     int tile = blockIdx.x;
     int lane = threadIdx.x;
@@ -157,6 +160,8 @@ k_bin(const int4 *__restrict__ boxes, int64_t S, int ntx, int nty, int TH, int p
     int ty = t / ntx, tx = t - ty * ntx;
     int X0 = tx * TILE_W, X1 = X0 + TILE_W, Y0 = ty * TH, Y1 = Y0 + TH;
     const int4 *bx = boxes + (int64_t)b * S;
+    const int *kd = kind + (int64_t)b * S;
+    int work = 0;
     int64_t base = 0;
     if (pass == 1) base = tile_off[tile];
     int count = 0;
@@ -166,6 +171,7 @@ k_bin(const int4 *__restrict__ boxes, int64_t S, int ntx, int nty, int TH, int p
         if (s < S) {
             int4 q = bx[s];
             hit = (q.x < X1) && (q.y > X0) && (q.z < Y1) && (q.w > Y0) && (q.y > q.x) && (q.w > q.z);
+            if (pass == 0 && hit) work += kd[s] * (min(q.w, Y1) - max(q.z, Y0) + 18);
         }
         unsigned long long m = __ballot(hit);
         if (pass == 1 && hit) {
@@ -175,9 +181,46 @@ k_bin(const int4 *__restrict__ boxes, int64_t S, int ntx, int nty, int TH, int p
         }
         count += __popcll(m);
     }
+    if (pass == 0) {
+        for (int o = 32; o > 0; o >>= 1) work += __shfl_down(work, o);
+    }
     if (pass == 0 && lane == 0) {
         tile_cnt[tile] = count;
+        tile_work[tile] = work;
         tile_off[tile] = (int64_t)atomicAdd(cursor, (unsigned long long)count);
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_order: heaviest-first launch order of the tiles (counting sort on the work estimate)
+// ------------------------------------------------------------------------------------------
+// Tile order never changes results (every tile is written once); it only shortens the tail of
+// k_render, whose tiles differ in work by orders of magnitude.  One block; 256 buckets.
+__global__ void __launch_bounds__(1024)
+k_order(const int *__restrict__ work, int T, int *__restrict__ order) {
+    __shared__ int hist[256];
+    __shared__ int red[1024];
+    const int tid = threadIdx.x;
+    int mx = 0;
+    for (int i = tid; i < T; i += 1024) mx = max(mx, work[i]);
+    red[tid] = mx;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = max(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    const long long wmax = red[0] > 0 ? red[0] : 1;
+    for (int i = tid; i < T; i += 1024) atomicAdd(&hist[255 - (int)(((long long)work[i] * 255) / wmax)], 1);
+    __syncthreads();
+    if (tid == 0) {   // exclusive scan, bucket 0 = heaviest
+        int run = 0;
+        for (int k = 0; k < 256; k++) { int c = hist[k]; hist[k] = run; run += c; }
+    }
+    __syncthreads();
+    for (int i = tid; i < T; i += 1024) {
+        int bkt = 255 - (int)(((long long)work[i] * 255) / wmax);
+        order[atomicAdd(&hist[bkt], 1)] = i;
+    }
+}

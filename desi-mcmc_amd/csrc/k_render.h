@@ -118,6 +118,7 @@ template <int G>
 __device__ inline void rec_group(const CompTab &T, const double *__restrict__ et, int k0, double x,
                                  int Y0, int ra, int rb, int L, bool on, double *__restrict__ acc_col) {
     double g[G], r[G], q[G];
+    const double aon = on ? 1.0 : 0.0;
     for (int sa = ra; sa < rb; sa += L) {
         const int sb = min(sa + L, rb);
         const double y0 = (double)(Y0 + sa);
@@ -129,20 +130,42 @@ __device__ inline void rec_group(const CompTab &T, const double *__restrict__ et
             double hx = qb * dx + qc * dy;                      // = -dE/dy
             double e = -0.5 * (T.qa[k] * dx * dx + (qb * dx + hx) * dy);
             double er = fmin(fmax(-(hx + 0.5 * qc), -REC_EMAX), REC_EMAX);
-            g[i] = on ? T.A[k] * exp_tab(e, et) : 0.0;
+            g[i] = (T.A[k] * aon) * exp_tab(e, et);
             r[i] = exp_tab(er, et);
             q[i] = T.eq[k];
         }
-        for (int row = sa; row < sb; row++) {
-            double s = g[0];
+        // two rows per trip: the register rotation of g/r cancels (no v_mov copies)
+        int row = sa;
+        for (; row + 1 < sb; row += 2) {
+            double s0 = g[0], s1, g1[G], r1[G];
 #pragma unroll
-            for (int i = 1; i < G; i++) s += g[i];
+            for (int i = 1; i < G; i++) s0 += g[i];
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                g1[i] = g[i] * r[i];
+                r1[i] = r[i] * q[i];
+            }
+            s1 = g1[0];
+#pragma unroll
+            for (int i = 1; i < G; i++) s1 += g1[i];
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                g[i] = g1[i] * r1[i];
+                r[i] = r1[i] * q[i];
+            }
+            acc_col[row * TILE_W] += s0;
+            acc_col[(row + 1) * TILE_W] += s1;
+        }
+        if (row < sb) {
+            double s0 = g[0];
+#pragma unroll
+            for (int i = 1; i < G; i++) s0 += g[i];
 #pragma unroll
             for (int i = 0; i < G; i++) {
                 g[i] *= r[i];
                 r[i] *= q[i];
             }
-            acc_col[row * TILE_W] += s;
+            acc_col[row * TILE_W] += s0;
         }
     }
 }
