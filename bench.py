@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="mixed10k_2048")
     ap.add_argument("--kernel", default="recurrence", choices=["direct", "recurrence"])
-    ap.add_argument("--tail-log", type=float, default=60.0)
+    ap.add_argument("--tail-log", type=float, default=40.0)
     ap.add_argument("--tile-rows", type=int, default=32, choices=[32, 64])
     ap.add_argument("--tile-order", type=int, default=1, choices=[0, 1])
     ap.add_argument("--cpu-sample", type=int, default=400, help="sources in the CPU baseline sample (0 = skip)")

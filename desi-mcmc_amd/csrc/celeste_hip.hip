@@ -66,6 +66,7 @@ static int fail(int code, const char *fmt, ...) {
 
 #include "device_common.h"
 #include "k_prep_bin.h"
+#include "k_bin2.h"
 #include "k_render.h"
 #include "k_misc.h"
 
@@ -85,7 +86,7 @@ struct cel_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int variant = 1;
-    double tail_T = 60.0;
+    double tail_T = 40.0;
     bool profile = false;
     bool tile_order = true;   // launch k_render tiles heaviest-first
     int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created
@@ -109,9 +110,14 @@ struct cel_images {
     int64_t recs_cap = 0;
     int *d_tile_cnt = nullptr, *d_tile_work = nullptr, *d_order = nullptr;
     int64_t *d_tile_off = nullptr;
-    unsigned long long *d_cursor = nullptr;   // [0] cursor, [1] overflow flag (as int)
+    unsigned long long *d_cursor = nullptr;   // fine cursor, fine overflow, coarse cursor, coarse overflow
     int *d_lists = nullptr;
     int64_t lists_cap = 0;
+    int nsx = 0, nsy = 0;                     // 256 x 256 super-tiles of the coarse binning level
+    int *d_sup_cnt = nullptr;
+    int64_t *d_sup_off = nullptr;
+    int *d_clist = nullptr;
+    int64_t clist_cap = 0;
     double *d_stats = nullptr;
     int64_t last_S = 0;
     double last_entries = 0;
@@ -329,7 +335,8 @@ int cel_images_destroy(cel_images *im) {
     (void)hipSetDevice(im->ctx->device);
     (void)hipStreamSynchronize(im->ctx->stream);
     void *ptrs[] = {im->d_bands, im->d_nelec, im->d_lambda, im->d_partials, im->d_llband, im->d_recs,
-                    im->d_boxes, im->d_kind, im->d_tile_cnt, im->d_tile_work, im->d_order, im->d_tile_off, im->d_cursor, im->d_lists, im->d_stats};
+                    im->d_boxes, im->d_kind, im->d_tile_cnt, im->d_tile_work, im->d_order, im->d_tile_off, im->d_cursor, im->d_lists, im->d_stats,
+                    im->d_sup_cnt, im->d_sup_off, im->d_clist};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete im;
@@ -348,6 +355,8 @@ int cel_images_create(cel_ctx *c, int B, int H, int W, const cel_band *bands, ce
     im->TH = c->tile_rows;
     im->ntx = (W + TILE_W - 1) / TILE_W;
     im->nty = (H + im->TH - 1) / im->TH;
+    im->nsx = (W + SUPER_W - 1) / SUPER_W;
+    im->nsy = (H + SUPER_H - 1) / SUPER_H;
     BandDev hb[MAX_BANDS];
     for (int b = 0; b < B; b++) {
         im->hb[b] = bands[b];
@@ -385,7 +394,9 @@ int cel_images_create(cel_ctx *c, int B, int H, int W, const cel_band *bands, ce
     IM_TRY(hipMalloc((void **)&im->d_tile_work, sizeof(int) * T));
     IM_TRY(hipMalloc((void **)&im->d_order, sizeof(int) * T));
     IM_TRY(hipMalloc((void **)&im->d_tile_off, sizeof(int64_t) * T));
-    IM_TRY(hipMalloc((void **)&im->d_cursor, sizeof(unsigned long long) * 2));
+    IM_TRY(hipMalloc((void **)&im->d_cursor, sizeof(unsigned long long) * 4));
+    IM_TRY(hipMalloc((void **)&im->d_sup_cnt, sizeof(int) * B * im->nsx * im->nsy));
+    IM_TRY(hipMalloc((void **)&im->d_sup_off, sizeof(int64_t) * B * im->nsx * im->nsy));
     IM_TRY(hipMalloc((void **)&im->d_stats, sizeof(double) * 2));
     IM_TRY(hipMemsetAsync(im->d_lambda, 0, sizeof(double) * npix, c->stream));
 #undef IM_TRY
@@ -517,6 +528,16 @@ static int ensure_lists(cel_images *im, int64_t n) {
     return CEL_OK;
 }
 
+static int ensure_clist(cel_images *im, int64_t n) {
+    if (n <= im->clist_cap) return CEL_OK;
+    HIP_TRY(hipStreamSynchronize(im->ctx->stream));
+    if (im->d_clist) (void)hipFree(im->d_clist);
+    im->d_clist = nullptr; im->clist_cap = 0;
+    HIP_TRY(hipMalloc((void **)&im->d_clist, sizeof(int) * n));
+    im->clist_cap = n;
+    return CEL_OK;
+}
+
 static double rsq_galaxy() {
     double q = 1.0 - 1e-5;           // celeste_galaxy_conditionals.py:207 error=1e-5
     return -2.0 * log1p(-q);         // scipy.stats.chi2.ppf(q, 2)
@@ -557,15 +578,22 @@ int cel_render_field(cel_images *im, cel_sources *src, int flags, double *ll_ban
         rc = ensure_lists(im, (S * im->B) * 6 + 1024);
         if (rc) return rc;
     }
+    if (im->clist_cap == 0) {
+        // first guess: every (band, source) touches ~3 super-tiles; grown on overflow below
+        rc = ensure_clist(im, (S * im->B) * 3 + 1024);
+        if (rc) return rc;
+    }
+    const int NS = im->B * im->nsx * im->nsy;
     for (int attempt = 0; attempt < 8; attempt++) {
-        HIP_TRY(hipMemsetAsync(im->d_cursor, 0, sizeof(unsigned long long) * 2, st));
+        // d_cursor: [0] fine cursor, [1] fine overflow, [2] coarse cursor, [3] coarse overflow
+        HIP_TRY(hipMemsetAsync(im->d_cursor, 0, sizeof(unsigned long long) * 4, st));
         int pi = prof_begin(c, CEL_K_BIN);
-        hipLaunchKernelGGL(k_bin, dim3(T), dim3(64), 0, st, im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, 0,
-                           im->d_tile_cnt, im->d_tile_work, im->d_tile_off, im->d_cursor, (int *)nullptr,
-                           im->lists_cap, (int *)(im->d_cursor + 1));
-        hipLaunchKernelGGL(k_bin, dim3(T), dim3(64), 0, st, im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, 1,
-                           im->d_tile_cnt, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists,
-                           im->lists_cap, (int *)(im->d_cursor + 1));
+        hipLaunchKernelGGL(k_bin_coarse, dim3(NS), dim3(256), 0, st, im->d_boxes, S, im->nsx, im->nsy, im->d_sup_cnt,
+                           im->d_sup_off, im->d_cursor + 2, im->d_clist, im->clist_cap, (int *)(im->d_cursor + 3));
+        hipLaunchKernelGGL(k_bin_fine, dim3(T), dim3(64), 0, st, im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH,
+                           im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
+                           im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
+                           (int *)(im->d_cursor + 1));
         if (c->tile_order)
             hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, im->d_tile_work, T, im->d_order);
         prof_end(c, pi);
@@ -587,17 +615,20 @@ int cel_render_field(cel_images *im, cel_sources *src, int flags, double *ll_ban
             HIP_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * im->B, hipMemcpyDeviceToHost, st));
         }
         // total list length + overflow flag ride back with the result
-        HIP_TRY(hipMemcpyAsync(c->pinned + MAX_BANDS + 2, im->d_cursor, sizeof(unsigned long long) * 2,
+        HIP_TRY(hipMemcpyAsync(c->pinned + MAX_BANDS + 2, im->d_cursor, sizeof(unsigned long long) * 4,
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipGetLastError());
         im->last_S = S;
         HIP_TRY(hipStreamSynchronize(st));
-        unsigned long long total, ovf;
-        memcpy(&total, c->pinned + MAX_BANDS + 2, sizeof(total));
-        memcpy(&ovf, c->pinned + MAX_BANDS + 3, sizeof(ovf));
-        im->last_entries = (double)total;
-        if ((ovf & 0xffffffffull) == 0 && (int64_t)total <= im->lists_cap) break;
-        rc = ensure_lists(im, (int64_t)total + (int64_t)total / 4 + 1024);   // rerun with room
+        unsigned long long cur[4];
+        memcpy(cur, c->pinned + MAX_BANDS + 2, sizeof(cur));
+        const bool fine_ok = (cur[1] & 0xffffffffull) == 0 && (int64_t)cur[0] <= im->lists_cap;
+        const bool coarse_ok = (cur[3] & 0xffffffffull) == 0 && (int64_t)cur[2] <= im->clist_cap;
+        if (coarse_ok) im->last_entries = (double)cur[0];
+        if (fine_ok && coarse_ok) break;
+        // rerun with room (a truncated coarse list also truncates the fine counts)
+        if (!coarse_ok) rc = ensure_clist(im, (int64_t)cur[2] + (int64_t)cur[2] / 4 + 1024);
+        if (!rc && !fine_ok) rc = ensure_lists(im, (int64_t)cur[0] + (int64_t)cur[0] / 4 + 1024);
         if (rc) return rc;
         if (attempt == 7) return fail(CEL_ERR_HIP, "tile lists kept overflowing");
     }
@@ -620,14 +651,11 @@ int cel_field_stats(cel_images *im, double *n_srcpix, double *n_gauss, double *n
     HIP_TRY(hipMemsetAsync(im->d_stats, 0, sizeof(double) * 2, c->stream));
     if (n > 0)
         hipLaunchKernelGGL(k_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, im->d_recs, n, im->d_stats);
-    HIP_TRY(hipMemcpyAsync(c->pinned + MAX_BANDS + 4, im->d_stats, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->pinned + MAX_BANDS + 2, im->d_cursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->pinned + MAX_BANDS + 6, im->d_stats, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (n_srcpix) *n_srcpix = c->pinned[MAX_BANDS + 4];
-    if (n_gauss) *n_gauss = c->pinned[MAX_BANDS + 5];
-    unsigned long long total;
-    memcpy(&total, c->pinned + MAX_BANDS + 2, sizeof(total));
-    if (n_tile_entries) *n_tile_entries = (double)total;
+    if (n_srcpix) *n_srcpix = c->pinned[MAX_BANDS + 6];
+    if (n_gauss) *n_gauss = c->pinned[MAX_BANDS + 7];
+    if (n_tile_entries) *n_tile_entries = im->last_entries;
     return CEL_OK;
 }
 

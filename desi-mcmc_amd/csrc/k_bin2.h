@@ -1,0 +1,129 @@
+// k_bin2.h -- two-level tile binning: per-tile source lists, in source order
+//
+// Level 1 (k_bin_coarse): one 256-thread block per 256 x 256-pixel super-tile scans the band's S
+//   boxes and writes the ordered list of sources whose box touches the super-tile.
+// Level 2 (k_bin_fine): one wave per 64 x TH render tile scans only its super-tile's candidates
+//   (a few hundred instead of S) and writes the tile's ordered source list, its length and a
+//   work estimate for the heaviest-first launch order.
+// Both levels compact with ballot + prefix popcount, so every list is in ascending source index:
+// the accumulation order in k_render -- and with it every output bit -- is reproducible.
+// List SEGMENTS are placed with one atomicAdd per list (segment order in the buffer is
+// arbitrary and irrelevant); no atomics touch list contents.
+#pragma once
+#include "device_common.h"
+
+#define SUPER_W 256
+#define SUPER_H 256
+
+__device__ inline bool box_hits(int4 q, int X0, int X1, int Y0, int Y1) {
+    return (q.x < X1) && (q.y > X0) && (q.z < Y1) && (q.w > Y0) && (q.y > q.x) && (q.w > q.z);
+}
+
+// grid = B * nsx * nsy blocks of 256 threads.  cursor[0]: coarse list cursor, cursor[1] (as int):
+// overflow flag.
+__global__ void __launch_bounds__(256)
+k_bin_coarse(const int4 *__restrict__ boxes, int64_t S, int nsx, int nsy, int *__restrict__ sup_cnt,
+             int64_t *__restrict__ sup_off, unsigned long long *cursor, int *__restrict__ clist,
+             int64_t capacity, int *overflow) {
+    __shared__ int wcnt[4];
+    __shared__ long long base_s;
+    const int st = blockIdx.x;
+    const int per_band = nsx * nsy;
+    const int b = st / per_band;
+    const int t = st - b * per_band;
+    const int sy = t / nsx, sx = t - sy * nsx;
+    const int X0 = sx * SUPER_W, X1 = X0 + SUPER_W, Y0 = sy * SUPER_H, Y1 = Y0 + SUPER_H;
+    const int4 *bx = boxes + (int64_t)b * S;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // each wave owns a contiguous quarter of the sources, so concatenating the four
+    // wave-ordered pieces keeps the whole list ordered
+    const int64_t per = ((S + 255) / 256) * 64;
+    const int64_t lo = per * wave, hi = (lo + per < S) ? lo + per : S;
+    int count = 0;
+    for (int64_t s0 = lo; s0 < hi; s0 += 64) {
+        int64_t s = s0 + lane;
+        bool hit = (s < hi) && box_hits(bx[s], X0, X1, Y0, Y1);
+        count += __popcll(__ballot(hit));
+    }
+    if (lane == 0) wcnt[wave] = count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        sup_cnt[st] = tot;
+        long long base = (long long)atomicAdd(cursor, (unsigned long long)tot);
+        sup_off[st] = base;
+        base_s = base;
+    }
+    __syncthreads();
+    int64_t at0 = base_s;
+    for (int w = 0; w < wave; w++) at0 += wcnt[w];
+    int run = 0;
+    for (int64_t s0 = lo; s0 < hi; s0 += 64) {
+        int64_t s = s0 + lane;
+        bool hit = (s < hi) && box_hits(bx[s], X0, X1, Y0, Y1);
+        unsigned long long m = __ballot(hit);
+        if (hit) {
+            int64_t at = at0 + run + __popcll(m & ((1ull << lane) - 1ull));
+            if (at < capacity) clist[at] = (int)s; else *overflow = 1;
+        }
+        run += __popcll(m);
+    }
+}
+
+// grid = B * ntx * nty waves.  cursor[0]: fine list cursor.
+__global__ void __launch_bounds__(64)
+k_bin_fine(const int4 *__restrict__ boxes, const int *__restrict__ kind, int64_t S, int ntx, int nty, int TH,
+           int nsx, int nsy, const int *__restrict__ sup_cnt, const int64_t *__restrict__ sup_off,
+           const int *__restrict__ clist, int64_t ccap, int *__restrict__ tile_cnt, int *__restrict__ tile_work,
+           int64_t *__restrict__ tile_off, unsigned long long *cursor, int *__restrict__ lists,
+           int64_t capacity, int *overflow) {
+    const int tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int per_band = ntx * nty;
+    const int b = tile / per_band;
+    const int t = tile - b * per_band;
+    const int ty = t / ntx, tx = t - ty * ntx;
+    const int X0 = tx * TILE_W, X1 = X0 + TILE_W, Y0 = ty * TH, Y1 = Y0 + TH;
+    const int st = (b * nsy + Y0 / SUPER_H) * nsx + X0 / SUPER_W;
+    const int4 *bx = boxes + (int64_t)b * S;
+    const int *kd = kind + (int64_t)b * S;
+    const int n = sup_cnt[st];
+    const int64_t coff = sup_off[st];
+    int count = 0, work = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        int i = i0 + lane;
+        bool hit = false;
+        if (i < n && coff + i < ccap) {
+            int s = clist[coff + i];
+            int4 q = bx[s];
+            hit = box_hits(q, X0, X1, Y0, Y1);
+            if (hit) work += kd[s] * (min(q.w, Y1) - max(q.z, Y0) + 18);
+        }
+        count += __popcll(__ballot(hit));
+    }
+    for (int o = 32; o > 0; o >>= 1) work += __shfl_down(work, o);
+    long long base = 0;
+    if (lane == 0) {
+        tile_cnt[tile] = count;
+        tile_work[tile] = work;
+        base = (long long)atomicAdd(cursor, (unsigned long long)count);
+        tile_off[tile] = base;
+    }
+    base = __shfl(base, 0);
+    int run = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        int i = i0 + lane;
+        bool hit = false;
+        int s = 0;
+        if (i < n && coff + i < ccap) {
+            s = clist[coff + i];
+            hit = box_hits(bx[s], X0, X1, Y0, Y1);
+        }
+        unsigned long long m = __ballot(hit);
+        if (hit) {
+            int64_t at = base + run + __popcll(m & ((1ull << lane) - 1ull));
+            if (at < capacity) lists[at] = s; else *overflow = 1;
+        }
+        run += __popcll(m);
+    }
+}

@@ -32,7 +32,7 @@ k_stamps(const BandDev *__restrict__ bands, int band, const SrcRec *__restrict__
     const int nx = ob.y - ob.x;
     double *o = out + offsets[jb.src];
     for (int y = jb.y0; y < jb.y1; y++) {
-        double v = eval_direct(T, 0, K, (double)xi, (double)y);
+        double v = eval_direct(T, 0, K, (double)xi, (double)y, 1.0);
         o[(int64_t)(y - ob.z) * nx + (xi - ob.x)] = v;
     }
 }

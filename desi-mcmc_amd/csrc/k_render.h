@@ -81,13 +81,37 @@ __device__ inline double exp_tab(double x, const double *__restrict__ et) {
     return ldexp(et[ni & 63] * p, ni >> 6);
 }
 
+// Same, for an argument already expressed in units of ln2/64 (t = x * 64/ln2): the table
+// builder folds that factor into the quadratic-form coefficients, which saves the scaling
+// multiply and the two-step reduction per seed.  f = t - rint(t) is exact; exp(f ln2/64) is
+// the same degree-5 polynomial with the powers of ln2/64 folded into its coefficients.
+__device__ inline double exp_tab64(double t, const double *__restrict__ et) {
+    const double c1 = 1.0830424696249145e-02;     // (ln2/64)
+    const double c2 = 5.864904955056169e-05;      // (ln2/64)^2 / 2
+    const double c3 = 2.1173137155464774e-07;     // (ln2/64)^3 / 6
+    const double c4 = 5.732851688640402e-10;      // (ln2/64)^4 / 24
+    const double c5 = 1.2417843701716923e-12;     // (ln2/64)^5 / 120
+    double n = rint(t);
+    double f = t - n;
+    int ni = (int)n;
+    double p = fma(f, c5, c4);
+    p = fma(p, f, c3);
+    p = fma(p, f, c2);
+    p = fma(p, f, c1);
+    p = fma(p, f, 1.0);
+    return ldexp(et[ni & 63] * p, ni >> 6);
+}
+
 // ---- direct evaluator: sum over components of A exp(-q/2) at (x, y) -------------------------
-__device__ inline double eval_direct(const CompTab &T, int k0, int k1, double x, double y) {
+// qscale = 1 for a table holding the inverse covariance itself (stamps), 1/EXP_SCALE for the
+// render kernel's table, whose qa/qb/qc carry the factor 64/ln2.
+#define EXP_SCALE 92.332482616893656758   // 64 / ln 2
+__device__ inline double eval_direct(const CompTab &T, int k0, int k1, double x, double y, double qscale) {
     double s = 0.0;
     for (int k = k0; k < k1; k++) {
         double dx = x - T.mx[k], dy = y - T.my[k];
         double q = T.qa[k] * dx * dx + 2.0 * T.qb[k] * dx * dy + T.qc[k] * dy * dy;
-        s += T.A[k] * exp(-0.5 * q);
+        s += T.A[k] * exp(-0.5 * qscale * q);
     }
     return s;
 }
@@ -125,13 +149,15 @@ __device__ inline void rec_group(const CompTab &T, const double *__restrict__ et
 #pragma unroll
         for (int i = 0; i < G; i++) {
             const int k = k0 + i;
+            // the table holds qa, qb, qc multiplied by 64/ln2 (EXP_SCALE): exponents come out
+            // directly in the units exp_tab64 wants
             double dx = x - T.mx[k], dy = y0 - T.my[k];
             double qb = T.qb[k], qc = T.qc[k];
-            double hx = qb * dx + qc * dy;                      // = -dE/dy
+            double hx = qb * dx + qc * dy;                      // = -dE/dy (scaled)
             double e = -0.5 * (T.qa[k] * dx * dx + (qb * dx + hx) * dy);
-            double er = fmin(fmax(-(hx + 0.5 * qc), -REC_EMAX), REC_EMAX);
-            g[i] = (T.A[k] * aon) * exp_tab(e, et);
-            r[i] = exp_tab(er, et);
+            double er = fmin(fmax(-(hx + 0.5 * qc), -REC_EMAX * EXP_SCALE), REC_EMAX * EXP_SCALE);
+            g[i] = (T.A[k] * aon) * exp_tab64(e, et);
+            r[i] = exp_tab64(er, et);
             q[i] = T.eq[k];
         }
         // two rows per trip: the register rotation of g/r cancels (no v_mov copies)
@@ -214,8 +240,12 @@ k_render(RenderArgs a) {
     const int cnt = a.tile_cnt[tile];
     const int64_t off = a.tile_off[tile];
     const SrcRec *recs = a.recs + (int64_t)b * a.S;
+    // Drop rule: a component is skipped on this tile when its contribution is below
+    // eps * e^-T everywhere on the part of the tile the source covers (eps = the band's sky
+    // level, so the bound is relative to lambda >= eps).  T <= 0 or eps <= 0: never drop.
     const double Tdrop = a.tail_T;
-    const double Tseg = Tdrop > 0.0 ? Tdrop : 100.0;
+    const double eps_sky = bd->eps;
+    const bool dropping = (a.variant != 0) && (Tdrop > 0.0) && (eps_sky > 0.0);
 
     for (int e = 0; e < cnt; e++) {
         int64_t at = off + e;
@@ -240,8 +270,10 @@ k_render(RenderArgs a) {
             c = make_comp(lane, type, rp->px, rp->py, rp->scale, rp->w00, rp->w01, rp->w11, rp->theta, bd);
             double ddx = dist_to_interval(c.mx, xa, xb), ddy = dist_to_interval(c.my, ya, yb);
             double qmin = fmax(ddx * ddx * c.ixx, ddy * ddy * c.iyy);   // lower bound of q on the rect
-            keep = (a.variant == 0) || (Tdrop <= 0.0) || (0.5 * qmin <= Tdrop);
-            Lk = seg_len(c.qc, Tseg);
+            // A e^E >= eps e^-T  <=>  E >= -(T + log(A/eps)) =: -Tk
+            double Tk = dropping ? Tdrop + (double)__logf((float)(fabs(c.A) / eps_sky)) : 100.0;
+            keep = !dropping || (0.5 * qmin <= Tk);
+            Lk = seg_len(c.qc, fmin(fmax(Tk, 1.0), 300.0));
         }
         const unsigned long long km = __ballot(keep);
         const int Kk = __popcll(km);
@@ -249,14 +281,14 @@ k_render(RenderArgs a) {
         if (keep) {
             int p = __popcll(km & ((1ull << lane) - 1ull));
             T.A[p] = c.A; T.mx[p] = c.mx; T.my[p] = c.my;
-            T.qa[p] = c.qa; T.qb[p] = c.qb; T.qc[p] = c.qc;
+            T.qa[p] = c.qa * EXP_SCALE; T.qb[p] = c.qb * EXP_SCALE; T.qc[p] = c.qc * EXP_SCALE;
             T.eq[p] = exp(-c.qc);
             T.L[p] = Lk;
         }
         __syncthreads();
         if (a.variant == 0) {
             for (int row = ra; row < rb; row++) {
-                double v = eval_direct(T, 0, Kk, x, (double)(Y0 + row));
+                double v = eval_direct(T, 0, Kk, x, (double)(Y0 + row), 1.0 / EXP_SCALE);
                 if (on) acc[row * TILE_W + lane] += v;
             }
             continue;
@@ -269,7 +301,7 @@ k_render(RenderArgs a) {
             if (L < 4) {
                 // pathologically sharp component: evaluate this group directly
                 for (int row = ra; row < rb; row++) {
-                    double v = eval_direct(T, k0, k0 + kn, x, (double)(Y0 + row));
+                    double v = eval_direct(T, k0, k0 + kn, x, (double)(Y0 + row), 1.0 / EXP_SCALE);
                     if (on) acc[row * TILE_W + lane] += v;
                 }
                 continue;

@@ -53,8 +53,11 @@ enum {
 /* cel_ctx_set_option keys */
 enum {
     CEL_OPT_KERNEL = 1,    /* 0 = direct exp per Gaussian-pixel, 1 = row-recurrence (default) */
-    CEL_OPT_TAIL_LOG = 2,  /* T >= 0: drop a component on a tile where its exponent is < -T
-                              everywhere (0 = never drop). default 60 (e^-60 = 8.8e-27)       */
+    CEL_OPT_TAIL_LOG = 2,  /* T >= 0: a mixture component is skipped on an image tile when its
+                              contribution stays below eps * e^-T everywhere on the part of the
+                              tile its source covers (eps = the band's sky level, so the bound is
+                              relative to lambda >= eps).  0 = never skip.  default 40:
+                              |d lambda| / lambda <= n_components * e^-40 = n * 4.2e-18       */
     CEL_OPT_PROFILE = 3,   /* 1 = bracket every kernel launch with HIP events              */
     CEL_OPT_TILE_ORDER = 4,/* 1 (default) = launch render tiles heaviest-first; never changes results */
     CEL_OPT_TILE_ROWS = 5  /* rows per render tile, 32 (default) or 64; read by cel_images_create  */
