@@ -136,6 +136,11 @@ __device__ inline int seg_len(double qc, double T) {
     return (int)fmin(L, 4096.0);
 }
 
+// acc += v as ONE LDS instruction (ds_add_f64, no return): no read-add-write dependency for the
+// wave to wait on.  A tile is owned by a single wave and LDS operations of one wave execute in
+// order, so the accumulation order -- and the result -- stays deterministic.
+__device__ inline void lds_add(double *p, double v) { atomicAdd(p, v); }
+
 // Accumulate components [k0, k0+G) over rows [ra, rb) of column x into acc_col (the LDS column of
 // this lane, stride TILE_W doubles).  `on` masks lanes outside the source box.
 template <int G>
@@ -179,8 +184,8 @@ __device__ inline void rec_group(const CompTab &T, const double *__restrict__ et
                 g[i] = g1[i] * r1[i];
                 r[i] = r1[i] * q[i];
             }
-            acc_col[row * TILE_W] += s0;
-            acc_col[(row + 1) * TILE_W] += s1;
+            lds_add(&acc_col[row * TILE_W], s0);
+            lds_add(&acc_col[(row + 1) * TILE_W], s1);
         }
         if (row < sb) {
             double s0 = g[0];
@@ -191,7 +196,7 @@ __device__ inline void rec_group(const CompTab &T, const double *__restrict__ et
                 g[i] *= r[i];
                 r[i] *= q[i];
             }
-            acc_col[row * TILE_W] += s0;
+            lds_add(&acc_col[row * TILE_W], s0);
         }
     }
 }
