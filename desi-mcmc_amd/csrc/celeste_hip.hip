@@ -588,9 +588,9 @@ int cel_render_field(cel_images *im, cel_sources *src, int flags, double *ll_ban
         // d_cursor: [0] fine cursor, [1] fine overflow, [2] coarse cursor, [3] coarse overflow
         HIP_TRY(hipMemsetAsync(im->d_cursor, 0, sizeof(unsigned long long) * 4, st));
         int pi = prof_begin(c, CEL_K_BIN);
-        hipLaunchKernelGGL(k_bin_coarse, dim3(NS), dim3(256), 0, st, im->d_boxes, S, im->nsx, im->nsy, im->d_sup_cnt,
+        hipLaunchKernelGGL(k_bin_coarse, dim3(NS), dim3(64 * COARSE_WAVES), 0, st, im->d_boxes, S, im->nsx, im->nsy, im->d_sup_cnt,
                            im->d_sup_off, im->d_cursor + 2, im->d_clist, im->clist_cap, (int *)(im->d_cursor + 3));
-        hipLaunchKernelGGL(k_bin_fine, dim3(T), dim3(64), 0, st, im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH,
+        hipLaunchKernelGGL(k_bin_fine_blk, dim3(NS), dim3(256), 0, st, im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH,
                            im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
                            im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
                            (int *)(im->d_cursor + 1));

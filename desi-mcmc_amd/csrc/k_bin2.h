@@ -21,11 +21,12 @@ __device__ inline bool box_hits(int4 q, int X0, int X1, int Y0, int Y1) {
 
 // grid = B * nsx * nsy blocks of 256 threads.  cursor[0]: coarse list cursor, cursor[1] (as int):
 // overflow flag.
-__global__ void __launch_bounds__(256)
+#define COARSE_WAVES 16
+__global__ void __launch_bounds__(64 * COARSE_WAVES)
 k_bin_coarse(const int4 *__restrict__ boxes, int64_t S, int nsx, int nsy, int *__restrict__ sup_cnt,
              int64_t *__restrict__ sup_off, unsigned long long *cursor, int *__restrict__ clist,
              int64_t capacity, int *overflow) {
-    __shared__ int wcnt[4];
+    __shared__ int wcnt[COARSE_WAVES];
     __shared__ long long base_s;
     const int st = blockIdx.x;
     const int per_band = nsx * nsy;
@@ -37,7 +38,7 @@ k_bin_coarse(const int4 *__restrict__ boxes, int64_t S, int nsx, int nsy, int *_
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // each wave owns a contiguous quarter of the sources, so concatenating the four
     // wave-ordered pieces keeps the whole list ordered
-    const int64_t per = ((S + 255) / 256) * 64;
+    const int64_t per = ((S + 64 * COARSE_WAVES - 1) / (64 * COARSE_WAVES)) * 64;
     const int64_t lo = per * wave, hi = (lo + per < S) ? lo + per : S;
     int count = 0;
     for (int64_t s0 = lo; s0 < hi; s0 += 64) {
@@ -48,7 +49,8 @@ k_bin_coarse(const int4 *__restrict__ boxes, int64_t S, int nsx, int nsy, int *_
     if (lane == 0) wcnt[wave] = count;
     __syncthreads();
     if (threadIdx.x == 0) {
-        int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        int tot = 0;
+        for (int w = 0; w < COARSE_WAVES; w++) tot += wcnt[w];
         sup_cnt[st] = tot;
         long long base = (long long)atomicAdd(cursor, (unsigned long long)tot);
         sup_off[st] = base;
@@ -125,5 +127,118 @@ k_bin_fine(const int4 *__restrict__ boxes, const int *__restrict__ kind, int64_t
             if (at < capacity) lists[at] = s; else *overflow = 1;
         }
         run += __popcll(m);
+    }
+}
+
+// Level 2, block form: one 256-thread block per super-tile stages the super-tile's candidates
+// (box, component count, source index) through LDS in chunks of BIN_CH and its four waves bin
+// them into the super-tile's render tiles (wave w takes tiles w, w+4, ...).  Pass 0 counts and
+// reserves each tile's list segment, pass 1 fills it; with n <= BIN_CH (the usual case) the
+// candidates are read from global memory once.  Same outputs as k_bin_fine, ~10x less latency:
+// every box test reads LDS instead of chasing clist -> boxes -> kind through L2.
+#define BIN_CH 1024
+#define BIN_TPW 8      // max tiles per wave: (256/64) * (256/32) / 4
+
+__global__ void __launch_bounds__(256)
+k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int64_t S, int ntx, int nty, int TH,
+               int nsx, int nsy, const int *__restrict__ sup_cnt, const int64_t *__restrict__ sup_off,
+               const int *__restrict__ clist, int64_t ccap, int *__restrict__ tile_cnt,
+               int *__restrict__ tile_work, int64_t *__restrict__ tile_off, unsigned long long *cursor,
+               int *__restrict__ lists, int64_t capacity, int *overflow) {
+    __shared__ int4 sbox[BIN_CH];
+    __shared__ int skind[BIN_CH];
+    __shared__ int sid[BIN_CH];
+    __shared__ int stcnt[4 * BIN_TPW], stoff[4 * BIN_TPW];
+    __shared__ long long sbase;
+    const int st = blockIdx.x;
+    const int per_band_s = nsx * nsy;
+    const int b = st / per_band_s;
+    const int t = st - b * per_band_s;
+    const int sy = t / nsx, sx = t - sy * nsx;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tpx = SUPER_W / TILE_W, tpy = SUPER_H / TH;      // tiles per super-tile in x / y
+    const int4 *bx = boxes + (int64_t)b * S;
+    const int *kd = kind + (int64_t)b * S;
+    int n = sup_cnt[st];
+    const int64_t coff = sup_off[st];
+    if (coff + n > ccap) n = (int)((ccap > coff) ? (ccap - coff) : 0);   // truncated coarse list (overflow is flagged)
+    int cnt[BIN_TPW], work[BIN_TPW], run[BIN_TPW];
+    long long base[BIN_TPW];
+#pragma unroll
+    for (int j = 0; j < BIN_TPW; j++) { cnt[j] = 0; work[j] = 0; run[j] = 0; base[j] = 0; }
+
+    for (int pass = 0; pass < 2; pass++) {
+        for (int c0 = 0; c0 < n || (c0 == 0 && n == 0 && pass == 0); c0 += BIN_CH) {
+            const int m = min(BIN_CH, n - c0);
+            if (pass == 0 || n > BIN_CH) {
+                __syncthreads();
+                for (int i = threadIdx.x; i < m; i += 256) {
+                    int s = clist[coff + c0 + i];
+                    sid[i] = s;
+                    sbox[i] = bx[s];
+                    skind[i] = kd[s];
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int j = 0; j < BIN_TPW; j++) {
+                const int tl = wave + 4 * j;                   // local tile index
+                if (tl >= tpx * tpy) continue;
+                const int tx = sx * tpx + (tl % tpx), ty = sy * tpy + (tl / tpx);
+                if (tx >= ntx || ty >= nty) continue;
+                const int X0 = tx * TILE_W, X1 = X0 + TILE_W, Y0 = ty * TH, Y1 = Y0 + TH;
+                for (int i0 = 0; i0 < m; i0 += 64) {
+                    const int i = i0 + lane;
+                    bool hit = false;
+                    int4 q = make_int4(0, 0, 0, 0);
+                    if (i < m) { q = sbox[i]; hit = box_hits(q, X0, X1, Y0, Y1); }
+                    const unsigned long long mk = __ballot(hit);
+                    if (pass == 0) {
+                        if (hit) work[j] += skind[i] * (min(q.w, Y1) - max(q.z, Y0) + 18);
+                        cnt[j] += __popcll(mk);
+                    } else {
+                        if (hit) {
+                            int64_t at = base[j] + run[j] + __popcll(mk & ((1ull << lane) - 1ull));
+                            if (at < capacity) lists[at] = sid[i]; else *overflow = 1;
+                        }
+                        run[j] += __popcll(mk);
+                    }
+                }
+            }
+            if (n == 0) break;
+        }
+        if (pass == 0) {
+            // ONE cursor atomic per super-tile (a single address sustains only ~90 returning
+            // atomics per microsecond: one per render tile cost 0.12 ms); the block's tiles get
+            // consecutive segments by an LDS prefix sum
+#pragma unroll
+            for (int j = 0; j < BIN_TPW; j++) {
+                const int tl = wave + 4 * j;
+                if (lane == 0 && tl < 4 * BIN_TPW) stcnt[tl] = (tl < tpx * tpy) ? cnt[j] : 0;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int tot = 0;
+                for (int k = 0; k < 4 * BIN_TPW; k++) { int c = stcnt[k]; stoff[k] = tot; tot += c; }
+                sbase = (long long)atomicAdd(cursor, (unsigned long long)tot);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < BIN_TPW; j++) {
+                const int tl = wave + 4 * j;
+                if (tl >= tpx * tpy) continue;
+                base[j] = sbase + stoff[tl];
+                const int tx = sx * tpx + (tl % tpx), ty = sy * tpy + (tl / tpx);
+                if (tx >= ntx || ty >= nty) continue;
+                const int tile = (b * nty + ty) * ntx + tx;
+                int w = work[j];
+                for (int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o);
+                if (lane == 0) {
+                    tile_cnt[tile] = cnt[j];
+                    tile_work[tile] = w;
+                    tile_off[tile] = base[j];
+                }
+            }
+        }
     }
 }

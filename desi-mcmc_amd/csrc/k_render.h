@@ -42,11 +42,13 @@ __device__ inline Comp make_comp(int k, int type, double px, double py, double s
     double inv = 1.0 / det;
     Comp c;
     c.qa = cyy * inv; c.qb = -cxy * inv; c.qc = cxx * inv;
-    c.A = scale * wt / (2.0 * PI_D * sqrt(det));
+    c.A = scale * wt * (0.5 / PI_D) * sqrt(inv);      // weight / (2 pi sqrt(det))
     c.mx = px + bd->mux[kk];
     c.my = py + bd->muy[kk];
-    c.ixx = 1.0 / cxx;
-    c.iyy = 1.0 / cyy;
+    // marginal precisions feed only the conservative drop test: fp32 reciprocals, shrunk by
+    // 1e-6 so that rounding can only make the test keep more, never less
+    c.ixx = (double)(__frcp_rn((float)cxx) * 0.999999f);
+    c.iyy = (double)(__frcp_rn((float)cyy) * 0.999999f);
     return c;
 }
 
@@ -130,10 +132,11 @@ __device__ inline double eval_direct(const CompTab &T, int k0, int k1, double x,
 #define REC_EMAX 680.0
 
 __device__ inline int seg_len(double qc, double T) {
-    // largest L with (L sqrt(qc/2) + sqrt(T))^2 <= REC_EMAX
-    double u = sqrt(REC_EMAX) - sqrt(T);
-    double L = u / sqrt(0.5 * qc);
-    return (int)fmin(L, 4096.0);
+    // largest L with (L sqrt(qc/2) + sqrt(T))^2 <= REC_EMAX.  fp32 is ample for a row count;
+    // the 0.999 keeps the rounding on the safe (shorter) side.  T <= 300 => u > 0.
+    float u = 26.0768f - __fsqrt_rn((float)T);                 // sqrt(680) = 26.0768
+    float L = u * __frsqrt_rn(0.5f * (float)qc) * 0.999f;
+    return (int)fminf(L, 4096.0f);
 }
 
 // acc += v as ONE LDS instruction (ds_add_f64, no return): no read-add-write dependency for the
