@@ -2,9 +2,9 @@
 //
 // Level 1 (k_bin_coarse): one 256-thread block per 256 x 256-pixel super-tile scans the band's S
 //   boxes and writes the ordered list of sources whose box touches the super-tile.
-// Level 2 (k_bin_fine): one wave per 64 x TH render tile scans only its super-tile's candidates
-//   (a few hundred instead of S) and writes the tile's ordered source list, its length and a
-//   work estimate for the heaviest-first launch order.
+// Level 2 (k_bin_fine_blk): one block per super-tile stages its candidates (a few hundred instead
+//   of S) in LDS and writes, for each of its 64 x TH render tiles, the ordered source list, its
+//   length and a work estimate for the heaviest-first launch order.
 // Both levels compact with ballot + prefix popcount, so every list is in ascending source index:
 // the accumulation order in k_render -- and with it every output bit -- is reproducible.
 // List SEGMENTS are placed with one atomicAdd per list (segment order in the buffer is
@@ -72,70 +72,11 @@ k_bin_coarse(const int4 *__restrict__ boxes, int64_t S, int nsx, int nsy, int *_
     }
 }
 
-// grid = B * ntx * nty waves.  cursor[0]: fine list cursor.
-__global__ void __launch_bounds__(64)
-k_bin_fine(const int4 *__restrict__ boxes, const int *__restrict__ kind, int64_t S, int ntx, int nty, int TH,
-           int nsx, int nsy, const int *__restrict__ sup_cnt, const int64_t *__restrict__ sup_off,
-           const int *__restrict__ clist, int64_t ccap, int *__restrict__ tile_cnt, int *__restrict__ tile_work,
-           int64_t *__restrict__ tile_off, unsigned long long *cursor, int *__restrict__ lists,
-           int64_t capacity, int *overflow) {
-    const int tile = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int per_band = ntx * nty;
-    const int b = tile / per_band;
-    const int t = tile - b * per_band;
-    const int ty = t / ntx, tx = t - ty * ntx;
-    const int X0 = tx * TILE_W, X1 = X0 + TILE_W, Y0 = ty * TH, Y1 = Y0 + TH;
-    const int st = (b * nsy + Y0 / SUPER_H) * nsx + X0 / SUPER_W;
-    const int4 *bx = boxes + (int64_t)b * S;
-    const int *kd = kind + (int64_t)b * S;
-    const int n = sup_cnt[st];
-    const int64_t coff = sup_off[st];
-    int count = 0, work = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        int i = i0 + lane;
-        bool hit = false;
-        if (i < n && coff + i < ccap) {
-            int s = clist[coff + i];
-            int4 q = bx[s];
-            hit = box_hits(q, X0, X1, Y0, Y1);
-            if (hit) work += kd[s] * (min(q.w, Y1) - max(q.z, Y0) + 18);
-        }
-        count += __popcll(__ballot(hit));
-    }
-    for (int o = 32; o > 0; o >>= 1) work += __shfl_down(work, o);
-    long long base = 0;
-    if (lane == 0) {
-        tile_cnt[tile] = count;
-        tile_work[tile] = work;
-        base = (long long)atomicAdd(cursor, (unsigned long long)count);
-        tile_off[tile] = base;
-    }
-    base = __shfl(base, 0);
-    int run = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        int i = i0 + lane;
-        bool hit = false;
-        int s = 0;
-        if (i < n && coff + i < ccap) {
-            s = clist[coff + i];
-            hit = box_hits(bx[s], X0, X1, Y0, Y1);
-        }
-        unsigned long long m = __ballot(hit);
-        if (hit) {
-            int64_t at = base + run + __popcll(m & ((1ull << lane) - 1ull));
-            if (at < capacity) lists[at] = s; else *overflow = 1;
-        }
-        run += __popcll(m);
-    }
-}
-
-// Level 2, block form: one 256-thread block per super-tile stages the super-tile's candidates
+// Level 2: one 256-thread block per super-tile stages the super-tile's candidates
 // (box, component count, source index) through LDS in chunks of BIN_CH and its four waves bin
 // them into the super-tile's render tiles (wave w takes tiles w, w+4, ...).  Pass 0 counts and
 // reserves each tile's list segment, pass 1 fills it; with n <= BIN_CH (the usual case) the
-// candidates are read from global memory once.  Same outputs as k_bin_fine, ~10x less latency:
-// every box test reads LDS instead of chasing clist -> boxes -> kind through L2.
+// candidates are read from global memory once; every box test reads LDS.
 #define BIN_CH 1024
 #define BIN_TPW 8      // max tiles per wave: (256/64) * (256/32) / 4
 

@@ -141,58 +141,6 @@ __global__ void k_stats(const SrcRec *__restrict__ recs, int64_t n, double *out)
 }
 
 // ------------------------------------------------------------------------------------------
-// k_bin: per-tile source lists, in source order
-// ------------------------------------------------------------------------------------------
-// pass 0 (lists == nullptr): count; the last lane-0 of each tile reserves its segment with one
-// atomicAdd on `cursor` (segment ORDER in the buffer is arbitrary, list CONTENT is not).
-// Pass 0 also writes a work estimate per tile (sum over its sources of K * (rows + seed cost)),
-// which k_order turns into a heaviest-first launch order for k_render.
-// pass 1: fill.  One wave per tile.
-__global__ void __launch_bounds__(64)
-k_bin(const int4 *__restrict__ boxes, const int *__restrict__ kind, int64_t S, int ntx, int nty, int TH,
-      int pass, int *__restrict__ tile_cnt, int *__restrict__ tile_work, int64_t *__restrict__ tile_off, unsigned long long *cursor,
-      int *__restrict__ lists, int64_t capacity, int *overflow) {
-    int tile = blockIdx.x;
-    int lane = threadIdx.x;
-    int per_band = ntx * nty;
-    int b = tile / per_band;
-    int t = tile - b * per_band;
-    int ty = t / ntx, tx = t - ty * ntx;
-    int X0 = tx * TILE_W, X1 = X0 + TILE_W, Y0 = ty * TH, Y1 = Y0 + TH;
-    const int4 *bx = boxes + (int64_t)b * S;
-    const int *kd = kind + (int64_t)b * S;
-    int work = 0;
-    int64_t base = 0;
-    if (pass == 1) base = tile_off[tile];
-    int count = 0;
-    for (int64_t s0 = 0; s0 < S; s0 += 64) {
-        int64_t s = s0 + lane;
-        bool hit = false;
-        if (s < S) {
-            int4 q = bx[s];
-            hit = (q.x < X1) && (q.y > X0) && (q.z < Y1) && (q.w > Y0) && (q.y > q.x) && (q.w > q.z);
-            if (pass == 0 && hit) work += kd[s] * (min(q.w, Y1) - max(q.z, Y0) + 18);
-        }
-        unsigned long long m = __ballot(hit);
-        if (pass == 1 && hit) {
-            int pos = __popcll(m & ((1ull << lane) - 1ull));
-            int64_t at = base + count + pos;
-            if (at < capacity) lists[at] = (int)s; else *overflow = 1;
-        }
-        count += __popcll(m);
-    }
-    if (pass == 0) {
-        for (int o = 32; o > 0; o >>= 1) work += __shfl_down(work, o);
-    }
-    if (pass == 0 && lane == 0) {
-        tile_cnt[tile] = count;
-        tile_work[tile] = work;
-        tile_off[tile] = (int64_t)atomicAdd(cursor, (unsigned long long)count);
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------
 // k_order: heaviest-first launch order of the tiles (counting sort on the work estimate)
 // ------------------------------------------------------------------------------------------
 // Tile order never changes results (every tile is written once); it only shortens the tail of
