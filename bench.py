@@ -29,14 +29,29 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TF = 78.6     # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 FLOP_PER_GAUSS = 35.0        # SURVEY 8d accounting: 10 arithmetic + exp counted as 25
 
+# HBM bytes per k_render launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+# separate passes, gfx950 correction 2*FETCH + WRITE re-calibrated for this access pattern with
+# tools/calib_traffic.hip).  Counters cannot be read from inside this process: the number is the
+# committed measurement of exactly this command and is reported only for the configuration it
+# was taken on; any other configuration gets null.
+PMC_TRAFFIC = {
+    ("mixed10k_2048", "recurrence", 40.0, 32): (383959848.0, "profiles/r01_v3_pmc_traffic.json"),
+}
+CPU_THREADS_MAX = 16         # the GPU box's CPU share for one GPU
+
 
 def cpu_baseline(field, nsample, orc):
     """The CPU oracle timed on a bounded sample of the SAME workload (first `nsample` sources,
-    all bands, full frame), all host threads.  Reported beside the GPU number; not the target."""
+    all bands, full frame) on the host's cores.  Reported beside the GPU number; not the target."""
     sl = slice(0, nsample)
     bands = field.bands.copy()
     for b in range(field.B):
         bands[b, 36] = field.images.band(b)[36]
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    orc.set_threads(max(1, min(orc.max_threads(), avail, CPU_THREADS_MAX)))
     t0 = time.perf_counter()
     lam, ll, st = orc.render_field(bands, field.H, field.W, field.src["type"][sl], field.src["radec"][sl],
                                    field.src["counts"][sl], field.src["shape"][sl], field.nelec)
@@ -129,6 +144,7 @@ def main():
         #   read nelec 8 B + write lambda 8 B per image pixel, + one 128-B record per (source, band)
         alg_bytes = 16.0 * n_imgpix + 128.0 * S * B
         achieved = alg_bytes / (t_render * 1e-3) / 1e9 if t_render > 0 else 0.0
+        pmc = PMC_TRAFFIC.get((args.workload, args.kernel, args.tail_log, args.tile_rows))
         out = {
             "metric": "source-pixel evals/sec (full-field Poisson log-lik, %d sources x %d bands x %dx%d)" % (S, B, H, W),
             "value": n_srcpix_all * args.steps / dt_max,
@@ -147,7 +163,8 @@ def main():
                        "tile_rows": args.tile_rows, "tile_order": args.tile_order,
                        "parallelism": "1 field per GPU, %d GPU(s), 1 all-reduce of %d doubles per step" % (world, B)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc[0] if pmc else None,
+                         "traffic_source": pmc[1] if pmc else None,
                          "kernel": "k_render", "kernel_ms": t_render, "launches": n_render,
                          "algorithmic_bytes_per_launch": alg_bytes},
             # the roof that actually binds this kernel: fp64 vector ALU

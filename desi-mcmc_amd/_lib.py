@@ -48,6 +48,7 @@ SYMBOLS = [
     ("cel_sources_set", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     ("cel_render_field", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_double_p, c_double_p]),
     ("cel_field_stats", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
+    ("cel_debug_tile_timing", C.c_int, [C.c_void_p, C.c_void_p, c_int64_p]),
     ("cel_stamp_boxes", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_int32_p, c_int32_p]),
     ("cel_render_stamps", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_int32_p, c_int64_p, C.c_void_p, C.c_int]),
     ("cel_gmm_like_2d", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p, C.c_int,

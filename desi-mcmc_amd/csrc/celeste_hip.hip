@@ -90,6 +90,7 @@ struct cel_ctx {
     bool profile = false;
     bool tile_order = true;   // launch k_render tiles heaviest-first
     int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created
+    bool tile_timing = false; // diagnostic: k_render stamps each tile's start/end wall clock
     Prof prof;
     double *pinned = nullptr;   // MAX_BANDS + 8 doubles of pinned host memory for readbacks
 };
@@ -118,6 +119,7 @@ struct cel_images {
     int64_t *d_sup_off = nullptr;
     int *d_clist = nullptr;
     int64_t clist_cap = 0;
+    unsigned long long *d_timing = nullptr;   // CEL_OPT_TILE_TIMING diagnostic stamps, 3 per tile
     double *d_stats = nullptr;
     int64_t last_S = 0;
     double last_entries = 0;
@@ -313,6 +315,9 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         if (v != 32.0 && v != 64.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TILE_ROWS must be 32 or 64");
         c->tile_rows = (int)v;
         return CEL_OK;
+    case CEL_OPT_TILE_TIMING:
+        c->tile_timing = (v != 0.0);
+        return CEL_OK;
     }
     return fail(CEL_ERR_INVALID, "unknown option %d", key);
 }
@@ -325,6 +330,7 @@ int cel_ctx_get_option(cel_ctx *c, int key, double *v) {
     case CEL_OPT_PROFILE: *v = c->profile ? 1.0 : 0.0; return CEL_OK;
     case CEL_OPT_TILE_ORDER: *v = c->tile_order ? 1.0 : 0.0; return CEL_OK;
     case CEL_OPT_TILE_ROWS: *v = c->tile_rows; return CEL_OK;
+    case CEL_OPT_TILE_TIMING: *v = c->tile_timing ? 1.0 : 0.0; return CEL_OK;
     }
     return fail(CEL_ERR_INVALID, "unknown option %d", key);
 }
@@ -336,7 +342,7 @@ int cel_images_destroy(cel_images *im) {
     (void)hipStreamSynchronize(im->ctx->stream);
     void *ptrs[] = {im->d_bands, im->d_nelec, im->d_lambda, im->d_partials, im->d_llband, im->d_recs,
                     im->d_boxes, im->d_kind, im->d_tile_cnt, im->d_tile_work, im->d_order, im->d_tile_off, im->d_cursor, im->d_lists, im->d_stats,
-                    im->d_sup_cnt, im->d_sup_off, im->d_clist};
+                    im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete im;
@@ -602,6 +608,11 @@ int cel_render_field(cel_images *im, cel_sources *src, int flags, double *ll_ban
         a.tile_off = im->d_tile_off; a.nelec = im->d_nelec; a.lambda = im->d_lambda; a.partials = im->d_partials;
         a.S = S; a.capacity = im->lists_cap; a.B = im->B; a.H = im->H; a.W = im->W; a.ntx = im->ntx; a.nty = im->nty;
         a.flags = flags; a.variant = c->variant; a.tail_T = c->tail_T; a.order = c->tile_order ? im->d_order : nullptr;
+        a.timing = nullptr;
+        if (c->tile_timing) {
+            if (!im->d_timing) HIP_TRY(hipMalloc((void **)&im->d_timing, sizeof(unsigned long long) * 3 * T));
+            a.timing = im->d_timing;
+        }
         pi = prof_begin(c, CEL_K_RENDER);
         if (im->TH == 64)
             hipLaunchKernelGGL((k_render<64>), dim3(T), dim3(64), 0, st, a);
@@ -641,6 +652,16 @@ int cel_render_field(cel_images *im, cel_sources *src, int flags, double *ll_ban
         if (ll_total) *ll_total = tot;
     }
     return CEL_OK;
+}
+
+int cel_debug_tile_timing(cel_images *im, uint64_t *out, int64_t *n_tiles) {
+    if (!im || !n_tiles) return fail(CEL_ERR_INVALID, "cel_debug_tile_timing: null argument");
+    const int T = im->B * im->ntx * im->nty;
+    *n_tiles = T;
+    if (!out) return CEL_OK;
+    if (!im->d_timing) return fail(CEL_ERR_INVALID, "no timing recorded: set CEL_OPT_TILE_TIMING before rendering");
+    HIP_TRY(hipSetDevice(im->ctx->device));
+    return copy_out(out, im->d_timing, sizeof(unsigned long long) * 3 * T, CEL_HOST, im->ctx->stream);
 }
 
 int cel_field_stats(cel_images *im, double *n_srcpix, double *n_gauss, double *n_tile_entries) {

@@ -14,6 +14,7 @@
 struct CompTab {
     double A[CT_N], mx[CT_N], my[CT_N], qa[CT_N], qb[CT_N], qc[CT_N], eq[CT_N];
     int L[CT_N];
+    int r0[CT_N], r1[CT_N];   // tile rows [r0, r1) on which the component can exceed the drop level
 };
 
 struct Comp {   // one component in registers
@@ -57,9 +58,25 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
-// distance from m to the closed interval [lo, hi]
-__device__ inline double dist_to_interval(double m, double lo, double hi) {
-    return fmax(fmax(lo - m, m - hi), 0.0);
+// Minimum of the positive-definite form a x^2 + 2 b x y + c y^2 over the rectangle
+// [x1,x2] x [y1,y2] (coordinates relative to the component mean).  0 when the mean is inside;
+// otherwise the minimum lies on the boundary: the smallest of the four 1-D constrained edge
+// minima.  The edge minimisers use fp32 reciprocals (second-order effect on the value); the
+// result is shrunk by 1e-5 so that the drop test built on it can only err towards keeping.
+__device__ inline double quad_min_rect(double a, double b, double c, double x1, double x2, double y1, double y2) {
+    if (x1 <= 0.0 && x2 >= 0.0 && y1 <= 0.0 && y2 >= 0.0) return 0.0;
+    const double rc = (double)__frcp_rn((float)c), ra = (double)__frcp_rn((float)a);
+    double best = INFINITY;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        double X = i ? x2 : x1;
+        double t = fmin(fmax(-b * X * rc, y1), y2);
+        best = fmin(best, a * X * X + (2.0 * b * X + c * t) * t);
+        double Y = i ? y2 : y1;
+        double u = fmin(fmax(-b * Y * ra, x1), x2);
+        best = fmin(best, c * Y * Y + (2.0 * b * Y + a * u) * u);
+    }
+    return best * 0.99999;
 }
 
 // ---- exp() for the recurrence seeds -----------------------------------------------------------
@@ -214,6 +231,7 @@ struct RenderArgs {
     const int *tile_cnt;
     const int64_t *tile_off;
     const int *order;     // tile launch order (heaviest first) or nullptr
+    unsigned long long *timing;   // diagnostic: per-tile {start, end} wall clock (100 MHz) + XCC/CU id, or nullptr
     const double *nelec;
     double *lambda;
     double *partials;
@@ -231,6 +249,7 @@ k_render(RenderArgs a) {
     __shared__ CompTab T;
     __shared__ double et[64];
     const int lane = threadIdx.x;
+    const unsigned long long t_start = a.timing ? wall_clock64() : 0ull;
     const int tile = a.order ? a.order[blockIdx.x] : blockIdx.x;
     const int per_band = a.ntx * a.nty;
     const int b = tile / per_band;
@@ -274,13 +293,23 @@ k_render(RenderArgs a) {
         bool keep = false;
         Comp c;
         int Lk = 0;
+        int rlo = ra, rhi = rb;
         if (lane < K) {
             c = make_comp(lane, type, rp->px, rp->py, rp->scale, rp->w00, rp->w01, rp->w11, rp->theta, bd);
-            double ddx = dist_to_interval(c.mx, xa, xb), ddy = dist_to_interval(c.my, ya, yb);
-            double qmin = fmax(ddx * ddx * c.ixx, ddy * ddy * c.iyy);   // lower bound of q on the rect
             // A e^E >= eps e^-T  <=>  E >= -(T + log(A/eps)) =: -Tk
             double Tk = dropping ? Tdrop + (double)__logf((float)(fabs(c.A) / eps_sky)) : 100.0;
-            keep = !dropping || (0.5 * qmin <= Tk);
+            if (dropping) {
+                // smallest value of the quadratic form on the covered rectangle
+                double qmin = quad_min_rect(c.qa, c.qb, c.qc, xa - c.mx, xb - c.mx, ya - c.my, yb - c.my);
+                keep = (0.5 * qmin <= Tk);
+                // rows on which the component can matter at all: |dy| <= sqrt(2 Tk Sigma_yy)
+                float half = __fsqrt_rn(2.0f * (float)fmax(Tk, 0.0) / (float)c.iyy) + 1.0f;
+                rlo = max(ra, (int)floorf((float)(c.my - (double)Y0) - half));
+                rhi = min(rb, (int)ceilf((float)(c.my - (double)Y0) + half) + 1);
+                keep = keep && (rhi > rlo);
+            } else {
+                keep = true;
+            }
             Lk = seg_len(c.qc, fmin(fmax(Tk, 1.0), 300.0));
         }
         const unsigned long long km = __ballot(keep);
@@ -292,6 +321,7 @@ k_render(RenderArgs a) {
             T.qa[p] = c.qa * EXP_SCALE; T.qb[p] = c.qb * EXP_SCALE; T.qc[p] = c.qc * EXP_SCALE;
             T.eq[p] = exp(-c.qc);
             T.L[p] = Lk;
+            T.r0[p] = rlo; T.r1[p] = rhi;
         }
         __syncthreads();
         if (a.variant == 0) {
@@ -303,12 +333,20 @@ k_render(RenderArgs a) {
         }
         for (int k0 = 0; k0 < Kk; k0 += REC_G) {
             const int kn = min(REC_G, Kk - k0);
-            int L = T.L[k0];
-            for (int i = 1; i < kn; i++) L = min(L, T.L[k0 + i]);
+            // the group walks the union of its components' row ranges with the shortest of their
+            // safe segment lengths (neighbouring k have similar widths, so little is wasted)
+            int L = T.L[k0], ga = T.r0[k0], gb = T.r1[k0];
+            for (int i = 1; i < kn; i++) {
+                L = min(L, T.L[k0 + i]);
+                ga = min(ga, T.r0[k0 + i]);
+                gb = max(gb, T.r1[k0 + i]);
+            }
             L = __builtin_amdgcn_readfirstlane(L);
+            ga = __builtin_amdgcn_readfirstlane(ga);
+            gb = __builtin_amdgcn_readfirstlane(gb);
             if (L < 4) {
                 // pathologically sharp component: evaluate this group directly
-                for (int row = ra; row < rb; row++) {
+                for (int row = ga; row < gb; row++) {
                     double v = eval_direct(T, k0, k0 + kn, x, (double)(Y0 + row), 1.0 / EXP_SCALE);
                     if (on) acc[row * TILE_W + lane] += v;
                 }
@@ -316,12 +354,12 @@ k_render(RenderArgs a) {
             }
             double *col = acc + lane;
             switch (kn) {
-            case 6: rec_group<6>(T, et, k0, x, Y0, ra, rb, L, on, col); break;
-            case 5: rec_group<5>(T, et, k0, x, Y0, ra, rb, L, on, col); break;
-            case 4: rec_group<4>(T, et, k0, x, Y0, ra, rb, L, on, col); break;
-            case 3: rec_group<3>(T, et, k0, x, Y0, ra, rb, L, on, col); break;
-            case 2: rec_group<2>(T, et, k0, x, Y0, ra, rb, L, on, col); break;
-            default: rec_group<1>(T, et, k0, x, Y0, ra, rb, L, on, col); break;
+            case 6: rec_group<6>(T, et, k0, x, Y0, ga, gb, L, on, col); break;
+            case 5: rec_group<5>(T, et, k0, x, Y0, ga, gb, L, on, col); break;
+            case 4: rec_group<4>(T, et, k0, x, Y0, ga, gb, L, on, col); break;
+            case 3: rec_group<3>(T, et, k0, x, Y0, ga, gb, L, on, col); break;
+            case 2: rec_group<2>(T, et, k0, x, Y0, ga, gb, L, on, col); break;
+            default: rec_group<1>(T, et, k0, x, Y0, ga, gb, L, on, col); break;
             }
         }
     }
@@ -347,6 +385,11 @@ k_render(RenderArgs a) {
     if (ll) {
         part = wave_sum(part);
         if (lane == 0) a.partials[tile] = part;
+    }
+    if (a.timing && lane == 0) {   // diagnostic build of the launch only (CEL_OPT_TILE_TIMING)
+        a.timing[3 * (size_t)blockIdx.x + 0] = t_start;
+        a.timing[3 * (size_t)blockIdx.x + 1] = wall_clock64();
+        a.timing[3 * (size_t)blockIdx.x + 2] = ((unsigned long long)tile << 32) | (unsigned)cnt;
     }
 }
 

@@ -60,7 +60,8 @@ enum {
                               |d lambda| / lambda <= n_components * e^-40 = n * 4.2e-18       */
     CEL_OPT_PROFILE = 3,   /* 1 = bracket every kernel launch with HIP events              */
     CEL_OPT_TILE_ORDER = 4,/* 1 (default) = launch render tiles heaviest-first; never changes results */
-    CEL_OPT_TILE_ROWS = 5  /* rows per render tile, 32 (default) or 64; read by cel_images_create  */
+    CEL_OPT_TILE_ROWS = 5, /* rows per render tile, 32 (default) or 64; read by cel_images_create  */
+    CEL_OPT_TILE_TIMING = 6 /* diagnostic: 1 = k_render stamps every tile's start/end wall clock   */
 };
 
 /* kernels reported by cel_profile_get */
@@ -146,6 +147,10 @@ int cel_render_field(cel_images *img, cel_sources *src, int flags, double *ll_ba
 /* work counters of the last cel_render_field: n_srcpix = sum of box areas (source-pixel
  * evaluations), n_gauss = sum of K*area, n_tile_entries = length of the tile lists */
 int cel_field_stats(cel_images *img, double *n_srcpix, double *n_gauss, double *n_tile_entries);
+/* diagnostic (CEL_OPT_TILE_TIMING): per launched render block i, out[3i] = start, out[3i+1] = end
+ * (100 MHz wall clock ticks), out[3i+2] = (tile index << 32) | list length.  out == NULL: only
+ * *n_tiles is returned.  Never enabled in a timed run. */
+int cel_debug_tile_timing(cel_images *img, uint64_t *out, int64_t *n_tiles);
 
 /* ---- stamps --------------------------------------------------------------------------- */
 /* gen_point_source_psf_image (celeste.py:114-176) / gen_galaxy_psf_image
