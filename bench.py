@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--tail-log", type=float, default=40.0)
     ap.add_argument("--tile-rows", type=int, default=32, choices=[32, 64])
     ap.add_argument("--tile-order", type=int, default=1, choices=[0, 1])
+    ap.add_argument("--layout", type=int, default=1, choices=[0, 1],
+                    help="render tile geometry: 0 = 64x32 (k_render), 1 = 32x64 half-wave (k_render_hw)")
     ap.add_argument("--cpu-sample", type=int, default=400, help="sources in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -92,6 +94,7 @@ def main():
     ctx.set_tail_log(args.tail_log)
     from desi_mcmc_amd import _lib
     ctx.set_option(_lib.CEL_OPT_TILE_ROWS, args.tile_rows)
+    ctx.set_option(7, args.layout)   # CEL_OPT_TILE_LAYOUT
     ctx.set_option(_lib.CEL_OPT_TILE_ORDER, args.tile_order)
 
     # one field per rank (weak scaling): same population, different seed

@@ -68,6 +68,7 @@ static int fail(int code, const char *fmt, ...) {
 #include "k_prep_bin.h"
 #include "k_bin2.h"
 #include "k_render.h"
+#include "k_render_hw.h"
 #include "k_misc.h"
 
 // ------------------------------------------------------------------------------------------
@@ -91,6 +92,8 @@ struct cel_ctx {
     bool tile_order = true;   // launch k_render tiles heaviest-first
     int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created
     bool tile_timing = false; // diagnostic: k_render stamps each tile's start/end wall clock
+    int tile_layout = 1;      // 0: 64 x tile_rows tiles, one lane per column (k_render)
+                              // 1: 32 x 64 tiles, two component groups per column (k_render_hw)
     Prof prof;
     double *pinned = nullptr;   // MAX_BANDS + 8 doubles of pinned host memory for readbacks
 };
@@ -99,7 +102,7 @@ struct cel_images {
     cel_ctx *ctx = nullptr;
     int B = 0, H = 0, W = 0;   // H = rows held on the device (the window height)
     int full_H = 0, win_y0 = 0;  // the window is rows [win_y0, win_y0 + H) of a full_H-row frame
-    int TH = 32, ntx = 0, nty = 0;
+    int TW = 64, TH = 32, ntx = 0, nty = 0;   // render tile geometry (fixed at creation)
     cel_band hb[MAX_BANDS];
     BandDev *d_bands = nullptr;
     double *d_nelec = nullptr, *d_lambda = nullptr, *d_partials = nullptr, *d_llband = nullptr;
@@ -318,6 +321,10 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
     case CEL_OPT_TILE_TIMING:
         c->tile_timing = (v != 0.0);
         return CEL_OK;
+    case CEL_OPT_TILE_LAYOUT:
+        if (v != 0.0 && v != 1.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TILE_LAYOUT must be 0 or 1");
+        c->tile_layout = (int)v;
+        return CEL_OK;
     }
     return fail(CEL_ERR_INVALID, "unknown option %d", key);
 }
@@ -331,6 +338,7 @@ int cel_ctx_get_option(cel_ctx *c, int key, double *v) {
     case CEL_OPT_TILE_ORDER: *v = c->tile_order ? 1.0 : 0.0; return CEL_OK;
     case CEL_OPT_TILE_ROWS: *v = c->tile_rows; return CEL_OK;
     case CEL_OPT_TILE_TIMING: *v = c->tile_timing ? 1.0 : 0.0; return CEL_OK;
+    case CEL_OPT_TILE_LAYOUT: *v = c->tile_layout; return CEL_OK;
     }
     return fail(CEL_ERR_INVALID, "unknown option %d", key);
 }
@@ -358,8 +366,9 @@ int cel_images_create(cel_ctx *c, int B, int H, int W, const cel_band *bands, ce
     if (!im) return fail(CEL_ERR_NOMEM, "out of host memory");
     im->ctx = c; im->B = B; im->H = H; im->W = W;
     im->full_H = H; im->win_y0 = 0;
-    im->TH = c->tile_rows;
-    im->ntx = (W + TILE_W - 1) / TILE_W;
+    if (c->tile_layout == 1) { im->TW = HW_TW; im->TH = HW_TH; }
+    else { im->TW = TILE_W; im->TH = c->tile_rows; }
+    im->ntx = (W + im->TW - 1) / im->TW;
     im->nty = (H + im->TH - 1) / im->TH;
     im->nsx = (W + SUPER_W - 1) / SUPER_W;
     im->nsy = (H + SUPER_H - 1) / SUPER_H;
@@ -596,7 +605,7 @@ int cel_render_field(cel_images *im, cel_sources *src, int flags, double *ll_ban
         int pi = prof_begin(c, CEL_K_BIN);
         hipLaunchKernelGGL(k_bin_coarse, dim3(NS), dim3(64 * COARSE_WAVES), 0, st, im->d_boxes, S, im->nsx, im->nsy, im->d_sup_cnt,
                            im->d_sup_off, im->d_cursor + 2, im->d_clist, im->clist_cap, (int *)(im->d_cursor + 3));
-        hipLaunchKernelGGL(k_bin_fine_blk, dim3(NS), dim3(256), 0, st, im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH,
+        hipLaunchKernelGGL(k_bin_fine_blk, dim3(NS), dim3(256), 0, st, im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
                            im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
                            im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
                            (int *)(im->d_cursor + 1));
@@ -614,7 +623,9 @@ int cel_render_field(cel_images *im, cel_sources *src, int flags, double *ll_ban
             a.timing = im->d_timing;
         }
         pi = prof_begin(c, CEL_K_RENDER);
-        if (im->TH == 64)
+        if (im->TW == HW_TW)
+            hipLaunchKernelGGL(k_render_hw, dim3(T), dim3(64), 0, st, a);
+        else if (im->TH == 64)
             hipLaunchKernelGGL((k_render<64>), dim3(T), dim3(64), 0, st, a);
         else
             hipLaunchKernelGGL((k_render<32>), dim3(T), dim3(64), 0, st, a);

@@ -82,7 +82,7 @@ k_bin_coarse(const int4 *__restrict__ boxes, int64_t S, int nsx, int nsy, int *_
 
 __global__ void __launch_bounds__(256)
 k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int64_t S, int ntx, int nty, int TH,
-               int nsx, int nsy, const int *__restrict__ sup_cnt, const int64_t *__restrict__ sup_off,
+               int TW, int nsx, int nsy, const int *__restrict__ sup_cnt, const int64_t *__restrict__ sup_off,
                const int *__restrict__ clist, int64_t ccap, int *__restrict__ tile_cnt,
                int *__restrict__ tile_work, int64_t *__restrict__ tile_off, unsigned long long *cursor,
                int *__restrict__ lists, int64_t capacity, int *overflow) {
@@ -97,7 +97,7 @@ k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int
     const int t = st - b * per_band_s;
     const int sy = t / nsx, sx = t - sy * nsx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tpx = SUPER_W / TILE_W, tpy = SUPER_H / TH;      // tiles per super-tile in x / y
+    const int tpx = SUPER_W / TW, tpy = SUPER_H / TH;          // tiles per super-tile in x / y (<= 32 in all)
     const int4 *bx = boxes + (int64_t)b * S;
     const int *kd = kind + (int64_t)b * S;
     int n = sup_cnt[st];
@@ -127,7 +127,7 @@ k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int
                 if (tl >= tpx * tpy) continue;
                 const int tx = sx * tpx + (tl % tpx), ty = sy * tpy + (tl / tpx);
                 if (tx >= ntx || ty >= nty) continue;
-                const int X0 = tx * TILE_W, X1 = X0 + TILE_W, Y0 = ty * TH, Y1 = Y0 + TH;
+                const int X0 = tx * TW, X1 = X0 + TW, Y0 = ty * TH, Y1 = Y0 + TH;
                 for (int i0 = 0; i0 < m; i0 += 64) {
                     const int i = i0 + lane;
                     bool hit = false;

@@ -10,11 +10,13 @@
 //   qa, qb, qc = inverse covariance [[qa, qb], [qb, qc]]
 //   eq  = exp(-qc): the row-to-row ratio of the recurrence's r
 //   L   = longest underflow-safe recurrence segment for this component (rows)
-#define CT_N (K_GAL + 6)
+#define CT_N (K_GAL + 12)   // + zero components the half-wave layout reads behind the table
 struct CompTab {
     double A[CT_N], mx[CT_N], my[CT_N], qa[CT_N], qb[CT_N], qc[CT_N], eq[CT_N];
-    int L[CT_N];
-    int r0[CT_N], r1[CT_N];   // tile rows [r0, r1) on which the component can exceed the drop level
+    // narrow types on purpose: accumulator tile + tables must stay <= 20 480 B per wave so that
+    // 8 waves fit a CU's 160 KB of LDS (at 20 576 B only 7 did, and the kernel ran 6 % slower)
+    short L[CT_N];            // <= 4096
+    signed char r0[CT_N], r1[CT_N];   // tile rows [r0, r1) on which the component can exceed the drop level
 };
 
 struct Comp {   // one component in registers

@@ -1,0 +1,221 @@
+// k_render_hw.h -- the render kernel on 32-column x 64-row tiles ("half-wave" layout)
+//
+// Same algorithm as k_render (k_render.h) with a different mapping of the 64 lanes:
+//   lanes  0..31  : the tile's 32 pixel columns, working on one group of components
+//   lanes 32..63  : the SAME 32 columns, working on the next group of components
+// Both halves add into one 32 x 64 fp64 LDS accumulator tile (16 KB, as before) with ds_add_f64.
+// Why: the recurrence's cost per (component, column) is a seed (two exp, ~54 instructions) plus
+// ~3.3 instructions per row.  With 64 x 32 tiles a column is walked for ~22 rows per source on
+// average, so seeds were 37 % of the instruction stream.  Here a column is walked for up to 64
+// rows (~36 on average): half as many seeds per evaluated pixel, and a 32-wide tile wastes fewer
+// lanes on the columns outside a source's box (84 % of lanes useful against 70 %).
+// Component parameters are read from LDS per half (two broadcast addresses per read).
+#pragma once
+#include "k_render.h"
+
+#define HW_TW 32
+#define HW_TH 64
+#define HW_PAD 12   // zero components behind the compacted table: a half's group may read past the end
+
+template <int G>
+__device__ inline void rec_group_hw(const CompTab &T, const double *__restrict__ et, int k0, double x,
+                                    int Y0, int ra, int rb, int L, bool on, double *__restrict__ acc_col) {
+    double g[G], r[G], q[G];
+    const double aon = on ? 1.0 : 0.0;
+    for (int sa = ra; sa < rb; sa += L) {
+        const int sb = min(sa + L, rb);
+        const double y0 = (double)(Y0 + sa);
+#pragma unroll
+        for (int i = 0; i < G; i++) {
+            const int k = k0 + i;                               // differs between the two halves
+            double dx = x - T.mx[k], dy = y0 - T.my[k];
+            double qb = T.qb[k], qc = T.qc[k];
+            double hx = qb * dx + qc * dy;
+            double e = -0.5 * (T.qa[k] * dx * dx + (qb * dx + hx) * dy);
+            double er = fmin(fmax(-(hx + 0.5 * qc), -REC_EMAX * EXP_SCALE), REC_EMAX * EXP_SCALE);
+            g[i] = (T.A[k] * aon) * exp_tab64(e, et);
+            r[i] = exp_tab64(er, et);
+            q[i] = T.eq[k];
+        }
+        int row = sa;
+        for (; row + 1 < sb; row += 2) {
+            double s0 = g[0], s1, g1[G], r1[G];
+#pragma unroll
+            for (int i = 1; i < G; i++) s0 += g[i];
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                g1[i] = g[i] * r[i];
+                r1[i] = r[i] * q[i];
+            }
+            s1 = g1[0];
+#pragma unroll
+            for (int i = 1; i < G; i++) s1 += g1[i];
+#pragma unroll
+            for (int i = 0; i < G; i++) {
+                g[i] = g1[i] * r1[i];
+                r[i] = r1[i] * q[i];
+            }
+            lds_add(&acc_col[row * HW_TW], s0);
+            lds_add(&acc_col[(row + 1) * HW_TW], s1);
+        }
+        if (row < sb) {
+            double s0 = g[0];
+#pragma unroll
+            for (int i = 1; i < G; i++) s0 += g[i];
+            lds_add(&acc_col[row * HW_TW], s0);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_render_hw(RenderArgs a) {
+    __shared__ double acc[HW_TH * HW_TW];
+    __shared__ CompTab T;
+    __shared__ double et[64];
+    const int lane = threadIdx.x;
+    const int half = lane >> 5, col = lane & 31;
+    const unsigned long long t_start = a.timing ? wall_clock64() : 0ull;
+    const int tile = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const int per_band = a.ntx * a.nty;
+    const int b = tile / per_band;
+    const int t = tile - b * per_band;
+    const int ty = t / a.ntx, tx = t - ty * a.ntx;
+    const int X0 = tx * HW_TW, Y0 = ty * HW_TH;
+    const int xi = X0 + col;
+    const double x = (double)xi;
+    const BandDev *bd = a.bands + b;
+
+    et[lane] = exp2((double)lane * (1.0 / 64.0));
+#pragma unroll
+    for (int r = 0; r < HW_TH / 2; r++) acc[r * 64 + lane] = 0.0;
+
+    const int cnt = a.tile_cnt[tile];
+    const int64_t off = a.tile_off[tile];
+    const SrcRec *recs = a.recs + (int64_t)b * a.S;
+    const double Tdrop = a.tail_T;
+    const double eps_sky = bd->eps;
+    const bool dropping = (a.variant != 0) && (Tdrop > 0.0) && (eps_sky > 0.0);
+
+    for (int e = 0; e < cnt; e++) {
+        int64_t at = off + e;
+        if (at >= a.capacity) break;
+        const int s = __builtin_amdgcn_readfirstlane(a.lists[at]);
+        const SrcRec *rp = recs + s;
+        const int type = rp->type;
+        const int K = (type == 0) ? K_PSF : K_GAL;
+        const int bx0 = rp->x0, bx1 = rp->x1, by0 = rp->y0, by1 = rp->y1;
+        const int ra = max(by0, Y0) - Y0, rb = min(by1, Y0 + HW_TH) - Y0;
+        const bool on = (xi >= bx0) && (xi < bx1);
+        const double xa = (double)max(bx0, X0), xb = (double)(min(bx1, X0 + HW_TW) - 1);
+        const double ya = (double)(Y0 + ra), yb = (double)(Y0 + rb - 1);
+
+        bool keep = false;
+        Comp c;
+        int Lk = 0, rlo = ra, rhi = rb;
+        if (lane < K) {
+            c = make_comp(lane, type, rp->px, rp->py, rp->scale, rp->w00, rp->w01, rp->w11, rp->theta, bd);
+            double Tk = dropping ? Tdrop + (double)__logf((float)(fabs(c.A) / eps_sky)) : 100.0;
+            if (dropping) {
+                double qmin = quad_min_rect(c.qa, c.qb, c.qc, xa - c.mx, xb - c.mx, ya - c.my, yb - c.my);
+                keep = (0.5 * qmin <= Tk);
+                float hw = __fsqrt_rn(2.0f * (float)fmax(Tk, 0.0) / (float)c.iyy) + 1.0f;
+                rlo = max(ra, (int)floorf((float)(c.my - (double)Y0) - hw));
+                rhi = min(rb, (int)ceilf((float)(c.my - (double)Y0) + hw) + 1);
+                keep = keep && (rhi > rlo);
+            } else {
+                keep = true;
+            }
+            Lk = seg_len(c.qc, fmin(fmax(Tk, 1.0), 300.0));
+        }
+        const unsigned long long km = __ballot(keep);
+        const int Kk = __popcll(km);
+        __syncthreads();   // previous source's table reads are done
+        if (keep) {
+            int p = __popcll(km & ((1ull << lane) - 1ull));
+            T.A[p] = c.A; T.mx[p] = c.mx; T.my[p] = c.my;
+            T.qa[p] = c.qa * EXP_SCALE; T.qb[p] = c.qb * EXP_SCALE; T.qc[p] = c.qc * EXP_SCALE;
+            T.eq[p] = exp(-c.qc);
+            T.L[p] = Lk;
+            T.r0[p] = rlo; T.r1[p] = rhi;
+        }
+        if (lane < HW_PAD) {   // zero components behind the table (amplitude 0, ratio 1)
+            int p = Kk + lane;
+            T.A[p] = 0.0; T.mx[p] = 0.0; T.my[p] = 0.0;
+            T.qa[p] = 0.0; T.qb[p] = 0.0; T.qc[p] = 0.0;
+            T.eq[p] = 1.0;
+        }
+        __syncthreads();
+        if (a.variant == 0) {
+            // direct evaluator: the halves split the kept components
+            const int kh = (Kk + 1) / 2;
+            const int k0 = half ? kh : 0, k1 = half ? Kk : kh;
+            for (int row = ra; row < rb; row++) {
+                double v = eval_direct(T, k0, k1, x, (double)(Y0 + row), 1.0 / EXP_SCALE);
+                if (on) lds_add(&acc[row * HW_TW + col], v);
+            }
+            continue;
+        }
+        // pairs of groups: the lower half takes gA components, the upper half the next gB
+        for (int p0 = 0; p0 < Kk; p0 += 2 * REC_G) {
+            const int R = min(2 * REC_G, Kk - p0);
+            const int gA = (R + 1) / 2;
+            int L = T.L[p0], ga = T.r0[p0], gb = T.r1[p0];
+            for (int i = 1; i < R; i++) {
+                L = min(L, T.L[p0 + i]);
+                ga = min(ga, T.r0[p0 + i]);
+                gb = max(gb, T.r1[p0 + i]);
+            }
+            L = __builtin_amdgcn_readfirstlane(L);
+            ga = __builtin_amdgcn_readfirstlane(ga);
+            gb = __builtin_amdgcn_readfirstlane(gb);
+            const int k0 = half ? p0 + gA : p0;
+            if (L < 4) {
+                // pathologically sharp component: evaluate this pair of groups directly
+                const int k1 = half ? p0 + R : p0 + gA;
+                for (int row = ga; row < gb; row++) {
+                    double v = eval_direct(T, k0, k1, x, (double)(Y0 + row), 1.0 / EXP_SCALE);
+                    if (on) lds_add(&acc[row * HW_TW + col], v);
+                }
+                continue;
+            }
+            double *colp = acc + col;
+            switch (gA) {
+            case 6: rec_group_hw<6>(T, et, k0, x, Y0, ga, gb, L, on, colp); break;
+            case 5: rec_group_hw<5>(T, et, k0, x, Y0, ga, gb, L, on, colp); break;
+            case 4: rec_group_hw<4>(T, et, k0, x, Y0, ga, gb, L, on, colp); break;
+            case 3: rec_group_hw<3>(T, et, k0, x, Y0, ga, gb, L, on, colp); break;
+            case 2: rec_group_hw<2>(T, et, k0, x, Y0, ga, gb, L, on, colp); break;
+            default: rec_group_hw<1>(T, et, k0, x, Y0, ga, gb, L, on, colp); break;
+            }
+        }
+    }
+
+    // epilogue: one wave-instruction covers two 256-B row segments (rows 2r and 2r+1)
+    __syncthreads();
+    const double eps = bd->eps;
+    const bool store = !(a.flags & CEL_RENDER_NO_STORE);
+    const bool ll = (a.flags & CEL_RENDER_LOGLIK) != 0;
+    double part = 0.0;
+    const int64_t plane = (int64_t)b * a.H * a.W;
+    if (xi < a.W) {
+#pragma unroll 4
+        for (int r = 0; r < HW_TH / 2; r++) {
+            int y = Y0 + 2 * r + half;
+            if (y < a.H) {
+                double lam = eps + acc[r * 64 + lane];
+                int64_t idx = plane + (int64_t)y * a.W + xi;
+                if (store) a.lambda[idx] = lam;
+                if (ll) part += a.nelec[idx] * log(lam) - lam;
+            }
+        }
+    }
+    if (ll) {
+        part = wave_sum(part);
+        if (lane == 0) a.partials[tile] = part;
+    }
+    if (a.timing && lane == 0) {
+        a.timing[3 * (size_t)blockIdx.x + 0] = t_start;
+        a.timing[3 * (size_t)blockIdx.x + 1] = wall_clock64();
+        a.timing[3 * (size_t)blockIdx.x + 2] = ((unsigned long long)tile << 32) | (unsigned)cnt;
+    }
+}

@@ -61,7 +61,10 @@ enum {
     CEL_OPT_PROFILE = 3,   /* 1 = bracket every kernel launch with HIP events              */
     CEL_OPT_TILE_ORDER = 4,/* 1 (default) = launch render tiles heaviest-first; never changes results */
     CEL_OPT_TILE_ROWS = 5, /* rows per render tile, 32 (default) or 64; read by cel_images_create  */
-    CEL_OPT_TILE_TIMING = 6 /* diagnostic: 1 = k_render stamps every tile's start/end wall clock   */
+    CEL_OPT_TILE_TIMING = 6,/* diagnostic: 1 = k_render stamps every tile's start/end wall clock   */
+    CEL_OPT_TILE_LAYOUT = 7 /* render tile geometry, read by cel_images_create:
+                               0 = 64 columns x TILE_ROWS rows, one lane per column;
+                               1 (default) = 32 columns x 64 rows, two component groups per column */
 };
 
 /* kernels reported by cel_profile_get */
