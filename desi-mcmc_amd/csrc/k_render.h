@@ -55,6 +55,78 @@ __device__ inline Comp make_comp(int k, int type, double px, double py, double s
     return c;
 }
 
+// ---- the same, with every load hoisted out of the per-source loop ------------------------------
+// What lane k needs from the band PSF and the profile tables depends only on k and on the source
+// kind, so both roles are fetched once per tile into registers (LaneConst); per source nothing but
+// the 128-byte record is read, and that record is fetched one source ahead, one dword per lane
+// (lanes 0..31), and broadcast to scalar registers with v_readlane (RecU).  Without this every
+// source of a tile started with three dependent global-memory round trips (list -> record ->
+// PSF/profile gathers), ~1-2 us of an ~10 us source, which two waves per SIMD cannot hide.
+struct LaneConst {
+    double g_cxx, g_cxy, g_cyy, g_w, g_mux, g_muy, g_var, g_amp;   // galaxy role: PSF comp k/14, profile order[k%14]
+    double s_cxx, s_cxy, s_cyy, s_w, s_mux, s_muy;                 // star role: PSF comp k (k < 3)
+    bool g_exp;
+};
+
+__device__ inline LaneConst lane_consts(int lane, const BandDev *__restrict__ bd) {
+    LaneConst lc;
+    const int kk = min(lane / K_PROF, K_PSF - 1);
+    const int j = c_prof_order[lane % K_PROF];
+    lc.g_cxx = bd->cxx[kk]; lc.g_cxy = bd->cxy[kk]; lc.g_cyy = bd->cyy[kk];
+    lc.g_w = bd->w[kk]; lc.g_mux = bd->mux[kk]; lc.g_muy = bd->muy[kk];
+    lc.g_var = c_prof_var[j]; lc.g_amp = c_prof_amp[j]; lc.g_exp = (j < K_EXP);
+    const int ks = min(lane, K_PSF - 1);
+    lc.s_cxx = bd->cxx[ks]; lc.s_cxy = bd->cxy[ks]; lc.s_cyy = bd->cyy[ks];
+    lc.s_w = bd->w[ks]; lc.s_mux = bd->mux[ks]; lc.s_muy = bd->muy[ks];
+    return lc;
+}
+
+struct RecU {   // a source record in wave-uniform registers
+    double px, py, scale, w00, w01, w11, theta;
+    int x0, x1, y0, y1, type;
+};
+
+__device__ inline double rl_double(int v, int dw) {
+    return __hiloint2double(__builtin_amdgcn_readlane(v, dw + 1), __builtin_amdgcn_readlane(v, dw));
+}
+
+// recw = dword (lane & 31) of the record, as loaded by rec_fetch
+__device__ inline RecU rec_unpack(int recw) {
+    RecU r;
+    r.px = rl_double(recw, 0); r.py = rl_double(recw, 2); r.scale = rl_double(recw, 4);
+    r.w00 = rl_double(recw, 6); r.w01 = rl_double(recw, 8); r.w11 = rl_double(recw, 10);
+    r.theta = rl_double(recw, 12);
+    r.x0 = __builtin_amdgcn_readlane(recw, 14); r.x1 = __builtin_amdgcn_readlane(recw, 15);
+    r.y0 = __builtin_amdgcn_readlane(recw, 16); r.y1 = __builtin_amdgcn_readlane(recw, 17);
+    r.type = __builtin_amdgcn_readlane(recw, 18);
+    return r;
+}
+
+__device__ inline int rec_fetch(const SrcRec *__restrict__ recs, int s, int lane) {
+    return reinterpret_cast<const int *>(recs + s)[lane & 31];
+}
+
+__device__ inline Comp make_comp_lc(const LaneConst &lc, const RecU &r) {
+    double cxx, cxy, cyy, wt, mux, muy;
+    if (r.type == 1) {
+        double amp = lc.g_exp ? r.theta * lc.g_amp : (1.0 - r.theta) * lc.g_amp;
+        cxx = lc.g_cxx + lc.g_var * r.w00; cxy = lc.g_cxy + lc.g_var * r.w01; cyy = lc.g_cyy + lc.g_var * r.w11;
+        wt = lc.g_w * amp; mux = lc.g_mux; muy = lc.g_muy;
+    } else {
+        cxx = lc.s_cxx; cxy = lc.s_cxy; cyy = lc.s_cyy; wt = lc.s_w; mux = lc.s_mux; muy = lc.s_muy;
+    }
+    double det = cxx * cyy - cxy * cxy;
+    double inv = 1.0 / det;
+    Comp c;
+    c.qa = cyy * inv; c.qb = -cxy * inv; c.qc = cxx * inv;
+    c.A = r.scale * wt * (0.5 / PI_D) * sqrt(inv);
+    c.mx = r.px + mux;
+    c.my = r.py + muy;
+    c.ixx = (double)(__frcp_rn((float)cxx) * 0.999999f);
+    c.iyy = (double)(__frcp_rn((float)cyy) * 0.999999f);
+    return c;
+}
+
 __device__ inline double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     return v;

@@ -96,12 +96,22 @@ k_render_hw(RenderArgs a) {
     const double eps_sky = bd->eps;
     const bool dropping = (a.variant != 0) && (Tdrop > 0.0) && (eps_sky > 0.0);
 
-    for (int e = 0; e < cnt; e++) {
-        int64_t at = off + e;
-        if (at >= a.capacity) break;
-        const int s = __builtin_amdgcn_readfirstlane(a.lists[at]);
-        const SrcRec *rp = recs + s;
-        const int type = rp->type;
+    const LaneConst lc = lane_consts(lane, bd);
+    // the tile's list, 64 indices per coalesced load; the next source's record is in flight while
+    // the current one is evaluated
+    const int nent = (int)min((int64_t)cnt, a.capacity > off ? a.capacity - off : (int64_t)0);
+    int idx64 = (lane < nent) ? a.lists[off + lane] : 0;
+    int recw_next = (nent > 0) ? rec_fetch(recs, __builtin_amdgcn_readlane(idx64, 0), lane) : 0;
+
+    for (int e = 0; e < nent; e++) {
+        const int recw = recw_next;
+        if (e + 1 < nent) {
+            if (((e + 1) & 63) == 0) idx64 = (e + 1 + lane < nent) ? a.lists[off + e + 1 + lane] : 0;
+            recw_next = rec_fetch(recs, __builtin_amdgcn_readlane(idx64, (e + 1) & 63), lane);
+        }
+        const RecU rec = rec_unpack(recw);
+        const RecU *rp = &rec;
+        const int type = rec.type;
         const int K = (type == 0) ? K_PSF : K_GAL;
         const int bx0 = rp->x0, bx1 = rp->x1, by0 = rp->y0, by1 = rp->y1;
         const int ra = max(by0, Y0) - Y0, rb = min(by1, Y0 + HW_TH) - Y0;
@@ -113,7 +123,7 @@ k_render_hw(RenderArgs a) {
         Comp c;
         int Lk = 0, rlo = ra, rhi = rb;
         if (lane < K) {
-            c = make_comp(lane, type, rp->px, rp->py, rp->scale, rp->w00, rp->w01, rp->w11, rp->theta, bd);
+            c = make_comp_lc(lc, rec);
             double Tk = dropping ? Tdrop + (double)__logf((float)(fabs(c.A) / eps_sky)) : 100.0;
             if (dropping) {
                 double qmin = quad_min_rect(c.qa, c.qb, c.qc, xa - c.mx, xb - c.mx, ya - c.my, yb - c.my);
