@@ -70,6 +70,7 @@ static int fail(int code, const char *fmt, ...) {
 #include "k_render.h"
 #include "k_render_hw.h"
 #include "k_misc.h"
+#include "k_patch_ll.h"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -711,7 +712,7 @@ int cel_stamp_boxes(cel_images *im, cel_sources *src, int band, int32_t *boxes, 
     for (int64_t s = 0; s < S; s++) {
         boxes[4 * s + 0] = h[s].y0; boxes[4 * s + 1] = h[s].y1;
         boxes[4 * s + 2] = h[s].x0; boxes[4 * s + 3] = h[s].x1;
-        status[s] = h[s].type >= 0 ? 1 : 0;
+        status[s] = h[s].type >= 0 ? 1 : (h[s].type == -3 ? -1 : 0);
     }
     return CEL_OK;
 }
@@ -736,10 +737,10 @@ int cel_render_stamps(cel_images *im, cel_sources *src, int band, int scaled, co
         bool ok;
         if (boxes_in) {
             y0 = boxes_in[4 * s]; y1 = boxes_in[4 * s + 1]; x0 = boxes_in[4 * s + 2]; x1 = boxes_in[4 * s + 3];
-            ok = (y1 > y0 && x1 > x0);
+            ok = (y1 > y0 && x1 > x0) && hs[s] != -1;   // an overlap-test miss is None whatever the limits
         } else {
             y0 = hb[4 * s]; y1 = hb[4 * s + 1]; x0 = hb[4 * s + 2]; x1 = hb[4 * s + 3];
-            ok = hs[s] != 0;
+            ok = hs[s] > 0;
         }
         obox[s] = make_int4(x0, x1, y0, y1);
         if (!ok) continue;
@@ -787,6 +788,78 @@ done:
     if (d_obox) (void)hipFree(d_obox);
     if (d_off) (void)hipFree(d_off);
     if (mem != CEL_DEVICE && d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+// ---- per-source conditional log-likelihoods ---------------------------------------------------
+int cel_patch_loglik(cel_images *im, cel_sources *src, const int32_t *boxes, const int64_t *offsets,
+                     const double *data, int mem, int mode, double *ll_out) {
+    if (!im || !src || !boxes || !offsets || !ll_out) return fail(CEL_ERR_INVALID, "cel_patch_loglik: null argument");
+    if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
+    if (mode != 0 && mode != 1) return fail(CEL_ERR_INVALID, "mode must be 0 (conditional) or 1 (isolated)");
+    cel_ctx *c = im->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int B = im->B;
+    const int64_t P = src->S;
+    if (P == 0) return CEL_OK;
+    std::vector<int4> hbox((size_t)B);
+    for (int b = 0; b < B; b++) {
+        int y0 = boxes[4 * b], y1 = boxes[4 * b + 1], x0 = boxes[4 * b + 2], x1 = boxes[4 * b + 3];
+        int64_t area = (y1 > y0 && x1 > x0) ? (int64_t)(y1 - y0) * (x1 - x0) : 0;
+        if (offsets[b + 1] - offsets[b] != area)
+            return fail(CEL_ERR_INVALID, "band %d: offsets give %lld patch values, the box has %lld pixels", b,
+                        (long long)(offsets[b + 1] - offsets[b]), (long long)area);
+        if (area > 0 && (y0 < 0 || x0 < 0 || y1 > im->H || x1 > im->W))
+            return fail(CEL_ERR_INVALID, "band %d: patch limits outside the image", b);
+        hbox[b] = make_int4(x0, x1, y0, y1);
+    }
+    if (offsets[B] > 0 && !data) return fail(CEL_ERR_INVALID, "cel_patch_loglik: null data");
+    int rc = run_prep(im, src);
+    if (rc) return rc;
+    im->last_S = P;
+    int4 *d_box = nullptr;
+    int64_t *d_off = nullptr;
+    double *d_data = nullptr, *d_out = nullptr;
+    std::vector<double> hout((size_t)(P * B));
+    hipError_t e;
+#define PL_TRY(expr)                                                                     \
+    do {                                                                                 \
+        e = (expr);                                                                      \
+        if (e != hipSuccess) { rc = fail(CEL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); goto done; } \
+    } while (0)
+    PL_TRY(hipMalloc((void **)&d_box, sizeof(int4) * B));
+    PL_TRY(hipMalloc((void **)&d_off, sizeof(int64_t) * (B + 1)));
+    PL_TRY(hipMalloc((void **)&d_out, sizeof(double) * P * B));
+    PL_TRY(hipMemcpyAsync(d_box, hbox.data(), sizeof(int4) * B, hipMemcpyHostToDevice, c->stream));
+    PL_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice, c->stream));
+    if (mem == CEL_DEVICE) {
+        d_data = const_cast<double *>(data);
+    } else {
+        PL_TRY(hipMalloc((void **)&d_data, sizeof(double) * (offsets[B] > 0 ? offsets[B] : 1)));
+        if (offsets[B] > 0)
+            PL_TRY(hipMemcpyAsync(d_data, data, sizeof(double) * offsets[B], hipMemcpyHostToDevice, c->stream));
+    }
+    {
+        int pi = prof_begin(c, CEL_K_STAMPS);
+        hipLaunchKernelGGL(k_patch_ll, dim3((unsigned)(P * B)), dim3(256), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                           d_box, d_off, d_data, mode, d_out);
+        prof_end(c, pi);
+    }
+    PL_TRY(hipGetLastError());
+    PL_TRY(hipMemcpyAsync(hout.data(), d_out, sizeof(double) * P * B, hipMemcpyDeviceToHost, c->stream));
+    PL_TRY(hipStreamSynchronize(c->stream));
+    for (int64_t p = 0; p < P; p++) {
+        double s = 0.0;
+        for (int b = 0; b < B; b++) s += hout[(size_t)(p * B + b)];   // band order, like the reference's image loop
+        ll_out[p] = s;
+    }
+#undef PL_TRY
+done:
+    (void)hipStreamSynchronize(c->stream);
+    if (d_box) (void)hipFree(d_box);
+    if (d_off) (void)hipFree(d_off);
+    if (d_out) (void)hipFree(d_out);
+    if (mem != CEL_DEVICE && d_data) (void)hipFree(d_data);
     return rc;
 }
 

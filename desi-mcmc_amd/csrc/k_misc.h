@@ -16,7 +16,9 @@ k_stamps(const BandDev *__restrict__ bands, int band, const SrcRec *__restrict__
     const SrcRec *rp = recs + jb.src;
     const int4 ob = obox[jb.src];           // output box: x0, x1, y0, y1
     int type = rp->type;
-    if (type < 0) type = -1 - type;         // caller-imposed limits: still a valid source kind
+    // caller-imposed limits: still a valid source kind.  Record types: 0/1 star/galaxy with a
+    // stamp, -1/-2 star/galaxy whose own box is empty, -3 star failing the overlap test
+    if (type < 0) type = (type == -2) ? 1 : 0;
     const int K = (type == 0) ? K_PSF : K_GAL;
     const BandDev *bd = bands + band;
     if (lane < K)

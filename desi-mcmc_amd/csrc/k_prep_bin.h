@@ -54,7 +54,7 @@ k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int w
         // celeste.py:130-140: overlap test (with the reference's axis mix-up, Q1) + int() box
         bool miss = (px < -50 || px > 2.0 * H || py < -50 || px > 2.0 * W);
         if (miss || !(px == px) || !(py == py)) {
-            r.type = -1;
+            r.type = -3;    // the reference returns (None, None, None) here, whatever the limits
         } else {
             double bound = bd.R;
             int lx = (int)clampd(px - bound, -BIG, BIG), hx = (int)clampd(px + bound + 1, -BIG, BIG);

@@ -199,6 +199,30 @@ class ImageSet(object):
         L.check(L.lib().cel_field_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(n_srcpix=a.value, n_gauss=b.value, n_tile_entries=c.value)
 
+    def patch_loglik(self, sources, boxes, patches, isolated=False):
+        """Conditional log-likelihood of each of the P proposals in `sources` on fixed patches.
+        boxes: (B,4) int y0,y1,x0,x1 (empty box = band without a sample image);
+        patches: list of B arrays (or None) of the box shapes.  -> ll[P]
+        (Source.log_likelihood / log_likelihood_isolated, sources.py:134-237)"""
+        boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(self.B, 4)
+        offs = np.zeros(self.B + 1, dtype=np.int64)
+        flat = []
+        for b in range(self.B):
+            y0, y1, x0, x1 = boxes[b]
+            n = int(y1 - y0) * int(x1 - x0) if (y1 > y0 and x1 > x0) else 0
+            if n:
+                p = L.f64(patches[b])
+                if p.shape != (y1 - y0, x1 - x0):
+                    raise ValueError("band %d: patch shape %s does not match its box" % (b, p.shape))
+                flat.append(p.ravel())
+            offs[b + 1] = offs[b] + n
+        data = np.concatenate(flat) if flat else np.zeros(1)
+        out = np.zeros(sources.S)
+        L.check(L.lib().cel_patch_loglik(self._h, sources._h, boxes.ctypes.data_as(L.c_int32_p),
+                                         offs.ctypes.data_as(L.c_int64_p), data.ctypes.data, L.CEL_HOST,
+                                         1 if isolated else 0, L.dptr(out)))
+        return out
+
     def stamp_boxes(self, sources, band):
         S = sources.S
         boxes = np.zeros((S, 4), dtype=np.int32)

@@ -158,8 +158,9 @@ int cel_debug_tile_timing(cel_images *img, uint64_t *out, int64_t *n_tiles);
 /* ---- stamps --------------------------------------------------------------------------- */
 /* gen_point_source_psf_image (celeste.py:114-176) / gen_galaxy_psf_image
  * (celeste_galaxy_conditionals.py:185-214) for every source of `src` in one band.
- * Step 1: boxes[s*4..] = y0, y1, x0, x1 and status[s] (1 = has a stamp, 0 = the reference
- *         returns (None, None, None) or the box is empty).  Host arrays.
+ * Step 1: boxes[s*4..] = y0, y1, x0, x1 and status[s]: 1 = has a stamp, 0 = the box is empty,
+ *         -1 = the reference's overlap test fails and it returns (None, None, None)
+ *         (celeste.py:130-135) whatever limits the caller imposes.  Host arrays.
  * Step 2: the caller sizes a packed buffer (offsets[s+1]-offsets[s] = box area, or the area of
  *         the caller-imposed box in boxes_in) and the stamps are written into it, row-major.
  *   scaled: 0 = unit flux, 1 = multiplied by counts[s][band] (gen_src_image_with_fluxes,
@@ -169,6 +170,23 @@ int cel_debug_tile_timing(cel_images *img, uint64_t *out, int64_t *n_tiles);
 int cel_stamp_boxes(cel_images *img, cel_sources *src, int band, int32_t *boxes, int32_t *status);
 int cel_render_stamps(cel_images *img, cel_sources *src, int band, int scaled, const int32_t *boxes_in,
                       const int64_t *offsets, double *out, int mem);
+
+/* ---- per-source conditional log-likelihoods --------------------------------------------- */
+/* Source.log_likelihood (CelestePy/sources.py:134-183) and Source.log_likelihood_isolated
+ * (:188-237) for a batch of P parameter proposals of ONE source -- what slice sampling / HMC
+ * call 10-50 times per source per sweep (sources.py:308-319).
+ *   src      P proposals (type, radec, counts[B], shape), usually one coordinate varied
+ *   boxes    B*4 ints: the fixed limits y0,y1,x0,x1 of the source's sample patch per band
+ *            (samp_img.y0/y1/x0/x1); an empty box = no sample image in that band
+ *   offsets  B+1: packed position of each band's patch data; offsets[b+1]-offsets[b] = box area
+ *   data     patch values, row-major per band: photons attributed to the source (mode 0) or
+ *            the observed nelec patch (mode 1); `mem` says host or device
+ *   mode 0   ll = sum_b [ sum_{m>0} log(m) z - counts_b sum(psf weights_b) ],  m = counts_b * stamp
+ *            (a star failing the overlap test contributes -counts_b sum(weights_b), :160-163)
+ *   mode 1   ll = sum_b [ sum log(m + eps_b) z - sum (m + eps_b) ]
+ *   ll_out   P doubles (host) */
+int cel_patch_loglik(cel_images *img, cel_sources *src, const int32_t *boxes, const int64_t *offsets,
+                     const double *data, int mem, int mode, double *ll_out);
 
 /* ---- generic evaluator ------------------------------------------------------------------ */
 /* gmm_like_2d (util/like/gmm_like_fast.pyx:130-176; wrapper util/like/__init__.py:7-11):

@@ -456,6 +456,45 @@ void orc_gen_model_image_fullframe(const orc_band *band, int H, int W, int64_t S
     free(f_s);
 }
 
+/* One image's term of Source.log_likelihood (sources.py:134-183, mode 0) or
+ * Source.log_likelihood_isolated (:188-237, mode 1): the source's unit stamp on the FIXED patch
+ * limits box = {y0,y1,x0,x1} (compute_scatter_on_pixels with xlim/ylim, :351-388), scaled by
+ * counts = flux_in_image (:120-129), against the patch data. */
+double orc_patch_loglik(const orc_band *b, int H, int W, int type, const double u[2],
+                        const double shape[4], double counts, const int box[4], const double *data,
+                        int mode) {
+    double wsum = (b->w[0] + b->w[1]) + b->w[2];            /* np.sum(fits_img.weights) */
+    int64_t n = (int64_t)(box[1] - box[0]) * (box[3] - box[2]);
+    if (n <= 0) return 0.0;
+    double *patch = (double *)malloc(sizeof(double) * (size_t)n);
+    if (type == 0) {
+        double v[2];
+        int own[4];
+        if (!orc_star_box(b, H, W, u, v, own)) {            /* psf_ns is None (:160-163) */
+            free(patch);
+            return -counts * wsum;
+        }
+        orc_star_patch(b, v, box, patch);
+    } else {
+        double pis[K_GAL], means[2 * K_GAL], covs[4 * K_GAL], pxy[2], Tinv[4];
+        orc_galaxy_table(b, shape, u, pis, means, covs, pxy, Tinv);
+        orc_galaxy_patch(pis, means, covs, box, patch);
+    }
+    long double a = 0.0L, msum = 0.0L;
+    for (int64_t i = 0; i < n; i++) {
+        double m = counts * patch[i];
+        if (mode == 0) {
+            if (m > 0.) a += (long double)(log(m) * data[i]);        /* mask = model_patch > 0 (:172-174) */
+        } else {
+            m += b->eps;                                              /* :219 */
+            a += (long double)(log(m) * data[i]);
+            msum += (long double)m;
+        }
+    }
+    free(patch);
+    return mode == 0 ? (double)a - counts * wsum : (double)(a - msum);
+}
+
 /* sources.py:6-12 poisson_loglike on a patch with mask (mask may be NULL). */
 double orc_poisson_loglike(const double *data, const double *model, const uint8_t *mask, int64_t n) {
     long double a = 0.0L, bsum = 0.0L;

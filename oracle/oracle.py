@@ -215,6 +215,18 @@ def gen_model_image_fullframe(band, H, W, radec, counts_b):
     return lam
 
 
+def patch_loglik(band, H, W, typ, u, shape, counts, box, data, mode=0):
+    """One image's term of Source.log_likelihood (mode 0) / log_likelihood_isolated (mode 1)."""
+    b, bp = _d(band)
+    u, up = _d(u)
+    sh, sp = _d(shape)
+    box = np.ascontiguousarray(box, dtype=np.int32)
+    data, dp = _d(data)
+    lib().orc_patch_loglik.restype = C.c_double
+    return lib().orc_patch_loglik(bp, C.c_int(H), C.c_int(W), C.c_int(int(typ)), up, sp, C.c_double(float(counts)),
+                                  box.ctypes.data_as(_ip), dp, C.c_int(int(mode)))
+
+
 def poisson_loglike(data, model, mask=None):
     data, dp = _d(data)
     model, mp = _d(model)

@@ -400,6 +400,60 @@ def gen_config1(imgs):
          one_u=star.u, one_flux=keep[b, 2:], one_patch=one, one_lam=one_lam, one_ll=np.array(one_ll))
 
 
+def gen_source_ll():
+    """source_ll.npz: the reference's Source.log_likelihood / log_likelihood_isolated
+    (CelestePy/sources.py:134-237) on fixed sample patches, for batches of proposals."""
+    import types
+
+    import CelestePy.sources as ref_src
+    H, W = 80, 96
+    rs = np.random.RandomState(5)
+    nelec = rs.poisson(400.0, size=(5, H, W)).astype(np.float64)
+    imgs = virtual_images("srcll", H, W, nelec=nelec)
+    out = stack_bands(imgs)
+    out.update(H=np.array(H), W=np.array(W), nelec=nelec, bands_used=np.array([1, 2, 3]))
+    specs = [(0, [40.3, 33.8], [0.5, 1.0, 0.0, 0.5]),
+             (1, [55.6, 41.2], [0.35, 1.2, 60.0, 0.55]),
+             (0, [3.2, 70.5], [0.5, 1.0, 0.0, 0.5])]
+    for ci, (kind, pix, shape) in enumerate(specs):
+        u = imgs[2].pixel2equa(np.array(pix))
+        flux = np.array([5.0, 12.0, 20.0, 26.0, 30.0])
+        params = SrcParams(u=u, a=kind, fluxes=flux, theta=shape[0], sigma=shape[1], phi=shape[2], rho=shape[3])
+        src = ref_src.Source(params, model=None)
+        boxes, zs = [], []
+        for bi in (1, 2, 3):
+            xlim, ylim = ref_src.Source.get_bounding_box(params, imgs[bi])
+            xlim, ylim = (int(xlim[0]), int(xlim[1])), (int(ylim[0]), int(ylim[1]))
+            patch, _, _ = src.compute_model_patch(imgs[bi], xlim=xlim, ylim=ylim)
+            z = rs.poisson(patch).astype(np.float64)
+            samp = types.SimpleNamespace(data=z, x0=xlim[0], x1=xlim[1], y0=ylim[0], y1=ylim[1])
+            src.sample_image_list.append((samp, imgs[bi], None))
+            boxes.append([ylim[0], ylim[1], xlim[0], xlim[1]])
+            zs.append(z)
+        P = 7
+        us = u[None, :] + rs.normal(0.0, 4e-5, size=(P, 2))
+        us[0] = u
+        fl = flux[None, :] * rs.uniform(0.5, 2.0, size=(P, 5))
+        fl[0] = flux
+        sh = np.array(shape)[None, :] * rs.uniform(0.8, 1.25, size=(P, 4))
+        sh[:, 0] = np.clip(sh[:, 0], 0.02, 0.98)
+        sh[:, 3] = np.clip(sh[:, 3], 0.1, 0.99)
+        sh[0] = shape
+        if kind == 0:
+            us[P - 1] = imgs[2].pixel2equa(np.array([-70.0, 20.0]))      # fails the overlap test: psf_ns is None
+        ll0 = np.array([src.log_likelihood(u=us[i], fluxes=fl[i], shape=sh[i]) for i in range(P)])
+        n_iso = P - 1 if kind == 0 else P                                  # the isolated form asserts on a miss
+        ll1 = np.array([src.log_likelihood_isolated(u=us[i], fluxes=fl[i], shape=sh[i]) for i in range(n_iso)])
+        flat, offs, shapes = pack_ragged(zs)
+        out.update({"c%d_kind" % ci: np.array(kind), "c%d_u" % ci: u, "c%d_flux" % ci: flux,
+                    "c%d_shape" % ci: np.array(shape), "c%d_boxes" % ci: np.array(boxes, dtype=np.int64),
+                    "c%d_z" % ci: flat, "c%d_zoffs" % ci: offs, "c%d_zshapes" % ci: shapes,
+                    "c%d_us" % ci: us, "c%d_fl" % ci: fl, "c%d_sh" % ci: sh, "c%d_ll0" % ci: ll0,
+                    "c%d_ll1" % ci: ll1})
+    out["ncases"] = np.array(len(specs))
+    save("source_ll.npz", **out)
+
+
 if __name__ == "__main__":
     imgs = gen_bands()
     gen_wcs(imgs)
@@ -409,3 +463,4 @@ if __name__ == "__main__":
     gen_galaxy_stamps(imgs)
     gen_mini_field()
     gen_config1(imgs)
+    gen_source_ll()

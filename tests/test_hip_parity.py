@@ -313,7 +313,8 @@ def test_edge_cases_empty_ragged_offimage(cel, ctx, orc):
     np.testing.assert_allclose(iset.model_images(), o_lam, rtol=RT_LAM)
     np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
     boxes, status = iset.stamp_boxes(sset, 0)
-    assert status[1] == 0 and status[4] == 0 and status[7] == 0        # Q1 miss, far galaxy boxes empty
+    # status: 1 stamp, 0 empty box, -1 the reference's overlap test fails (Q1: returns None)
+    assert status[1] == -1 and status[4] == 0 and status[7] == 0
 
 
 def test_sharp_psf_forces_direct_fallback_and_short_segments(cel, ctx, orc):
@@ -421,3 +422,42 @@ def test_row_strips_tile_the_frame(cel, ctx, world):
     np.testing.assert_allclose(parts, llb, rtol=1e-13)
     with pytest.raises(ValueError):
         cel.ImageSet(ctx, f.bands, 64, W).set_window(150, H)       # window does not fit the frame
+
+
+def test_source_conditional_loglik_golden(cel):
+    """Source.log_likelihood / log_likelihood_isolated / compute_model_patch (sources.py:134-237,
+    351-395) against values the reference's own Source class produced"""
+    from desi_mcmc_amd import sources
+    g = load_golden("source_ll.npz")
+    H, W = int(g["H"]), int(g["W"])
+    imgs = frame_images(cel, {k: g[k] for k in g}, H, W, nelec=g["nelec"])
+    used = g["bands_used"]
+    for ci in range(int(g["ncases"])):
+        kind = int(g["c%d_kind" % ci])
+        shape = g["c%d_shape" % ci]
+        params = cel.SrcParams(u=g["c%d_u" % ci], a=kind, fluxes=g["c%d_flux" % ci], theta=shape[0],
+                               sigma=shape[1], phi=shape[2], rho=shape[3])
+        src = sources.Source(params)
+        zs = unpack_ragged(g["c%d_z" % ci], g["c%d_zoffs" % ci], g["c%d_zshapes" % ci])
+        boxes = g["c%d_boxes" % ci]
+        for j, b in enumerate(used):
+            # the box the reference derived (Source.get_bounding_box, sources.py:83-96)
+            xlim, ylim = sources.Source.get_bounding_box(params, imgs[b])
+            assert (int(ylim[0]), int(ylim[1]), int(xlim[0]), int(xlim[1])) == tuple(boxes[j])
+            samp = sources.SamplePatch(zs[j], (boxes[j, 0], boxes[j, 1]), (boxes[j, 2], boxes[j, 3]))
+            src.sample_image_list.append((samp, imgs[b], None))
+        us, fl, sh = g["c%d_us" % ci], g["c%d_fl" % ci], g["c%d_sh" % ci]
+        ll0 = src.log_likelihood_batch(us, fl, sh)
+        np.testing.assert_allclose(ll0, g["c%d_ll0" % ci], rtol=1e-11)
+        n1 = len(g["c%d_ll1" % ci])
+        ll1 = src.log_likelihood_batch(us[:n1], fl[:n1], sh[:n1], isolated=True)
+        np.testing.assert_allclose(ll1, g["c%d_ll1" % ci], rtol=1e-11)
+        # scalar forms with the reference's signatures
+        np.testing.assert_allclose(src.log_likelihood(), g["c%d_ll0" % ci][0], rtol=1e-11)
+        np.testing.assert_allclose(src.log_likelihood(u=us[2], fluxes=fl[2], shape=sh[2]), g["c%d_ll0" % ci][2], rtol=1e-11)
+        np.testing.assert_allclose(src.location_likelihood(us[1]),
+                                   src.log_likelihood_batch(us[1:2])[0], rtol=1e-14)
+        np.testing.assert_allclose(src.log_likelihood_isolated(), g["c%d_ll1" % ci][0], rtol=1e-11)
+        # compute_model_patch reproduces the Poisson mean the golden's photons were drawn from
+        p, yl, xl = src.compute_model_patch(imgs[used[0]], xlim=(boxes[0, 2], boxes[0, 3]), ylim=(boxes[0, 0], boxes[0, 1]))
+        assert p.shape == zs[0].shape and p.min() >= 0

@@ -236,3 +236,27 @@ def test_poisson_loglike_mask():
     good = (m > 0) & mask
     exp = np.sum(np.log(m[good]) * d[good]) - np.sum(m[good])   # sources.py:6-12
     np.testing.assert_allclose(orc.poisson_loglike(d, m, mask), exp, rtol=1e-13)
+
+
+def test_source_conditional_loglik_golden():
+    """Source.log_likelihood / log_likelihood_isolated (sources.py:134-237) run by the reference"""
+    g = load_golden("source_ll.npz")
+    B = orc.pack_bands(g)
+    H, W = int(g["H"]), int(g["W"])
+    used = g["bands_used"]
+    for ci in range(int(g["ncases"])):
+        kind = int(g["c%d_kind" % ci])
+        zs = unpack_ragged(g["c%d_z" % ci], g["c%d_zoffs" % ci], g["c%d_zshapes" % ci])
+        boxes = g["c%d_boxes" % ci]
+        us, fl, sh = g["c%d_us" % ci], g["c%d_fl" % ci], g["c%d_sh" % ci]
+        for mode, key in ((0, "ll0"), (1, "ll1")):
+            exp = g["c%d_%s" % (ci, key)]
+            for p in range(len(exp)):
+                ll = 0.0
+                for j, b in enumerate(used):
+                    counts = fl[p, b] / g["calib"][b] * g["kappa"][b]      # flux_in_image, sources.py:120-129
+                    data = zs[j] if mode == 0 else g["nelec"][b, boxes[j, 0]:boxes[j, 1], boxes[j, 2]:boxes[j, 3]]
+                    ll += orc.patch_loglik(B[b], H, W, kind, us[p], sh[p], counts, boxes[j], data, mode)
+                np.testing.assert_allclose(ll, exp[p], rtol=1e-12)
+        if kind == 0:
+            assert g["c%d_ll0" % ci][-1] < 0     # the overlap-miss proposal: -flux * sum(weights) only
