@@ -221,6 +221,30 @@ def gen_src_prob_layers(srcs, img):
     return probs
 
 
+def estep_statistics(srcs, imgs):
+    """What celeste_em reduces gen_src_prob_layers to (celeste_em.py:38-91), without building the
+    (S+1, H, W) layers -- usable at 10 000 sources x 2048^2 where the layers would need 335 GB/band:
+        X_tildes[s, n] = sum(all_src_probs[n][s+1] * imgs[n].nelec)          (celeste_em.py:85)
+        sum_fs[s, n]   = min(1, sum(unit stamp of source s in image n))      (celeste_em.py:89)
+        noise[n]       = sum(imgs[n].nelec * src_probs[0])                   (celeste_em.py:62, x size)
+    -> (X_tildes (S, N), sum_fs (S, N), noise (N,))"""
+    imgs = list(imgs)
+    S = len(srcs)
+    X, F, Z = np.zeros((S, len(imgs))), np.zeros((S, len(imgs))), np.zeros(len(imgs))
+    i = 0
+    while i < len(imgs):
+        j = i + 1
+        while j < len(imgs) and j - i < 16 and imgs[j].nelec.shape == imgs[i].nelec.shape:
+            j += 1
+        group = tuple(imgs[i:j])
+        iset = _image_set(group)
+        typ, radec, counts, shape = _source_arrays(srcs, group)
+        xt, ms, nz = iset.estep_stats(iset._sources(typ, radec, counts, shape))
+        X[:, i:j], F[:, i:j], Z[i:j] = xt, np.minimum(1.0, ms), nz
+        i = j
+    return X, F, Z
+
+
 # ---- celeste.py:237-252 -----------------------------------------------------------------------
 def celeste_likelihood(srcs, image):
     """Poisson log-likelihood sum(nelec*log(lambda) - lambda)  -- celeste.py:237-240"""

@@ -71,6 +71,7 @@ static int fail(int code, const char *fmt, ...) {
 #include "k_render_hw.h"
 #include "k_misc.h"
 #include "k_patch_ll.h"
+#include "k_estep.h"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -860,6 +861,53 @@ done:
     if (d_off) (void)hipFree(d_off);
     if (d_out) (void)hipFree(d_out);
     if (mem != CEL_DEVICE && d_data) (void)hipFree(d_data);
+    return rc;
+}
+
+// ---- E-step statistics -------------------------------------------------------------------------
+int cel_estep_stats(cel_images *im, cel_sources *src, double *xtilde, double *mass, double *noise) {
+    if (!im || !src) return fail(CEL_ERR_INVALID, "cel_estep_stats: null argument");
+    if (!im->have_nelec) return fail(CEL_ERR_INVALID, "cel_estep_stats needs cel_images_set_nelec first");
+    cel_ctx *c = im->ctx;
+    // lambda for exactly these sources must be resident (this also runs k_prep for them)
+    int rc = cel_render_field(im, src, 0, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const int B = im->B;
+    const int64_t S = src->S;
+    const int nblk = im->ntx * im->nty;                 // d_partials holds B * nblk doubles
+    double *d_x = nullptr, *d_m = nullptr;
+    std::vector<double> hx((size_t)(S * B)), hm((size_t)(S * B));
+    hipError_t e;
+#define ES_TRY(expr)                                                                     \
+    do {                                                                                 \
+        e = (expr);                                                                      \
+        if (e != hipSuccess) { rc = fail(CEL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); goto done; } \
+    } while (0)
+    if (S > 0) {
+        ES_TRY(hipMalloc((void **)&d_x, sizeof(double) * S * B));
+        ES_TRY(hipMalloc((void **)&d_m, sizeof(double) * S * B));
+        int pi = prof_begin(c, CEL_K_STAMPS);
+        hipLaunchKernelGGL(k_estep_src, dim3((unsigned)(S * B)), dim3(256), 0, c->stream, im->d_bands, B, im->H, im->W,
+                           S, im->d_recs, im->d_nelec, im->d_lambda, d_x, d_m);
+        prof_end(c, pi);
+        ES_TRY(hipMemcpyAsync(hx.data(), d_x, sizeof(double) * S * B, hipMemcpyDeviceToHost, c->stream));
+        ES_TRY(hipMemcpyAsync(hm.data(), d_m, sizeof(double) * S * B, hipMemcpyDeviceToHost, c->stream));
+    }
+    hipLaunchKernelGGL(k_estep_noise, dim3(B * nblk), dim3(256), 0, c->stream, im->d_bands, (int64_t)im->H * im->W, nblk,
+                       im->d_nelec, im->d_lambda, im->d_partials);
+    hipLaunchKernelGGL(k_reduce, dim3(B), dim3(256), 0, c->stream, im->d_partials, nblk, im->d_llband);
+    ES_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
+    ES_TRY(hipGetLastError());
+    ES_TRY(hipStreamSynchronize(c->stream));
+    if (xtilde) memcpy(xtilde, hx.data(), sizeof(double) * S * B);
+    if (mass) memcpy(mass, hm.data(), sizeof(double) * S * B);
+    if (noise) for (int b = 0; b < B; b++) noise[b] = c->pinned[b];
+#undef ES_TRY
+done:
+    (void)hipStreamSynchronize(c->stream);
+    if (d_x) (void)hipFree(d_x);
+    if (d_m) (void)hipFree(d_m);
     return rc;
 }
 

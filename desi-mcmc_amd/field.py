@@ -199,6 +199,13 @@ class ImageSet(object):
         L.check(L.lib().cel_field_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(n_srcpix=a.value, n_gauss=b.value, n_tile_entries=c.value)
 
+    def estep_stats(self, sources):
+        """E-step reductions (celeste_em.py:38-91) -> (xtilde[S,B], mass[S,B], noise[B])."""
+        S = sources.S
+        xt, ms, nz = np.zeros((S, self.B)), np.zeros((S, self.B)), np.zeros(self.B)
+        L.check(L.lib().cel_estep_stats(self._h, sources._h, L.dptr(xt), L.dptr(ms), L.dptr(nz)))
+        return xt, ms, nz
+
     def patch_loglik(self, sources, boxes, patches, isolated=False):
         """Conditional log-likelihood of each of the P proposals in `sources` on fixed patches.
         boxes: (B,4) int y0,y1,x0,x1 (empty box = band without a sample image);

@@ -188,6 +188,15 @@ int cel_render_stamps(cel_images *img, cel_sources *src, int band, int scaled, c
 int cel_patch_loglik(cel_images *img, cel_sources *src, const int32_t *boxes, const int64_t *offsets,
                      const double *data, int mem, int mode, double *ll_out);
 
+/* ---- E-step sufficient statistics -------------------------------------------------------- */
+/* What celeste_em (CelestePy/celeste_em.py:38-91) reduces gen_src_prob_layers
+ * (celeste.py:222-234) to, without building the (S+1) x H x W responsibility tensor:
+ *   xtilde[s*B+b] = sum_pixels nelec * F_s / lambda     (celeste_em.py:85)
+ *   mass[s*B+b]   = sum_pixels unit stamp of s in band b (celeste_em.py:89, before the min(1, .))
+ *   noise[b]      = sum_pixels nelec * eps / lambda      (celeste_em.py:62, before the / size)
+ * Renders lambda for `src` first.  Host outputs; any of them may be NULL. */
+int cel_estep_stats(cel_images *img, cel_sources *src, double *xtilde, double *mass, double *noise);
+
 /* ---- generic evaluator ------------------------------------------------------------------ */
 /* gmm_like_2d (util/like/gmm_like_fast.pyx:130-176; wrapper util/like/__init__.py:7-11):
  * probs[n] = sum_k ws[k] N(x[n]; mus[k], sigs[k]).  x: N*2, mus: K*2, sigs: K*4 covariances.

@@ -495,6 +495,41 @@ double orc_patch_loglik(const orc_band *b, int H, int W, int type, const double 
     return mode == 0 ? (double)a - counts * wsum : (double)(a - msum);
 }
 
+/* The reductions celeste_em.py:38-91 takes of gen_src_prob_layers (celeste.py:222-234):
+ *   xtilde[s*B+b] = sum nelec * F_s / lambda, mass[s*B+b] = sum unit stamp, noise[b] = sum nelec * eps / lambda
+ * lambda (B*H*W) must be the model image of exactly these sources (orc_render_field). */
+void orc_estep_stats(const orc_band *bands, int B, int H, int W, int64_t S, const int32_t *type,
+                     const double *radec, const double *counts, const double *shape, const double *nelec,
+                     const double *lambda, double *xtilde, double *mass, double *noise) {
+    for (int b = 0; b < B; b++) {
+        const double *lam = lambda + (int64_t)b * H * W, *ne = nelec + (int64_t)b * H * W;
+        long double z = 0.0L;
+        for (int64_t i = 0; i < (int64_t)H * W; i++) z += (long double)(ne[i] * (bands[b].eps / lam[i]));
+        noise[b] = (double)z;
+        for (int64_t s = 0; s < S; s++) {
+            int box[4];
+            int64_t n = orc_source_patch(&bands[b], H, W, type[s], radec + 2 * s, shape + 4 * s, box, NULL);
+            xtilde[s * B + b] = 0.0;
+            mass[s * B + b] = 0.0;
+            if (n <= 0) continue;
+            double *patch = (double *)malloc(sizeof(double) * (size_t)n);
+            orc_source_patch(&bands[b], H, W, type[s], radec + 2 * s, shape + 4 * s, box, patch);
+            long double xt = 0.0L, ms = 0.0L;
+            int nx = box[3] - box[2];
+            for (int y = box[0]; y < box[1]; y++)
+                for (int x = box[2]; x < box[3]; x++) {
+                    double u = patch[(int64_t)(y - box[0]) * nx + (x - box[2])];
+                    int64_t i = (int64_t)y * W + x;
+                    xt += (long double)((u * counts[s * B + b]) / lam[i] * ne[i]);
+                    ms += (long double)u;
+                }
+            xtilde[s * B + b] = (double)xt;
+            mass[s * B + b] = (double)ms;
+            free(patch);
+        }
+    }
+}
+
 /* sources.py:6-12 poisson_loglike on a patch with mask (mask may be NULL). */
 double orc_poisson_loglike(const double *data, const double *model, const uint8_t *mask, int64_t n) {
     long double a = 0.0L, bsum = 0.0L;

@@ -227,6 +227,24 @@ def patch_loglik(band, H, W, typ, u, shape, counts, box, data, mode=0):
                                   box.ctypes.data_as(_ip), dp, C.c_int(int(mode)))
 
 
+def estep_stats(bands, H, W, typ, radec, counts, shape, nelec):
+    """-> (xtilde[S,B], mass[S,B], noise[B]) : celeste_em.py:38-91 reductions"""
+    lam, _, _ = render_field(bands, H, W, typ, radec, counts, shape, nelec)
+    bands, bp = _d(bands)
+    B = bands.shape[0]
+    typ = np.ascontiguousarray(typ, dtype=np.int32)
+    S = typ.shape[0]
+    radec, rp = _d(radec)
+    counts, cp = _d(counts)
+    shape, sp = _d(shape)
+    nelec, np_ = _d(nelec)
+    lam, lp = _d(lam)
+    xt, ms, nz = np.zeros((S, B)), np.zeros((S, B)), np.zeros(B)
+    lib().orc_estep_stats(bp, C.c_int(B), C.c_int(H), C.c_int(W), C.c_int64(S), typ.ctypes.data_as(C.POINTER(C.c_int32)),
+                          rp, cp, sp, np_, lp, xt.ctypes.data_as(_dp), ms.ctypes.data_as(_dp), nz.ctypes.data_as(_dp))
+    return xt, ms, nz
+
+
 def poisson_loglike(data, model, mask=None):
     data, dp = _d(data)
     model, mp = _d(model)

@@ -454,6 +454,27 @@ def gen_source_ll():
     save("source_ll.npz", **out)
 
 
+def gen_estep():
+    """estep.npz: the reductions celeste_em.py:38-91 takes of the reference's
+    gen_src_prob_layers (celeste.py:222-234), stars of the mini field, all five bands."""
+    g = dict(np.load(os.path.join(HERE, "mini_field.npz")))
+    H, W = int(g["H"]), int(g["W"])
+    imgs = virtual_images("estep", H, W, nelec=g["nelec"])
+    idx = g["star_idx"]
+    stars = [SrcParams(u=g["radec"][s], a=0, fluxes=dict(zip(BANDS, g["flux"][s]))) for s in idx]
+    X = np.zeros((len(stars), 5))
+    F = np.zeros((len(stars), 5))
+    Z = np.zeros(5)
+    for n, img in enumerate(imgs):
+        probs = ref_cel.gen_src_prob_layers(stars, img)
+        Z[n] = np.sum(img.nelec * probs[0])                                   # celeste_em.py:62 (x size)
+        for s in range(len(stars)):
+            X[s, n] = np.sum(probs[s + 1] * img.nelec)                        # celeste_em.py:85
+            patch, _, _ = ref_cel.gen_point_source_psf_image(stars[s].u, img)
+            F[s, n] = 0.0 if patch is None else np.sum(patch)                 # celeste_em.py:89
+    save("estep.npz", star_idx=idx, xtilde=X, mass=F, noise=Z)
+
+
 if __name__ == "__main__":
     imgs = gen_bands()
     gen_wcs(imgs)
@@ -464,3 +485,4 @@ if __name__ == "__main__":
     gen_mini_field()
     gen_config1(imgs)
     gen_source_ll()
+    gen_estep()

@@ -424,6 +424,69 @@ def test_row_strips_tile_the_frame(cel, ctx, world):
         cel.ImageSet(ctx, f.bands, 64, W).set_window(150, H)       # window does not fit the frame
 
 
+def test_estep_statistics_and_model_classes(cel, orc):
+    """E-step reductions (celeste_em.py:38-91) and the CelesteBase render / likelihood surface
+    (models.py:88-108) on the mini field"""
+    from desi_mcmc_amd import celeste, models, sources
+    g = load_golden("mini_field.npz")
+    e = load_golden("estep.npz")
+    H, W = int(g["H"]), int(g["W"])
+    imgs = frame_images(cel, {k: g[k] for k in g}, H, W, nelec=g["nelec"])
+    idx = e["star_idx"]
+    stars = [cel.SrcParams(u=g["radec"][s], a=0, fluxes=dict(zip(BANDS, g["flux"][s]))) for s in idx]
+    X, F, Z = celeste.estep_statistics(stars, imgs)
+    np.testing.assert_allclose(X, e["xtilde"], rtol=1e-10)
+    np.testing.assert_allclose(F, np.minimum(1.0, e["mass"]), rtol=1e-10)
+    np.testing.assert_allclose(Z, e["noise"], rtol=1e-11)
+    # mixed star/galaxy list against the oracle, and conservation of photons
+    srcs = [cel.SrcParams(u=g["radec"][s], a=int(g["is_gal"][s]), fluxes=g["flux"][s], theta=g["shape"][s, 0],
+                          sigma=g["shape"][s, 1], phi=g["shape"][s, 2], rho=g["shape"][s, 3]) for s in range(12)]
+    X, F, Z = celeste.estep_statistics(srcs, imgs)
+    counts = g["flux"] / g["calib"][None, :] * g["kappa"][None, :]
+    from desi_mcmc_amd import field
+    ob = field.pack_bands(g)
+    ob[:, 36] = [im.R for im in imgs]
+    oxt, oms, onz = orc.estep_stats(ob, H, W, g["is_gal"], g["radec"], counts, g["shape"], g["nelec"])
+    np.testing.assert_allclose(X, oxt, rtol=1e-10)
+    np.testing.assert_allclose(F, np.minimum(1.0, oms), rtol=1e-10)
+    np.testing.assert_allclose(X.sum(axis=0) + Z, g["nelec"].sum(axis=(1, 2)), rtol=1e-12)
+    # model classes: render_model_image / img_log_likelihood / log_likelihood
+    m = models.Celeste()
+    m.initialize_sources(init_src_params=srcs)
+    assert isinstance(m.srcs[0], sources.Source) and list(m.source_types[:2]) == ["star", "galaxy"]
+    np.testing.assert_allclose(m.render_model_image(imgs[2]), g["lam"][2], rtol=RT_LAM)
+    np.testing.assert_allclose(m.img_log_likelihood(imgs[1]), g["ll_band"][1], rtol=RT_LL)
+    np.testing.assert_allclose(m.img_log_likelihood(imgs[1], mod_img=g["lam"][1]), g["ll_band"][1], rtol=1e-12)
+    # excluding a source removes exactly its patch
+    full = m.render_model_image(imgs[2])
+    wo = m.render_model_image(imgs[2], exclude=m.srcs[3])
+    p, yl, xl = m.srcs[3].compute_model_patch(imgs[2])
+    diff = full - wo
+    np.testing.assert_allclose(diff[int(yl[0]):int(yl[1]), int(xl[0]):int(xl[1])], p, rtol=1e-9, atol=1e-9)
+    # caller-imposed limits crop to the box (models.py:99-100)
+    sub = m.render_model_image(imgs[2], xlim=(10, 60), ylim=(5, 50))
+    assert sub.shape == (45, 50)
+    one = models.Celeste()
+    one.initialize_sources(init_src_params=[srcs[0]])
+    # with imposed limits the source is evaluated on the WHOLE box (compute_model_patch gets the
+    # limits, models.py:96), i.e. also beyond its own bounding box: equal inside it, >= outside
+    lim = one.render_model_image(imgs[2], xlim=(10, 60), ylim=(5, 50))
+    own = one.render_model_image(imgs[2])[5:50, 10:60]
+    _, yl0, xl0 = one.srcs[0].compute_model_patch(imgs[2])
+    ys = slice(max(int(yl0[0]), 5) - 5, min(int(yl0[1]), 50) - 5)
+    xs = slice(max(int(xl0[0]), 10) - 10, min(int(xl0[1]), 60) - 10)
+    np.testing.assert_allclose(lim[ys, xs], own[ys, xs], rtol=1e-9)
+    assert np.all(lim >= own * (1 - 1e-12)) and np.max(lim / own) < 1 + 1e-5
+    # add_field sets epsilon to the median (models.py:115-117) and log_likelihood sums the field
+    old = [im.epsilon for im in imgs]
+    m.add_field(dict(zip(BANDS, imgs)))
+    assert imgs[0].epsilon == np.median(imgs[0].nelec)
+    ll = m.log_likelihood()
+    np.testing.assert_allclose(ll, sum(m.img_log_likelihood(im) for im in imgs), rtol=1e-12)
+    for im, o in zip(imgs, old):
+        im.epsilon = o
+
+
 def test_source_conditional_loglik_golden(cel):
     """Source.log_likelihood / log_likelihood_isolated / compute_model_patch (sources.py:134-237,
     351-395) against values the reference's own Source class produced"""

@@ -260,3 +260,20 @@ def test_source_conditional_loglik_golden():
                 np.testing.assert_allclose(ll, exp[p], rtol=1e-12)
         if kind == 0:
             assert g["c%d_ll0" % ci][-1] < 0     # the overlap-miss proposal: -flux * sum(weights) only
+
+
+def test_estep_statistics_golden():
+    """celeste_em.py:38-91 reductions of the reference's gen_src_prob_layers (stars, 5 bands)"""
+    g = load_golden("mini_field.npz")
+    e = load_golden("estep.npz")
+    B = orc.pack_bands(g)
+    H, W = int(g["H"]), int(g["W"])
+    idx = e["star_idx"]
+    counts = (g["flux"] / g["calib"][None, :] * g["kappa"][None, :])[idx]
+    xt, ms, nz = orc.estep_stats(B, H, W, np.zeros(len(idx), np.int32), g["radec"][idx], counts,
+                                 g["shape"][idx], g["nelec"])
+    np.testing.assert_allclose(xt, e["xtilde"], rtol=1e-11)
+    np.testing.assert_allclose(ms, e["mass"], rtol=1e-11)
+    np.testing.assert_allclose(nz, e["noise"], rtol=1e-12)
+    # every observed photon is attributed to a source or to the sky
+    np.testing.assert_allclose(xt.sum(axis=0) + nz, g["nelec"].sum(axis=(1, 2)), rtol=1e-12)
