@@ -72,6 +72,7 @@ static int fail(int code, const char *fmt, ...) {
 #include "k_misc.h"
 #include "k_patch_ll.h"
 #include "k_estep.h"
+#include "k_split.h"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -861,6 +862,93 @@ done:
     if (d_off) (void)hipFree(d_off);
     if (d_out) (void)hipFree(d_out);
     if (mem != CEL_DEVICE && d_data) (void)hipFree(d_data);
+    return rc;
+}
+
+// ---- photon split -------------------------------------------------------------------------------
+int cel_source_boxes(cel_images *im, cel_sources *src, int32_t *boxes, int32_t *status) {
+    if (!im || !src || !boxes || !status) return fail(CEL_ERR_INVALID, "cel_source_boxes: null argument");
+    if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
+    cel_ctx *c = im->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = run_prep(im, src);
+    if (rc) return rc;
+    im->last_S = src->S;
+    const int64_t n = src->S * im->B;
+    std::vector<SrcRec> h((size_t)n);
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(h.data(), im->d_recs, sizeof(SrcRec) * n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    for (int64_t i = 0; i < n; i++) {
+        boxes[4 * i + 0] = h[i].y0; boxes[4 * i + 1] = h[i].y1;
+        boxes[4 * i + 2] = h[i].x0; boxes[4 * i + 3] = h[i].x1;
+        status[i] = h[i].type >= 0 ? 1 : (h[i].type == -3 ? -1 : 0);
+    }
+    return CEL_OK;
+}
+
+int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int64_t *offsets, double *samp,
+                     int mem, double *noise) {
+    if (!im || !src || !offsets || !samp) return fail(CEL_ERR_INVALID, "cel_photon_split: null argument");
+    if (!im->have_nelec) return fail(CEL_ERR_INVALID, "cel_photon_split needs cel_images_set_nelec first");
+    if (im->TW * im->TH != 2048) return fail(CEL_ERR_INVALID, "cel_photon_split needs 2048-pixel render tiles");
+    cel_ctx *c = im->ctx;
+    // records + tile lists for exactly these sources (renders lambda on the way)
+    int rc = cel_render_field(im, src, 0, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const int B = im->B;
+    const int64_t S = src->S, n = S * B;
+    const int T = B * im->ntx * im->nty;
+    const int64_t total = offsets[n];
+    int64_t *d_off = nullptr;
+    double *d_samp = nullptr;
+    hipError_t e;
+#define PS_TRY(expr)                                                                     \
+    do {                                                                                 \
+        e = (expr);                                                                      \
+        if (e != hipSuccess) { rc = fail(CEL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); goto done; } \
+    } while (0)
+    PS_TRY(hipMalloc((void **)&d_off, sizeof(int64_t) * (n + 1)));
+    PS_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, c->stream));
+    if (mem == CEL_DEVICE) d_samp = samp; else PS_TRY(hipMalloc((void **)&d_samp, sizeof(double) * (total > 0 ? total : 1)));
+    PS_TRY(hipMemsetAsync(d_samp, 0, sizeof(double) * (total > 0 ? total : 1), c->stream));
+    {
+        SplitArgs a;
+        a.bands = im->d_bands; a.recs = im->d_recs; a.lists = im->d_lists; a.tile_cnt = im->d_tile_cnt;
+        a.tile_off = im->d_tile_off; a.nelec = im->d_nelec; a.offsets = d_off; a.samp = d_samp;
+        a.partials = im->d_partials; a.S = S; a.capacity = im->lists_cap; a.B = B; a.H = im->H; a.W = im->W;
+        a.ntx = im->ntx; a.nty = im->nty; a.TW = im->TW; a.TH = im->TH; a.seed = seed;
+        int pi = prof_begin(c, CEL_K_STAMPS);
+        hipLaunchKernelGGL(k_photon_split, dim3(T), dim3(64), 0, c->stream, a);
+        prof_end(c, pi);
+    }
+    hipLaunchKernelGGL(k_reduce, dim3(B), dim3(256), 0, c->stream, im->d_partials, im->ntx * im->nty, im->d_llband);
+    PS_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
+    if (mem != CEL_DEVICE && total > 0)
+        PS_TRY(hipMemcpyAsync(samp, d_samp, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream));
+    PS_TRY(hipGetLastError());
+    PS_TRY(hipStreamSynchronize(c->stream));
+    if (noise) for (int b = 0; b < B; b++) noise[b] = c->pinned[b];
+#undef PS_TRY
+done:
+    (void)hipStreamSynchronize(c->stream);
+    if (d_off) (void)hipFree(d_off);
+    if (mem != CEL_DEVICE && d_samp) (void)hipFree(d_samp);
+    return rc;
+}
+
+int cel_debug_binomial(cel_ctx *c, int64_t n, double p, uint64_t seed, int64_t N, int64_t *out) {
+    if (!c || !out || N < 0 || n < 0) return fail(CEL_ERR_INVALID, "cel_debug_binomial: bad argument");
+    if (N == 0) return CEL_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, sizeof(long long) * N));
+    hipLaunchKernelGGL(k_binomial_draws, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (long long)n, p,
+                       (unsigned long long)seed, N, d);
+    int rc = copy_out(out, d, sizeof(long long) * N, CEL_HOST, c->stream);
+    (void)hipFree(d);
     return rc;
 }
 

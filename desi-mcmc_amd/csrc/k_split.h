@@ -1,0 +1,261 @@
+// k_split.h -- the per-pixel multinomial split of observed photons among overlapping sources
+//
+// Gibbs step of CelestePy's sampler: sample_source_counts / sample_multinomial
+// (CelestePy/celeste_sample_sources.pyx:61-156), driven by
+// sample_source_photons_single_image_cython (celeste_mcmc.py:98-150) and Field.resample_photons
+// (models.py:123-160).  For every pixel the nelec observed photons are split among the sources
+// whose patch contains the pixel and the sky, z ~ Multinomial(nelec; F_1, ..., F_k, eps), by
+// the conditional-binomial method in source order with the sky last (:139-155).
+//
+// Reference semantics kept on purpose:
+//   * a source takes part at a pixel only if the pixel is STRICTLY inside its box in x0 and y0
+//     (`x > x0 and x < x1 and y > y0 and y < y1`, :50-51): the first row and column of every
+//     sample patch stay 0;
+//   * photons of a pixel nobody covers all go to the noise sum (:91-93).
+// The reference draws binomials from randomkit's MT19937 stream (deps/randomkit); a GPU cannot
+// reproduce that stream, so parity is statistical: the draws here come from a
+// counter-based Philox4x32-10 generator keyed by (seed; band, pixel, source), so a result
+// depends only on the seed and the inputs -- not on tiling, launch order or GPU count.
+// Binomial variates: inversion for n*min(p,1-p) <= 30, BTPE (Kachitvichyanukul & Schmeiser 1988)
+// above, the same split randomkit makes (distributions.c:422-455).
+//
+// One wave per render tile (the tile lists of k_bin_*).  Pass A accumulates every pixel's total
+// rate in LDS, pass B walks the sources again in order and draws.  Stamps use the direct
+// evaluator: exact, every component.
+#pragma once
+#include "k_render.h"
+
+struct Philox {
+    unsigned k0, k1, c0, c1, c2, c3;
+    unsigned out[4];
+    int have;
+};
+
+__device__ inline void philox_block(Philox &g) {
+    unsigned c0 = g.c0, c1 = g.c1, c2 = g.c2, c3 = g.c3, k0 = g.k0, k1 = g.k1;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    g.out[0] = c0; g.out[1] = c1; g.out[2] = c2; g.out[3] = c3;
+    g.have = 4;
+    g.c0 += 1;      // next block of this stream
+}
+
+__device__ inline Philox philox_init(unsigned long long seed, unsigned long long pixel, unsigned stream) {
+    Philox g;
+    g.k0 = (unsigned)seed; g.k1 = (unsigned)(seed >> 32);
+    g.c0 = 0; g.c1 = stream; g.c2 = (unsigned)pixel; g.c3 = (unsigned)(pixel >> 32);
+    g.have = 0;
+    return g;
+}
+
+// uniform double in [0, 1) with 53 random bits
+__device__ inline double philox_double(Philox &g) {
+    if (g.have < 2) philox_block(g);
+    unsigned a = g.out[g.have - 1] >> 5, b = g.out[g.have - 2] >> 6;
+    g.have -= 2;
+    return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
+
+// Stirling-series tail used by BTPE's final acceptance test
+__device__ inline double btpe_st(double x) {
+    double x2 = x * x;
+    return (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / x2) / x2) / x2) / x2) / x / 166320.0;
+}
+
+// Binomial(n, r) for r <= 1/2, n r <= 30: sequential inversion (BINV)
+__device__ inline long long binom_inversion(long long n, double r, Philox &g) {
+    const double q = 1.0 - r;
+    const double qn = exp((double)n * log1p(-r));
+    const double np = (double)n * r;
+    const long long bound = (long long)fmin((double)n, np + 10.0 * sqrt(np * q + 1.0));
+    long long X = 0;
+    double px = qn, U = philox_double(g);
+    while (U > px) {
+        X++;
+        if (X > bound) {            // numerical tail: start over
+            X = 0; px = qn; U = philox_double(g);
+        } else {
+            U -= px;
+            px = ((double)(n - X + 1) * r * px) / ((double)X * q);
+        }
+    }
+    return X;
+}
+
+// Binomial(n, r) for r <= 1/2, n r > 30: BTPE (triangle / parallelogram / exponential tails)
+__device__ inline long long binom_btpe(long long n, double r, Philox &g) {
+    const double q = 1.0 - r, nd = (double)n;
+    const double nrq = nd * r * q;
+    const double fm = nd * r + r;
+    const long long m = (long long)floor(fm);
+    const double p1 = floor(2.195 * sqrt(nrq) - 4.6 * q) + 0.5;
+    const double xm = (double)m + 0.5, xl = xm - p1, xr = xm + p1;
+    const double c = 0.134 + 20.5 / (15.3 + (double)m);
+    double a = (fm - xl) / (fm - xl * r);
+    const double laml = a * (1.0 + a / 2.0);
+    a = (xr - fm) / (xr * q);
+    const double lamr = a * (1.0 + a / 2.0);
+    const double p2 = p1 * (1.0 + 2.0 * c), p3 = p2 + c / laml, p4 = p3 + c / lamr;
+    long long y;
+    for (int guard = 0; guard < 100000; guard++) {
+        double u = philox_double(g) * p4, v = philox_double(g);
+        if (u <= p1) {                                   // triangular centre: accept at once
+            y = (long long)floor(xm - p1 * v + u);
+            return y;
+        }
+        if (u <= p2) {                                   // parallelograms
+            double x = xl + (u - p1) / c;
+            v = v * c + 1.0 - fabs((double)m - x + 0.5) / p1;
+            if (v > 1.0) continue;
+            y = (long long)floor(x);
+        } else if (u <= p3) {                            // left exponential tail
+            y = (long long)floor(xl + log(v) / laml);
+            if (y < 0) continue;
+            v = v * (u - p2) * laml;
+        } else {                                         // right exponential tail
+            y = (long long)floor(xr - log(v) / lamr);
+            if (y > n) continue;
+            v = v * (u - p3) * lamr;
+        }
+        const double k = fabs((double)(y - m));
+        if (k <= 20.0 || k >= nrq / 2.0 - 1.0) {
+            // evaluate f(y)/f(m) by the recurrence
+            const double s = r / q, aa = s * (nd + 1.0);
+            double F = 1.0;
+            if (m < y) { for (long long i = m + 1; i <= y; i++) F *= (aa / (double)i - s); }
+            else if (m > y) { for (long long i = y + 1; i <= m; i++) F /= (aa / (double)i - s); }
+            if (v > F) continue;
+            return y;
+        }
+        // squeezes, then the Stirling bound
+        const double rho = (k / nrq) * ((k * (k / 3.0 + 0.625) + 0.16666666666666666) / nrq + 0.5);
+        const double t = -k * k / (2.0 * nrq);
+        const double A = log(v);
+        if (A < t - rho) return y;
+        if (A > t + rho) continue;
+        const double x1 = (double)y + 1.0, f1 = (double)m + 1.0, z = nd + 1.0 - (double)m, w = nd - (double)y + 1.0;
+        const double bound = xm * log(f1 / x1) + (nd - (double)m + 0.5) * log(z / w) +
+                             (double)(y - m) * log(w * r / (x1 * q)) + btpe_st(f1) + btpe_st(z) + btpe_st(x1) + btpe_st(w);
+        if (A > bound) continue;
+        return y;
+    }
+    return m;   // unreachable in practice (acceptance > 0.8 per trial); keeps the loop bounded
+}
+
+__device__ inline long long binomial_draw(long long n, double p, Philox &g) {
+    if (n <= 0 || !(p > 0.0)) return 0;
+    if (p >= 1.0) return n;
+    const bool flip = p > 0.5;
+    const double r = flip ? 1.0 - p : p;
+    long long y = (r * (double)n <= 30.0) ? binom_inversion(n, r, g) : binom_btpe(n, r, g);
+    return flip ? n - y : y;
+}
+
+// diagnostic: N independent Binomial(n, p) draws (stream i), for the sampler's own tests
+__global__ void __launch_bounds__(256)
+k_binomial_draws(long long n, double p, unsigned long long seed, int64_t N, long long *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    Philox g = philox_init(seed, (unsigned long long)i, 0u);
+    out[i] = binomial_draw(n, p, g);
+}
+
+struct SplitArgs {
+    const BandDev *bands;
+    const SrcRec *recs;
+    const int *lists;
+    const int *tile_cnt;
+    const int64_t *tile_off;
+    const double *nelec;
+    const int64_t *offsets;     // [B*S + 1] packed position of each (band, source) sample patch
+    double *samp;               // packed sample patches, zero-initialised by the caller
+    double *partials;           // per-tile noise sums
+    int64_t S, capacity;
+    int B, H, W, ntx, nty, TW, TH;
+    unsigned long long seed;
+};
+
+__global__ void __launch_bounds__(64)
+k_photon_split(SplitArgs a) {
+    __shared__ double rate[2048];     // remaining total rate of the pixel (sources not yet drawn + sky)
+    __shared__ int left[2048];        // photons of the pixel not yet attributed
+    __shared__ CompTab T;
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int per_band = a.ntx * a.nty;
+    const int b = tile / per_band;
+    const int t = tile - b * per_band;
+    const int ty = t / a.ntx, tx = t - ty * a.ntx;
+    const int X0 = tx * a.TW, Y0 = ty * a.TH;
+    const int col = lane % a.TW, rsub = lane / a.TW, rstep = 64 / a.TW;
+    const int niter = a.TH / rstep;              // TW * TH = 2048 in both layouts
+    const int xi = X0 + col;
+    const BandDev *bd = a.bands + b;
+    const double eps = bd->eps;
+    const int64_t plane = (int64_t)b * a.H * a.W;
+    const int cnt = a.tile_cnt[tile];
+    const int64_t off = a.tile_off[tile];
+    const SrcRec *recs = a.recs + (int64_t)b * a.S;
+
+    for (int i = 0; i < niter; i++) {
+        const int y = Y0 + i * rstep + rsub;
+        const bool in = (xi < a.W) && (y < a.H);
+        rate[i * 64 + lane] = eps;
+        left[i * 64 + lane] = in ? (int)a.nelec[plane + (int64_t)y * a.W + xi] : 0;
+    }
+
+    for (int pass = 0; pass < 2; pass++) {
+        for (int e = 0; e < cnt; e++) {
+            const int64_t at = off + e;
+            if (at >= a.capacity) break;
+            const int s = __builtin_amdgcn_readfirstlane(a.lists[at]);
+            const SrcRec *rp = recs + s;
+            const int type = rp->type;
+            const int K = (type == 0) ? K_PSF : K_GAL;
+            const int bx0 = rp->x0, bx1 = rp->x1, by0 = rp->y0, by1 = rp->y1;
+            const double counts = rp->scale;
+            __syncthreads();
+            if (lane < K) {
+                Comp c = make_comp(lane, type, rp->px, rp->py, 1.0, rp->w00, rp->w01, rp->w11, rp->theta, bd);
+                T.A[lane] = c.A; T.mx[lane] = c.mx; T.my[lane] = c.my;
+                T.qa[lane] = c.qa; T.qb[lane] = c.qb; T.qc[lane] = c.qc;
+            }
+            __syncthreads();
+            const int nx = bx1 - bx0;
+            double *patch = a.samp + a.offsets[(int64_t)b * a.S + s];
+            const bool colin = (xi > bx0) && (xi < bx1);                 // strict on the low side (:50)
+            for (int i = 0; i < niter; i++) {
+                const int y = Y0 + i * rstep + rsub;
+                if (!(colin && y > by0 && y < by1)) continue;
+                const double F = counts * eval_direct(T, 0, K, (double)xi, (double)y, 1.0);
+                const int li = i * 64 + lane;
+                if (pass == 0) {
+                    rate[li] += F;
+                } else {
+                    const int n = left[li];
+                    double tot = rate[li];
+                    long long z = 0;
+                    if (n > 0) {
+                        Philox g = philox_init(a.seed, (unsigned long long)(plane + (int64_t)y * a.W + xi), (unsigned)s);
+                        z = binomial_draw((long long)n, F / tot, g);      // curr_prob / sum_probs (:147)
+                    }
+                    left[li] = n - (int)z;
+                    rate[li] = tot - F;                                   // sum_probs -= curr_prob (:152)
+                    patch[(int64_t)(y - by0) * nx + (xi - bx0)] = (double)z;
+                }
+            }
+        }
+    }
+    // what is left belongs to the sky (:153, :91-93)
+    double noise = 0.0;
+    for (int i = 0; i < niter; i++) noise += (double)left[i * 64 + lane];
+    noise = wave_sum(noise);
+    if (lane == 0) a.partials[tile] = noise;
+}

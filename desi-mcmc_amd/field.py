@@ -199,6 +199,40 @@ class ImageSet(object):
         L.check(L.lib().cel_field_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(n_srcpix=a.value, n_gauss=b.value, n_tile_entries=c.value)
 
+    def source_boxes(self, sources):
+        """(boxes[B,S,4] = y0,y1,x0,x1, status[B,S]) for every band."""
+        S = sources.S
+        boxes = np.zeros((self.B, S, 4), dtype=np.int32)
+        status = np.zeros((self.B, S), dtype=np.int32)
+        L.check(L.lib().cel_source_boxes(self._h, sources._h, boxes.ctypes.data_as(L.c_int32_p),
+                                         status.ctypes.data_as(L.c_int32_p)))
+        return boxes, status
+
+    def photon_split(self, sources, seed):
+        """Gibbs photon split (celeste_sample_sources.pyx:61-156) for every band.
+        -> (patches[b][s] 2-D arrays or None, boxes[B,S,4], noise_sum[B])"""
+        S = sources.S
+        boxes, status = self.source_boxes(sources)
+        area = np.where(status > 0, (boxes[..., 1] - boxes[..., 0]).astype(np.int64) * (boxes[..., 3] - boxes[..., 2]), 0)
+        offs = np.zeros(self.B * S + 1, dtype=np.int64)
+        np.cumsum(area.ravel(), out=offs[1:])
+        flat = np.zeros(max(int(offs[-1]), 1))
+        noise = np.zeros(self.B)
+        L.check(L.lib().cel_photon_split(self._h, sources._h, C.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                         offs.ctypes.data_as(L.c_int64_p), flat.ctypes.data, L.CEL_HOST, L.dptr(noise)))
+        out = []
+        for b in range(self.B):
+            row = []
+            for s in range(S):
+                i = b * S + s
+                if status[b, s] > 0:
+                    row.append(flat[offs[i]:offs[i + 1]].reshape(boxes[b, s, 1] - boxes[b, s, 0],
+                                                                 boxes[b, s, 3] - boxes[b, s, 2]))
+                else:
+                    row.append(None)
+            out.append(row)
+        return out, boxes, noise
+
     def estep_stats(self, sources):
         """E-step reductions (celeste_em.py:38-91) -> (xtilde[S,B], mass[S,B], noise[B])."""
         S = sources.S

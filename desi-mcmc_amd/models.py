@@ -2,9 +2,10 @@
 
 `CelesteBase` keeps the reference's field list, source list and the two methods that sit on the
 render path -- render_model_image and img_log_likelihood (models.py:88-108) -- on top of the
-device-resident image sets.  The Gibbs drivers (resample_model, Field.resample_photons) are host
-control flow around the path; resample_photons needs the photon split, which
-is not built yet, so those methods are not reproduced here.
+device-resident image sets, and Field.resample_photons (models.py:123-160) on top of the device
+photon split.  The per-source samplers (Source.resample*, slice sampling, Gamma draws) are host
+control flow around the path and are not reproduced here; they call Source.log_likelihood,
+which is (sources.py mirror).
 
 Quirk Q4: the reference's render_model_image re-uses its `xlim` / `ylim` loop variables,
 so every source after the first is rendered onto the FIRST source's box and the result is
@@ -33,6 +34,36 @@ class Field(object):
             img.epsilon = np.median(img.nelec)      # models.py:115-117: noise level := median
         self.a_0 = 5
         self.b_0 = .005
+
+    def resample_photons(self, srcs, verbose=False, seed=None, rng=None):
+        """resample photons, store source-specific sample images, resample each image's noise level
+        -- models.py:123-160.  One device pass splits the photons of all the field's bands."""
+        from . import celeste_mcmc as cel_mcmc
+        rng = np.random if rng is None else rng
+        for src in srcs:
+            src.clear_sample_images()
+        bands = list(self.img_dict.keys())
+        imgs = [self.img_dict[b] for b in bands]
+        same = all(im.nelec.shape == imgs[0].nelec.shape for im in imgs)
+        groups = [imgs] if same and len(imgs) <= 16 else [[im] for im in imgs]
+        noise_sums = {}
+        k = 0
+        for group in groups:
+            samp, noise = cel_mcmc.sample_source_photons_multi_image(
+                group, [s.params for s in srcs], seed=None if seed is None else seed + k)
+            for n, img in enumerate(group):
+                for src, samp_img in zip(srcs, samp[n]):
+                    if samp_img is not None:
+                        # the reference caches a pixel grid per sample image (models.py:146-150);
+                        # the device evaluators need none
+                        src.sample_image_list.append((samp_img, img, None))
+                noise_sums[bands[k]] = noise[n]
+                k += 1
+        for band, img in self.img_dict.items():
+            a_n = self.a_0 + noise_sums[band]
+            b_n = self.b_0 + img.nelec.size
+            img.epsilon = rng.gamma(a_n, 1. / b_n)           # models.py:156-160
+        return noise_sums
 
 
 class CelesteBase(object):

@@ -188,6 +188,25 @@ int cel_render_stamps(cel_images *img, cel_sources *src, int band, int scaled, c
 int cel_patch_loglik(cel_images *img, cel_sources *src, const int32_t *boxes, const int64_t *offsets,
                      const double *data, int mem, int mode, double *ll_out);
 
+/* ---- photon split (Gibbs step) ------------------------------------------------------------ */
+/* boxes[(b*S+s)*4..] = y0,y1,x0,x1 and status[b*S+s] (as cel_stamp_boxes) for every band at once */
+int cel_source_boxes(cel_images *img, cel_sources *src, int32_t *boxes, int32_t *status);
+/* sample_source_counts / sample_multinomial (CelestePy/celeste_sample_sources.pyx:61-156) for every
+ * band image: each pixel's nelec photons are split among the sources whose patch strictly contains
+ * the pixel (:50-51) and the sky, by conditional binomials in source order, sky last.
+ *   offsets  B*S+1: packed position of the sample patch of (band b, source s) at index b*S+s;
+ *            offsets[i+1]-offsets[i] = that source's box area (cel_source_boxes), 0 without a patch
+ *   samp     packed sample patches (doubles holding integers, as NativePatch.data), zeroed here
+ *   noise    B doubles (host): photons attributed to the sky, the reference's noise_sum
+ * Random numbers: Philox4x32-10 keyed by (seed; band, pixel, source) -- a result depends only on
+ * the seed and the inputs.  The reference's randomkit stream cannot be reproduced on a GPU:
+ * parity with it is statistical. */
+int cel_photon_split(cel_images *img, cel_sources *src, uint64_t seed, const int64_t *offsets, double *samp,
+                     int mem, double *noise);
+
+/* diagnostic: N independent Binomial(n, p) variates from the split's sampler (stream i = draw i) */
+int cel_debug_binomial(cel_ctx *ctx, int64_t n, double p, uint64_t seed, int64_t N, int64_t *out);
+
 /* ---- E-step sufficient statistics -------------------------------------------------------- */
 /* What celeste_em (CelestePy/celeste_em.py:38-91) reduces gen_src_prob_layers
  * (celeste.py:222-234) to, without building the (S+1) x H x W responsibility tensor:

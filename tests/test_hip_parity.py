@@ -487,6 +487,141 @@ def test_estep_statistics_and_model_classes(cel, orc):
         im.epsilon = o
 
 
+def test_binomial_sampler_distribution(cel, ctx):
+    """the split's Binomial(n, p) sampler (inversion / BTPE) against the exact pmf: the reference's
+    randomkit stream cannot be reproduced, so parity is statistical"""
+    import ctypes as C
+    from scipy import stats
+    from desi_mcmc_amd import _lib
+    N = 200000
+    cases = [(10, 0.3), (1000, 0.01), (200, 0.5), (5000, 0.37), (100000, 0.9), (50, 0.999), (3000, 0.011),
+             (40, 0.75), (123456, 0.5), (914, 6.29e-16)]      # the last: test_celeste_sample_sources.py:6
+    for i, (n, p) in enumerate(cases):
+        out = np.zeros(N, dtype=np.int64)
+        _lib.check(_lib.lib().cel_debug_binomial(ctx._h, n, p, 1234 + i, N, out.ctypes.data_as(_lib.c_int64_p)))
+        assert out.min() >= 0 and out.max() <= n
+        mean, var = n * p, n * p * (1 - p)
+        if var < 1e-9:
+            assert np.all(out == round(mean))
+            continue
+        assert abs(out.mean() - mean) < 5 * np.sqrt(var / N), (n, p, out.mean(), mean)
+        assert abs(out.var() / var - 1) < 0.03, (n, p, out.var(), var)
+        # chi-square against the exact pmf on cells with expectation >= 10
+        lo, hi = int(max(0, mean - 6 * np.sqrt(var))), int(min(n, mean + 6 * np.sqrt(var)))
+        ks = np.arange(lo, hi + 1)
+        pmf = stats.binom.pmf(ks, n, p)
+        obs = np.bincount(np.clip(out, lo, hi) - lo, minlength=len(ks)).astype(float)
+        exp = pmf * N
+        exp[0] += stats.binom.cdf(lo - 1, n, p) * N
+        exp[-1] += stats.binom.sf(hi, n, p) * N
+        keep = exp >= 10
+        chi2 = np.sum((obs[keep] - exp[keep]) ** 2 / exp[keep]) + (obs[~keep].sum() - exp[~keep].sum()) ** 2 / max(exp[~keep].sum(), 1)
+        dof = keep.sum()
+        assert stats.chi2.sf(chi2, dof) > 1e-6, (n, p, chi2, dof)
+    # deterministic in the seed
+    a, b = np.zeros(1000, np.int64), np.zeros(1000, np.int64)
+    _lib.check(_lib.lib().cel_debug_binomial(ctx._h, 500, 0.2, 7, 1000, a.ctypes.data_as(_lib.c_int64_p)))
+    _lib.check(_lib.lib().cel_debug_binomial(ctx._h, 500, 0.2, 7, 1000, b.ctypes.data_as(_lib.c_int64_p)))
+    assert np.array_equal(a, b)
+
+
+def test_photon_split_conservation_moments_quirks(cel, ctx, orc):
+    """sample_source_counts (celeste_sample_sources.pyx:61-156): exact photon conservation, the
+    strict-box quirk, first moments against nelec * F_s / lambda, seed determinism, and
+    independence of the draws from the tile layout"""
+    from desi_mcmc_amd import field
+    g = load_golden("mini_field.npz")
+    H, W = int(g["H"]), int(g["W"])
+    bands = field.pack_bands(g)
+    counts = g["flux"] / g["calib"][None, :] * g["kappa"][None, :] * 20.0      # bright: many photons per pixel
+    S = 12
+    results = {}
+    for layout in (1, 0):
+        c2 = cel.Context(0)
+        c2.set_option(7, layout)
+        iset = cel.ImageSet(c2, bands, H, W, nelec=g["nelec"])
+        sset = cel.SourceSet(c2, S, 5).set(g["is_gal"], g["radec"], counts, g["shape"])
+        patches, boxes, noise = iset.photon_split(sset, seed=99)
+        results[layout] = (patches, boxes, noise)
+        if layout == 1:
+            p2, _, n2 = iset.photon_split(sset, seed=99)
+            p3, _, n3 = iset.photon_split(sset, seed=100)
+            assert all(np.array_equal(a, b) for ra, rb in zip(patches, p2) for a, b in zip(ra, rb) if a is not None)
+            assert np.array_equal(noise, n2)
+            assert any(not np.array_equal(a, b) for ra, rb in zip(patches, p3) for a, b in zip(ra, rb) if a is not None)
+            ob = bands.copy()
+            ob[:, 36] = [iset.band(b)[36] for b in range(5)]
+    pa, ba, na = results[1]
+    pb, bb, nb = results[0]
+    assert np.array_equal(ba, bb) and np.array_equal(na, nb)                     # same draws whatever the tiling
+    assert all(np.array_equal(a, b) for ra, rb in zip(pa, pb) for a, b in zip(ra, rb) if a is not None)
+    patches, boxes, noise = results[1]
+    for b in range(5):
+        tot = noise[b]
+        lam_strict = np.full((H, W), bands[b, 0])
+        F = []
+        for s in range(S):
+            p, yl, xl = orc.source_patch(ob[b], H, W, g["is_gal"][s], g["radec"][s], g["shape"][s])
+            if p is None:
+                F.append(None)
+                assert patches[b][s] is None
+                continue
+            assert (yl[0], yl[1], xl[0], xl[1]) == tuple(boxes[b, s])
+            f = p * counts[s, b]
+            f[0, :] = 0.0                # strict box: y > y0
+            f[:, 0] = 0.0                #             x > x0   (celeste_sample_sources.pyx:50-51)
+            lam_strict[yl[0]:yl[1], xl[0]:xl[1]] += f
+            F.append((f, yl, xl))
+        for s in range(S):
+            if F[s] is None:
+                continue
+            f, yl, xl = F[s]
+            z = patches[b][s]
+            assert z.shape == f.shape and np.all(z == np.round(z)) and z.min() >= 0
+            assert np.all(z[0, :] == 0) and np.all(z[:, 0] == 0)                  # the quirk
+            tot += z.sum()
+            n = g["nelec"][b, yl[0]:yl[1], xl[0]:xl[1]]
+            pr = f / lam_strict[yl[0]:yl[1], xl[0]:xl[1]]
+            mean, var = n * pr, n * pr * (1 - pr)
+            zscore = (z.sum() - mean.sum()) / np.sqrt(var.sum())
+            assert abs(zscore) < 5.0, (b, s, zscore)
+            # per-pixel dispersion: sum of squared standardised residuals ~ chi2(npix)
+            ok = var > 5
+            if ok.sum() > 50:
+                r2 = ((z[ok] - mean[ok]) ** 2 / var[ok]).sum()
+                assert abs(r2 - ok.sum()) / np.sqrt(2.0 * ok.sum()) < 5.0, (b, s, r2 / ok.sum())
+        assert tot == g["nelec"][b].sum()                                         # every photon lands exactly once
+
+
+def test_field_resample_photons_feeds_source_loglik(cel):
+    """Field.resample_photons (models.py:123-160) -> Source.log_likelihood on the sampled patches"""
+    from desi_mcmc_amd import models
+    g = load_golden("mini_field.npz")
+    H, W = int(g["H"]), int(g["W"])
+    imgs = frame_images(cel, {k: g[k] for k in g}, H, W, nelec=g["nelec"])
+    srcs = [cel.SrcParams(u=g["radec"][s], a=int(g["is_gal"][s]), fluxes=g["flux"][s], theta=g["shape"][s, 0],
+                          sigma=g["shape"][s, 1], phi=g["shape"][s, 2], rho=g["shape"][s, 3]) for s in range(12)]
+    m = models.Celeste()
+    m.initialize_sources(init_src_params=srcs)
+    old = [im.epsilon for im in imgs]
+    m.add_field(dict(zip(BANDS, imgs)))
+    for im, o in zip(imgs, old):
+        im.epsilon = o                                   # keep the sky level the photons were drawn with
+    noise = m.field_list[0].resample_photons(m.srcs, seed=5, rng=np.random.RandomState(0))
+    assert set(noise) == set(BANDS)
+    n_samp = [len(s.sample_image_list) for s in m.srcs]
+    assert max(n_samp) == 5 and min(n_samp) >= 1
+    for im, o in zip(imgs, old):
+        assert im.epsilon > 0 and abs(im.epsilon / o - 1) < 0.2           # Gamma posterior sits near the truth
+    # the conditional likelihood prefers the true fluxes to badly wrong ones
+    src = m.srcs[0]
+    ll_true = src.log_likelihood()
+    ll_bad = src.log_likelihood(fluxes=np.asarray(src.params.fluxes) * 3.0)
+    assert np.isfinite(ll_true) and ll_true > ll_bad
+    for im, o in zip(imgs, old):
+        im.epsilon = o
+
+
 def test_source_conditional_loglik_golden(cel):
     """Source.log_likelihood / log_likelihood_isolated / compute_model_patch (sources.py:134-237,
     351-395) against values the reference's own Source class produced"""
