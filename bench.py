@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="mixed10k_2048")
     ap.add_argument("--kernel", default="recurrence", choices=["direct", "recurrence"])
-    ap.add_argument("--tail-log", type=float, default=40.0)
+    ap.add_argument("--tail-log", type=float, default=32.0)
     ap.add_argument("--tile-rows", type=int, default=32, choices=[32, 64])
     ap.add_argument("--tile-order", type=int, default=1, choices=[0, 1])
     ap.add_argument("--layout", type=int, default=1, choices=[0, 1],
@@ -83,11 +83,14 @@ def main():
     import desi_mcmc_amd as cel
     from desi_mcmc_amd import dist, synth
 
-    rank, world, local = dist.init_from_env()
+    # CEL_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs than ranks
+    # (ranks then share GPUs and the collective runs on the host); the driver's runs use RCCL.
+    rank, world, local = dist.init_from_env(backend=os.environ.get("CEL_BENCH_BACKEND"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     ctx = cel.Context(local)
     ctx.set_kernel(args.kernel)
@@ -131,7 +134,8 @@ def main():
     agg = torch.tensor([dt, stats["n_srcpix"], stats["n_gauss"]], dtype=torch.float64)
     if world > 1:
         import torch.distributed as td
-        agg = agg.cuda(local)
+        if td.get_backend() == "nccl":
+            agg = agg.cuda(local)
         tmax = agg[:1].clone()
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         tsum = agg[1:].clone()

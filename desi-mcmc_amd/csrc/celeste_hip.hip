@@ -90,7 +90,7 @@ struct cel_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int variant = 1;
-    double tail_T = 40.0;
+    double tail_T = 32.0;
     bool profile = false;
     bool tile_order = true;   // launch k_render tiles heaviest-first
     int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created

@@ -96,6 +96,7 @@ k_render_hw(RenderArgs a) {
     const double eps_sky = bd->eps;
     const bool dropping = (a.variant != 0) && (Tdrop > 0.0) && (eps_sky > 0.0);
 
+    unsigned dbg_pairrows = 0, dbg_comprows = 0, dbg_pairs = 0;   // only counted under CEL_OPT_TILE_TIMING
     const LaneConst lc = lane_consts(lane, bd);
     // the tile's list, 64 indices per coalesced load; the next source's record is in flight while
     // the current one is evaluated
@@ -178,6 +179,7 @@ k_render_hw(RenderArgs a) {
             L = __builtin_amdgcn_readfirstlane(L);
             ga = __builtin_amdgcn_readfirstlane(ga);
             gb = __builtin_amdgcn_readfirstlane(gb);
+            if (a.timing) { dbg_pairrows += (unsigned)(gb - ga) * (unsigned)gA; dbg_comprows += (unsigned)(gb - ga) * (unsigned)R; dbg_pairs += 1; }
             const int k0 = half ? p0 + gA : p0;
             if (L < 4) {
                 // pathologically sharp component: evaluate this pair of groups directly
@@ -226,6 +228,9 @@ k_render_hw(RenderArgs a) {
     if (a.timing && lane == 0) {
         a.timing[3 * (size_t)blockIdx.x + 0] = t_start;
         a.timing[3 * (size_t)blockIdx.x + 1] = wall_clock64();
-        a.timing[3 * (size_t)blockIdx.x + 2] = ((unsigned long long)tile << 32) | (unsigned)cnt;
+        // work counters of this tile (diagnostic): sources | pairs of groups << 12 | kept component-rows << 32
+        a.timing[3 * (size_t)blockIdx.x + 2] = (unsigned long long)(unsigned)cnt | ((unsigned long long)dbg_pairs << 12) |
+                                               ((unsigned long long)dbg_comprows << 32);
+        (void)dbg_pairrows;
     }
 }

@@ -56,8 +56,9 @@ enum {
     CEL_OPT_TAIL_LOG = 2,  /* T >= 0: a mixture component is skipped on an image tile when its
                               contribution stays below eps * e^-T everywhere on the part of the
                               tile its source covers (eps = the band's sky level, so the bound is
-                              relative to lambda >= eps).  0 = never skip.  default 40:
-                              |d lambda| / lambda <= n_components * e^-40 = n * 4.2e-18       */
+                              relative to lambda >= eps).  0 = never skip.  default 32:
+                              |d lambda| / lambda <= n_skipped * e^-32 = n * 1.3e-14, eight
+                              orders inside the 1e-6 parity bar even for thousands of skips  */
     CEL_OPT_PROFILE = 3,   /* 1 = bracket every kernel launch with HIP events              */
     CEL_OPT_TILE_ORDER = 4,/* 1 (default) = launch render tiles heaviest-first; never changes results */
     CEL_OPT_TILE_ROWS = 5, /* rows per render tile, 32 (default) or 64; read by cel_images_create  */

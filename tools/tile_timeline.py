@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="mixed10k_2048")
 ap.add_argument("--tile-order", type=int, default=1)
-ap.add_argument("--tail-log", type=float, default=40.0)
+ap.add_argument("--tail-log", type=float, default=32.0)
 args = ap.parse_args()
 
 import desi_mcmc_amd as cel  # noqa: E402
@@ -37,7 +37,13 @@ buf = np.zeros(3 * n.value, dtype=np.uint64)
 _lib.check(_lib.lib().cel_debug_tile_timing(f.images._h, buf.ctypes.data, C.byref(n)))
 t = buf.reshape(-1, 3)
 start, end = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)
-cnt = (t[:, 2] & np.uint64(0xffffffff)).astype(np.int64)
+cnt = (t[:, 2] & np.uint64(0xfff)).astype(np.int64)
+pairs = ((t[:, 2] >> np.uint64(12)) & np.uint64(0xfffff)).astype(np.int64)
+comprows = (t[:, 2] >> np.uint64(32)).astype(np.int64)
+print("work: sources %d  pairs of groups %d (%.2f per source)  kept component-rows %.3e (%.1f per pair, "
+      "x32 columns = %.3e kept Gaussian-pixel evaluations)"
+      % (cnt.sum(), pairs.sum(), pairs.sum() / max(cnt.sum(), 1), comprows.sum(), comprows.sum() / max(pairs.sum(), 1),
+         comprows.sum() * 32.0))
 t0 = start.min()
 start, end = (start - t0) / 100.0, (end - t0) / 100.0            # microseconds (100 MHz clock)
 dur = end - start
