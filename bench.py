@@ -34,8 +34,12 @@ FLOP_PER_GAUSS = 35.0        # SURVEY 8d accounting: 10 arithmetic + exp counted
 # tools/calib_traffic.hip).  Counters cannot be read from inside this process: the number is the
 # committed measurement of exactly this command and is reported only for the configuration it
 # was taken on; any other configuration gets null.
-PMC_TRAFFIC = {
-    ("mixed10k_2048", "recurrence", 40.0, 32): (383959848.0, "profiles/r01_v3_pmc_traffic.json"),
+PMC_TRAFFIC = {   # (workload, kernel, tail_log, layout) -> (HBM bytes per k_render launch, source)
+    ("mixed10k_2048", "recurrence", 32.0, 1): (383275349.0, "profiles/r01_final_pmc.json"),
+}
+# same provenance: SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * kernel cycles) and SQ_INSTS_VALU of that launch
+PMC_VALU = {
+    ("mixed10k_2048", "recurrence", 32.0, 1): (0.72, 7.66e8, "profiles/r01_final_pmc.json"),
 }
 CPU_THREADS_MAX = 16         # the GPU box's CPU share for one GPU
 
@@ -151,7 +155,7 @@ def main():
         #   read nelec 8 B + write lambda 8 B per image pixel, + one 128-B record per (source, band)
         alg_bytes = 16.0 * n_imgpix + 128.0 * S * B
         achieved = alg_bytes / (t_render * 1e-3) / 1e9 if t_render > 0 else 0.0
-        pmc = PMC_TRAFFIC.get((args.workload, args.kernel, args.tail_log, args.tile_rows))
+        pmc = PMC_TRAFFIC.get((args.workload, args.kernel, args.tail_log, args.layout))
         out = {
             "metric": "source-pixel evals/sec (full-field Poisson log-lik, %d sources x %d bands x %dx%d)" % (S, B, H, W),
             "value": n_srcpix_all * args.steps / dt_max,
@@ -167,7 +171,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "sources": S, "bands": B, "frame": [H, W],
                        "galaxy_fraction": fg, "kernel": args.kernel, "tail_log": args.tail_log,
-                       "tile_rows": args.tile_rows, "tile_order": args.tile_order,
+                       "tile_layout": "32x64 half-wave" if args.layout == 1 else "64x%d" % args.tile_rows,
+                       "tile_order": args.tile_order,
                        "parallelism": "1 field per GPU, %d GPU(s), 1 all-reduce of %d doubles per step" % (world, B)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc[0] if pmc else None,
@@ -184,6 +189,12 @@ def main():
             "loglik": float(np.sum(llb)),
         }
         out["fp64_valu"]["frac"] = out["fp64_valu"]["achieved"] / FP64_VALU_PEAK_TF
+        vp = PMC_VALU.get((args.workload, args.kernel, args.tail_log, args.layout))
+        if vp:
+            # how busy the vector ALUs really are, and the executed instruction stream, from the
+            # committed PMC profile of this configuration (not re-measured here)
+            out["fp64_valu"].update({"valu_busy_frac_pmc": vp[0], "valu_wave_instructions_per_launch_pmc": vp[1],
+                                     "pmc_source": vp[2]})
         if world == 1 and args.cpu_sample > 0:
             from oracle import oracle as orc      # cpu_baseline leg only
             out["cpu_baseline"] = cpu_baseline(field, min(args.cpu_sample, S), orc)

@@ -13,10 +13,13 @@
 // Design (DESIGN.md has the long form):
 //   k_prep    one thread per (band, source): pixel position, galaxy shape matrix, bounding
 //             radius, clipped box -> a 128-byte record + a 16-byte box.
-//   k_bin     one wave per (band, 64 x TH image tile): scans the band's boxes 64 at a time
-//             (ballot + prefix popcount) and writes the tile's source list in source order:
-//             deterministic, no sort, no atomics on the data path.
-//   k_render  one wave per tile, lane = pixel column (coalesced 512-B rows).  Gathers every
+//   k_bin_*   two-level binning (256 x 256 super-tiles, then render tiles) with ballot + prefix
+//             popcount compaction: every tile's source list comes out in source order --
+//             deterministic, no sort, no atomics on list contents; k_order launches the
+//             heaviest tiles first.
+//   k_render_hw / k_render
+//             one wave per tile (32 x 64 with two component groups per column, or 64 x 32 with
+//             one lane per column), coalesced row segments.  Gathers every
 //             source of the tile's list into an LDS accumulator tile, then writes
 //             lambda = eps + acc ONCE and fuses the Poisson term nelec*log(lambda) - lambda
 //             with a wavefront shuffle reduction.  Component tables (K = 3 star, 42 galaxy)
@@ -29,6 +32,8 @@
 //   k_reduce  fixed-order sum of the per-tile partials -> ll per band (bitwise reproducible).
 //   k_stamps  per-source stamps into a packed buffer (same column evaluators, no accumulator).
 //   k_gmm     generic N-point evaluator (gmm_like_2d).
+//   k_patch_ll / k_estep_* / k_photon_split
+//             per-source conditional log-likelihoods, E-step reductions, Gibbs photon split.
 // All arithmetic is fp64 on the vector ALU; MFMA is not used (no contraction in this path).
 
 #include <hip/hip_runtime.h>

@@ -17,6 +17,10 @@ CONFIGS = {
     "stamp51": (1, 1, 51, 51, 0.0),
     "stars1k_512": (1000, 5, 512, 512, 0.0),
     "mixed10k_2048": (10000, 5, 2048, 2048, 0.5),
+    # not a BASELINE config: the star-only regime of the same frame, where the HBM roof binds
+    # (3-component stamps: ~9 fp64 ops per source-pixel against 16 B per image pixel)
+    "stars10k_2048": (10000, 5, 2048, 2048, 0.0),
+    "stars2k_4096": (2000, 5, 4096, 4096, 0.0),
 }
 
 
