@@ -34,6 +34,12 @@ static_assert(sizeof(SrcRec) == 128, "SrcRec must be 128 bytes");
 __constant__ double c_prof_amp[K_PROF];
 __constant__ double c_prof_var[K_PROF];
 
+// log() table of the render epilogue (log_tab in k_render.h): for c_j = 1 + (j + 1/2)/64,
+// c_log_ic[j] = fl(1/c_j) and c_log_lc[j] = -log(c_log_ic[j]) evaluated in long double on the
+// host, so that log(m) = lc[j] + log1p(m * ic[j] - 1) holds to the last bit for m in [1, 2).
+__constant__ double c_log_ic[64];
+__constant__ double c_log_lc[64];
+
 static const double H_EXP_AMP[6] = {2.34853813e-03, 3.07995260e-02, 2.23364214e-01,
                                     1.17949102e+00, 4.33873750e+00, 5.99820770e+00};
 static const double H_EXP_VAR[6] = {1.20078965e-03, 8.84526493e-03, 3.91463084e-02,

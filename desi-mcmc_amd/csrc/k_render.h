@@ -195,6 +195,32 @@ __device__ inline double exp_tab64(double t, const double *__restrict__ et) {
     return ldexp(et[ni & 63] * p, ni >> 6);
 }
 
+// ---- log() for the Poisson term of the epilogue -----------------------------------------------
+// log(x) = e ln2 + lc[j] + log1p(r), x = 2^e m, m in [1,2), j = floor(64 (m - 1)),
+// r = m * ic[j] - 1 with |r| <= 2^-7, log1p by its series to r^7 (truncation r^8/8 < 2e-18).
+// ~19 fp64-rate instructions against ~95 for the library log (which carries double-double
+// arithmetic for arguments this path never sees); error <= ~1.5 ulp.  x must be positive,
+// finite and normal: lambda >= eps > 0 here.  lt = 128 doubles in LDS: ic[64] then lc[64].
+__device__ inline double log_tab(double x, const double *__restrict__ lt) {
+    const double LN2_HI = 0x1.62e42fee00000p-1;      // ln 2, upper 32 bits (e * HI is exact)
+    const double LN2_LO = 0x1.a39ef35793c76p-33;     // ln 2 - HI
+    if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return log(x);   // 0, <0, denormal, inf, NaN
+    int ex;
+    double m = frexp(x, &ex) * 2.0;                  // [1, 2)
+    ex -= 1;
+    int j = (int)((m - 1.0) * 64.0);
+    double r = fma(m, lt[j], -1.0);
+    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+    p = fma(p, r, 1.0 / 5.0);
+    p = fma(p, r, -0.25);
+    p = fma(p, r, 1.0 / 3.0);
+    p = fma(p, r, -0.5);
+    p = fma(p, r, 1.0);
+    p *= r;
+    double e = (double)ex;
+    return fma(e, LN2_HI, lt[64 + j] + fma(e, LN2_LO, p));
+}
+
 // ---- direct evaluator: sum over components of A exp(-q/2) at (x, y) -------------------------
 // qscale = 1 for a table holding the inverse covariance itself (stamps), 1/EXP_SCALE for the
 // render kernel's table, whose qa/qb/qc carry the factor 64/ln2.

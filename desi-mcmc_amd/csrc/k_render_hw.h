@@ -202,7 +202,13 @@ k_render_hw(RenderArgs a) {
         }
     }
 
-    // epilogue: one wave-instruction covers two 256-B row segments (rows 2r and 2r+1)
+    // epilogue: one wave-instruction covers two 256-B row segments (rows 2r and 2r+1).
+    // The component table is dead now: its LDS holds the log table (128 doubles) instead.
+    __syncthreads();
+    double *lt = reinterpret_cast<double *>(&T);
+    static_assert(sizeof(CompTab) >= 128 * sizeof(double), "log table must fit the component table");
+    lt[lane] = c_log_ic[lane];
+    lt[64 + lane] = c_log_lc[lane];
     __syncthreads();
     const double eps = bd->eps;
     const bool store = !(a.flags & CEL_RENDER_NO_STORE);
@@ -210,14 +216,19 @@ k_render_hw(RenderArgs a) {
     double part = 0.0;
     const int64_t plane = (int64_t)b * a.H * a.W;
     if (xi < a.W) {
-#pragma unroll 4
+        // all of the tile's nelec loads are issued before the first use: 16 KB in flight per
+        // wave (an empty-sky tile is pure streaming, and 8 waves per CU must cover HBM latency)
+        double ne[HW_TH / 2];
+        const int64_t base = plane + (int64_t)(Y0 + half) * a.W + xi;
+#pragma unroll
+        for (int r = 0; r < HW_TH / 2; r++)
+            ne[r] = (ll && Y0 + 2 * r + half < a.H) ? a.nelec[base + (int64_t)(2 * r) * a.W] : 0.0;
+#pragma unroll
         for (int r = 0; r < HW_TH / 2; r++) {
-            int y = Y0 + 2 * r + half;
-            if (y < a.H) {
+            if (Y0 + 2 * r + half < a.H) {
                 double lam = eps + acc[r * 64 + lane];
-                int64_t idx = plane + (int64_t)y * a.W + xi;
-                if (store) a.lambda[idx] = lam;
-                if (ll) part += a.nelec[idx] * log(lam) - lam;
+                if (store) a.lambda[base + (int64_t)(2 * r) * a.W] = lam;
+                if (ll) part += ne[r] * log_tab(lam, lt) - lam;
             }
         }
     }
