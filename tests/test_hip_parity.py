@@ -487,6 +487,79 @@ def test_estep_statistics_and_model_classes(cel, orc):
         im.epsilon = o
 
 
+def test_crowded_field_exercises_list_chunking_and_regrowth(cel, ctx, orc):
+    """8 000 stars + 300 galaxies on 320 x 448 x 2 bands: > 1024 candidates per super-tile (the fine binning
+    pass streams them through LDS in chunks), > 64 sources per render tile (the render kernel reloads
+    its index window), and tile lists that outgrow their first allocation (overflow -> regrow -> rerun)"""
+    from desi_mcmc_amd import synth
+    H, W, S = 320, 448, 8300
+    bands = synth.make_bands(H, W, 2)
+    src = synth.make_sources(S, H, W, bands, frac_gal=0.0, seed=3)
+    src["type"][:300] = 1
+    rs = np.random.RandomState(4)
+    nelec = rs.poisson(2000.0, size=(2, H, W)).astype(float)
+    for layout in (1, 0):
+        c2 = cel.Context(0)
+        c2.set_option(7, layout)
+        iset = cel.ImageSet(c2, bands, H, W, nelec=nelec)
+        # a 10-source render first: the list buffers get sized for it (10*2*6 + 1024 entries) ...
+        small = cel.SourceSet(c2, 16, 2).set(src["type"][:10], src["radec"][:10], src["counts"][:10], src["shape"][:10])
+        iset.render(small, loglik=True)
+        # ... and the crowded catalogue must overflow them, be detected on the device, and rerun
+        sset = cel.SourceSet(c2, S, 2).set(src["type"], src["radec"], src["counts"], src["shape"])
+        ll, llb = iset.render(sset, loglik=True)
+        st = iset.stats()
+        assert st["n_tile_entries"] > 20 * (10 * 2 * 6 + 1024)
+        lam = iset.model_images()
+        ll2, llb2 = iset.render(sset, loglik=True)                # steady state: same answer, bit for bit
+        assert np.array_equal(llb, llb2) and np.array_equal(lam, iset.model_images())
+        if layout == 1:
+            ob = bands.copy()
+            ob[:, 36] = [iset.band(0)[36], iset.band(1)[36]]
+            o_lam, o_ll, o_st = orc.render_field(ob, H, W, src["type"], src["radec"], src["counts"], src["shape"], nelec)
+            assert st["n_srcpix"] == o_st["n_srcpix"]
+            lam1, llb1 = lam, llb
+        np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM)
+        np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
+    np.testing.assert_allclose(lam, lam1, rtol=1e-11)
+
+
+def test_abi_error_paths(cel, ctx):
+    """bad arguments come back as ValueError (CEL_ERR_INVALID), never as a crash"""
+    from desi_mcmc_amd import synth
+    bands = synth.make_bands(64, 64, 2)
+    iset = cel.ImageSet(ctx, bands, 64, 64)
+    sset = cel.SourceSet(ctx, 4, 2).set(np.zeros(1, np.int32), np.zeros((1, 2)), np.ones((1, 2)), np.zeros((1, 4)))
+    with pytest.raises(ValueError, match="set_nelec"):
+        iset.render(sset, loglik=True)                          # log-lik before nelec was uploaded
+    with pytest.raises(ValueError):
+        iset.set_nelec(np.zeros((2, 64, 63)))
+    with pytest.raises(ValueError):
+        cel.SourceSet(ctx, 2, 2).set(np.zeros(3, np.int32), np.zeros((3, 2)), np.ones((3, 2)), np.zeros((3, 4)))
+    with pytest.raises(ValueError, match="bands"):
+        iset.render(cel.SourceSet(ctx, 4, 3).set(np.zeros(1, np.int32), np.zeros((1, 2)), np.ones((1, 3)), None))
+    bad = bands.copy()
+    bad[0, 12:16] = [1.0, 2.0, 2.0, 1.0]                         # PSF covariance not positive definite
+    with pytest.raises(ValueError, match="positive definite"):
+        cel.ImageSet(ctx, bad, 64, 64)
+    with pytest.raises(ValueError):
+        cel.ImageSet(ctx, bands, 0, 64)
+    with pytest.raises(ValueError):
+        ctx.set_option(1, 7.0)
+    with pytest.raises(ValueError):
+        ctx.set_tail_log(-1.0)
+    with pytest.raises(ValueError):
+        iset.patch_loglik(sset, np.array([[0, 10, 0, 10], [0, 0, 0, 0]]), [np.zeros((9, 10)), None])
+    iset.set_nelec(np.ones((2, 64, 64)))
+    with pytest.raises(ValueError, match="outside"):
+        iset.patch_loglik(sset, np.array([[0, 70, 0, 10], [0, 0, 0, 0]]), [np.zeros((70, 10)), None])
+    # NaN source parameters contribute nothing instead of poisoning the field
+    nan_src = cel.SourceSet(ctx, 4, 2).set(np.array([0, 1], np.int32), np.full((2, 2), np.nan), np.ones((2, 2)),
+                                           np.tile([0.5, 1.0, 0.0, 0.5], (2, 1)))
+    ll, llb = iset.render(nan_src, loglik=True)
+    assert np.all(iset.model_images() == bands[:, 0][:, None, None]) and np.isfinite(ll)
+
+
 def test_binomial_sampler_distribution(cel, ctx):
     """the split's Binomial(n, p) sampler (inversion / BTPE) against the exact pmf: the reference's
     randomkit stream cannot be reproduced, so parity is statistical"""
