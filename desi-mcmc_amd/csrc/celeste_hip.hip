@@ -104,7 +104,25 @@ struct cel_ctx {
                               // 1: 32 x 64 tiles, two component groups per column (k_render_hw)
     Prof prof;
     double *pinned = nullptr;   // MAX_BANDS + 8 doubles of pinned host memory for readbacks
+    // grow-only device scratch for the small per-call buffers of the stamp / patch-ll entry
+    // points (a hipMalloc + hipFree pair per call costs more than the kernels they bracket)
+    void *scratch[8] = {nullptr};
+    size_t scratch_cap[8] = {0};
 };
+
+static int scratch_get(cel_ctx *c, int slot, size_t bytes, void **out) {
+    if (bytes == 0) bytes = 8;
+    if (bytes > c->scratch_cap[slot]) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->scratch[slot]) (void)hipFree(c->scratch[slot]);
+        c->scratch[slot] = nullptr; c->scratch_cap[slot] = 0;
+        size_t cap = bytes + bytes / 2 + 256;
+        HIP_TRY(hipMalloc(&c->scratch[slot], cap));
+        c->scratch_cap[slot] = cap;
+    }
+    *out = c->scratch[slot];
+    return CEL_OK;
+}
 
 struct cel_images {
     cel_ctx *ctx = nullptr;
@@ -289,6 +307,8 @@ int cel_ctx_destroy(cel_ctx *c) {
     for (int i = 0; i < c->prof.cap; i++) (void)hipEventDestroy(c->prof.ev[i]);
     free(c->prof.ev);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    for (void *p : c->scratch)
+        if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return CEL_OK;
@@ -524,11 +544,14 @@ int cel_sources_set(cel_sources *s, int64_t S, const int32_t *type, const double
     if (S < 0 || S > s->cap) return fail(CEL_ERR_INVALID, "S=%lld exceeds capacity %lld", (long long)S, (long long)s->cap);
     HIP_TRY(hipSetDevice(s->ctx->device));
     hipStream_t st = s->ctx->stream;
-    int rc;
-    if ((rc = copy_in(s->d_type, type, sizeof(int) * S, mem, st))) return rc;
-    if ((rc = copy_in(s->d_radec, radec, sizeof(double) * 2 * S, mem, st))) return rc;
-    if ((rc = copy_in(s->d_counts, counts, sizeof(double) * s->B * S, mem, st))) return rc;
-    if ((rc = copy_in(s->d_shape, shape, sizeof(double) * 4 * S, mem, st))) return rc;
+    if (S > 0) {
+        const hipMemcpyKind kind = (mem == CEL_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        HIP_TRY(hipMemcpyAsync(s->d_type, type, sizeof(int) * S, kind, st));
+        HIP_TRY(hipMemcpyAsync(s->d_radec, radec, sizeof(double) * 2 * S, kind, st));
+        HIP_TRY(hipMemcpyAsync(s->d_counts, counts, sizeof(double) * s->B * S, kind, st));
+        HIP_TRY(hipMemcpyAsync(s->d_shape, shape, sizeof(double) * 4 * S, kind, st));
+        if (mem != CEL_DEVICE) HIP_TRY(hipStreamSynchronize(st));   // pageable sources must stay valid: one sync for the four
+    }
     s->S = S;
     return CEL_OK;
 }
@@ -780,10 +803,12 @@ int cel_render_stamps(cel_images *im, cel_sources *src, int band, int scaled, co
         e = (expr);                                                                      \
         if (e != hipSuccess) { rc = fail(CEL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); goto done; } \
     } while (0)
-    ST_TRY(hipMalloc((void **)&d_jobs, sizeof(StampJob) * jobs.size()));
-    ST_TRY(hipMalloc((void **)&d_obox, sizeof(int4) * S));
-    ST_TRY(hipMalloc((void **)&d_off, sizeof(int64_t) * (S + 1)));
-    if (mem == CEL_DEVICE) d_out = out; else ST_TRY(hipMalloc((void **)&d_out, sizeof(double) * (total > 0 ? total : 1)));
+    if ((rc = scratch_get(c, 4, sizeof(StampJob) * jobs.size(), (void **)&d_jobs)) ||
+        (rc = scratch_get(c, 5, sizeof(int4) * S, (void **)&d_obox)) ||
+        (rc = scratch_get(c, 6, sizeof(int64_t) * (S + 1), (void **)&d_off)))
+        return rc;
+    if (mem == CEL_DEVICE) d_out = out;
+    else if ((rc = scratch_get(c, 7, sizeof(double) * (total > 0 ? total : 1), (void **)&d_out))) return rc;
     ST_TRY(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(StampJob) * jobs.size(), hipMemcpyHostToDevice, c->stream));
     ST_TRY(hipMemcpyAsync(d_obox, obox.data(), sizeof(int4) * S, hipMemcpyHostToDevice, c->stream));
     ST_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (S + 1), hipMemcpyHostToDevice, c->stream));
@@ -799,10 +824,6 @@ int cel_render_stamps(cel_images *im, cel_sources *src, int band, int scaled, co
 #undef ST_TRY
 done:
     (void)hipStreamSynchronize(c->stream);
-    if (d_jobs) (void)hipFree(d_jobs);
-    if (d_obox) (void)hipFree(d_obox);
-    if (d_off) (void)hipFree(d_off);
-    if (mem != CEL_DEVICE && d_out) (void)hipFree(d_out);
     return rc;
 }
 
@@ -842,15 +863,16 @@ int cel_patch_loglik(cel_images *im, cel_sources *src, const int32_t *boxes, con
         e = (expr);                                                                      \
         if (e != hipSuccess) { rc = fail(CEL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); goto done; } \
     } while (0)
-    PL_TRY(hipMalloc((void **)&d_box, sizeof(int4) * B));
-    PL_TRY(hipMalloc((void **)&d_off, sizeof(int64_t) * (B + 1)));
-    PL_TRY(hipMalloc((void **)&d_out, sizeof(double) * P * B));
+    if ((rc = scratch_get(c, 0, sizeof(int4) * B, (void **)&d_box)) ||
+        (rc = scratch_get(c, 1, sizeof(int64_t) * (B + 1), (void **)&d_off)) ||
+        (rc = scratch_get(c, 2, sizeof(double) * P * B, (void **)&d_out)))
+        return rc;
     PL_TRY(hipMemcpyAsync(d_box, hbox.data(), sizeof(int4) * B, hipMemcpyHostToDevice, c->stream));
     PL_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice, c->stream));
     if (mem == CEL_DEVICE) {
         d_data = const_cast<double *>(data);
     } else {
-        PL_TRY(hipMalloc((void **)&d_data, sizeof(double) * (offsets[B] > 0 ? offsets[B] : 1)));
+        if ((rc = scratch_get(c, 3, sizeof(double) * (offsets[B] > 0 ? offsets[B] : 1), (void **)&d_data))) return rc;
         if (offsets[B] > 0)
             PL_TRY(hipMemcpyAsync(d_data, data, sizeof(double) * offsets[B], hipMemcpyHostToDevice, c->stream));
     }
@@ -871,10 +893,6 @@ int cel_patch_loglik(cel_images *im, cel_sources *src, const int32_t *boxes, con
 #undef PL_TRY
 done:
     (void)hipStreamSynchronize(c->stream);
-    if (d_box) (void)hipFree(d_box);
-    if (d_off) (void)hipFree(d_off);
-    if (d_out) (void)hipFree(d_out);
-    if (mem != CEL_DEVICE && d_data) (void)hipFree(d_data);
     return rc;
 }
 
