@@ -52,6 +52,8 @@ SYMBOLS = [
     ("cel_stamp_boxes", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_int32_p, c_int32_p]),
     ("cel_render_stamps", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_int32_p, c_int64_p, C.c_void_p, C.c_int]),
     ("cel_patch_loglik", C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, c_int64_p, C.c_void_p, C.c_int, C.c_int, c_double_p]),
+    ("cel_patch_loglik_multi", C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_int64, c_int32_p, c_int64_p, C.c_void_p,
+                                          C.c_int, C.c_int, c_double_p]),
     ("cel_source_boxes", C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, c_int32_p]),
     ("cel_photon_split", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, c_int64_p, C.c_void_p, C.c_int, c_double_p]),
     ("cel_debug_binomial", C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_uint64, C.c_int64, c_int64_p]),

@@ -828,33 +828,39 @@ done:
 }
 
 // ---- per-source conditional log-likelihoods ---------------------------------------------------
-int cel_patch_loglik(cel_images *im, cel_sources *src, const int32_t *boxes, const int64_t *offsets,
-                     const double *data, int mem, int mode, double *ll_out) {
+int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owner, int64_t NB,
+                           const int32_t *boxes, const int64_t *offsets, const double *data, int mem, int mode,
+                           double *ll_out) {
     if (!im || !src || !boxes || !offsets || !ll_out) return fail(CEL_ERR_INVALID, "cel_patch_loglik: null argument");
     if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
     if (mode != 0 && mode != 1) return fail(CEL_ERR_INVALID, "mode must be 0 (conditional) or 1 (isolated)");
+    if (NB < 1 || (NB > 1 && !owner)) return fail(CEL_ERR_INVALID, "cel_patch_loglik: NB patch sets need an owner array");
     cel_ctx *c = im->ctx;
     HIP_TRY(hipSetDevice(c->device));
     const int B = im->B;
-    const int64_t P = src->S;
+    const int64_t P = src->S, nb = NB * B;
     if (P == 0) return CEL_OK;
-    std::vector<int4> hbox((size_t)B);
-    for (int b = 0; b < B; b++) {
-        int y0 = boxes[4 * b], y1 = boxes[4 * b + 1], x0 = boxes[4 * b + 2], x1 = boxes[4 * b + 3];
+    std::vector<int4> hbox((size_t)nb);
+    for (int64_t i = 0; i < nb; i++) {
+        int y0 = boxes[4 * i], y1 = boxes[4 * i + 1], x0 = boxes[4 * i + 2], x1 = boxes[4 * i + 3];
         int64_t area = (y1 > y0 && x1 > x0) ? (int64_t)(y1 - y0) * (x1 - x0) : 0;
-        if (offsets[b + 1] - offsets[b] != area)
-            return fail(CEL_ERR_INVALID, "band %d: offsets give %lld patch values, the box has %lld pixels", b,
-                        (long long)(offsets[b + 1] - offsets[b]), (long long)area);
+        if (offsets[i + 1] - offsets[i] != area)
+            return fail(CEL_ERR_INVALID, "patch set %lld band %d: offsets give %lld patch values, the box has %lld pixels",
+                        (long long)(i / B), (int)(i % B), (long long)(offsets[i + 1] - offsets[i]), (long long)area);
         if (area > 0 && (y0 < 0 || x0 < 0 || y1 > im->H || x1 > im->W))
-            return fail(CEL_ERR_INVALID, "band %d: patch limits outside the image", b);
-        hbox[b] = make_int4(x0, x1, y0, y1);
+            return fail(CEL_ERR_INVALID, "patch set %lld band %d: patch limits outside the image", (long long)(i / B), (int)(i % B));
+        hbox[(size_t)i] = make_int4(x0, x1, y0, y1);
     }
-    if (offsets[B] > 0 && !data) return fail(CEL_ERR_INVALID, "cel_patch_loglik: null data");
+    if (owner)
+        for (int64_t p = 0; p < P; p++)
+            if (owner[p] < 0 || owner[p] >= NB) return fail(CEL_ERR_INVALID, "owner[%lld] = %d out of range", (long long)p, owner[p]);
+    if (offsets[nb] > 0 && !data) return fail(CEL_ERR_INVALID, "cel_patch_loglik: null data");
     int rc = run_prep(im, src);
     if (rc) return rc;
     im->last_S = P;
     int4 *d_box = nullptr;
     int64_t *d_off = nullptr;
+    int *d_owner = nullptr;
     double *d_data = nullptr, *d_out = nullptr;
     std::vector<double> hout((size_t)(P * B));
     hipError_t e;
@@ -863,23 +869,27 @@ int cel_patch_loglik(cel_images *im, cel_sources *src, const int32_t *boxes, con
         e = (expr);                                                                      \
         if (e != hipSuccess) { rc = fail(CEL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); goto done; } \
     } while (0)
-    if ((rc = scratch_get(c, 0, sizeof(int4) * B, (void **)&d_box)) ||
-        (rc = scratch_get(c, 1, sizeof(int64_t) * (B + 1), (void **)&d_off)) ||
+    if ((rc = scratch_get(c, 0, sizeof(int4) * nb + sizeof(int) * (owner ? P : 0), (void **)&d_box)) ||
+        (rc = scratch_get(c, 1, sizeof(int64_t) * (nb + 1), (void **)&d_off)) ||
         (rc = scratch_get(c, 2, sizeof(double) * P * B, (void **)&d_out)))
         return rc;
-    PL_TRY(hipMemcpyAsync(d_box, hbox.data(), sizeof(int4) * B, hipMemcpyHostToDevice, c->stream));
-    PL_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (B + 1), hipMemcpyHostToDevice, c->stream));
+    PL_TRY(hipMemcpyAsync(d_box, hbox.data(), sizeof(int4) * nb, hipMemcpyHostToDevice, c->stream));
+    PL_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice, c->stream));
+    if (owner) {
+        d_owner = reinterpret_cast<int *>(d_box + nb);
+        PL_TRY(hipMemcpyAsync(d_owner, owner, sizeof(int) * P, hipMemcpyHostToDevice, c->stream));
+    }
     if (mem == CEL_DEVICE) {
         d_data = const_cast<double *>(data);
     } else {
-        if ((rc = scratch_get(c, 3, sizeof(double) * (offsets[B] > 0 ? offsets[B] : 1), (void **)&d_data))) return rc;
-        if (offsets[B] > 0)
-            PL_TRY(hipMemcpyAsync(d_data, data, sizeof(double) * offsets[B], hipMemcpyHostToDevice, c->stream));
+        if ((rc = scratch_get(c, 3, sizeof(double) * (offsets[nb] > 0 ? offsets[nb] : 1), (void **)&d_data))) return rc;
+        if (offsets[nb] > 0)
+            PL_TRY(hipMemcpyAsync(d_data, data, sizeof(double) * offsets[nb], hipMemcpyHostToDevice, c->stream));
     }
     {
         int pi = prof_begin(c, CEL_K_STAMPS);
         hipLaunchKernelGGL(k_patch_ll, dim3((unsigned)(P * B)), dim3(256), 0, c->stream, im->d_bands, B, P, im->d_recs,
-                           d_box, d_off, d_data, mode, d_out);
+                           d_owner, d_box, d_off, d_data, mode, d_out);
         prof_end(c, pi);
     }
     PL_TRY(hipGetLastError());
@@ -894,6 +904,11 @@ int cel_patch_loglik(cel_images *im, cel_sources *src, const int32_t *boxes, con
 done:
     (void)hipStreamSynchronize(c->stream);
     return rc;
+}
+
+int cel_patch_loglik(cel_images *im, cel_sources *src, const int32_t *boxes, const int64_t *offsets,
+                     const double *data, int mem, int mode, double *ll_out) {
+    return cel_patch_loglik_multi(im, src, nullptr, 1, boxes, offsets, data, mem, mode, ll_out);
 }
 
 // ---- photon split -------------------------------------------------------------------------------

@@ -14,7 +14,8 @@
 
 __global__ void __launch_bounds__(256)
 k_patch_ll(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__restrict__ recs,
-           const int4 *__restrict__ pbox /* B: x0, x1, y0, y1 */, const int64_t *__restrict__ offsets,
+           const int *__restrict__ owner /* P: which patch set a proposal is scored on, or nullptr = 0 */,
+           const int4 *__restrict__ pbox /* NB*B: x0, x1, y0, y1 */, const int64_t *__restrict__ offsets /* NB*B+1 */,
            const double *__restrict__ data, int mode, double *__restrict__ out /* P*B */) {
     __shared__ CompTab T;
     __shared__ double red[256], red2[256];
@@ -24,7 +25,8 @@ k_patch_ll(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__
     const int64_t p = job / B;
     const BandDev *bd = bands + b;
     const SrcRec *rp = recs + (int64_t)b * P + p;
-    const int4 bx = pbox[b];
+    const int64_t ob = (int64_t)(owner ? owner[p] : 0) * B + b;
+    const int4 bx = pbox[ob];
     const int nx = bx.y - bx.x, ny = bx.w - bx.z;
     double wsum = bd->w[0] + bd->w[1] + bd->w[2];
     int type = rp->type;
@@ -47,7 +49,7 @@ k_patch_ll(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__
     }
     __syncthreads();
     const double eps = bd->eps;
-    const double *z = data + offsets[b];
+    const double *z = data + offsets[ob];
     double a = 0.0, m = 0.0;
     const int n = nx * ny;
     for (int i = tid; i < n; i += 256) {

@@ -264,6 +264,33 @@ class ImageSet(object):
                                          1 if isolated else 0, L.dptr(out)))
         return out
 
+    def patch_loglik_multi(self, sources, owner, boxes, patches, isolated=False):
+        """patch_loglik for proposals of many sources at once.  owner[p]: which patch set proposal p
+        is scored on; boxes (NB, B, 4); patches[set][band] arrays or None.  -> ll[P]"""
+        boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, self.B, 4)
+        NB = boxes.shape[0]
+        owner = np.ascontiguousarray(owner, dtype=np.int32)
+        if owner.shape != (sources.S,):
+            raise ValueError("owner must have one entry per proposal")
+        offs = np.zeros(NB * self.B + 1, dtype=np.int64)
+        flat = []
+        for o in range(NB):
+            for b in range(self.B):
+                y0, y1, x0, x1 = boxes[o, b]
+                n = int(y1 - y0) * int(x1 - x0) if (y1 > y0 and x1 > x0) else 0
+                if n:
+                    p = L.f64(patches[o][b])
+                    if p.shape != (y1 - y0, x1 - x0):
+                        raise ValueError("set %d band %d: patch shape %s does not match its box" % (o, b, p.shape))
+                    flat.append(p.ravel())
+                offs[o * self.B + b + 1] = offs[o * self.B + b] + n
+        data = np.concatenate(flat) if flat else np.zeros(1)
+        out = np.zeros(sources.S)
+        L.check(L.lib().cel_patch_loglik_multi(self._h, sources._h, owner.ctypes.data_as(L.c_int32_p), NB,
+                                               boxes.ctypes.data_as(L.c_int32_p), offs.ctypes.data_as(L.c_int64_p),
+                                               data.ctypes.data, L.CEL_HOST, 1 if isolated else 0, L.dptr(out)))
+        return out
+
     def stamp_boxes(self, sources, band):
         S = sources.S
         boxes = np.zeros((S, 4), dtype=np.int32)

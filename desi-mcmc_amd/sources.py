@@ -34,6 +34,50 @@ class SamplePatch(object):
         self.x0, self.x1 = int(xlim[0]), int(xlim[1])
 
 
+def log_likelihood_sweep(srcs, us, fluxes=None, shapes=None, isolated=False):
+    """Source.log_likelihood for proposals of MANY sources in one device launch -- what a whole
+    sweep of per-source location / flux / shape updates needs (sources.py:242-349).
+        srcs   list of Source, all with sample images on the same image objects
+        us     (S, P, 2) proposed locations; fluxes (S, P, 5) / shapes (S, P, 4) or None (current)
+    -> ll (S, P)"""
+    S = len(srcs)
+    us = np.asarray(us, dtype=np.float64)
+    P = us.shape[1]
+    imgs = None
+    for s in srcs:
+        cur = tuple(id(fi) for (_, fi, _) in s.sample_image_list)
+        if s.sample_image_list:
+            if imgs is None:
+                imgs = tuple(fi for (_, fi, _) in s.sample_image_list)
+            elif not set(cur) <= set(id(i) for i in imgs):
+                raise ValueError("log_likelihood_sweep: sources sampled on different image sets")
+    if imgs is None:
+        return np.zeros((S, P))
+    if len(imgs) > 16 or any(im.nelec.shape != imgs[0].nelec.shape for im in imgs):
+        raise ValueError("log_likelihood_sweep needs <= 16 same-shape images; use Source.log_likelihood_batch")
+    iset = _celeste._image_set(imgs)
+    B = len(imgs)
+    pos = {id(im): b for b, im in enumerate(imgs)}
+    typ = np.repeat(np.array([1 if s.is_galaxy() else 0 for s in srcs], dtype=np.int32), P)
+    fl = np.empty((S, P, 5))
+    sh = np.zeros((S, P, 4))
+    for i, s in enumerate(srcs):
+        fl[i] = np.array([s.params.flux_dict[b] for b in BANDS]) if fluxes is None else fluxes[i]
+        if s.is_galaxy():
+            sh[i] = np.asarray(s.params.shape, dtype=np.float64) if shapes is None else shapes[i]
+    counts = np.stack([(fl[..., BANDS.index(im.band)] / im.calib) * im.kappa for im in imgs], axis=-1).reshape(S * P, B)
+    boxes = np.zeros((S, B, 4), dtype=np.int32)
+    patches = [[None] * B for _ in range(S)]
+    for i, s in enumerate(srcs):
+        for (samp, im, _) in s.sample_image_list:
+            b = pos[id(im)]
+            boxes[i, b] = [samp.y0, samp.y1, samp.x0, samp.x1]
+            patches[i][b] = im.nelec[samp.y0:samp.y1, samp.x0:samp.x1] if isolated else np.array(samp.data)
+    sset = iset._sources(typ, us.reshape(S * P, 2), counts, sh.reshape(S * P, 4))
+    owner = np.repeat(np.arange(S, dtype=np.int32), P)
+    return iset.patch_loglik_multi(sset, owner, boxes, patches, isolated=isolated).reshape(S, P)
+
+
 class Source(object):
     """Holds one source's parameters and its sample images; scores parameter proposals."""
 

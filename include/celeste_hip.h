@@ -188,6 +188,12 @@ int cel_render_stamps(cel_images *img, cel_sources *src, int band, int scaled, c
  *   ll_out   P doubles (host) */
 int cel_patch_loglik(cel_images *img, cel_sources *src, const int32_t *boxes, const int64_t *offsets,
                      const double *data, int mem, int mode, double *ll_out);
+/* The same for proposals of MANY sources in one launch (a whole sweep of per-source updates):
+ * NB patch sets (boxes NB*B*4, offsets NB*B+1, index set*B + band) and owner[p] = the patch set
+ * proposal p is scored on (the source it is a proposal for). */
+int cel_patch_loglik_multi(cel_images *img, cel_sources *src, const int32_t *owner, int64_t NB,
+                           const int32_t *boxes, const int64_t *offsets, const double *data, int mem, int mode,
+                           double *ll_out);
 
 /* ---- photon split (Gibbs step) ------------------------------------------------------------ */
 /* boxes[(b*S+s)*4..] = y0,y1,x0,x1 and status[b*S+s] (as cel_stamp_boxes) for every band at once */

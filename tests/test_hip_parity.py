@@ -691,6 +691,16 @@ def test_field_resample_photons_feeds_source_loglik(cel):
     ll_true = src.log_likelihood()
     ll_bad = src.log_likelihood(fluxes=np.asarray(src.params.fluxes) * 3.0)
     assert np.isfinite(ll_true) and ll_true > ll_bad
+    # one launch for the proposals of every source == the per-source batches
+    from desi_mcmc_amd import sources
+    rs = np.random.RandomState(3)
+    us = np.array([s.params.u for s in m.srcs])[:, None, :] + rs.normal(0, 3e-5, size=(12, 5, 2))
+    sweep = sources.log_likelihood_sweep(m.srcs, us)
+    assert sweep.shape == (12, 5)
+    for i, s in enumerate(m.srcs):
+        np.testing.assert_allclose(sweep[i], s.log_likelihood_batch(us=us[i]), rtol=1e-13)
+    iso = sources.log_likelihood_sweep(m.srcs[:3], us[:3], isolated=True)
+    np.testing.assert_allclose(iso[1], m.srcs[1].log_likelihood_batch(us=us[1], isolated=True), rtol=1e-13)
     for im, o in zip(imgs, old):
         im.epsilon = o
 
