@@ -154,30 +154,13 @@ __device__ inline double quad_min_rect(double a, double b, double c, double x1, 
 }
 
 // ---- exp() for the recurrence seeds -----------------------------------------------------------
-// exp(x) = 2^e * 2^(j/64) * exp(r), x = (64 e + j) ln2/64 + r, |r| <= ln2/128:
-// a 64-entry table of 2^(j/64) in LDS and a degree-5 polynomial (truncation r^6/720 < 4e-17).
-// ~11 fp64 ops against ~17 + range checks for the library exp; error <= ~2 ulp.  Inputs are
-// finite and <= 709 here; large negative inputs flush to 0 through ldexp.
-__device__ inline double exp_tab(double x, const double *__restrict__ et) {
-    const double INV = 92.332482616893656758;        // 64 / ln 2
-    const double LN2_64_HI = 0x1.62e42fee00000p-7;         // ln2/64, upper 32 bits (n * HI is exact)
-    const double LN2_64_LO = 2.9815858269852933e-12;       // ln2/64 - HI
-    double n = rint(x * INV);
-    double r = fma(n, -LN2_64_HI, x);
-    r = fma(n, -LN2_64_LO, r);
-    int ni = (int)n;
-    double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(et[ni & 63] * p, ni >> 6);
-}
-
-// Same, for an argument already expressed in units of ln2/64 (t = x * 64/ln2): the table
-// builder folds that factor into the quadratic-form coefficients, which saves the scaling
-// multiply and the two-step reduction per seed.  f = t - rint(t) is exact; exp(f ln2/64) is
-// the same degree-5 polynomial with the powers of ln2/64 folded into its coefficients.
+// exp(x) = 2^e * 2^(j/64) * exp(r), x = (64 e + j) ln2/64 + r, |r| <= ln2/128: a 64-entry table
+// of 2^(j/64) in LDS and a degree-5 polynomial (truncation r^6/720 < 4e-17), ~9 fp64 ops against
+// ~17 + range checks for the library exp; error <= ~2 ulp.  The argument arrives already in units
+// of ln2/64 (t = x * 64/ln2: the table builder folds that factor into the quadratic-form
+// coefficients, which saves the scaling multiply and the two-step reduction per seed).
+// f = t - rint(t) is exact; the powers of ln2/64 are folded into the polynomial's coefficients.
+// Inputs are finite and <= 709*64/ln2 here; large negative inputs flush to 0 through ldexp.
 __device__ inline double exp_tab64(double t, const double *__restrict__ et) {
     const double c1 = 1.0830424696249145e-02;     // (ln2/64)
     const double c2 = 5.864904955056169e-05;      // (ln2/64)^2 / 2
