@@ -56,6 +56,8 @@ SYMBOLS = [
                                           C.c_int, C.c_int, c_double_p]),
     ("cel_source_boxes", C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, c_int32_p]),
     ("cel_photon_split", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, c_int64_p, C.c_void_p, C.c_int, c_double_p]),
+    ("cel_samples_info", C.c_int, [C.c_void_p, c_int64_p, c_int64_p]),
+    ("cel_samples_fetch", C.c_int, [C.c_void_p, c_int32_p, c_int64_p, C.c_void_p, c_double_p]),
     ("cel_debug_binomial", C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_uint64, C.c_int64, c_int64_p]),
     ("cel_estep_stats", C.c_int, [C.c_void_p, C.c_void_p, c_double_p, c_double_p, c_double_p]),
     ("cel_gmm_like_2d", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p, C.c_int,

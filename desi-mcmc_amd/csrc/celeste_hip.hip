@@ -149,6 +149,12 @@ struct cel_images {
     int *d_clist = nullptr;
     int64_t clist_cap = 0;
     unsigned long long *d_timing = nullptr;   // CEL_OPT_TILE_TIMING diagnostic stamps, 3 per tile
+    // device-resident sample patches of the last resident photon split (source-major, index s*B+b)
+    double *d_samp = nullptr;
+    int64_t samp_cap = 0;
+    int4 *d_sbox = nullptr;
+    int64_t *d_soff = nullptr;
+    int64_t slay_cap = 0, samp_S = 0, samp_total = 0;
     double *d_stats = nullptr;
     int64_t last_S = 0;
     double last_entries = 0;
@@ -386,7 +392,7 @@ int cel_images_destroy(cel_images *im) {
     (void)hipStreamSynchronize(im->ctx->stream);
     void *ptrs[] = {im->d_bands, im->d_nelec, im->d_lambda, im->d_partials, im->d_llband, im->d_recs,
                     im->d_boxes, im->d_kind, im->d_tile_cnt, im->d_tile_work, im->d_order, im->d_tile_off, im->d_cursor, im->d_lists, im->d_stats,
-                    im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing};
+                    im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete im;
@@ -831,17 +837,25 @@ done:
 int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owner, int64_t NB,
                            const int32_t *boxes, const int64_t *offsets, const double *data, int mem, int mode,
                            double *ll_out) {
-    if (!im || !src || !boxes || !offsets || !ll_out) return fail(CEL_ERR_INVALID, "cel_patch_loglik: null argument");
+    if (!im || !src || !ll_out) return fail(CEL_ERR_INVALID, "cel_patch_loglik: null argument");
     if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
     if (mode != 0 && mode != 1) return fail(CEL_ERR_INVALID, "mode must be 0 (conditional) or 1 (isolated)");
+    // resident form: boxes == offsets == data == NULL -> the patches of the last resident photon
+    // split (mode 0) or the observed image on those boxes (mode 1); NB must be that split's S
+    const bool resident = (!boxes && !offsets && !data);
+    if (!resident && (!boxes || !offsets)) return fail(CEL_ERR_INVALID, "cel_patch_loglik: null boxes / offsets");
+    if (resident && (im->samp_S <= 0 || NB != im->samp_S))
+        return fail(CEL_ERR_INVALID, "resident form needs a resident photon split of NB = %lld sources (have %lld)",
+                    (long long)NB, (long long)im->samp_S);
     if (NB < 1 || (NB > 1 && !owner)) return fail(CEL_ERR_INVALID, "cel_patch_loglik: NB patch sets need an owner array");
+    if (resident && mode == 1 && !im->have_nelec) return fail(CEL_ERR_INVALID, "the isolated form needs cel_images_set_nelec");
     cel_ctx *c = im->ctx;
     HIP_TRY(hipSetDevice(c->device));
     const int B = im->B;
     const int64_t P = src->S, nb = NB * B;
     if (P == 0) return CEL_OK;
-    std::vector<int4> hbox((size_t)nb);
-    for (int64_t i = 0; i < nb; i++) {
+    std::vector<int4> hbox((size_t)(resident ? 0 : nb));
+    for (int64_t i = 0; i < (resident ? 0 : nb); i++) {
         int y0 = boxes[4 * i], y1 = boxes[4 * i + 1], x0 = boxes[4 * i + 2], x1 = boxes[4 * i + 3];
         int64_t area = (y1 > y0 && x1 > x0) ? (int64_t)(y1 - y0) * (x1 - x0) : 0;
         if (offsets[i + 1] - offsets[i] != area)
@@ -854,7 +868,7 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
     if (owner)
         for (int64_t p = 0; p < P; p++)
             if (owner[p] < 0 || owner[p] >= NB) return fail(CEL_ERR_INVALID, "owner[%lld] = %d out of range", (long long)p, owner[p]);
-    if (offsets[nb] > 0 && !data) return fail(CEL_ERR_INVALID, "cel_patch_loglik: null data");
+    if (!resident && offsets[nb] > 0 && !data) return fail(CEL_ERR_INVALID, "cel_patch_loglik: null data");
     int rc = run_prep(im, src);
     if (rc) return rc;
     im->last_S = P;
@@ -869,17 +883,24 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
         e = (expr);                                                                      \
         if (e != hipSuccess) { rc = fail(CEL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); goto done; } \
     } while (0)
-    if ((rc = scratch_get(c, 0, sizeof(int4) * nb + sizeof(int) * (owner ? P : 0), (void **)&d_box)) ||
+    if ((rc = scratch_get(c, 0, sizeof(int4) * (resident ? 0 : nb) + sizeof(int) * (owner ? P : 0), (void **)&d_box)) ||
         (rc = scratch_get(c, 1, sizeof(int64_t) * (nb + 1), (void **)&d_off)) ||
         (rc = scratch_get(c, 2, sizeof(double) * P * B, (void **)&d_out)))
         return rc;
-    PL_TRY(hipMemcpyAsync(d_box, hbox.data(), sizeof(int4) * nb, hipMemcpyHostToDevice, c->stream));
-    PL_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice, c->stream));
     if (owner) {
-        d_owner = reinterpret_cast<int *>(d_box + nb);
+        d_owner = reinterpret_cast<int *>(d_box + (resident ? 0 : nb));
         PL_TRY(hipMemcpyAsync(d_owner, owner, sizeof(int) * P, hipMemcpyHostToDevice, c->stream));
     }
-    if (mem == CEL_DEVICE) {
+    if (resident) {
+        d_box = im->d_sbox;
+        d_off = im->d_soff;
+        d_data = (mode == 0) ? im->d_samp : nullptr;      // mode 1 reads nelec on the boxes
+    } else {
+        PL_TRY(hipMemcpyAsync(d_box, hbox.data(), sizeof(int4) * nb, hipMemcpyHostToDevice, c->stream));
+        PL_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice, c->stream));
+    }
+    if (resident) {
+    } else if (mem == CEL_DEVICE) {
         d_data = const_cast<double *>(data);
     } else {
         if ((rc = scratch_get(c, 3, sizeof(double) * (offsets[nb] > 0 ? offsets[nb] : 1), (void **)&d_data))) return rc;
@@ -889,7 +910,7 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
     {
         int pi = prof_begin(c, CEL_K_STAMPS);
         hipLaunchKernelGGL(k_patch_ll, dim3((unsigned)(P * B)), dim3(256), 0, c->stream, im->d_bands, B, P, im->d_recs,
-                           d_owner, d_box, d_off, d_data, mode, d_out);
+                           d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, mode, d_out);
         prof_end(c, pi);
     }
     PL_TRY(hipGetLastError());
@@ -936,7 +957,9 @@ int cel_source_boxes(cel_images *im, cel_sources *src, int32_t *boxes, int32_t *
 
 int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int64_t *offsets, double *samp,
                      int mem, double *noise) {
-    if (!im || !src || !offsets || !samp) return fail(CEL_ERR_INVALID, "cel_photon_split: null argument");
+    if (!im || !src) return fail(CEL_ERR_INVALID, "cel_photon_split: null argument");
+    const bool resident = (offsets == nullptr);
+    if (!resident && !samp) return fail(CEL_ERR_INVALID, "cel_photon_split: offsets given without an output buffer");
     if (!im->have_nelec) return fail(CEL_ERR_INVALID, "cel_photon_split needs cel_images_set_nelec first");
     if (im->TW * im->TH != 2048) return fail(CEL_ERR_INVALID, "cel_photon_split needs 2048-pixel render tiles");
     cel_ctx *c = im->ctx;
@@ -947,19 +970,44 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
     const int B = im->B;
     const int64_t S = src->S, n = S * B;
     const int T = B * im->ntx * im->nty;
-    const int64_t total = offsets[n];
+    int64_t total = 0;
     int64_t *d_off = nullptr;
     double *d_samp = nullptr;
-    hipError_t e;
-#define PS_TRY(expr)                                                                     \
-    do {                                                                                 \
-        e = (expr);                                                                      \
-        if (e != hipSuccess) { rc = fail(CEL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); goto done; } \
-    } while (0)
-    PS_TRY(hipMalloc((void **)&d_off, sizeof(int64_t) * (n + 1)));
-    PS_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, c->stream));
-    if (mem == CEL_DEVICE) d_samp = samp; else PS_TRY(hipMalloc((void **)&d_samp, sizeof(double) * (total > 0 ? total : 1)));
-    PS_TRY(hipMemsetAsync(d_samp, 0, sizeof(double) * (total > 0 ? total : 1), c->stream));
+    if (resident) {
+        // patch boxes + offsets laid out on the device; only the total size comes back
+        if (n + 1 > im->slay_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (im->d_sbox) (void)hipFree(im->d_sbox);
+            if (im->d_soff) (void)hipFree(im->d_soff);
+            im->d_sbox = nullptr; im->d_soff = nullptr; im->slay_cap = 0;
+            int64_t cap = n + n / 4 + 64;
+            HIP_TRY(hipMalloc((void **)&im->d_sbox, sizeof(int4) * cap));
+            HIP_TRY(hipMalloc((void **)&im->d_soff, sizeof(int64_t) * cap));
+            im->slay_cap = cap;
+        }
+        hipLaunchKernelGGL(k_samp_layout, dim3(1), dim3(1024), 0, c->stream, im->d_recs, S, B, im->d_sbox, im->d_soff);
+        HIP_TRY(hipMemcpyAsync(c->pinned + MAX_BANDS + 2, im->d_soff + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        memcpy(&total, c->pinned + MAX_BANDS + 2, sizeof(total));
+        if (total > im->samp_cap) {
+            if (im->d_samp) (void)hipFree(im->d_samp);
+            im->d_samp = nullptr; im->samp_cap = 0;
+            int64_t cap = total + total / 8 + 1024;
+            HIP_TRY(hipMalloc((void **)&im->d_samp, sizeof(double) * cap));
+            im->samp_cap = cap;
+        }
+        d_off = im->d_soff;
+        d_samp = im->d_samp;
+        im->samp_S = S;
+        im->samp_total = total;
+    } else {
+        total = offsets[n];
+        if ((rc = scratch_get(c, 1, sizeof(int64_t) * (n + 1), (void **)&d_off))) return rc;
+        HIP_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, c->stream));
+        if (mem == CEL_DEVICE) d_samp = samp;
+        else if ((rc = scratch_get(c, 3, sizeof(double) * (total > 0 ? total : 1), (void **)&d_samp))) return rc;
+    }
+    if (total > 0) HIP_TRY(hipMemsetAsync(d_samp, 0, sizeof(double) * total, c->stream));
     {
         SplitArgs a;
         a.bands = im->d_bands; a.recs = im->d_recs; a.lists = im->d_lists; a.tile_cnt = im->d_tile_cnt;
@@ -971,18 +1019,46 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         prof_end(c, pi);
     }
     hipLaunchKernelGGL(k_reduce, dim3(B), dim3(256), 0, c->stream, im->d_partials, im->ntx * im->nty, im->d_llband);
-    PS_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
-    if (mem != CEL_DEVICE && total > 0)
-        PS_TRY(hipMemcpyAsync(samp, d_samp, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream));
-    PS_TRY(hipGetLastError());
-    PS_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
+    if (!resident && mem != CEL_DEVICE && total > 0)
+        HIP_TRY(hipMemcpyAsync(samp, d_samp, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
     if (noise) for (int b = 0; b < B; b++) noise[b] = c->pinned[b];
-#undef PS_TRY
-done:
-    (void)hipStreamSynchronize(c->stream);
-    if (d_off) (void)hipFree(d_off);
-    if (mem != CEL_DEVICE && d_samp) (void)hipFree(d_samp);
-    return rc;
+    return CEL_OK;
+}
+
+int cel_samples_info(cel_images *im, int64_t *S, int64_t *total) {
+    if (!im || !S || !total) return fail(CEL_ERR_INVALID, "cel_samples_info: null argument");
+    *S = im->samp_S;
+    *total = im->samp_total;
+    return CEL_OK;
+}
+
+int cel_samples_fetch(cel_images *im, int32_t *boxes, int64_t *offsets, double *data, double *sums) {
+    if (!im) return fail(CEL_ERR_INVALID, "cel_samples_fetch: null argument");
+    if (im->samp_S <= 0) return fail(CEL_ERR_INVALID, "no resident photon split: call cel_photon_split with offsets = NULL first");
+    cel_ctx *c = im->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t n = im->samp_S * im->B;
+    int rc = CEL_OK;
+    if (boxes) {
+        std::vector<int4> hb((size_t)n);
+        if ((rc = copy_out(hb.data(), im->d_sbox, sizeof(int4) * n, CEL_HOST, c->stream))) return rc;
+        for (int64_t i = 0; i < n; i++) {
+            boxes[4 * i] = hb[i].z; boxes[4 * i + 1] = hb[i].w; boxes[4 * i + 2] = hb[i].x; boxes[4 * i + 3] = hb[i].y;
+        }
+    }
+    if (offsets && (rc = copy_out(offsets, im->d_soff, sizeof(int64_t) * (n + 1), CEL_HOST, c->stream))) return rc;
+    if (data && im->samp_total > 0 &&
+        (rc = copy_out(data, im->d_samp, sizeof(double) * im->samp_total, CEL_HOST, c->stream))) return rc;
+    if (sums) {
+        double *d_sums = nullptr;
+        if ((rc = scratch_get(c, 2, sizeof(double) * n, (void **)&d_sums))) return rc;
+        hipLaunchKernelGGL(k_patch_sums, dim3((unsigned)n), dim3(256), 0, c->stream, im->d_soff, im->d_samp, d_sums);
+        if ((rc = copy_out(sums, d_sums, sizeof(double) * n, CEL_HOST, c->stream))) return rc;
+    }
+    return CEL_OK;
 }
 
 int cel_debug_binomial(cel_ctx *c, int64_t n, double p, uint64_t seed, int64_t N, int64_t *out) {

@@ -16,7 +16,8 @@ __global__ void __launch_bounds__(256)
 k_patch_ll(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__restrict__ recs,
            const int *__restrict__ owner /* P: which patch set a proposal is scored on, or nullptr = 0 */,
            const int4 *__restrict__ pbox /* NB*B: x0, x1, y0, y1 */, const int64_t *__restrict__ offsets /* NB*B+1 */,
-           const double *__restrict__ data, int mode, double *__restrict__ out /* P*B */) {
+           const double *__restrict__ data, const double *__restrict__ nelec /* used when data == nullptr */,
+           int H, int W, int mode, double *__restrict__ out /* P*B */) {
     __shared__ CompTab T;
     __shared__ double red[256], red2[256];
     const int tid = threadIdx.x;
@@ -49,17 +50,21 @@ k_patch_ll(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__
     }
     __syncthreads();
     const double eps = bd->eps;
-    const double *z = data + offsets[ob];
+    // patch data: a packed buffer (photons attributed to the source), or -- when none is given --
+    // the observed image itself on the box (the isolated form reads nelec, sources.py:204)
+    const double *z = data ? data + offsets[ob] : nelec + (int64_t)b * H * W + (int64_t)bx.z * W + bx.x;
+    const int zpitch = data ? nx : W;
     double a = 0.0, m = 0.0;
     const int n = nx * ny;
     for (int i = tid; i < n; i += 256) {
         int yy = i / nx, xx = i - yy * nx;
         double v = counts * eval_direct(T, 0, K, (double)(bx.x + xx), (double)(bx.z + yy), 1.0);
+        const double zi = z[(int64_t)yy * zpitch + xx];
         if (mode == 0) {
-            if (v > 0.0) a += log(v) * z[i];
+            if (v > 0.0) a += log(v) * zi;
         } else {
             v += eps;
-            a += log(v) * z[i];
+            a += log(v) * zi;
             m += v;
         }
     }

@@ -158,6 +158,64 @@ __device__ inline long long binomial_draw(long long n, double p, Philox &g) {
     return flip ? n - y : y;
 }
 
+// ---- device-resident sample patches ------------------------------------------------------------
+// The split's output is consumed on the device by the per-source conditional likelihoods
+// (k_patch_ll), so the patches need never cross PCIe (3.2 GB at config 3).  k_samp_layout turns
+// the (band, source) records into source-major patch boxes and offsets (an exclusive scan of the
+// box areas) in ONE block; k_patch_sums reduces every patch to its photon count (what the flux
+// Gibbs step conditions on, sources.py:327-345).
+__global__ void __launch_bounds__(1024)
+k_samp_layout(const SrcRec *__restrict__ recs, int64_t S, int B, int4 *__restrict__ sbox /* S*B: x0,x1,y0,y1 */,
+              int64_t *__restrict__ soff /* S*B + 1 */) {
+    __shared__ long long part[1024];
+    __shared__ long long carry;
+    const int tid = threadIdx.x;
+    const int64_t n = S * B;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + tid;          // i = s*B + b
+        long long area = 0;
+        if (i < n) {
+            const int64_t s = i / B;
+            const int b = (int)(i - s * B);
+            const SrcRec &r = recs[(int64_t)b * S + s];
+            const bool ok = r.type >= 0;
+            sbox[i] = ok ? make_int4(r.x0, r.x1, r.y0, r.y1) : make_int4(0, 0, 0, 0);
+            area = ok ? (long long)(r.x1 - r.x0) * (r.y1 - r.y0) : 0;
+        }
+        part[tid] = area;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {            // inclusive Hillis-Steele scan
+            long long v = (tid >= o) ? part[tid - o] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        if (i < n) soff[i] = carry + part[tid] - area;   // exclusive
+        __syncthreads();
+        if (tid == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) soff[n] = carry;
+}
+
+__global__ void __launch_bounds__(256)
+k_patch_sums(const int64_t *__restrict__ soff, const double *__restrict__ samp, double *__restrict__ sums) {
+    __shared__ double red[256];
+    const int64_t i = blockIdx.x;
+    const int64_t lo = soff[i], hi = soff[i + 1];
+    double a = 0.0;
+    for (int64_t k = lo + threadIdx.x; k < hi; k += 256) a += samp[k];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[i] = red[0];
+}
+
 // diagnostic: N independent Binomial(n, p) draws (stream i), for the sampler's own tests
 __global__ void __launch_bounds__(256)
 k_binomial_draws(long long n, double p, unsigned long long seed, int64_t N, long long *__restrict__ out) {
@@ -174,7 +232,7 @@ struct SplitArgs {
     const int *tile_cnt;
     const int64_t *tile_off;
     const double *nelec;
-    const int64_t *offsets;     // [B*S + 1] packed position of each (band, source) sample patch
+    const int64_t *offsets;     // [S*B + 1] packed position of the sample patch of (source s, band b) at s*B + b
     double *samp;               // packed sample patches, zero-initialised by the caller
     double *partials;           // per-tile noise sums
     int64_t S, capacity;
@@ -229,7 +287,7 @@ k_photon_split(SplitArgs a) {
             }
             __syncthreads();
             const int nx = bx1 - bx0;
-            double *patch = a.samp + a.offsets[(int64_t)b * a.S + s];
+            double *patch = a.samp + a.offsets[(int64_t)s * a.B + b];    // source-major, like cel_patch_loglik_multi
             const bool colin = (xi > bx0) && (xi < bx1);                 // strict on the low side (:50)
             for (int i = 0; i < niter; i++) {
                 const int y = Y0 + i * rstep + rsub;

@@ -215,7 +215,7 @@ class ImageSet(object):
         boxes, status = self.source_boxes(sources)
         area = np.where(status > 0, (boxes[..., 1] - boxes[..., 0]).astype(np.int64) * (boxes[..., 3] - boxes[..., 2]), 0)
         offs = np.zeros(self.B * S + 1, dtype=np.int64)
-        np.cumsum(area.ravel(), out=offs[1:])
+        np.cumsum(area.T.ravel(), out=offs[1:])              # source-major: index s*B + b
         flat = np.zeros(max(int(offs[-1]), 1))
         noise = np.zeros(self.B)
         L.check(L.lib().cel_photon_split(self._h, sources._h, C.c_uint64(int(seed) & (2 ** 64 - 1)),
@@ -224,7 +224,7 @@ class ImageSet(object):
         for b in range(self.B):
             row = []
             for s in range(S):
-                i = b * S + s
+                i = s * self.B + b
                 if status[b, s] > 0:
                     row.append(flat[offs[i]:offs[i + 1]].reshape(boxes[b, s, 1] - boxes[b, s, 0],
                                                                  boxes[b, s, 3] - boxes[b, s, 2]))
@@ -232,6 +232,48 @@ class ImageSet(object):
                     row.append(None)
             out.append(row)
         return out, boxes, noise
+
+    # ---- device-resident Gibbs pieces: nothing but proposals and scalars crosses PCIe -------------
+    def photon_split_resident(self, sources, seed):
+        """The photon split with the sample patches kept in device memory (3.2 GB at 10 000
+        sources x 5 bands x 2048^2 never leave the GPU).  -> noise_sum[B]"""
+        noise = np.zeros(self.B)
+        L.check(L.lib().cel_photon_split(self._h, sources._h, C.c_uint64(int(seed) & (2 ** 64 - 1)), None, None,
+                                         L.CEL_DEVICE, L.dptr(noise)))
+        return noise
+
+    def patch_loglik_resident(self, proposals, owner, isolated=False):
+        """Conditional log-likelihoods of proposals against the resident sample patches
+        (isolated=True: against the observed image on the same boxes).  owner[p] = index of the
+        source (of the split) that proposal p belongs to.  -> ll[P]"""
+        owner = np.ascontiguousarray(owner, dtype=np.int32)
+        if owner.shape != (proposals.S,):
+            raise ValueError("owner must have one entry per proposal")
+        S, tot = C.c_int64(0), C.c_int64(0)
+        L.check(L.lib().cel_samples_info(self._h, C.byref(S), C.byref(tot)))
+        out = np.zeros(proposals.S)
+        L.check(L.lib().cel_patch_loglik_multi(self._h, proposals._h, owner.ctypes.data_as(L.c_int32_p), S.value,
+                                               None, None, None, L.CEL_DEVICE, 1 if isolated else 0, L.dptr(out)))
+        return out
+
+    def sample_sums(self):
+        """photons attributed to every (source, band) by the resident split -> (S, B)"""
+        S, tot = C.c_int64(0), C.c_int64(0)
+        L.check(L.lib().cel_samples_info(self._h, C.byref(S), C.byref(tot)))
+        sums = np.zeros((S.value, self.B))
+        L.check(L.lib().cel_samples_fetch(self._h, None, None, None, L.dptr(sums)))
+        return sums
+
+    def fetch_samples(self):
+        """host copies of the resident split: (boxes[S,B,4] = y0,y1,x0,x1, offsets[S*B+1], data)"""
+        S, tot = C.c_int64(0), C.c_int64(0)
+        L.check(L.lib().cel_samples_info(self._h, C.byref(S), C.byref(tot)))
+        boxes = np.zeros((S.value, self.B, 4), dtype=np.int32)
+        offs = np.zeros(S.value * self.B + 1, dtype=np.int64)
+        data = np.zeros(max(tot.value, 1))
+        L.check(L.lib().cel_samples_fetch(self._h, boxes.ctypes.data_as(L.c_int32_p), offs.ctypes.data_as(L.c_int64_p),
+                                          data.ctypes.data, None))
+        return boxes, offs, data[:tot.value]
 
     def estep_stats(self, sources):
         """E-step reductions (celeste_em.py:38-91) -> (xtilde[S,B], mass[S,B], noise[B])."""

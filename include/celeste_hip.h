@@ -190,7 +190,10 @@ int cel_patch_loglik(cel_images *img, cel_sources *src, const int32_t *boxes, co
                      const double *data, int mem, int mode, double *ll_out);
 /* The same for proposals of MANY sources in one launch (a whole sweep of per-source updates):
  * NB patch sets (boxes NB*B*4, offsets NB*B+1, index set*B + band) and owner[p] = the patch set
- * proposal p is scored on (the source it is a proposal for). */
+ * proposal p is scored on (the source it is a proposal for).
+ * RESIDENT form: boxes = offsets = data = NULL and NB = the S of the last resident
+ * cel_photon_split: mode 0 scores against that split's device-resident sample patches, mode 1
+ * against the observed image on the same boxes -- nothing crosses PCIe but the proposals. */
 int cel_patch_loglik_multi(cel_images *img, cel_sources *src, const int32_t *owner, int64_t NB,
                            const int32_t *boxes, const int64_t *offsets, const double *data, int mem, int mode,
                            double *ll_out);
@@ -201,8 +204,11 @@ int cel_source_boxes(cel_images *img, cel_sources *src, int32_t *boxes, int32_t 
 /* sample_source_counts / sample_multinomial (CelestePy/celeste_sample_sources.pyx:61-156) for every
  * band image: each pixel's nelec photons are split among the sources whose patch strictly contains
  * the pixel (:50-51) and the sky, by conditional binomials in source order, sky last.
- *   offsets  B*S+1: packed position of the sample patch of (band b, source s) at index b*S+s;
- *            offsets[i+1]-offsets[i] = that source's box area (cel_source_boxes), 0 without a patch
+ *   offsets  S*B+1: packed position of the sample patch of (source s, band b) at index s*B+b (the
+ *            patch-set layout of cel_patch_loglik_multi); offsets[i+1]-offsets[i] = that box's area
+ *            (cel_source_boxes), 0 without a patch.
+ *            NULL = RESIDENT form: the library lays the patches out itself and keeps them in
+ *            device memory for cel_patch_loglik_multi / cel_samples_fetch; samp is ignored
  *   samp     packed sample patches (doubles holding integers, as NativePatch.data), zeroed here
  *   noise    B doubles (host): photons attributed to the sky, the reference's noise_sum
  * Random numbers: Philox4x32-10 keyed by (seed; band, pixel, source) -- a result depends only on
@@ -211,6 +217,13 @@ int cel_source_boxes(cel_images *img, cel_sources *src, int32_t *boxes, int32_t 
 int cel_photon_split(cel_images *img, cel_sources *src, uint64_t seed, const int64_t *offsets, double *samp,
                      int mem, double *noise);
 
+/* the resident split's bookkeeping: number of sources and of packed patch values */
+int cel_samples_info(cel_images *img, int64_t *S, int64_t *total);
+/* copy out what the resident split holds; every output may be NULL:
+ *   boxes S*B*4 (y0,y1,x0,x1 at s*B+b), offsets S*B+1, data (offsets[S*B] doubles),
+ *   sums S*B = photons attributed to source s in band b (the flux Gibbs step's statistic,
+ *   sources.py:327-345), reduced on the device */
+int cel_samples_fetch(cel_images *img, int32_t *boxes, int64_t *offsets, double *data, double *sums);
 /* diagnostic: N independent Binomial(n, p) variates from the split's sampler (stream i = draw i) */
 int cel_debug_binomial(cel_ctx *ctx, int64_t n, double p, uint64_t seed, int64_t N, int64_t *out);
 

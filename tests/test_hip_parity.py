@@ -666,6 +666,56 @@ def test_photon_split_conservation_moments_quirks(cel, ctx, orc):
         assert tot == g["nelec"][b].sum()                                         # every photon lands exactly once
 
 
+def test_resident_split_and_loglik_equal_host_buffer_forms(cel, ctx):
+    """device-resident sample patches (cel_photon_split with offsets = NULL, resident
+    cel_patch_loglik_multi) give exactly what the host-buffer forms give for the same seed"""
+    from desi_mcmc_amd import field
+    g = load_golden("mini_field.npz")
+    H, W, S = int(g["H"]), int(g["W"]), 12
+    bands = field.pack_bands(g)
+    counts = g["flux"] / g["calib"][None, :] * g["kappa"][None, :] * 5.0
+    iset = cel.ImageSet(ctx, bands, H, W, nelec=g["nelec"])
+    sset = cel.SourceSet(ctx, S, 5).set(g["is_gal"], g["radec"], counts, g["shape"])
+    patches, boxes, noise = iset.photon_split(sset, seed=21)
+    noise_r = iset.photon_split_resident(sset, seed=21)
+    assert np.array_equal(noise, noise_r)
+    rb, roff, rdata = iset.fetch_samples()
+    sums = iset.sample_sums()
+    for s in range(S):
+        for b in range(5):
+            i = s * 5 + b
+            if patches[b][s] is None:
+                assert roff[i + 1] == roff[i] and sums[s, b] == 0
+                continue
+            assert tuple(rb[s, b]) == tuple(boxes[b, s])
+            assert np.array_equal(rdata[roff[i]:roff[i + 1]].reshape(patches[b][s].shape), patches[b][s])
+            assert sums[s, b] == patches[b][s].sum()
+    # proposals of several sources against the resident patches == against host copies of them
+    rs = np.random.RandomState(8)
+    P = 4
+    own = np.repeat(np.arange(S, dtype=np.int32), P)
+    prop = cel.SourceSet(ctx, S * P, 5).set(np.repeat(g["is_gal"], P), np.repeat(g["radec"], P, axis=0) +
+                                            rs.normal(0, 3e-5, size=(S * P, 2)), np.repeat(counts, P, axis=0),
+                                            np.repeat(g["shape"], P, axis=0))
+    ll_res = iset.patch_loglik_resident(prop, own)
+    host_boxes = np.transpose(boxes, (1, 0, 2))
+    host_patches = [[patches[b][s] for b in range(5)] for s in range(S)]
+    for s in range(S):
+        for b in range(5):
+            if host_patches[s][b] is None:
+                host_boxes[s, b] = 0
+    ll_host = iset.patch_loglik_multi(prop, own, host_boxes, host_patches)
+    assert np.array_equal(ll_res, ll_host)
+    iso_res = iset.patch_loglik_resident(prop, own, isolated=True)
+    iso_host = iset.patch_loglik_multi(prop, own, host_boxes,
+                                       [[None if host_patches[s][b] is None else
+                                         g["nelec"][b, host_boxes[s, b, 0]:host_boxes[s, b, 1], host_boxes[s, b, 2]:host_boxes[s, b, 3]]
+                                         for b in range(5)] for s in range(S)], isolated=True)
+    assert np.array_equal(iso_res, iso_host)
+    with pytest.raises(ValueError, match="resident"):
+        cel.ImageSet(ctx, bands, H, W, nelec=g["nelec"]).patch_loglik_resident(prop, own)
+
+
 def test_field_resample_photons_feeds_source_loglik(cel):
     """Field.resample_photons (models.py:123-160) -> Source.log_likelihood on the sampled patches"""
     from desi_mcmc_amd import models
