@@ -151,6 +151,8 @@ struct cel_images {
     unsigned long long *d_timing = nullptr;   // CEL_OPT_TILE_TIMING diagnostic stamps, 3 per tile
     // device-resident sample patches of the last resident photon split (source-major, index s*B+b)
     double *d_samp = nullptr;
+    int4 *d_snz = nullptr;      // nonzero rectangles of the resident sample patches (k_patch_nzbox)
+    double *d_rate = nullptr;   // per-pixel total rates of the photon split (strict boxes), B*H*W, on first use
     int64_t samp_cap = 0;
     int4 *d_sbox = nullptr;
     int64_t *d_soff = nullptr;
@@ -392,7 +394,7 @@ int cel_images_destroy(cel_images *im) {
     (void)hipStreamSynchronize(im->ctx->stream);
     void *ptrs[] = {im->d_bands, im->d_nelec, im->d_lambda, im->d_partials, im->d_llband, im->d_recs,
                     im->d_boxes, im->d_kind, im->d_tile_cnt, im->d_tile_work, im->d_order, im->d_tile_off, im->d_cursor, im->d_lists, im->d_stats,
-                    im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff};
+                    im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff, im->d_rate, im->d_snz};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete im;
@@ -618,7 +620,17 @@ static int run_prep(cel_images *im, cel_sources *src) {
     return CEL_OK;
 }
 
+// internal render flag: sources take part only strictly inside their boxes on the low side
+// (x > x0, y > y0), the photon split's membership rule (celeste_sample_sources.pyx:50-51)
+#define CEL_RENDER_STRICT 4
+static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_band, double *ll_total, double *lambda_out);
+
 int cel_render_field(cel_images *im, cel_sources *src, int flags, double *ll_band, double *ll_total) {
+    if (flags & ~(CEL_RENDER_LOGLIK | CEL_RENDER_NO_STORE)) return fail(CEL_ERR_INVALID, "cel_render_field: unknown flag bits");
+    return render_impl(im, src, flags, ll_band, ll_total, nullptr);
+}
+
+static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_band, double *ll_total, double *lambda_out) {
     if (!im || !src) return fail(CEL_ERR_INVALID, "cel_render_field: null argument");
     if (src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "images and sources belong to different contexts");
     if (src->B != im->B) return fail(CEL_ERR_INVALID, "sources carry %d bands, images %d", src->B, im->B);
@@ -659,7 +671,7 @@ int cel_render_field(cel_images *im, cel_sources *src, int flags, double *ll_ban
         prof_end(c, pi);
         RenderArgs a;
         a.bands = im->d_bands; a.recs = im->d_recs; a.lists = im->d_lists; a.tile_cnt = im->d_tile_cnt;
-        a.tile_off = im->d_tile_off; a.nelec = im->d_nelec; a.lambda = im->d_lambda; a.partials = im->d_partials;
+        a.tile_off = im->d_tile_off; a.nelec = im->d_nelec; a.lambda = lambda_out ? lambda_out : im->d_lambda; a.partials = im->d_partials;
         a.S = S; a.capacity = im->lists_cap; a.B = im->B; a.H = im->H; a.W = im->W; a.ntx = im->ntx; a.nty = im->nty;
         a.flags = flags; a.variant = c->variant; a.tail_T = c->tail_T; a.order = c->tile_order ? im->d_order : nullptr;
         a.timing = nullptr;
@@ -883,15 +895,18 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
         e = (expr);                                                                      \
         if (e != hipSuccess) { rc = fail(CEL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); goto done; } \
     } while (0)
-    if ((rc = scratch_get(c, 0, sizeof(int4) * (resident ? 0 : nb) + sizeof(int) * (owner ? P : 0), (void **)&d_box)) ||
+    int4 *d_nz = nullptr;
+    if ((rc = scratch_get(c, 0, sizeof(int4) * (resident ? 0 : 2 * nb) + sizeof(int) * (owner ? P : 0), (void **)&d_box)) ||
         (rc = scratch_get(c, 1, sizeof(int64_t) * (nb + 1), (void **)&d_off)) ||
         (rc = scratch_get(c, 2, sizeof(double) * P * B, (void **)&d_out)))
         return rc;
     if (owner) {
-        d_owner = reinterpret_cast<int *>(d_box + (resident ? 0 : nb));
+        d_owner = reinterpret_cast<int *>(d_box + (resident ? 0 : 2 * nb));
         PL_TRY(hipMemcpyAsync(d_owner, owner, sizeof(int) * P, hipMemcpyHostToDevice, c->stream));
     }
+    if (!resident) d_nz = d_box + nb;
     if (resident) {
+        d_nz = im->d_snz;
         d_box = im->d_sbox;
         d_off = im->d_soff;
         d_data = (mode == 0) ? im->d_samp : nullptr;      // mode 1 reads nelec on the boxes
@@ -909,8 +924,17 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
     }
     {
         int pi = prof_begin(c, CEL_K_STAMPS);
-        hipLaunchKernelGGL(k_patch_ll, dim3((unsigned)(P * B)), dim3(256), 0, c->stream, im->d_bands, B, P, im->d_recs,
-                           d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, mode, d_out);
+        if (c->variant == 0)
+            hipLaunchKernelGGL(k_patch_ll, dim3((unsigned)(P * B)), dim3(256), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                               d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, mode, d_out);
+        else if (mode == 0) {
+            if (!resident)
+                hipLaunchKernelGGL(k_patch_nzbox, dim3((unsigned)nb), dim3(64), 0, c->stream, d_box, d_off, d_data, d_nz);
+            hipLaunchKernelGGL(k_patch_ll_hw<0>, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                               d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, d_nz, c->tail_T, d_out);
+        } else
+            hipLaunchKernelGGL(k_patch_ll_hw<1>, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                               d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
         prof_end(c, pi);
     }
     PL_TRY(hipGetLastError());
@@ -967,6 +991,13 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
     int rc = cel_render_field(im, src, 0, nullptr, nullptr);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
+    // recurrence form: the pixels' total rates are an image of their own, rendered with the split's
+    // strict boxes (same records and lists: the source set has not changed)
+    const bool hw = (c->variant != 0) && (im->TW == HW_TW);
+    if (hw) {
+        if (!im->d_rate) HIP_TRY(hipMalloc((void **)&im->d_rate, sizeof(double) * (size_t)im->B * im->H * im->W));
+        if ((rc = render_impl(im, src, CEL_RENDER_STRICT, nullptr, nullptr, im->d_rate))) return rc;
+    }
     const int B = im->B;
     const int64_t S = src->S, n = S * B;
     const int T = B * im->ntx * im->nty;
@@ -979,9 +1010,11 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (im->d_sbox) (void)hipFree(im->d_sbox);
             if (im->d_soff) (void)hipFree(im->d_soff);
-            im->d_sbox = nullptr; im->d_soff = nullptr; im->slay_cap = 0;
+            if (im->d_snz) (void)hipFree(im->d_snz);
+            im->d_sbox = nullptr; im->d_soff = nullptr; im->d_snz = nullptr; im->slay_cap = 0;
             int64_t cap = n + n / 4 + 64;
             HIP_TRY(hipMalloc((void **)&im->d_sbox, sizeof(int4) * cap));
+            HIP_TRY(hipMalloc((void **)&im->d_snz, sizeof(int4) * cap));
             HIP_TRY(hipMalloc((void **)&im->d_soff, sizeof(int64_t) * cap));
             im->slay_cap = cap;
         }
@@ -1014,11 +1047,16 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         a.tile_off = im->d_tile_off; a.nelec = im->d_nelec; a.offsets = d_off; a.samp = d_samp;
         a.partials = im->d_partials; a.S = S; a.capacity = im->lists_cap; a.B = B; a.H = im->H; a.W = im->W;
         a.ntx = im->ntx; a.nty = im->nty; a.TW = im->TW; a.TH = im->TH; a.seed = seed;
+        a.rate_img = im->d_rate; a.tail_T = c->tail_T;
+        if (hw && (rc = scratch_get(c, 2, sizeof(double) * 2 * (size_t)T, (void **)&a.partials))) return rc;
         int pi = prof_begin(c, CEL_K_STAMPS);
-        hipLaunchKernelGGL(k_photon_split, dim3(T), dim3(64), 0, c->stream, a);
+        if (hw) hipLaunchKernelGGL(k_photon_split_hw, dim3(2 * T), dim3(64), 0, c->stream, a);
+        else hipLaunchKernelGGL(k_photon_split, dim3(T), dim3(64), 0, c->stream, a);
         prof_end(c, pi);
+        hipLaunchKernelGGL(k_reduce, dim3(B), dim3(256), 0, c->stream, a.partials, (hw ? 2 : 1) * im->ntx * im->nty, im->d_llband);
+        if (resident && n > 0)   // where each patch's photons are: the conditional likelihoods evaluate only there
+            hipLaunchKernelGGL(k_patch_nzbox, dim3((unsigned)n), dim3(64), 0, c->stream, im->d_sbox, im->d_soff, im->d_samp, im->d_snz);
     }
-    hipLaunchKernelGGL(k_reduce, dim3(B), dim3(256), 0, c->stream, im->d_partials, im->ntx * im->nty, im->d_llband);
     HIP_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
     if (!resident && mem != CEL_DEVICE && total > 0)
         HIP_TRY(hipMemcpyAsync(samp, d_samp, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream));

@@ -9,8 +9,16 @@
 //   mode 0:  sum_{m>0} log(m) * z  -  counts * sum(psf weights),   m = counts * stamp
 //   mode 1:  sum log(m + eps) * z  -  sum (m + eps)
 // z = the patch data (photons attributed to the source, or nelec for the isolated form).
+//
+// Two kernels with the same contract:
+//   k_patch_ll     reference form: one 256-thread block per (proposal, band), direct evaluator,
+//                  every component on every pixel (CEL_OPT_KERNEL = 0).
+//   k_patch_ll_hw  default: one wave per (proposal, band); the patch is covered by 32 x 64 chunks,
+//                  each rendered into an LDS tile by the column recurrence (hw_source.h) with the
+//                  drop rule relative to the source itself (mode 0) or to the sky (mode 1), then
+//                  reduced against the patch data with the table log.
 #pragma once
-#include "k_render.h"
+#include "hw_source.h"
 
 __global__ void __launch_bounds__(256)
 k_patch_ll(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__restrict__ recs,
@@ -75,4 +83,126 @@ k_patch_ll(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__
         __syncthreads();
     }
     if (tid == 0) out[job] = (mode == 0) ? red[0] - counts * wsum : red[0] - red2[0];
+}
+
+// The smallest rectangle of a patch that holds all of its nonzero data.  The conditional form
+// (mode 0) sums log(m) * z, to which a pixel with z = 0 contributes exactly nothing, so the model
+// need only be evaluated inside this rectangle -- for a faint source a small fraction of its box
+// (the photons sit in the core, the box reaches out to the 1e-5 contour).  One wave per patch.
+__global__ void __launch_bounds__(64)
+k_patch_nzbox(const int4 *__restrict__ pbox, const int64_t *__restrict__ offsets, const double *__restrict__ data,
+              int4 *__restrict__ nz /* x0, x1, y0, y1 (absolute), all 0 when the patch holds no photon */) {
+    const int64_t i = blockIdx.x;
+    const int4 bx = pbox[i];
+    const int nx = bx.y - bx.x, ny = bx.w - bx.z;
+    const int lane = threadIdx.x;
+    int xlo = INT_MAX, xhi = -1, ylo = INT_MAX, yhi = -1;
+    if (nx > 0 && ny > 0) {
+        const double *z = data + offsets[i];
+        const int64_t n = (int64_t)nx * ny;
+        int yy = 0, xx = lane;
+        while (xx >= nx) { xx -= nx; yy++; }
+        for (int64_t k = lane; k < n; k += 64) {
+            if (z[k] != 0.0) {
+                xlo = min(xlo, xx); xhi = max(xhi, xx);
+                ylo = min(ylo, yy); yhi = max(yhi, yy);
+            }
+            xx += 64;
+            while (xx >= nx) { xx -= nx; yy++; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        xlo = min(xlo, __shfl_xor(xlo, o)); xhi = max(xhi, __shfl_xor(xhi, o));
+        ylo = min(ylo, __shfl_xor(ylo, o)); yhi = max(yhi, __shfl_xor(yhi, o));
+    }
+    if (lane == 0) nz[i] = (xhi >= 0) ? make_int4(bx.x + xlo, bx.x + xhi + 1, bx.z + ylo, bx.z + yhi + 1) : make_int4(0, 0, 0, 0);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__restrict__ recs,
+              const int *__restrict__ owner, const int4 *__restrict__ pbox, const int64_t *__restrict__ offsets,
+              const double *__restrict__ data, const double *__restrict__ nelec, int H, int W,
+              const int4 *__restrict__ nzbox /* NB*B from k_patch_nzbox, or nullptr: evaluate the whole patch */,
+              double Tdrop, double *__restrict__ out /* P*B */) {
+    __shared__ double acc[HW_TH * HW_TW];
+    __shared__ CompTab T;
+    __shared__ double et[64];
+    __shared__ double lt[128];
+    const int lane = threadIdx.x;
+    const int half = lane >> 5, col = lane & 31;
+    const int64_t job = blockIdx.x;
+    const int b = (int)(job % B);
+    const int64_t p = job / B;
+    const BandDev *bd = bands + b;
+    const int64_t ob = (int64_t)(owner ? owner[p] : 0) * B + b;
+    const int4 bx = pbox[ob];
+    const int nx = bx.y - bx.x, ny = bx.w - bx.z;
+    const int4 ev = (MODE == 0 && nzbox) ? nzbox[ob] : bx;     // the rectangle that has to be evaluated
+    RecU rec = rec_unpack(rec_fetch(recs + (int64_t)b * P, (int)p, lane));
+    const double counts = rec.scale;
+    const double wsum = bd->w[0] + bd->w[1] + bd->w[2];
+    if (nx <= 0 || ny <= 0) {           // no sample image in this band
+        if (lane == 0) out[job] = 0.0;
+        return;
+    }
+    if (rec.type == -3 && MODE == 0) {  // psf_ns is None (sources.py:160-163)
+        if (lane == 0) out[job] = -counts * wsum;
+        return;
+    }
+    if (rec.type < 0) rec.type = (rec.type == -2) ? 1 : 0;    // imposed limits: the kind still renders
+    rec.scale = 1.0;                                          // the tile holds the unit stamp
+    et[lane] = exp2((double)lane * (1.0 / 64.0));
+    lt[lane] = c_log_ic[lane];
+    lt[64 + lane] = c_log_lc[lane];
+    const LaneConst lc = lane_consts(lane, bd);
+    const double eps = bd->eps;
+    // mode 1 drops against the sky seen from the unit stamp: counts * g < eps e^-T
+    int dropmode = HW_DROP_NONE;
+    double log_floor = 0.0;
+    if (Tdrop > 0.0) {
+        if (MODE == 0) dropmode = HW_DROP_SELF;
+        else if (eps > 0.0 && counts > 0.0) { dropmode = HW_DROP_SKY; log_floor = (double)__logf((float)(eps / counts)); }
+    }
+    const double *z = data ? data + offsets[ob] : nelec + (int64_t)b * H * W + (int64_t)bx.z * W + bx.x;
+    const int64_t zpitch = data ? nx : W;
+    double a = 0.0, m = 0.0;
+    for (int Y0 = ev.z; Y0 < ev.w; Y0 += HW_TH) {
+        const int rb = min(HW_TH, ev.w - Y0);
+        for (int X0 = ev.x; X0 < ev.y; X0 += HW_TW) {
+            const int xi = X0 + col;
+            const bool on = xi < ev.y;
+#pragma unroll
+            for (int r = 0; r < HW_TH / 2; r++) acc[r * 64 + lane] = 0.0;
+            bool direct;
+            const int Kk = hw_build(T, lc, rec, lane, dropmode, Tdrop, log_floor, Y0, X0, min(ev.y, X0 + HW_TW) - 1, 0, rb, direct);
+            hw_walk(T, et, Kk, (double)xi, Y0, 0, rb, on, direct, acc, lane);
+            __syncthreads();
+            // the chunk's patch data, 16 rows of loads in flight at a time (addresses clamped into
+            // the chunk instead of predicated), issued only once the walk's registers are free
+            const double *zp = z + (int64_t)(Y0 - bx.z) * zpitch + (min(xi, ev.y - 1) - bx.x);
+            for (int r0 = 0; r0 < HW_TH / 2 && 2 * r0 < rb; r0 += 8) {
+                double zz[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) zz[r] = zp[(int64_t)min(2 * (r0 + r) + half, rb - 1) * zpitch];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    if (on && 2 * (r0 + r) + half < rb) {
+                        double v = counts * acc[(r0 + r) * 64 + lane];
+                        if (MODE == 0) {
+                            if (v > 0.0) a += log_tab(v, lt) * zz[r];
+                        } else {
+                            v += eps;
+                            a += log_tab(v, lt) * zz[r];
+                            m += v;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    a = wave_sum(a);
+    m = wave_sum(m);
+    if (lane == 0) out[job] = (MODE == 0) ? a - counts * wsum : a - m;
 }

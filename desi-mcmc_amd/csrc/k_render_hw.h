@@ -95,6 +95,7 @@ k_render_hw(RenderArgs a) {
     const double Tdrop = a.tail_T;
     const double eps_sky = bd->eps;
     const bool dropping = (a.variant != 0) && (Tdrop > 0.0) && (eps_sky > 0.0);
+    const int strict = (a.flags >> 2) & 1;   // photon-split totals: boxes open on the low side (internal flag)
 
     unsigned dbg_pairrows = 0, dbg_comprows = 0, dbg_pairs = 0;   // only counted under CEL_OPT_TILE_TIMING
     const LaneConst lc = lane_consts(lane, bd);
@@ -114,7 +115,7 @@ k_render_hw(RenderArgs a) {
         const RecU *rp = &rec;
         const int type = rec.type;
         const int K = (type == 0) ? K_PSF : K_GAL;
-        const int bx0 = rp->x0, bx1 = rp->x1, by0 = rp->y0, by1 = rp->y1;
+        const int bx0 = rp->x0 + strict, bx1 = rp->x1, by0 = rp->y0 + strict, by1 = rp->y1;
         const int ra = max(by0, Y0) - Y0, rb = min(by1, Y0 + HW_TH) - Y0;
         const bool on = (xi >= bx0) && (xi < bx1);
         const double xa = (double)max(bx0, X0), xb = (double)(min(bx1, X0 + HW_TW) - 1);

@@ -23,7 +23,7 @@
 // rate in LDS, pass B walks the sources again in order and draws.  Stamps use the direct
 // evaluator: exact, every component.
 #pragma once
-#include "k_render.h"
+#include "hw_source.h"
 
 struct Philox {
     unsigned k0, k1, c0, c1, c2, c3;
@@ -69,14 +69,21 @@ __device__ inline double btpe_st(double x) {
     return (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / x2) / x2) / x2) / x2) / x / 166320.0;
 }
 
-// Binomial(n, r) for r <= 1/2, n r <= 30: sequential inversion (BINV)
-__device__ inline long long binom_inversion(long long n, double r, Philox &g) {
+// Binomial(n, r) for r <= 1/2, n r <= 30: sequential inversion (BINV).
+// P(X = 0) = (1 - r)^n >= 1 - n r, so a uniform at or below 1 - n r returns 0 before anything
+// transcendental is evaluated (most draws of a split: a pixel in a source's tail).  Otherwise
+// (1 - r)^n comes from the table log / table exp of k_render.h (et: 64 doubles, lt: 128 doubles in
+// LDS): the exponent n log(1 - r) >= -42 carries an absolute error of ~n * 1e-16.
+__device__ inline long long binom_inversion(long long n, double r, Philox &g, const double *__restrict__ et,
+                                            const double *__restrict__ lt) {
     const double q = 1.0 - r;
-    const double qn = exp((double)n * log1p(-r));
     const double np = (double)n * r;
+    double U = philox_double(g);
+    if (U <= 1.0 - np) return 0;
+    const double qn = exp_tab64((double)n * log_tab(q, lt) * EXP_SCALE, et);
     const long long bound = (long long)fmin((double)n, np + 10.0 * sqrt(np * q + 1.0));
     long long X = 0;
-    double px = qn, U = philox_double(g);
+    double px = qn;
     while (U > px) {
         X++;
         if (X > bound) {            // numerical tail: start over
@@ -149,12 +156,13 @@ __device__ inline long long binom_btpe(long long n, double r, Philox &g) {
     return m;   // unreachable in practice (acceptance > 0.8 per trial); keeps the loop bounded
 }
 
-__device__ inline long long binomial_draw(long long n, double p, Philox &g) {
+__device__ inline long long binomial_draw(long long n, double p, Philox &g, const double *__restrict__ et,
+                                          const double *__restrict__ lt) {
     if (n <= 0 || !(p > 0.0)) return 0;
     if (p >= 1.0) return n;
     const bool flip = p > 0.5;
     const double r = flip ? 1.0 - p : p;
-    long long y = (r * (double)n <= 30.0) ? binom_inversion(n, r, g) : binom_btpe(n, r, g);
+    long long y = (r * (double)n <= 30.0) ? binom_inversion(n, r, g, et, lt) : binom_btpe(n, r, g);
     return flip ? n - y : y;
 }
 
@@ -219,10 +227,17 @@ k_patch_sums(const int64_t *__restrict__ soff, const double *__restrict__ samp, 
 // diagnostic: N independent Binomial(n, p) draws (stream i), for the sampler's own tests
 __global__ void __launch_bounds__(256)
 k_binomial_draws(long long n, double p, unsigned long long seed, int64_t N, long long *__restrict__ out) {
+    __shared__ double et[64], lt[128];
+    if (threadIdx.x < 64) {
+        et[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
+        lt[threadIdx.x] = c_log_ic[threadIdx.x];
+        lt[64 + threadIdx.x] = c_log_lc[threadIdx.x];
+    }
+    __syncthreads();
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     Philox g = philox_init(seed, (unsigned long long)i, 0u);
-    out[i] = binomial_draw(n, p, g);
+    out[i] = binomial_draw(n, p, g, et, lt);
 }
 
 struct SplitArgs {
@@ -238,6 +253,8 @@ struct SplitArgs {
     int64_t S, capacity;
     int B, H, W, ntx, nty, TW, TH;
     unsigned long long seed;
+    const double *rate_img;     // k_photon_split_hw: every pixel's total rate (strict boxes), rendered beforehand
+    double tail_T;              // k_photon_split_hw: drop threshold of the per-source tiles
 };
 
 __global__ void __launch_bounds__(64)
@@ -245,8 +262,12 @@ k_photon_split(SplitArgs a) {
     __shared__ double rate[2048];     // remaining total rate of the pixel (sources not yet drawn + sky)
     __shared__ int left[2048];        // photons of the pixel not yet attributed
     __shared__ CompTab T;
+    __shared__ double et[64], lt[128];
     const int lane = threadIdx.x;
     const int tile = blockIdx.x;
+    et[lane] = exp2((double)lane * (1.0 / 64.0));
+    lt[lane] = c_log_ic[lane];
+    lt[64 + lane] = c_log_lc[lane];
     const int per_band = a.ntx * a.nty;
     const int b = tile / per_band;
     const int t = tile - b * per_band;
@@ -302,7 +323,7 @@ k_photon_split(SplitArgs a) {
                     long long z = 0;
                     if (n > 0) {
                         Philox g = philox_init(a.seed, (unsigned long long)(plane + (int64_t)y * a.W + xi), (unsigned)s);
-                        z = binomial_draw((long long)n, F / tot, g);      // curr_prob / sum_probs (:147)
+                        z = binomial_draw((long long)n, F / tot, g, et, lt);   // curr_prob / sum_probs (:147)
                     }
                     left[li] = n - (int)z;
                     rate[li] = tot - F;                                   // sum_probs -= curr_prob (:152)
@@ -316,4 +337,112 @@ k_photon_split(SplitArgs a) {
     for (int i = 0; i < niter; i++) noise += (double)left[i * 64 + lane];
     noise = wave_sum(noise);
     if (lane == 0) a.partials[tile] = noise;
+}
+
+// ---- the same split on the column recurrence ------------------------------------------------------
+// k_photon_split above evaluates every (source, pixel) twice with the direct evaluator (once for
+// the pixel totals, once for the draws): ~85 ms at config 3, 45 x the render step.  Here
+//   * the totals are an image rendered beforehand by the field kernel with the reference's strict
+//     boxes (CEL_RENDER_STRICT: a source takes part only where x > x0 and y > y0), and
+//   * each source is rendered ONCE, by the recurrence, into a scratch LDS tile (hw_source.h), from
+//     which the lanes draw their pixels' binomials.
+// One wave per 32 x 32 half of a render tile (three 32 x 32 LDS planes: the source's tile, the
+// remaining rate, the photons left), sources in list order = source order, as the reference.
+// A pixel's draw uses the Philox stream (seed; band, pixel, source) as above; the probabilities
+// agree with the direct kernel's to ~1e-13, so the two kernels make the same draws except where a
+// uniform falls within that distance of a decision boundary.
+#define SP_TH 32
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+k_photon_split_hw(SplitArgs a) {
+    __shared__ double one[SP_TH * HW_TW];
+    __shared__ double rate[SP_TH * HW_TW];
+    __shared__ int left[SP_TH * HW_TW];
+    __shared__ CompTab T;
+    __shared__ double et[64], lt[128];
+    const int lane = threadIdx.x;
+    const int half = lane >> 5, col = lane & 31;
+    const int tile = blockIdx.x >> 1, sub = blockIdx.x & 1;
+    const int per_band = a.ntx * a.nty;
+    const int b = tile / per_band;
+    const int t = tile - b * per_band;
+    const int ty = t / a.ntx, tx = t - ty * a.ntx;
+    const int X0 = tx * HW_TW, Y0 = ty * HW_TH + sub * SP_TH;
+    const int xi = X0 + col;
+    const double x = (double)xi;
+    const BandDev *bd = a.bands + b;
+    const double eps = bd->eps;
+    const int64_t plane = (int64_t)b * a.H * a.W;
+    et[lane] = exp2((double)lane * (1.0 / 64.0));
+    lt[lane] = c_log_ic[lane];
+    lt[64 + lane] = c_log_lc[lane];
+#pragma unroll
+    for (int r = 0; r < SP_TH / 2; r++) {
+        const int y = Y0 + 2 * r + half;
+        const bool in = (xi < a.W) && (y < a.H);
+        const int64_t idx = plane + (int64_t)y * a.W + xi;
+        one[r * 64 + lane] = 0.0;
+        rate[r * 64 + lane] = in ? a.rate_img[idx] : eps;
+        left[r * 64 + lane] = in ? (int)a.nelec[idx] : 0;
+    }
+    const int cnt = a.tile_cnt[tile];
+    const int64_t off = a.tile_off[tile];
+    const SrcRec *recs = a.recs + (int64_t)b * a.S;
+    const int dropmode = (a.tail_T > 0.0 && eps > 0.0) ? HW_DROP_SKY : HW_DROP_NONE;
+    const double log_sky = (eps > 0.0) ? (double)__logf((float)eps) : 0.0;
+    const LaneConst lc = lane_consts(lane, bd);
+    const int nent = (Y0 < a.H) ? (int)min((int64_t)cnt, a.capacity > off ? a.capacity - off : (int64_t)0) : 0;
+    int idx64 = (lane < nent) ? a.lists[off + lane] : 0;
+    int s_next = __builtin_amdgcn_readlane(idx64, 0);
+    int recw_next = (nent > 0) ? rec_fetch(recs, s_next, lane) : 0;
+    int64_t poff_next = (nent > 0) ? a.offsets[(int64_t)s_next * a.B + b] : 0;
+
+    for (int e = 0; e < nent; e++) {
+        const int recw = recw_next;
+        const int s = s_next;
+        const int64_t poff = poff_next;
+        if (e + 1 < nent) {
+            if (((e + 1) & 63) == 0) idx64 = (e + 1 + lane < nent) ? a.lists[off + e + 1 + lane] : 0;
+            s_next = __builtin_amdgcn_readlane(idx64, (e + 1) & 63);
+            recw_next = rec_fetch(recs, s_next, lane);
+            poff_next = a.offsets[(int64_t)s_next * a.B + b];
+        }
+        const RecU rec = rec_unpack(recw);
+        // strictly inside the box on the low side (celeste_sample_sources.pyx:50-51)
+        const int sx0 = rec.x0 + 1, sy0 = rec.y0 + 1;
+        const int ra = max(sy0, Y0) - Y0, rb = min(rec.y1, Y0 + SP_TH) - Y0;
+        const int xa = max(sx0, X0), xb = min(rec.x1, X0 + HW_TW) - 1;
+        if (ra >= rb || xa > xb) continue;          // touches the tile's other half only (wave-uniform)
+        const bool on = (xi >= xa) && (xi <= xb);
+        bool direct;
+        const int Kk = hw_build(T, lc, rec, lane, dropmode, a.tail_T, log_sky, Y0, xa, xb, ra, rb, direct);
+        hw_walk(T, et, Kk, x, Y0, ra, rb, on, direct, one, lane);
+        __syncthreads();
+        if (on) {
+            const int nx = rec.x1 - rec.x0;
+            double *patch = a.samp + poff + (int64_t)(Y0 - rec.y0) * nx + (xi - rec.x0);
+            for (int r = (ra - half + 1) >> 1; 2 * r + half < rb; r++) {
+                const int row = 2 * r + half;
+                const int li = r * 64 + lane;
+                const double F = one[li];
+                one[li] = 0.0;                        // the scratch tile is clean again for the next source
+                const int n = left[li];
+                const double tot = rate[li];
+                long long z = 0;
+                if (n > 0) {
+                    Philox g = philox_init(a.seed, (unsigned long long)(plane + (int64_t)(Y0 + row) * a.W + xi), (unsigned)s);
+                    z = binomial_draw((long long)n, F / tot, g, et, lt);  // curr_prob / sum_probs (:147)
+                }
+                left[li] = n - (int)z;
+                rate[li] = tot - F;                                       // sum_probs -= curr_prob (:152)
+                patch[(int64_t)row * nx] = (double)z;
+            }
+        }
+        __syncthreads();
+    }
+    // what is left belongs to the sky (:153, :91-93)
+    double noise = 0.0;
+#pragma unroll
+    for (int r = 0; r < SP_TH / 2; r++) noise += (double)left[r * 64 + lane];
+    noise = wave_sum(noise);
+    if (lane == 0) a.partials[blockIdx.x] = noise;
 }

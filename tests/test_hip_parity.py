@@ -792,3 +792,52 @@ def test_source_conditional_loglik_golden(cel):
         # compute_model_patch reproduces the Poisson mean the golden's photons were drawn from
         p, yl, xl = src.compute_model_patch(imgs[used[0]], xlim=(boxes[0, 2], boxes[0, 3]), ylim=(boxes[0, 0], boxes[0, 1]))
         assert p.shape == zs[0].shape and p.min() >= 0
+
+
+@pytest.mark.parametrize("kernel", ["direct", "recurrence"])
+def test_patch_loglik_adversarial_patches_vs_oracle(cel, ctx, orc, kernel):
+    """cel_patch_loglik on patches the recurrence kernel must chunk (wider than 32, taller than
+    64), shift away from the source (deep tails: every pixel carries data, so log(m) is exercised
+    where m is tiny), and give up on (a patch so far out that the seeds would underflow: direct
+    fallback).  Both forms, both kernels, against the oracle."""
+    from desi_mcmc_amd import synth
+    H, W = 300, 420
+    bands = synth.make_bands(H, W, 2)
+    rs = np.random.RandomState(11)
+    pix = np.array([[200.3, 150.6], [201.0, 149.0], [60.2, 40.9], [199.7, 151.2]])
+    typ = np.array([0, 1, 1, 0], np.int32)
+    radec = synth.pixel2equa(bands[0], pix)
+    shape = np.array([[0.5, 2.0, 30.0, 0.5], [0.3, 3.5, 110.0, 0.4], [0.8, 0.7, 10.0, 0.9], [0.5, 1.0, 0.0, 0.5]])
+    counts = np.array([[4e4, 3e4], [9e4, 1e5], [2e3, 5e3], [0.0, 7e2]])
+    nelec = rs.poisson(200.0, size=(2, H, W)).astype(float)
+    iset = cel.ImageSet(ctx, bands, H, W, nelec=nelec)
+    sset = cel.SourceSet(ctx, 4, 2).set(typ, radec, counts, shape)
+    ob = bands.copy()
+    ob[:, 36] = [iset.band(0)[36], iset.band(1)[36]]
+    cases = [
+        np.array([[130, 171, 181, 222], [120, 190, 170, 233]]),     # around sources 0/1/3: 41x41 and 70x63
+        np.array([[60, 260, 100, 300], [149, 152, 199, 202]]),      # 200 x 200 (chunks both ways) and 3 x 3
+        np.array([[150, 215, 230, 263], [0, 0, 0, 0]]),             # shifted off the centre; no patch in band 1
+        np.array([[0, 64, 388, 420], [236, 300, 0, 33]]),           # far corners: below the seed-safe range
+    ]
+    ctx.set_kernel(kernel)
+    try:
+        for boxes in cases:
+            data = [rs.poisson(3.0, size=(bx[1] - bx[0], bx[3] - bx[2])).astype(float) + 1.0 if bx[1] > bx[0] else None
+                    for bx in boxes]
+            if data[0].shape[0] == 200:     # photons in one corner only: the conditional form crops to them
+                data[0][:150] = 0.0
+                data[0][:, 37:] = 0.0
+            for isolated in (False, True):
+                got = iset.patch_loglik(sset, boxes, data, isolated=isolated)
+                for s in range(4):
+                    want = 0.0
+                    for b in range(2):
+                        bx = boxes[b]
+                        if bx[1] <= bx[0]:
+                            continue
+                        want += orc.patch_loglik(ob[b], H, W, typ[s], radec[s], shape[s], counts[s, b], bx,
+                                                 data[b], 1 if isolated else 0)
+                    np.testing.assert_allclose(got[s], want, rtol=RT_LL, err_msg="src %d boxes %s iso %s" % (s, boxes, isolated))
+    finally:
+        ctx.set_kernel("recurrence")

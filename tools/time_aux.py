@@ -37,3 +37,21 @@ print("k_photon_split kernel alone: %.2f ms" % ctx.profile_get("stamps")[0])
 ctx.profile(True)
 f.images.estep_stats(f.sources)
 print("k_estep_src kernel alone: %.2f ms" % ctx.profile_get("stamps")[0])
+
+# conditional log-likelihoods of 16 proposals per source against the resident split
+P = 16
+prop = cel.SourceSet(ctx, f.S * P, f.B)
+owner = np.repeat(np.arange(f.S, dtype=np.int32), P)
+rs = np.random.RandomState(0)
+us = np.repeat(f.src["radec"], P, axis=0) + rs.normal(0.0, 2e-5, size=(f.S * P, 2))
+prop.set(np.repeat(f.src["type"], P), us, np.repeat(f.src["counts"], P, axis=0), np.repeat(f.src["shape"], P, axis=0))
+f.images.photon_split_resident(f.sources, seed=1)
+timed("resident split (5 bands)", lambda: f.images.photon_split_resident(f.sources, seed=1), 3)
+ctx.profile(True)
+f.images.photon_split_resident(f.sources, seed=1)
+print("  split kernel alone: %.2f ms, render kernels: %.2f ms" % (ctx.profile_get("stamps")[0], ctx.profile_get("render")[0]))
+timed("conditional ll, %d proposals" % (f.S * P), lambda: f.images.patch_loglik_resident(prop, owner), 3)
+ctx.profile(True)
+f.images.patch_loglik_resident(prop, owner)
+print("  k_prep: %.2f ms, k_patch_ll: %.2f ms" % (ctx.profile_get("prep")[0], ctx.profile_get("stamps")[0]))
+ctx.profile(False)
