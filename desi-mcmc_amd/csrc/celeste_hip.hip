@@ -1136,8 +1136,12 @@ int cel_estep_stats(cel_images *im, cel_sources *src, double *xtilde, double *ma
         ES_TRY(hipMalloc((void **)&d_x, sizeof(double) * S * B));
         ES_TRY(hipMalloc((void **)&d_m, sizeof(double) * S * B));
         int pi = prof_begin(c, CEL_K_STAMPS);
-        hipLaunchKernelGGL(k_estep_src, dim3((unsigned)(S * B)), dim3(256), 0, c->stream, im->d_bands, B, im->H, im->W,
-                           S, im->d_recs, im->d_nelec, im->d_lambda, d_x, d_m);
+        if (c->variant == 0)
+            hipLaunchKernelGGL(k_estep_src, dim3((unsigned)(S * B)), dim3(256), 0, c->stream, im->d_bands, B, im->H, im->W,
+                               S, im->d_recs, im->d_nelec, im->d_lambda, d_x, d_m);
+        else
+            hipLaunchKernelGGL(k_estep_src_hw, dim3((unsigned)(S * B)), dim3(64), 0, c->stream, im->d_bands, B, im->H, im->W,
+                               S, im->d_recs, im->d_nelec, im->d_lambda, c->tail_T, d_x, d_m);
         prof_end(c, pi);
         ES_TRY(hipMemcpyAsync(hx.data(), d_x, sizeof(double) * S * B, hipMemcpyDeviceToHost, c->stream));
         ES_TRY(hipMemcpyAsync(hm.data(), d_m, sizeof(double) * S * B, hipMemcpyDeviceToHost, c->stream));

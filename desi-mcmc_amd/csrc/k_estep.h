@@ -9,8 +9,13 @@
 // resident model image.  One 256-thread block per (source, band) re-evaluates the source's
 // stamp on its own box (direct evaluator, exact) against lambda and nelec; a strided kernel
 // reduces the sky term.  Both reductions run in a fixed order.
+//
+// k_estep_src_hw is the same reduction on the column recurrence (hw_source.h): one wave per
+// (source, band), the box covered by 32 x 64 chunks, each rendered as the unit stamp into an LDS
+// tile with the drop rule relative to the source itself (both sums are linear in the stamp, so
+// their relative error stays below K e^-T), then reduced against nelec / lambda.
 #pragma once
-#include "k_render.h"
+#include "hw_source.h"
 
 __global__ void __launch_bounds__(256)
 k_estep_src(const BandDev *__restrict__ bands, int B, int H, int W, int64_t S, const SrcRec *__restrict__ recs,
@@ -55,6 +60,68 @@ k_estep_src(const BandDev *__restrict__ bands, int B, int H, int W, int64_t S, c
         __syncthreads();
     }
     if (tid == 0) { xt[job] = red[0]; mass[job] = red2[0]; }
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+k_estep_src_hw(const BandDev *__restrict__ bands, int B, int H, int W, int64_t S, const SrcRec *__restrict__ recs,
+               const double *__restrict__ nelec, const double *__restrict__ lambda, double Tdrop,
+               double *__restrict__ xt /* S*B */, double *__restrict__ mass /* S*B */) {
+    __shared__ double acc[HW_TH * HW_TW];
+    __shared__ CompTab T;
+    __shared__ double et[64];
+    const int lane = threadIdx.x;
+    const int half = lane >> 5, col = lane & 31;
+    const int64_t job = blockIdx.x;
+    const int b = (int)(job % B);
+    const int64_t s = job / B;
+    RecU rec = rec_unpack(rec_fetch(recs + (int64_t)b * S, (int)s, lane));
+    if (rec.type < 0) {
+        if (lane == 0) { xt[job] = 0.0; mass[job] = 0.0; }
+        return;
+    }
+    const BandDev *bd = bands + b;
+    const double counts = rec.scale;
+    rec.scale = 1.0;
+    et[lane] = exp2((double)lane * (1.0 / 64.0));
+    const LaneConst lc = lane_consts(lane, bd);
+    const int dropmode = (Tdrop > 0.0) ? HW_DROP_SELF : HW_DROP_NONE;
+    const int64_t plane = (int64_t)b * H * W;
+    double a = 0.0, m = 0.0;
+    for (int Y0 = rec.y0; Y0 < rec.y1; Y0 += HW_TH) {
+        const int rb = min(HW_TH, rec.y1 - Y0);
+        for (int X0 = rec.x0; X0 < rec.x1; X0 += HW_TW) {
+            const int xi = X0 + col;
+            const bool on = xi < rec.x1;
+#pragma unroll
+            for (int r = 0; r < HW_TH / 2; r++) acc[r * 64 + lane] = 0.0;
+            bool direct;
+            const int Kk = hw_build(T, lc, rec, lane, dropmode, Tdrop, 0.0, Y0, X0, min(rec.x1, X0 + HW_TW) - 1, 0, rb, direct);
+            hw_walk(T, et, Kk, (double)xi, Y0, 0, rb, on, direct, acc, lane);
+            __syncthreads();
+            const int64_t base = plane + (int64_t)Y0 * W + min(xi, rec.x1 - 1);
+            for (int r0 = 0; r0 < HW_TH / 2 && 2 * r0 < rb; r0 += 8) {
+                double ne[8], la[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int64_t idx = base + (int64_t)min(2 * (r0 + r) + half, rb - 1) * W;
+                    ne[r] = nelec[idx];
+                    la[r] = lambda[idx];
+                }
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    if (on && 2 * (r0 + r) + half < rb) {
+                        const double u = acc[(r0 + r) * 64 + lane];
+                        a += ne[r] * (counts * u) / la[r];
+                        m += u;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    a = wave_sum(a);
+    m = wave_sum(m);
+    if (lane == 0) { xt[job] = a; mass[job] = m; }
 }
 
 // sky responsibility: partial[b][blk] = sum over the block's pixel chunk of nelec * eps / lambda
