@@ -788,6 +788,7 @@ int cel_render_stamps(cel_images *im, cel_sources *src, int band, int scaled, co
     std::vector<int4> obox((size_t)S);
     std::vector<StampJob> jobs;
     const int ROWS = 64;
+    const int strip_w = (c->variant == 0) ? TILE_W : HW_TW;     // the recurrence kernel works on 32 x 64 chunks
     for (int64_t s = 0; s < S; s++) {
         int y0, y1, x0, x1;
         bool ok;
@@ -804,7 +805,7 @@ int cel_render_stamps(cel_images *im, cel_sources *src, int band, int scaled, co
         if (offsets[s + 1] - offsets[s] != area)
             return fail(CEL_ERR_INVALID, "offsets[%lld+1]-offsets[%lld] = %lld but the stamp has %lld pixels",
                         (long long)s, (long long)s, (long long)(offsets[s + 1] - offsets[s]), (long long)area);
-        for (int xs = x0; xs < x1; xs += TILE_W)
+        for (int xs = x0; xs < x1; xs += strip_w)
             for (int ys = y0; ys < y1; ys += ROWS)
                 jobs.push_back(StampJob{(int)s, xs, ys, ys + ROWS < y1 ? ys + ROWS : y1});
     }
@@ -832,8 +833,12 @@ int cel_render_stamps(cel_images *im, cel_sources *src, int band, int scaled, co
     ST_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (S + 1), hipMemcpyHostToDevice, c->stream));
     {
         int pi = prof_begin(c, CEL_K_STAMPS);
-        hipLaunchKernelGGL(k_stamps, dim3((unsigned)jobs.size()), dim3(64), 0, c->stream, im->d_bands, band,
-                           im->d_recs + (int64_t)band * S, d_jobs, d_obox, d_off, scaled, d_out);
+        if (c->variant == 0)
+            hipLaunchKernelGGL(k_stamps, dim3((unsigned)jobs.size()), dim3(64), 0, c->stream, im->d_bands, band,
+                               im->d_recs + (int64_t)band * S, d_jobs, d_obox, d_off, scaled, d_out);
+        else
+            hipLaunchKernelGGL(k_stamps_hw, dim3((unsigned)jobs.size()), dim3(64), 0, c->stream, im->d_bands, band,
+                               im->d_recs + (int64_t)band * S, d_jobs, d_obox, d_off, scaled, c->tail_T, d_out);
         prof_end(c, pi);
     }
     ST_TRY(hipGetLastError());

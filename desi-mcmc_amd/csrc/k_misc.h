@@ -1,6 +1,6 @@
 // k_misc.h -- stamp and generic-evaluator kernels
 #pragma once
-#include "k_render.h"
+#include "hw_source.h"
 // ------------------------------------------------------------------------------------------
 // k_stamps: one wave per (source, 64-column strip, row chunk) job
 // ------------------------------------------------------------------------------------------
@@ -37,6 +37,44 @@ k_stamps(const BandDev *__restrict__ bands, int band, const SrcRec *__restrict__
         double v = eval_direct(T, 0, K, (double)xi, (double)y, 1.0);
         o[(int64_t)(y - ob.z) * nx + (xi - ob.x)] = v;
     }
+}
+
+// k_stamps_hw: the same output from the column recurrence -- one wave per (source, 32-column x
+// 64-row chunk) job renders the chunk into an LDS tile (hw_source.h, drop rule relative to the
+// source itself: every stored pixel keeps a relative error below K e^-T) and stores it.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+k_stamps_hw(const BandDev *__restrict__ bands, int band, const SrcRec *__restrict__ recs,
+            const StampJob *__restrict__ jobs, const int4 *__restrict__ obox,
+            const int64_t *__restrict__ offsets, int scaled, double Tdrop, double *__restrict__ out) {
+    __shared__ double acc[HW_TH * HW_TW];
+    __shared__ CompTab T;
+    __shared__ double et[64];
+    const int lane = threadIdx.x;
+    const int half = lane >> 5, col = lane & 31;
+    const StampJob jb = jobs[blockIdx.x];
+    const int4 ob = obox[jb.src];           // output box: x0, x1, y0, y1
+    RecU rec = rec_unpack(rec_fetch(recs, jb.src, lane));
+    if (rec.type < 0) rec.type = (rec.type == -2) ? 1 : 0;
+    if (!scaled) rec.scale = 1.0;
+    const BandDev *bd = bands + band;
+    et[lane] = exp2((double)lane * (1.0 / 64.0));
+#pragma unroll
+    for (int r = 0; r < HW_TH / 2; r++) acc[r * 64 + lane] = 0.0;
+    const LaneConst lc = lane_consts(lane, bd);
+    const int xi = jb.x0 + col;
+    const bool on = xi < ob.y;
+    const int rb = jb.y1 - jb.y0;
+    bool direct;
+    const int Kk = hw_build(T, lc, rec, lane, (Tdrop > 0.0) ? HW_DROP_SELF : HW_DROP_NONE, Tdrop, 0.0, jb.y0, jb.x0,
+                            min(ob.y, jb.x0 + HW_TW) - 1, 0, rb, direct);
+    hw_walk(T, et, Kk, (double)xi, jb.y0, 0, rb, on, direct, acc, lane);
+    __syncthreads();
+    if (!on) return;
+    const int nx = ob.y - ob.x;
+    double *o = out + offsets[jb.src] + (int64_t)(jb.y0 - ob.z) * nx + (xi - ob.x);
+#pragma unroll 8
+    for (int r = 0; r < HW_TH / 2; r++)
+        if (2 * r + half < rb) o[(int64_t)(2 * r + half) * nx] = acc[r * 64 + lane];
 }
 
 // ------------------------------------------------------------------------------------------
