@@ -399,6 +399,49 @@ def test_full_size_spot_check_vs_oracle(cel, ctx, orc, big_field):
         np.testing.assert_allclose(lam[b, y0:y0 + h, x0:x0 + w], o_lam[0, y0:y0 + h, x0:x0 + w], rtol=RT_LAM)
 
 
+def test_full_size_gibbs_kernels_properties(cel, ctx, big_field):
+    """BASELINE-size field (10 000 sources x 5 bands x 2048^2), the per-source kernels, through
+    properties that do not need the oracle: photon conservation of the split, the E-step's
+    responsibilities summing to one, and the recurrence kernels against the direct ones."""
+    f = big_field
+    nel = f.nelec.reshape(f.B, -1).sum(axis=1)
+    # (1) split: every observed photon goes to exactly one source or to the sky (integers: exact)
+    noise = f.images.photon_split_resident(f.sources, seed=9)
+    sums = f.images.sample_sums()
+    assert np.array_equal(sums.sum(axis=0) + noise, nel)
+    # same seed, same split (counter-based generator, fixed order)
+    noise2 = f.images.photon_split_resident(f.sources, seed=9)
+    assert np.array_equal(noise, noise2) and np.array_equal(sums, f.images.sample_sums())
+    # the expected share of each source: E[sum z] = X~ of the E-step (celeste_em.py:85) -- the
+    # totals over all sources agree to sampling noise, sqrt(N) on ~1e9 photons
+    xt, mass, nz = f.images.estep_stats(f.sources)
+    np.testing.assert_allclose(xt.sum(axis=0) + nz, nel, rtol=1e-9)          # (2) responsibilities sum to one
+    wsum = f.bands[:, 3:6].sum(axis=1)                   # a stamp's mass is at most the PSF weights' sum
+    assert np.all(mass <= wsum[None, :] * (1 + 1e-9)) and np.all(mass >= 0.0)
+    # the split's strict boxes lose each source's first row/column, so its share is a little below X~
+    tot_split, tot_e = sums.sum(axis=0), xt.sum(axis=0)
+    assert np.all(tot_split <= tot_e * (1 + 1e-3)) and np.all(tot_split >= tot_e * 0.9)
+    # (3) recurrence kernels == direct kernels on a sample of proposals / all sources
+    rs = np.random.RandomState(5)
+    pick = rs.choice(f.S, 300, replace=False).astype(np.int32)
+    prop = cel.SourceSet(ctx, 300, f.B).set(f.src["type"][pick], f.src["radec"][pick] + rs.normal(0, 2e-5, (300, 2)),
+                                            f.src["counts"][pick], f.src["shape"][pick])
+    ll_r = f.images.patch_loglik_resident(prop, pick)
+    iso_r = f.images.patch_loglik_resident(prop, pick, isolated=True)
+    ctx.set_kernel("direct")
+    try:
+        ll_d = f.images.patch_loglik_resident(prop, pick)
+        iso_d = f.images.patch_loglik_resident(prop, pick, isolated=True)
+        xt_d, mass_d, nz_d = f.images.estep_stats(f.sources)
+    finally:
+        ctx.set_kernel("recurrence")
+    np.testing.assert_allclose(ll_r, ll_d, rtol=RT_LL)
+    np.testing.assert_allclose(iso_r, iso_d, rtol=RT_LL)
+    np.testing.assert_allclose(xt, xt_d, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(mass, mass_d, rtol=1e-10)
+    np.testing.assert_allclose(nz, nz_d, rtol=1e-12)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_row_strips_tile_the_frame(cel, ctx, world):
     """strong-scaling partition on ONE gpu: strips rendered through cel_images_set_window must
