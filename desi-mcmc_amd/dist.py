@@ -78,6 +78,69 @@ def allreduce_loglik(ll_band, device=None, deterministic=False):
     return t.cpu().numpy()
 
 
+class LoglikReducer(object):
+    """The same all-reduce, pipelined: submit() starts the sum of one evaluation's B per-band
+    doubles and returns at once; result() hands back the oldest outstanding sum.  With fields
+    dealt to ranks the chains of different fields never wait for the global log-likelihood (it
+    is a diagnostic of the whole survey), so the collective of evaluation k can ride under the
+    render of evaluation k+1 instead of adding its latency (launch + xGMI hop + D2H, ~0.1 ms
+    against a 1.9 ms step) to every step.  Buffers are allocated once: a ring of `depth` device
+    tensors and pinned host mirrors."""
+
+    def __init__(self, B, device=None, depth=2):
+        import torch
+        import torch.distributed as dist
+        self.B, self.depth = int(B), int(depth)
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.pending = []          # (slot, work handle)
+        self.slot = 0
+        self.gpu = self.active and dist.get_backend() == "nccl"
+        if not self.active:
+            self.host = [np.zeros(self.B) for _ in range(self.depth)]
+            return
+        self.dev = torch.device("cuda", device if device is not None else torch.cuda.current_device()) if self.gpu else None
+        self.host_t = [torch.zeros(self.B, dtype=torch.float64, pin_memory=self.gpu) for _ in range(self.depth)]
+        self.dev_t = [torch.zeros(self.B, dtype=torch.float64, device=self.dev) for _ in range(self.depth)] if self.gpu else None
+
+    def submit(self, ll_band):
+        """Start summing ll_band (B doubles, numpy) over ranks.  At most `depth` may be outstanding."""
+        if len(self.pending) >= self.depth:
+            raise RuntimeError("LoglikReducer: %d sums outstanding, call result() first" % len(self.pending))
+        s = self.slot
+        self.slot = (s + 1) % self.depth
+        if not self.active:
+            self.host[s][:] = ll_band
+            self.pending.append((s, None))
+            return
+        import torch
+        import torch.distributed as dist
+        self.host_t[s].copy_(torch.from_numpy(np.ascontiguousarray(ll_band, dtype=np.float64)))
+        if self.gpu:
+            self.dev_t[s].copy_(self.host_t[s], non_blocking=True)
+            work = dist.all_reduce(self.dev_t[s], op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            work = dist.all_reduce(self.host_t[s], op=dist.ReduceOp.SUM, async_op=True)
+        self.pending.append((s, work))
+
+    def result(self):
+        """The oldest outstanding sum -> (B,) numpy (a copy)."""
+        if not self.pending:
+            raise RuntimeError("LoglikReducer: nothing outstanding")
+        s, work = self.pending.pop(0)
+        if not self.active:
+            return self.host[s].copy()
+        work.wait()
+        if self.gpu:
+            self.host_t[s].copy_(self.dev_t[s])        # blocking D2H: orders after the collective on the current stream
+        return self.host_t[s].numpy().copy()
+
+    def drain(self):
+        out = []
+        while self.pending:
+            out.append(self.result())
+        return out
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

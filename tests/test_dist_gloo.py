@@ -43,6 +43,19 @@ def _worker(rank, world, port, mode, out_dir):
             part += np.array([orc.poisson_loglike(g["nelec"][b] + f, lam[b]) for b in range(5)])
     tot = dist.allreduce_loglik(part)
     tot_det = dist.allreduce_loglik(part, deterministic=True)
+    # the pipelined form bench.py uses: results come back in submission order, one step late
+    red = dist.LoglikReducer(5, depth=2)
+    got = []
+    for k in range(4):
+        red.submit(part * (k + 1))
+        if len(red.pending) > 1:
+            got.append(red.result())
+    got += red.drain()
+    assert len(got) == 4 and not red.pending
+    for k in range(4):
+        np.testing.assert_allclose(got[k], tot * (k + 1), rtol=1e-14)
+    with pytest.raises(RuntimeError):
+        red.result()
     dist.barrier()
     np.save(os.path.join(out_dir, "%s_%d.npy" % (mode, rank)), np.stack([tot, tot_det, part]))
     import torch.distributed as td
