@@ -83,6 +83,7 @@ __device__ inline int hw_build(CompTab &T, const LaneConst &lc, const RecU &rec,
     const int Kk = __popcll(km);
     direct = (__ballot(far) != 0ull);
     __syncthreads();   // the previous table's reads are done
+    if (lane < 4) { T.gL[lane] = 4096; T.gr0[lane] = HW_TH; T.gr1[lane] = 0; }
     if (keep) {
         int p = __popcll(km & ((1ull << lane) - 1ull));
         T.A[p] = c.A; T.mx[p] = c.mx; T.my[p] = c.my;
@@ -90,6 +91,10 @@ __device__ inline int hw_build(CompTab &T, const LaneConst &lc, const RecU &rec,
         T.eq[p] = exp(-c.qc);
         T.L[p] = Lk;
         T.r0[p] = rlo; T.r1[p] = rhi;
+        const int gi = p / (2 * REC_G);     // per pair of groups: shortest segment, union of the row ranges
+        atomicMin(&T.gL[gi], Lk);
+        atomicMin(&T.gr0[gi], rlo);
+        atomicMax(&T.gr1[gi], rhi);
     }
     if (lane < HW_PAD) {   // zero components behind the table (amplitude 0, ratio 1)
         int p = Kk + lane;
@@ -119,15 +124,10 @@ __device__ inline void hw_walk(const CompTab &T, const double *__restrict__ et, 
     for (int p0 = 0; p0 < Kk; p0 += 2 * REC_G) {
         const int R = min(2 * REC_G, Kk - p0);
         const int gA = (R + 1) / 2;
-        int L = T.L[p0], ga = T.r0[p0], gb = T.r1[p0];
-        for (int i = 1; i < R; i++) {
-            L = min(L, T.L[p0 + i]);
-            ga = min(ga, T.r0[p0 + i]);
-            gb = max(gb, T.r1[p0 + i]);
-        }
-        L = __builtin_amdgcn_readfirstlane(L);
-        ga = __builtin_amdgcn_readfirstlane(ga);
-        gb = __builtin_amdgcn_readfirstlane(gb);
+        const int gi = p0 / (2 * REC_G);
+        const int L = __builtin_amdgcn_readfirstlane(T.gL[gi]);
+        const int ga = __builtin_amdgcn_readfirstlane(T.gr0[gi]);
+        const int gb = __builtin_amdgcn_readfirstlane(T.gr1[gi]);
         const int k0 = half ? p0 + gA : p0;
         if (L < 4) {   // pathologically sharp component: evaluate this pair of groups directly
             const int k1 = half ? p0 + R : p0 + gA;

@@ -142,13 +142,19 @@ k_render_hw(RenderArgs a) {
         const unsigned long long km = __ballot(keep);
         const int Kk = __popcll(km);
         __syncthreads();   // previous source's table reads are done
+        if (lane < 4) { T.gL[lane] = 4096; T.gr0[lane] = HW_TH; T.gr1[lane] = 0; }
         if (keep) {
             int p = __popcll(km & ((1ull << lane) - 1ull));
             T.A[p] = c.A; T.mx[p] = c.mx; T.my[p] = c.my;
             T.qa[p] = c.qa * EXP_SCALE; T.qb[p] = c.qb * EXP_SCALE; T.qc[p] = c.qc * EXP_SCALE;
-            T.eq[p] = exp(-c.qc);
+            T.eq[p] = exp_tab64(-c.qc * EXP_SCALE, et);
             T.L[p] = Lk;
             T.r0[p] = rlo; T.r1[p] = rhi;
+            // LDS operations of one wave execute in order: the min/max below land after the resets above
+            const int gi = p / (2 * REC_G);
+            atomicMin(&T.gL[gi], Lk);
+            atomicMin(&T.gr0[gi], rlo);
+            atomicMax(&T.gr1[gi], rhi);
         }
         if (lane < HW_PAD) {   // zero components behind the table (amplitude 0, ratio 1)
             int p = Kk + lane;
@@ -171,15 +177,10 @@ k_render_hw(RenderArgs a) {
         for (int p0 = 0; p0 < Kk; p0 += 2 * REC_G) {
             const int R = min(2 * REC_G, Kk - p0);
             const int gA = (R + 1) / 2;
-            int L = T.L[p0], ga = T.r0[p0], gb = T.r1[p0];
-            for (int i = 1; i < R; i++) {
-                L = min(L, T.L[p0 + i]);
-                ga = min(ga, T.r0[p0 + i]);
-                gb = max(gb, T.r1[p0 + i]);
-            }
-            L = __builtin_amdgcn_readfirstlane(L);
-            ga = __builtin_amdgcn_readfirstlane(ga);
-            gb = __builtin_amdgcn_readfirstlane(gb);
+            const int gi = p0 / (2 * REC_G);
+            const int L = __builtin_amdgcn_readfirstlane(T.gL[gi]);
+            const int ga = __builtin_amdgcn_readfirstlane(T.gr0[gi]);
+            const int gb = __builtin_amdgcn_readfirstlane(T.gr1[gi]);
             if (a.timing) { dbg_pairrows += (unsigned)(gb - ga) * (unsigned)gA; dbg_comprows += (unsigned)(gb - ga) * (unsigned)R; dbg_pairs += 1; }
             const int k0 = half ? p0 + gA : p0;
             if (L < 4) {
