@@ -39,6 +39,9 @@ __device__ inline void rec_group_hw(const CompTab &T, const double *__restrict__
         }
         int row = sa;
         for (; row + 1 < sb; row += 2) {
+            // no FMA contraction here: fusing g*r into the row sum would not save the product
+            // (g*r is needed by itself for the next row) and costs one extra multiply per component pair
+#pragma clang fp contract(off)
             double s0 = g[0], s1, g1[G], r1[G];
 #pragma unroll
             for (int i = 1; i < G; i++) s0 += g[i];
