@@ -25,6 +25,9 @@
 #pragma once
 #include "hw_source.h"
 
+#ifndef PHILOX_ROUNDS
+#define PHILOX_ROUNDS 10      // Philox4x32-10 (Salmon et al. 2011); lower values only for timing experiments
+#endif
 struct Philox {
     unsigned k0, k1, c0, c1, c2, c3;
     unsigned out[4];
@@ -34,7 +37,7 @@ struct Philox {
 __device__ inline void philox_block(Philox &g) {
     unsigned c0 = g.c0, c1 = g.c1, c2 = g.c2, c3 = g.c3, k0 = g.k0, k1 = g.k1;
 #pragma unroll
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < PHILOX_ROUNDS; r++) {
         unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
         unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
         unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
