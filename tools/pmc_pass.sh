@@ -15,23 +15,21 @@ done
 python3 - "$root" "$tag" <<'PY'
 import csv, glob, json, sys, collections
 root, tag = sys.argv[1], sys.argv[2]
-out = collections.defaultdict(lambda: collections.defaultdict(float))
-cnt = collections.defaultdict(lambda: collections.defaultdict(int))
-for f in glob.glob("%s/gpurun_out/pmc_%s_*/**/*counter_collection.csv" % (root, tag), recursive=True):
+# per kernel, per counter: {dispatch id: value summed over the counter's hardware instances}
+per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+for f in sorted(glob.glob("%s/gpurun_out/pmc_%s_*/**/*counter_collection.csv" % (root, tag), recursive=True)):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        out[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        cnt[k][r["Counter_Name"]] += 1
+        per[k][r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
 res = {}
-for k in out:
-    if "k_render" not in k and "k_patch" not in k and "k_photon" not in k:
-        continue
-    # per launch: a dispatch contributes one row per counter (dimension instances are summed by the tool or listed; sum either way)
-    res[k] = {c: out[k][c] for c in sorted(out[k])}
-    res[k]["_rows"] = {c: cnt[k][c] for c in sorted(cnt[k])}
+for k in per:
+    res[k] = {c: [per[k][c][d] for d in sorted(per[k][c])] for c in sorted(per[k])}
 json.dump(res, open("%s/gpurun_out/pmc_%s.json" % (root, tag), "w"), indent=1)
-for k in res:
+for k in sorted(res):
+    if not any(t in k for t in ("k_render", "k_patch", "k_photon", "k_estep")):
+        continue
     print(k)
-    for c in sorted(out[k]):
-        print("   %-28s %16.0f  rows %d" % (c, out[k][c], cnt[k][c]))
+    for c in sorted(res[k]):
+        v = res[k][c]
+        print("   %-28s launches %2d  mean %16.0f  last %16.0f" % (c, len(v), sum(v) / len(v), v[-1]))
 PY
