@@ -62,9 +62,13 @@ __device__ inline int hw_build(CompTab &T, const LaneConst &lc, const RecU &rec,
     int Lk = 0, rlo = ra, rhi = rb;
     if (lane < K) {
         // A e^E >= floor e^-T  <=>  -E <= T + log A - log floor =: Tk
-        double Tk = (dropmode == HW_DROP_NONE) ? 100.0 : Tdrop + (double)logA - log_floor;
+        double Tk = Tdrop + (double)logA - log_floor;
         if (dropmode == HW_DROP_NONE) {
+            // nothing is dropped, so the component matters wherever it is evaluated: the seeds must
+            // be safe down to its smallest value on the rectangle
+            Tk = 0.5 * quad_max_rect(c.qa, c.qb, c.qc, xad - c.mx, xbd - c.mx, yad - c.my, ybd - c.my);
             keep = true;
+            far = !(Tk <= 300.0);
         } else if (Tk == Tk && Tk < 1e30) {
             double qmin = quad_min_rect(c.qa, c.qb, c.qc, xad - c.mx, xbd - c.mx, yad - c.my, ybd - c.my);
             keep = (0.5 * qmin <= Tk);

@@ -837,8 +837,8 @@ def test_source_conditional_loglik_golden(cel):
         assert p.shape == zs[0].shape and p.min() >= 0
 
 
-@pytest.mark.parametrize("kernel", ["direct", "recurrence"])
-def test_patch_loglik_adversarial_patches_vs_oracle(cel, ctx, orc, kernel):
+@pytest.mark.parametrize("kernel,tail", [("direct", 32.0), ("recurrence", 32.0), ("recurrence", 0.0)])
+def test_patch_loglik_adversarial_patches_vs_oracle(cel, ctx, orc, kernel, tail):
     """cel_patch_loglik on patches the recurrence kernel must chunk (wider than 32, taller than
     64), shift away from the source (deep tails: every pixel carries data, so log(m) is exercised
     where m is tiny), and give up on (a patch so far out that the seeds would underflow: direct
@@ -864,6 +864,7 @@ def test_patch_loglik_adversarial_patches_vs_oracle(cel, ctx, orc, kernel):
         np.array([[0, 64, 388, 420], [236, 300, 0, 33]]),           # far corners: below the seed-safe range
     ]
     ctx.set_kernel(kernel)
+    ctx.set_tail_log(tail)          # 0: no component is ever dropped
     try:
         for boxes in cases:
             data = [rs.poisson(3.0, size=(bx[1] - bx[0], bx[3] - bx[2])).astype(float) + 1.0 if bx[1] > bx[0] else None
@@ -884,3 +885,4 @@ def test_patch_loglik_adversarial_patches_vs_oracle(cel, ctx, orc, kernel):
                     np.testing.assert_allclose(got[s], want, rtol=RT_LL, err_msg="src %d boxes %s iso %s" % (s, boxes, isolated))
     finally:
         ctx.set_kernel("recurrence")
+        ctx.set_tail_log(32.0)
