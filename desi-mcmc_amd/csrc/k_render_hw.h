@@ -88,11 +88,58 @@ k_render_hw(RenderArgs a) {
     const double x = (double)xi;
     const BandDev *bd = a.bands + b;
 
+    const int cnt = a.tile_cnt[tile];
+    if (cnt == 0 && !a.timing) {
+        // empty sky: lambda = eps on the whole tile -- pure streaming (nelec in, eps out), one log
+        // per wave instead of one per pixel, no LDS.  Same arithmetic per pixel as the general
+        // epilogue (ne * log(lam) - lam, rows in the same order).
+        const double eps = bd->eps;
+        const bool store = !(a.flags & CEL_RENDER_NO_STORE);
+        const bool ll = (a.flags & CEL_RENDER_LOGLIK) != 0;
+        const int64_t base = (int64_t)b * a.H * a.W + (int64_t)(Y0 + half) * a.W + xi;
+        double part = 0.0;
+        if ((a.W & 31) == 0 && Y0 + HW_TH <= a.H) {
+            // whole tile inside an aligned frame: 16 B per lane (4 rows of 16 lane-pairs per
+            // instruction), all 16 loads in flight before the first use
+            const int cp = lane & 15, rq = lane >> 4;
+            const int64_t b2 = (int64_t)b * a.H * a.W + (int64_t)(Y0 + rq) * a.W + X0 + 2 * cp;
+            const double leps = ll ? log(eps) : 0.0;
+            double2 ne2[HW_TH / 4];
+            if (ll) {
+#pragma unroll
+                for (int r = 0; r < HW_TH / 4; r++)
+                    ne2[r] = *reinterpret_cast<const double2 *>(a.nelec + b2 + (int64_t)(4 * r) * a.W);
+            }
+#pragma unroll
+            for (int r = 0; r < HW_TH / 4; r++) {
+                if (store) *reinterpret_cast<double2 *>(a.lambda + b2 + (int64_t)(4 * r) * a.W) = make_double2(eps, eps);
+                if (ll) part += (ne2[r].x * leps - eps) + (ne2[r].y * leps - eps);
+            }
+        } else if (xi < a.W) {
+            double ne[HW_TH / 2];
+#pragma unroll
+            for (int r = 0; r < HW_TH / 2; r++)
+                ne[r] = (ll && Y0 + 2 * r + half < a.H) ? a.nelec[base + (int64_t)(2 * r) * a.W] : 0.0;
+            const double leps = ll ? log(eps) : 0.0;
+#pragma unroll
+            for (int r = 0; r < HW_TH / 2; r++) {
+                if (Y0 + 2 * r + half < a.H) {
+                    if (store) a.lambda[base + (int64_t)(2 * r) * a.W] = eps;
+                    if (ll) part += ne[r] * leps - eps;
+                }
+            }
+        }
+        if (ll) {
+            part = wave_sum(part);
+            if (lane == 0) a.partials[tile] = part;
+        }
+        return;
+    }
+
     et[lane] = exp2((double)lane * (1.0 / 64.0));
 #pragma unroll
     for (int r = 0; r < HW_TH / 2; r++) acc[r * 64 + lane] = 0.0;
 
-    const int cnt = a.tile_cnt[tile];
     const int64_t off = a.tile_off[tile];
     const SrcRec *recs = a.recs + (int64_t)b * a.S;
     const double Tdrop = a.tail_T;

@@ -293,6 +293,22 @@ def test_edge_cases_empty_ragged_offimage(cel, ctx, orc):
         for b in range(2):
             assert np.all(lam[b] == bands[b, 0])
             np.testing.assert_allclose(llb[b], H * W * (3.0 * np.log(bands[b, 0]) - bands[b, 0]), rtol=1e-13)
+    # mostly empty sky on a tile-aligned frame: the streaming path of empty tiles (16 B per lane)
+    H, W = 192, 128
+    bands = synth.make_bands(H, W, 2)
+    nelec = np.random.RandomState(4).poisson(250.0, size=(2, H, W)).astype(float)
+    iset = cel.ImageSet(ctx, bands, H, W, nelec=nelec)
+    radec = synth.pixel2equa(bands[0], np.array([[20.5, 30.25]]))
+    sset = cel.SourceSet(ctx, 1, 2).set(np.zeros(1, np.int32), radec, np.full((1, 2), 3e4), np.tile([0.5, 2.0, 30.0, 0.5], (1, 1)))
+    ll, llb = iset.render(sset, loglik=True)
+    ob = bands.copy()
+    ob[:, 36] = [iset.band(0)[36], iset.band(1)[36]]
+    o_lam, o_ll, _ = orc.render_field(ob, H, W, np.zeros(1, np.int32), radec, np.full((1, 2), 3e4),
+                                      np.tile([0.5, 2.0, 30.0, 0.5], (1, 1)), nelec)
+    lam = iset.model_images()
+    np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM)
+    np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
+    assert np.all(lam[:, 128:, :] == bands[:, 0][:, None, None])        # untouched tiles hold eps exactly
     # sources off-image / on the border / failing the Q1 test / degenerate galaxy sizes
     H, W = 70, 130
     bands = synth.make_bands(H, W, 2)
