@@ -52,13 +52,19 @@ enum {
 
 /* cel_ctx_set_option keys */
 enum {
-    CEL_OPT_KERNEL = 1,    /* 0 = direct exp per Gaussian-pixel, 1 = row-recurrence (default) */
+    CEL_OPT_KERNEL = 1,    /* 0 = direct exp per Gaussian-pixel, 1 = row-recurrence (default).
+                              Selects the form of every evaluating kernel: field render, stamps,
+                              conditional log-likelihoods, photon split, E-step reductions        */
     CEL_OPT_TAIL_LOG = 2,  /* T >= 0: a mixture component is skipped on an image tile when its
                               contribution stays below eps * e^-T everywhere on the part of the
                               tile its source covers (eps = the band's sky level, so the bound is
                               relative to lambda >= eps).  0 = never skip.  default 32:
                               |d lambda| / lambda <= n_skipped * e^-32 = n * 1.3e-14, eight
-                              orders inside the 1e-6 parity bar even for thousands of skips  */
+                              orders inside the 1e-6 parity bar even for thousands of skips.
+                              The per-source kernels whose output has no sky in it (stamps, the
+                              conditional log-likelihood, the E-step sums) use the same T against
+                              the source's own smallest value on the tile instead of eps: the
+                              relative error of every pixel stays below n_components * e^-T    */
     CEL_OPT_PROFILE = 3,   /* 1 = bracket every kernel launch with HIP events              */
     CEL_OPT_TILE_ORDER = 4,/* 1 (default) = launch render tiles heaviest-first; never changes results */
     CEL_OPT_TILE_ROWS = 5, /* rows per render tile, 32 (default) or 64; read by cel_images_create  */
