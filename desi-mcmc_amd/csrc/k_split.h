@@ -72,6 +72,13 @@ __device__ inline double btpe_st(double x) {
     return (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / x2) / x2) / x2) / x2) / x / 166320.0;
 }
 
+// 1/x to ~4e-15 relative for x of fp32 range: fp32 reciprocal + one Newton step (4 instructions
+// against ~15 for an IEEE fp64 division).  Used where a probability or a pmf ratio is formed.
+__device__ inline double fast_rcp(double x) {
+    double y = (double)__frcp_rn((float)x);
+    return fma(y, fma(-x, y, 1.0), y);
+}
+
 // Binomial(n, r) for r <= 1/2, n r <= 30: sequential inversion (BINV).
 // P(X = 0) = (1 - r)^n >= 1 - n r, so a uniform at or below 1 - n r returns 0 before anything
 // transcendental is evaluated (most draws of a split: a pixel in a source's tail).  Otherwise
@@ -80,23 +87,27 @@ __device__ inline double btpe_st(double x) {
 __device__ inline long long binom_inversion(long long n, double r, Philox &g, const double *__restrict__ et,
                                             const double *__restrict__ lt) {
     const double q = 1.0 - r;
-    const double np = (double)n * r;
+    const double nd = (double)n;
+    const double np = nd * r;
     double U = philox_double(g);
     if (U <= 1.0 - np) return 0;
-    const double qn = exp_tab64((double)n * log_tab(q, lt) * EXP_SCALE, et);
-    const long long bound = (long long)fmin((double)n, np + 10.0 * sqrt(np * q + 1.0));
-    long long X = 0;
-    double px = qn;
+    const double qn = exp_tab64(nd * log_tab(q, lt) * EXP_SCALE, et);
+    if (U <= qn) return 0;
+    // p(X) = p(X-1) (n - X + 1)/X r/q: one division for r/q, 1/X from an fp32 reciprocal and
+    // one Newton step (4e-15; the recurrence needs no more)
+    const double s = r / q;
+    const double bound = fmin(nd, np + 10.0 * sqrt(np * q + 1.0));
+    double X = 0.0, px = qn;
     while (U > px) {
-        X++;
+        X += 1.0;
         if (X > bound) {            // numerical tail: start over
-            X = 0; px = qn; U = philox_double(g);
+            X = 0.0; px = qn; U = philox_double(g);
         } else {
             U -= px;
-            px = ((double)(n - X + 1) * r * px) / ((double)X * q);
+            px *= (nd + 1.0 - X) * s * fast_rcp(X);
         }
     }
-    return X;
+    return (long long)X;
 }
 
 // Binomial(n, r) for r <= 1/2, n r > 30: BTPE (triangle / parallelogram / exponential tails)
@@ -326,7 +337,7 @@ k_photon_split(SplitArgs a) {
                     long long z = 0;
                     if (n > 0) {
                         Philox g = philox_init(a.seed, (unsigned long long)(plane + (int64_t)y * a.W + xi), (unsigned)s);
-                        z = binomial_draw((long long)n, F / tot, g, et, lt);   // curr_prob / sum_probs (:147)
+                        z = binomial_draw((long long)n, F * fast_rcp(tot), g, et, lt);   // curr_prob / sum_probs (:147)
                     }
                     left[li] = n - (int)z;
                     rate[li] = tot - F;                                   // sum_probs -= curr_prob (:152)
@@ -433,7 +444,7 @@ k_photon_split_hw(SplitArgs a) {
                 long long z = 0;
                 if (n > 0) {
                     Philox g = philox_init(a.seed, (unsigned long long)(plane + (int64_t)(Y0 + row) * a.W + xi), (unsigned)s);
-                    z = binomial_draw((long long)n, F / tot, g, et, lt);  // curr_prob / sum_probs (:147)
+                    z = binomial_draw((long long)n, F * fast_rcp(tot), g, et, lt);  // curr_prob / sum_probs (:147)
                 }
                 left[li] = n - (int)z;
                 rate[li] = tot - F;                                       // sum_probs -= curr_prob (:152)

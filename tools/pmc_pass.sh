@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc_pass.sh <tag> "<counters of pass 1>" "<counters of pass 2>" ...
-# One rocprofv3 --pmc pass per argument over a short bench.py run; per-kernel sums are printed and
+# One rocprofv3 --pmc pass per argument over a short bench.py run (or PMC_PROG="script.py args"); per-kernel sums are printed and
 # written to gpurun_out/pmc_<tag>.json.  (Counters only with --kernel-trace: see the gpurun rules.)
 set -e
 tag=$1; shift
@@ -10,7 +10,7 @@ i=0
 for grp in "$@"; do
   i=$((i+1))
   rm -rf $root/gpurun_out/pmc_${tag}_$i
-  (cd $root && rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $root/gpurun_out/pmc_${tag}_$i -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 > $root/gpurun_out/pmc_${tag}_$i.log 2>&1)
+  (cd $root && rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $root/gpurun_out/pmc_${tag}_$i -- python3 ${PMC_PROG:-bench.py --steps 3 --warmup 1 --cpu-sample 0} > $root/gpurun_out/pmc_${tag}_$i.log 2>&1)
 done
 python3 - "$root" "$tag" <<'PY'
 import csv, glob, json, sys, collections
