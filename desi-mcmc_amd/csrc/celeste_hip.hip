@@ -992,17 +992,21 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
     if (!im->have_nelec) return fail(CEL_ERR_INVALID, "cel_photon_split needs cel_images_set_nelec first");
     if (im->TW * im->TH != 2048) return fail(CEL_ERR_INVALID, "cel_photon_split needs 2048-pixel render tiles");
     cel_ctx *c = im->ctx;
-    // records + tile lists for exactly these sources (renders lambda on the way)
-    int rc = cel_render_field(im, src, 0, nullptr, nullptr);
-    if (rc) return rc;
+    if (src->ctx != im->ctx || src->B != im->B) return fail(CEL_ERR_INVALID, "sources do not match images");
     HIP_TRY(hipSetDevice(c->device));
-    // recurrence form: the pixels' total rates are an image of their own, rendered with the split's
-    // strict boxes (same records and lists: the source set has not changed)
+    // records + tile lists for exactly these sources come from a render.  Recurrence form: that
+    // render is the one the split needs anyway -- every pixel's total rate, an image of its own
+    // with the split's strict boxes (the model image of cel_images_get_lambda is left alone).
+    // Direct form: a plain render (its kernel accumulates the totals itself).
     const bool hw = (c->variant != 0) && (im->TW == HW_TW);
+    int rc;
     if (hw) {
         if (!im->d_rate) HIP_TRY(hipMalloc((void **)&im->d_rate, sizeof(double) * (size_t)im->B * im->H * im->W));
-        if ((rc = render_impl(im, src, CEL_RENDER_STRICT, nullptr, nullptr, im->d_rate))) return rc;
+        rc = render_impl(im, src, CEL_RENDER_STRICT, nullptr, nullptr, im->d_rate);
+    } else {
+        rc = cel_render_field(im, src, 0, nullptr, nullptr);
     }
+    if (rc) return rc;
     const int B = im->B;
     const int64_t S = src->S, n = S * B;
     const int T = B * im->ntx * im->nty;
