@@ -1049,21 +1049,27 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         if (mem == CEL_DEVICE) d_samp = samp;
         else if ((rc = scratch_get(c, 3, sizeof(double) * (total > 0 ? total : 1), (void **)&d_samp))) return rc;
     }
-    if (total > 0) HIP_TRY(hipMemsetAsync(d_samp, 0, sizeof(double) * total, c->stream));
+    // resident + recurrence form: the kernel writes every interior pixel and reduces the photon
+    // rectangles itself; otherwise zero the buffer and (resident) find the rectangles afterwards
+    const bool fused_nz = resident && hw && n > 0;
+    if (fused_nz)
+        hipLaunchKernelGGL(k_samp_prepare, dim3((unsigned)n), dim3(64), 0, c->stream, im->d_sbox, im->d_soff, d_samp, im->d_snz);
+    else if (total > 0)
+        HIP_TRY(hipMemsetAsync(d_samp, 0, sizeof(double) * total, c->stream));
     {
         SplitArgs a;
         a.bands = im->d_bands; a.recs = im->d_recs; a.lists = im->d_lists; a.tile_cnt = im->d_tile_cnt;
         a.tile_off = im->d_tile_off; a.nelec = im->d_nelec; a.offsets = d_off; a.samp = d_samp;
         a.partials = im->d_partials; a.S = S; a.capacity = im->lists_cap; a.B = B; a.H = im->H; a.W = im->W;
         a.ntx = im->ntx; a.nty = im->nty; a.TW = im->TW; a.TH = im->TH; a.seed = seed;
-        a.rate_img = im->d_rate; a.tail_T = c->tail_T;
+        a.rate_img = im->d_rate; a.tail_T = c->tail_T; a.nz = fused_nz ? im->d_snz : nullptr;
         if (hw && (rc = scratch_get(c, 2, sizeof(double) * 2 * (size_t)T, (void **)&a.partials))) return rc;
         int pi = prof_begin(c, CEL_K_STAMPS);
         if (hw) hipLaunchKernelGGL(k_photon_split_hw, dim3(2 * T), dim3(64), 0, c->stream, a);
         else hipLaunchKernelGGL(k_photon_split, dim3(T), dim3(64), 0, c->stream, a);
         prof_end(c, pi);
         hipLaunchKernelGGL(k_reduce, dim3(B), dim3(256), 0, c->stream, a.partials, (hw ? 2 : 1) * im->ntx * im->nty, im->d_llband);
-        if (resident && n > 0)   // where each patch's photons are: the conditional likelihoods evaluate only there
+        if (resident && n > 0 && !fused_nz)   // where each patch's photons are: the conditional likelihoods evaluate only there
             hipLaunchKernelGGL(k_patch_nzbox, dim3((unsigned)n), dim3(64), 0, c->stream, im->d_sbox, im->d_soff, im->d_samp, im->d_snz);
     }
     HIP_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));

@@ -238,6 +238,22 @@ k_patch_sums(const int64_t *__restrict__ soff, const double *__restrict__ samp, 
     if (threadIdx.x == 0) sums[i] = red[0];
 }
 
+// Before a resident split on the recurrence kernel: that kernel writes every pixel strictly inside
+// a box exactly once, so only the first row and column of each patch need zeroing (not the whole
+// 3.2 GB buffer), and the photon rectangles it will reduce with atomics need their identity.
+__global__ void __launch_bounds__(64)
+k_samp_prepare(const int4 *__restrict__ sbox, const int64_t *__restrict__ soff, double *__restrict__ samp,
+               int4 *__restrict__ nz) {
+    const int64_t i = blockIdx.x;
+    const int4 bx = sbox[i];
+    const int nx = bx.y - bx.x, ny = bx.w - bx.z;
+    if (threadIdx.x == 0) nz[i] = make_int4(INT_MAX, 0, INT_MAX, 0);      // x0, x1, y0, y1: empty
+    if (nx <= 0 || ny <= 0) return;
+    double *p = samp + soff[i];
+    for (int x = threadIdx.x; x < nx; x += 64) p[x] = 0.0;
+    for (int y = threadIdx.x; y < ny; y += 64) p[(int64_t)y * nx] = 0.0;
+}
+
 // diagnostic: N independent Binomial(n, p) draws (stream i), for the sampler's own tests
 __global__ void __launch_bounds__(256)
 k_binomial_draws(long long n, double p, unsigned long long seed, int64_t N, long long *__restrict__ out) {
@@ -269,6 +285,7 @@ struct SplitArgs {
     unsigned long long seed;
     const double *rate_img;     // k_photon_split_hw: every pixel's total rate (strict boxes), rendered beforehand
     double tail_T;              // k_photon_split_hw: drop threshold of the per-source tiles
+    int4 *nz;                   // k_photon_split_hw: per patch, the rectangle holding its photons (min/max by atomics), or nullptr
 };
 
 __global__ void __launch_bounds__(64)
@@ -431,6 +448,7 @@ k_photon_split_hw(SplitArgs a) {
         const int Kk = hw_build(T, lc, rec, lane, dropmode, a.tail_T, log_sky, Y0, xa, xb, ra, rb, direct);
         hw_walk(T, et, Kk, x, Y0, ra, rb, on, direct, one, lane);
         __syncthreads();
+        int zlo = INT_MAX, zhi = -1;                  // rows of this lane's column that received photons
         if (on) {
             const int nx = rec.x1 - rec.x0;
             double *patch = a.samp + poff + (int64_t)(Y0 - rec.y0) * nx + (xi - rec.x0);
@@ -449,6 +467,23 @@ k_photon_split_hw(SplitArgs a) {
                 left[li] = n - (int)z;
                 rate[li] = tot - F;                                       // sum_probs -= curr_prob (:152)
                 patch[(int64_t)row * nx] = (double)z;
+                if (z > 0) { zlo = min(zlo, row); zhi = max(zhi, row); }
+            }
+        }
+        if (a.nz && __ballot(zhi >= 0)) {
+            // the patch's photon rectangle (what the conditional likelihoods will evaluate): one
+            // wave reduction per (source, half-tile), four atomics by one lane.  (Tracking it in
+            // scalar registers from a ballot per step needs a wave-uniform step loop and measured
+            // slower: 10.7 against 10.4 ms; a separate pass over the 3.2 GB of patches costs 1.1 ms.)
+            int xlo = (zhi >= 0) ? xi : INT_MAX, xhi = (zhi >= 0) ? xi : -1;
+            for (int o = 32; o > 0; o >>= 1) {
+                zlo = min(zlo, __shfl_xor(zlo, o)); zhi = max(zhi, __shfl_xor(zhi, o));
+                xlo = min(xlo, __shfl_xor(xlo, o)); xhi = max(xhi, __shfl_xor(xhi, o));
+            }
+            if (lane == 0) {
+                int *q = reinterpret_cast<int *>(a.nz + ((int64_t)s * a.B + b));
+                atomicMin(q + 0, xlo); atomicMax(q + 1, xhi + 1);
+                atomicMin(q + 2, Y0 + zlo); atomicMax(q + 3, Y0 + zhi + 1);
             }
         }
         __syncthreads();
