@@ -902,3 +902,57 @@ def test_patch_loglik_adversarial_patches_vs_oracle(cel, ctx, orc, kernel, tail)
     finally:
         ctx.set_kernel("recurrence")
         ctx.set_tail_log(32.0)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CEL_FUZZ_SEEDS", "10"))))
+def test_fuzz_random_fields_vs_oracle(cel, ctx, orc, seed):
+    """Seeded random small fields at the extremes the synthetic benchmark population never visits:
+    frames of any size, sharp and broad PSFs, sky levels over six decades, galaxy scales from
+    below a pixel to a third of the frame, degenerate axis ratios and profile mixes, counts from 1
+    to 1e7, sources on and beyond the border.  Model image, log-likelihood, E-step reductions and
+    conditional likelihoods on the sources' own boxes, all against the oracle."""
+    from desi_mcmc_amd import synth
+    rs = np.random.RandomState(1000 + seed)
+    H, W = int(rs.randint(40, 260)), int(rs.randint(40, 300))
+    B = int(rs.randint(1, 4))
+    S = int(rs.randint(1, 50))
+    bands = synth.make_bands(H, W, B)
+    bands[:, 12:24] *= rs.choice([0.35, 1.0, 3.0])                  # PSF covariances
+    bands[:, 0] *= 10.0 ** rs.uniform(-3, 3)                         # sky level
+    bands[:, 36] = 0.0                                               # let the library derive the radius
+    pix = np.column_stack([rs.uniform(-40, W + 40, S), rs.uniform(-40, H + 40, S)])
+    typ = (rs.rand(S) < rs.rand()).astype(np.int32)
+    radec = synth.pixel2equa(bands[0], pix)
+    theta = np.where(rs.rand(S) < 0.2, rs.choice([0.0, 1.0], S), rs.rand(S))
+    sigma = np.exp(rs.uniform(np.log(0.05), np.log(0.33 * min(H, W) * 0.396), S))   # arcsec; 0.396 arcsec per pixel
+    shape = np.column_stack([theta, sigma, rs.uniform(0, 180, S), rs.uniform(0.03, 1.0, S)])
+    counts = np.exp(rs.uniform(0.0, np.log(1e7), size=(S, B)))
+    nelec = rs.poisson(np.clip(bands[:, 0], 1.0, 1e4)[:, None, None], size=(B, H, W)).astype(float)
+    iset = cel.ImageSet(ctx, bands, H, W, nelec=nelec)
+    sset = cel.SourceSet(ctx, S, B).set(typ, radec, counts, shape)
+    ll, llb = iset.render(sset, loglik=True)
+    ob = bands.copy()
+    ob[:, 36] = [iset.band(b)[36] for b in range(B)]
+    o_lam, o_ll, o_st = orc.render_field(ob, H, W, typ, radec, counts, shape, nelec)
+    np.testing.assert_allclose(iset.model_images(), o_lam, rtol=RT_LAM)
+    np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
+    assert iset.stats()["n_srcpix"] == o_st["n_srcpix"]
+    xt, ms, nz = iset.estep_stats(sset)
+    oxt, oms, onz = orc.estep_stats(ob, H, W, typ, radec, counts, shape, nelec)
+    np.testing.assert_allclose(xt, oxt, rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(ms, oms, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(nz, onz, rtol=1e-11)
+    # conditional likelihoods of each source on its own boxes, data = the observed pixels there
+    boxes, status = iset.source_boxes(sset)
+    for s in range(min(S, 6)):
+        bx = boxes[:, s]
+        data = [nelec[b, bx[b, 0]:bx[b, 1], bx[b, 2]:bx[b, 3]]
+                if status[b, s] > 0 and bx[b, 1] > bx[b, 0] and bx[b, 3] > bx[b, 2] else None for b in range(B)]
+        bxs = np.array([bx[b] if data[b] is not None else [0, 0, 0, 0] for b in range(B)])
+        one = cel.SourceSet(ctx, 1, B).set(typ[s:s + 1], radec[s:s + 1], counts[s:s + 1], shape[s:s + 1])
+        for isolated in (False, True):
+            got = iset.patch_loglik(one, bxs, data, isolated=isolated)[0]
+            want = sum(orc.patch_loglik(ob[b], H, W, typ[s], radec[s], shape[s], counts[s, b], bxs[b],
+                                        np.ascontiguousarray(data[b]), 1 if isolated else 0)
+                       for b in range(B) if data[b] is not None)
+            np.testing.assert_allclose(got, want, rtol=RT_LL, atol=1e-9, err_msg="seed %d src %d iso %s" % (seed, s, isolated))
