@@ -1148,8 +1148,9 @@ int cel_estep_stats(cel_images *im, cel_sources *src, double *xtilde, double *ma
         if (e != hipSuccess) { rc = fail(CEL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); goto done; } \
     } while (0)
     if (S > 0) {
-        ES_TRY(hipMalloc((void **)&d_x, sizeof(double) * S * B));
-        ES_TRY(hipMalloc((void **)&d_m, sizeof(double) * S * B));
+        // the context's scratch arena (slots 4/5), not a hipMalloc per call: EM iterates this
+        if ((rc = scratch_get(c, 4, sizeof(double) * S * B, (void **)&d_x)) ||
+            (rc = scratch_get(c, 5, sizeof(double) * S * B, (void **)&d_m))) goto done;
         int pi = prof_begin(c, CEL_K_STAMPS);
         if (c->variant == 0)
             hipLaunchKernelGGL(k_estep_src, dim3((unsigned)(S * B)), dim3(256), 0, c->stream, im->d_bands, B, im->H, im->W,
@@ -1173,8 +1174,6 @@ int cel_estep_stats(cel_images *im, cel_sources *src, double *xtilde, double *ma
 #undef ES_TRY
 done:
     (void)hipStreamSynchronize(c->stream);
-    if (d_x) (void)hipFree(d_x);
-    if (d_m) (void)hipFree(d_m);
     return rc;
 }
 
