@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--kernel", default="recurrence", choices=["direct", "recurrence"])
     ap.add_argument("--tail-log", type=float, default=32.0)
     ap.add_argument("--tile-rows", type=int, default=32, choices=[32, 64])
-    ap.add_argument("--tile-order", type=int, default=1, choices=[0, 1])
+    ap.add_argument("--tile-order", type=int, default=1, choices=[0, 1, 2])
     ap.add_argument("--layout", type=int, default=1, choices=[0, 1],
                     help="render tile geometry: 0 = 64x32 (k_render), 1 = 32x64 half-wave (k_render_hw)")
     ap.add_argument("--cpu-sample", type=int, default=400, help="sources in the CPU baseline sample (0 = skip)")

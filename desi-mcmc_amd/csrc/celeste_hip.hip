@@ -97,7 +97,7 @@ struct cel_ctx {
     int variant = 1;
     double tail_T = 32.0;
     bool profile = false;
-    bool tile_order = true;   // launch k_render tiles heaviest-first
+    int tile_order = 1;       // 0 = launch k_render tiles in index order, 1 = heaviest first by the last render's measured tile durations (estimate when none), 2 = heaviest first by the estimate only
     int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created
     bool tile_timing = false; // diagnostic: k_render stamps each tile's start/end wall clock
     int tile_layout = 1;      // 0: 64 x tile_rows tiles, one lane per column (k_render)
@@ -139,6 +139,8 @@ struct cel_images {
     int *d_kind = nullptr;
     int64_t recs_cap = 0;
     int *d_tile_cnt = nullptr, *d_tile_work = nullptr, *d_order = nullptr;
+    int *d_tile_cost = nullptr;   // measured duration of every tile in the last render (the next render's launch order)
+    int64_t cost_S = -1;          // number of sources that render had (-1: nothing measured yet)
     int64_t *d_tile_off = nullptr;
     unsigned long long *d_cursor = nullptr;   // fine cursor, fine overflow, coarse cursor, coarse overflow
     int *d_lists = nullptr;
@@ -356,7 +358,8 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         c->profile = (v != 0.0);
         return CEL_OK;
     case CEL_OPT_TILE_ORDER:
-        c->tile_order = (v != 0.0);
+        if (v != 0.0 && v != 1.0 && v != 2.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TILE_ORDER must be 0, 1 or 2");
+        c->tile_order = (int)v;
         return CEL_OK;
     case CEL_OPT_TILE_ROWS:
         if (v != 32.0 && v != 64.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TILE_ROWS must be 32 or 64");
@@ -379,7 +382,7 @@ int cel_ctx_get_option(cel_ctx *c, int key, double *v) {
     case CEL_OPT_KERNEL: *v = c->variant; return CEL_OK;
     case CEL_OPT_TAIL_LOG: *v = c->tail_T; return CEL_OK;
     case CEL_OPT_PROFILE: *v = c->profile ? 1.0 : 0.0; return CEL_OK;
-    case CEL_OPT_TILE_ORDER: *v = c->tile_order ? 1.0 : 0.0; return CEL_OK;
+    case CEL_OPT_TILE_ORDER: *v = (double)c->tile_order; return CEL_OK;
     case CEL_OPT_TILE_ROWS: *v = c->tile_rows; return CEL_OK;
     case CEL_OPT_TILE_TIMING: *v = c->tile_timing ? 1.0 : 0.0; return CEL_OK;
     case CEL_OPT_TILE_LAYOUT: *v = c->tile_layout; return CEL_OK;
@@ -393,7 +396,7 @@ int cel_images_destroy(cel_images *im) {
     (void)hipSetDevice(im->ctx->device);
     (void)hipStreamSynchronize(im->ctx->stream);
     void *ptrs[] = {im->d_bands, im->d_nelec, im->d_lambda, im->d_partials, im->d_llband, im->d_recs,
-                    im->d_boxes, im->d_kind, im->d_tile_cnt, im->d_tile_work, im->d_order, im->d_tile_off, im->d_cursor, im->d_lists, im->d_stats,
+                    im->d_boxes, im->d_kind, im->d_tile_cnt, im->d_tile_work, im->d_tile_cost, im->d_order, im->d_tile_off, im->d_cursor, im->d_lists, im->d_stats,
                     im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff, im->d_rate, im->d_snz};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -451,6 +454,7 @@ int cel_images_create(cel_ctx *c, int B, int H, int W, const cel_band *bands, ce
     IM_TRY(hipMalloc((void **)&im->d_llband, sizeof(double) * MAX_BANDS));
     IM_TRY(hipMalloc((void **)&im->d_tile_cnt, sizeof(int) * T));
     IM_TRY(hipMalloc((void **)&im->d_tile_work, sizeof(int) * T));
+    IM_TRY(hipMalloc((void **)&im->d_tile_cost, sizeof(int) * T));
     IM_TRY(hipMalloc((void **)&im->d_order, sizeof(int) * T));
     IM_TRY(hipMalloc((void **)&im->d_tile_off, sizeof(int64_t) * T));
     IM_TRY(hipMalloc((void **)&im->d_cursor, sizeof(unsigned long long) * 4));
@@ -667,7 +671,11 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
                            im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
                            (int *)(im->d_cursor + 1));
         if (c->tile_order)
-            hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, im->d_tile_work, T, im->d_order);
+            // heaviest first: by the durations the tiles had in the previous render when that was
+            // of the same source count (an MCMC chain changes little from one evaluation to the
+            // next), by the binning pass's estimate otherwise.  The order never changes results.
+            hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (im->cost_S == S && c->tile_order == 1) ? im->d_tile_cost : im->d_tile_work,
+                               T, im->d_order);
         prof_end(c, pi);
         RenderArgs a;
         a.bands = im->d_bands; a.recs = im->d_recs; a.lists = im->d_lists; a.tile_cnt = im->d_tile_cnt;
@@ -675,6 +683,7 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         a.S = S; a.capacity = im->lists_cap; a.B = im->B; a.H = im->H; a.W = im->W; a.ntx = im->ntx; a.nty = im->nty;
         a.flags = flags; a.variant = c->variant; a.tail_T = c->tail_T; a.order = c->tile_order ? im->d_order : nullptr;
         a.timing = nullptr;
+        a.cost = (im->TW == HW_TW) ? im->d_tile_cost : nullptr;
         if (c->tile_timing) {
             if (!im->d_timing) HIP_TRY(hipMalloc((void **)&im->d_timing, sizeof(unsigned long long) * 3 * T));
             a.timing = im->d_timing;
@@ -704,7 +713,8 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         const bool fine_ok = (cur[1] & 0xffffffffull) == 0 && (int64_t)cur[0] <= im->lists_cap;
         const bool coarse_ok = (cur[3] & 0xffffffffull) == 0 && (int64_t)cur[2] <= im->clist_cap;
         if (coarse_ok) im->last_entries = (double)cur[0];
-        if (fine_ok && coarse_ok) break;
+        if (fine_ok && coarse_ok) { im->cost_S = (im->TW == HW_TW) ? S : -1; break; }
+        im->cost_S = -1;
         // rerun with room (a truncated coarse list also truncates the fine counts)
         if (!coarse_ok) rc = ensure_clist(im, (int64_t)cur[2] + (int64_t)cur[2] / 4 + 1024);
         if (!rc && !fine_ok) rc = ensure_lists(im, (int64_t)cur[0] + (int64_t)cur[0] / 4 + 1024);

@@ -319,6 +319,7 @@ struct RenderArgs {
     const int64_t *tile_off;
     const int *order;     // tile launch order (heaviest first) or nullptr
     unsigned long long *timing;   // diagnostic: per-tile {start, end} wall clock (100 MHz) + XCC/CU id, or nullptr
+    int *cost;            // out: every tile's measured duration (100 MHz ticks, >= 1): the next launch's order; or nullptr
     const double *nelec;
     double *lambda;
     double *partials;

@@ -77,7 +77,7 @@ k_render_hw(RenderArgs a) {
     __shared__ double et[64];
     const int lane = threadIdx.x;
     const int half = lane >> 5, col = lane & 31;
-    const unsigned long long t_start = a.timing ? wall_clock64() : 0ull;
+    const unsigned long long t_start = (a.timing || a.cost) ? wall_clock64() : 0ull;
     const int tile = a.order ? a.order[blockIdx.x] : blockIdx.x;
     const int per_band = a.ntx * a.nty;
     const int b = tile / per_band;
@@ -133,6 +133,7 @@ k_render_hw(RenderArgs a) {
             part = wave_sum(part);
             if (lane == 0) a.partials[tile] = part;
         }
+        if (a.cost && lane == 0) a.cost[tile] = (int)min(wall_clock64() - t_start, 0x3fffffffull) + 1;
         return;
     }
 
@@ -288,6 +289,7 @@ k_render_hw(RenderArgs a) {
         part = wave_sum(part);
         if (lane == 0) a.partials[tile] = part;
     }
+    if (a.cost && lane == 0) a.cost[tile] = (int)min(wall_clock64() - t_start, 0x3fffffffull) + 1;
     if (a.timing && lane == 0) {
         a.timing[3 * (size_t)blockIdx.x + 0] = t_start;
         a.timing[3 * (size_t)blockIdx.x + 1] = wall_clock64();

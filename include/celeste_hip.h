@@ -66,7 +66,10 @@ enum {
                               the source's own smallest value on the tile instead of eps: the
                               relative error of every pixel stays below n_components * e^-T    */
     CEL_OPT_PROFILE = 3,   /* 1 = bracket every kernel launch with HIP events              */
-    CEL_OPT_TILE_ORDER = 4,/* 1 (default) = launch render tiles heaviest-first; never changes results */
+    CEL_OPT_TILE_ORDER = 4,/* launch order of the render tiles; never changes results.  0 = index order,
+                              1 (default) = heaviest first by the durations the tiles had in the previous
+                              render of the same number of sources (the binning pass's estimate when there
+                              is none), 2 = heaviest first by the estimate only                         */
     CEL_OPT_TILE_ROWS = 5, /* rows per render tile, 32 (default) or 64; read by cel_images_create  */
     CEL_OPT_TILE_TIMING = 6,/* diagnostic: 1 = k_render stamps every tile's start/end wall clock   */
     CEL_OPT_TILE_LAYOUT = 7 /* render tile geometry, read by cel_images_create:
