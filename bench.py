@@ -35,11 +35,11 @@ FLOP_PER_GAUSS = 35.0        # SURVEY 8d accounting: 10 arithmetic + exp counted
 # committed measurement of exactly this command and is reported only for the configuration it
 # was taken on; any other configuration gets null.
 PMC_TRAFFIC = {   # (workload, kernel, tail_log, layout) -> (HBM bytes per k_render launch, source)
-    ("mixed10k_2048", "recurrence", 32.0, 1): (384155712.0, "profiles/r01_final_pmc.json"),
+    ("mixed10k_2048", "recurrence", 32.0, 1): (386329760.0, "profiles/r01_final_pmc.json"),
 }
 # same provenance: 2 * SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (two waves per SIMD) and SQ_INSTS_VALU of that launch
 PMC_VALU = {
-    ("mixed10k_2048", "recurrence", 32.0, 1): (0.81, 6.64e8, "profiles/r01_final_pmc.json"),
+    ("mixed10k_2048", "recurrence", 32.0, 1): (0.82, 6.64e8, "profiles/r01_final_pmc.json"),
 }
 CPU_THREADS_MAX = 16         # the GPU box's CPU share for one GPU
 
