@@ -1073,6 +1073,7 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         a.partials = im->d_partials; a.S = S; a.capacity = im->lists_cap; a.B = B; a.H = im->H; a.W = im->W;
         a.ntx = im->ntx; a.nty = im->nty; a.TW = im->TW; a.TH = im->TH; a.seed = seed;
         a.rate_img = im->d_rate; a.tail_T = c->tail_T; a.nz = fused_nz ? im->d_snz : nullptr;
+        a.order = (hw && c->tile_order) ? im->d_order : nullptr;
         if (hw && (rc = scratch_get(c, 2, sizeof(double) * 2 * (size_t)T, (void **)&a.partials))) return rc;
         int pi = prof_begin(c, CEL_K_STAMPS);
         if (hw) hipLaunchKernelGGL(k_photon_split_hw, dim3(2 * T), dim3(64), 0, c->stream, a);

@@ -286,6 +286,7 @@ struct SplitArgs {
     const double *rate_img;     // k_photon_split_hw: every pixel's total rate (strict boxes), rendered beforehand
     double tail_T;              // k_photon_split_hw: drop threshold of the per-source tiles
     int4 *nz;                   // k_photon_split_hw: per patch, the rectangle holding its photons (min/max by atomics), or nullptr
+    const int *order;           // k_photon_split_hw: tile launch order (heaviest first, from the totals render), or nullptr
 };
 
 __global__ void __launch_bounds__(64)
@@ -392,7 +393,8 @@ k_photon_split_hw(SplitArgs a) {
     __shared__ double et[64], lt[128];
     const int lane = threadIdx.x;
     const int half = lane >> 5, col = lane & 31;
-    const int tile = blockIdx.x >> 1, sub = blockIdx.x & 1;
+    const int sub = blockIdx.x & 1;
+    const int tile = a.order ? a.order[blockIdx.x >> 1] : (int)(blockIdx.x >> 1);
     const int per_band = a.ntx * a.nty;
     const int b = tile / per_band;
     const int t = tile - b * per_band;
@@ -493,5 +495,5 @@ k_photon_split_hw(SplitArgs a) {
 #pragma unroll
     for (int r = 0; r < SP_TH / 2; r++) noise += (double)left[r * 64 + lane];
     noise = wave_sum(noise);
-    if (lane == 0) a.partials[blockIdx.x] = noise;
+    if (lane == 0) a.partials[2 * tile + sub] = noise;
 }
