@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--tail-log", type=float, default=32.0)
     ap.add_argument("--tile-rows", type=int, default=32, choices=[32, 64])
     ap.add_argument("--tile-order", type=int, default=1, choices=[0, 1, 2])
-    ap.add_argument("--layout", type=int, default=1, choices=[0, 1],
+    ap.add_argument("--layout", type=int, default=1, choices=[0, 1, 2],
                     help="render tile geometry: 0 = 64x32 (k_render), 1 = 32x64 half-wave (k_render_hw)")
     ap.add_argument("--cpu-sample", type=int, default=400, help="sources in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -185,7 +185,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "sources": S, "bands": B, "frame": [H, W],
                        "galaxy_fraction": fg, "kernel": args.kernel, "tail_log": args.tail_log,
-                       "tile_layout": "32x64 half-wave" if args.layout == 1 else "64x%d" % args.tile_rows,
+                       "tile_layout": {1: "32x64 half-wave", 2: "16x128 quarter-wave"}.get(args.layout, "64x%d" % args.tile_rows),
                        "tile_order": args.tile_order,
                        "parallelism": "1 field per GPU, %d GPU(s), 1 all-reduce of %d doubles per step (overlapped with the next step's render)" % (world, B)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -74,6 +74,7 @@ static int fail(int code, const char *fmt, ...) {
 #include "k_bin2.h"
 #include "k_render.h"
 #include "k_render_hw.h"
+#include "k_render_qw.h"
 #include "k_misc.h"
 #include "k_patch_ll.h"
 #include "k_estep.h"
@@ -369,7 +370,7 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         c->tile_timing = (v != 0.0);
         return CEL_OK;
     case CEL_OPT_TILE_LAYOUT:
-        if (v != 0.0 && v != 1.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TILE_LAYOUT must be 0 or 1");
+        if (v != 0.0 && v != 1.0 && v != 2.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TILE_LAYOUT must be 0, 1 or 2");
         c->tile_layout = (int)v;
         return CEL_OK;
     }
@@ -414,6 +415,7 @@ int cel_images_create(cel_ctx *c, int B, int H, int W, const cel_band *bands, ce
     im->ctx = c; im->B = B; im->H = H; im->W = W;
     im->full_H = H; im->win_y0 = 0;
     if (c->tile_layout == 1) { im->TW = HW_TW; im->TH = HW_TH; }
+    else if (c->tile_layout == 2) { im->TW = QW_TW; im->TH = QW_TH; }
     else { im->TW = TILE_W; im->TH = c->tile_rows; }
     im->ntx = (W + im->TW - 1) / im->TW;
     im->nty = (H + im->TH - 1) / im->TH;
@@ -683,13 +685,15 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         a.S = S; a.capacity = im->lists_cap; a.B = im->B; a.H = im->H; a.W = im->W; a.ntx = im->ntx; a.nty = im->nty;
         a.flags = flags; a.variant = c->variant; a.tail_T = c->tail_T; a.order = c->tile_order ? im->d_order : nullptr;
         a.timing = nullptr;
-        a.cost = (im->TW == HW_TW) ? im->d_tile_cost : nullptr;
+        a.cost = (im->TW == HW_TW || im->TW == QW_TW) ? im->d_tile_cost : nullptr;
         if (c->tile_timing) {
             if (!im->d_timing) HIP_TRY(hipMalloc((void **)&im->d_timing, sizeof(unsigned long long) * 3 * T));
             a.timing = im->d_timing;
         }
         pi = prof_begin(c, CEL_K_RENDER);
-        if (im->TW == HW_TW)
+        if (im->TW == QW_TW)
+            hipLaunchKernelGGL(k_render_qw, dim3(T), dim3(64), 0, st, a);
+        else if (im->TW == HW_TW)
             hipLaunchKernelGGL(k_render_hw, dim3(T), dim3(64), 0, st, a);
         else if (im->TH == 64)
             hipLaunchKernelGGL((k_render<64>), dim3(T), dim3(64), 0, st, a);
@@ -713,7 +717,7 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         const bool fine_ok = (cur[1] & 0xffffffffull) == 0 && (int64_t)cur[0] <= im->lists_cap;
         const bool coarse_ok = (cur[3] & 0xffffffffull) == 0 && (int64_t)cur[2] <= im->clist_cap;
         if (coarse_ok) im->last_entries = (double)cur[0];
-        if (fine_ok && coarse_ok) { im->cost_S = (im->TW == HW_TW) ? S : -1; break; }
+        if (fine_ok && coarse_ok) { im->cost_S = a.cost ? S : -1; break; }
         im->cost_S = -1;
         // rerun with room (a truncated coarse list also truncates the fine counts)
         if (!coarse_ok) rc = ensure_clist(im, (int64_t)cur[2] + (int64_t)cur[2] / 4 + 1024);

@@ -16,7 +16,7 @@ struct CompTab {
     // narrow types on purpose: accumulator tile + tables must stay <= 20 480 B per wave so that
     // 8 waves fit a CU's 160 KB of LDS (at 20 576 B only 7 did, and the kernel ran 6 % slower)
     short L[CT_N];            // <= 4096
-    signed char r0[CT_N], r1[CT_N];   // tile rows [r0, r1) on which the component can exceed the drop level
+    unsigned char r0[CT_N], r1[CT_N];   // tile rows [r0, r1) (<= 128) on which the component can exceed the drop level
     // per pair of groups (12 consecutive kept components, the unit the half-wave kernels walk):
     // shortest safe segment and the union of the row ranges, reduced with LDS min/max while the
     // table is written, so that the walk reads three values instead of looping over 12 entries

@@ -17,7 +17,7 @@
 #define HW_TH 64
 #define HW_PAD 12   // zero components behind the compacted table: a half's group may read past the end
 
-template <int G>
+template <int G, int STRIDE = HW_TW>   // STRIDE = doubles between consecutive rows of the accumulator tile
 __device__ inline void rec_group_hw(const CompTab &T, const double *__restrict__ et, int k0, double x,
                                     int Y0, int ra, int rb, int L, bool on, double *__restrict__ acc_col) {
     double g[G], r[G], q[G];
@@ -58,14 +58,14 @@ __device__ inline void rec_group_hw(const CompTab &T, const double *__restrict__
                 g[i] = g1[i] * r1[i];
                 r[i] = r1[i] * q[i];
             }
-            lds_add(&acc_col[row * HW_TW], s0);
-            lds_add(&acc_col[(row + 1) * HW_TW], s1);
+            lds_add(&acc_col[row * STRIDE], s0);
+            lds_add(&acc_col[(row + 1) * STRIDE], s1);
         }
         if (row < sb) {
             double s0 = g[0];
 #pragma unroll
             for (int i = 1; i < G; i++) s0 += g[i];
-            lds_add(&acc_col[row * HW_TW], s0);
+            lds_add(&acc_col[row * STRIDE], s0);
         }
     }
 }

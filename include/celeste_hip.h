@@ -74,7 +74,10 @@ enum {
     CEL_OPT_TILE_TIMING = 6,/* diagnostic: 1 = k_render stamps every tile's start/end wall clock   */
     CEL_OPT_TILE_LAYOUT = 7 /* render tile geometry, read by cel_images_create:
                                0 = 64 columns x TILE_ROWS rows, one lane per column;
-                               1 (default) = 32 columns x 64 rows, two component groups per column */
+                               1 (default) = 32 columns x 64 rows, two component groups per column;
+                               2 = 16 columns x 128 rows, four component groups per column (fewer
+                               recurrence seeds, more per-tile set-up: measured 4 % slower than 1
+                               on the benchmark field, kept for fields of tall narrow boxes)      */
 };
 
 /* kernels reported by cel_profile_get */

@@ -262,14 +262,18 @@ def test_config2_stars_512_vs_oracle(cel, ctx, orc, kernel):
         ctx.set_kernel("recurrence")
 
 
-@pytest.mark.parametrize("kernel", ["direct", "recurrence"])
-def test_mixed_field_vs_oracle(cel, ctx, orc, kernel):
+@pytest.mark.parametrize("kernel,layout", [("direct", 1), ("recurrence", 1), ("recurrence", 0), ("direct", 2),
+                                           ("recurrence", 2)])
+def test_mixed_field_vs_oracle(cel, ctx, orc, kernel, layout):
     """config 3's source population at a size the oracle finishes in seconds: 400 sources, 3 bands,
-    non-multiple-of-tile frame 500 x 333"""
+    non-multiple-of-tile frame 500 x 333; every render-tile layout (CEL_OPT_TILE_LAYOUT: 64 x 32
+    full-wave, 32 x 64 half-wave = default, 16 x 128 quarter-wave)"""
     from desi_mcmc_amd import synth
     ctx.set_kernel(kernel)
+    ctx.set_option(7, layout)            # read when the image set is created
     try:
         f = synth.SyntheticField(ctx, 400, 3, 333, 500, frac_gal=0.5, seed=7)
+        ctx.set_option(7, 1)
         ll, llb = f.images.render(f.sources, loglik=True)
         lam = f.images.model_images()
         o_lam, o_ll, o_st = orc.render_field(oracle_bands(f), f.H, f.W, f.src["type"], f.src["radec"],
@@ -279,6 +283,7 @@ def test_mixed_field_vs_oracle(cel, ctx, orc, kernel):
         assert f.images.stats()["n_srcpix"] == o_st["n_srcpix"]
     finally:
         ctx.set_kernel("recurrence")
+        ctx.set_option(7, 1)
 
 
 def test_edge_cases_empty_ragged_offimage(cel, ctx, orc):
@@ -928,7 +933,11 @@ def test_fuzz_random_fields_vs_oracle(cel, ctx, orc, seed):
     shape = np.column_stack([theta, sigma, rs.uniform(0, 180, S), rs.uniform(0.03, 1.0, S)])
     counts = np.exp(rs.uniform(0.0, np.log(1e7), size=(S, B)))
     nelec = rs.poisson(np.clip(bands[:, 0], 1.0, 1e4)[:, None, None], size=(B, H, W)).astype(float)
-    iset = cel.ImageSet(ctx, bands, H, W, nelec=nelec)
+    ctx.set_option(7, int(__import__("os").environ.get("CEL_TEST_LAYOUT", "1")))     # render-tile layout under test
+    try:
+        iset = cel.ImageSet(ctx, bands, H, W, nelec=nelec)
+    finally:
+        ctx.set_option(7, 1)
     sset = cel.SourceSet(ctx, S, B).set(typ, radec, counts, shape)
     ll, llb = iset.render(sset, loglik=True)
     ob = bands.copy()
