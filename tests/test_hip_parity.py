@@ -562,7 +562,7 @@ def test_crowded_field_exercises_list_chunking_and_regrowth(cel, ctx, orc):
     src["type"][:300] = 1
     rs = np.random.RandomState(4)
     nelec = rs.poisson(2000.0, size=(2, H, W)).astype(float)
-    for layout in (1, 0):
+    for layout in (1, 0, 2):
         c2 = cel.Context(0)
         c2.set_option(7, layout)
         iset = cel.ImageSet(c2, bands, H, W, nelec=nelec)
@@ -673,7 +673,7 @@ def test_photon_split_conservation_moments_quirks(cel, ctx, orc):
     counts = g["flux"] / g["calib"][None, :] * g["kappa"][None, :] * 20.0      # bright: many photons per pixel
     S = 12
     results = {}
-    for layout in (1, 0):
+    for layout in (1, 0, 2):
         c2 = cel.Context(0)
         c2.set_option(7, layout)
         iset = cel.ImageSet(c2, bands, H, W, nelec=g["nelec"])
@@ -692,6 +692,9 @@ def test_photon_split_conservation_moments_quirks(cel, ctx, orc):
     pb, bb, nb = results[0]
     assert np.array_equal(ba, bb) and np.array_equal(na, nb)                     # same draws whatever the tiling
     assert all(np.array_equal(a, b) for ra, rb in zip(pa, pb) for a, b in zip(ra, rb) if a is not None)
+    pc, bc, nc = results[2]
+    assert np.array_equal(ba, bc) and np.array_equal(na, nc)
+    assert all(np.array_equal(a, b) for ra, rb in zip(pa, pc) for a, b in zip(ra, rb) if a is not None)
     patches, boxes, noise = results[1]
     for b in range(5):
         tot = noise[b]
