@@ -968,3 +968,68 @@ def test_fuzz_random_fields_vs_oracle(cel, ctx, orc, seed):
                                         np.ascontiguousarray(data[b]), 1 if isolated else 0)
                        for b in range(B) if data[b] is not None)
             np.testing.assert_allclose(got, want, rtol=RT_LL, atol=1e-9, err_msg="seed %d src %d iso %s" % (seed, s, isolated))
+
+
+def test_integration_md_ctypes_binding(cel, orc):
+    """The direct ctypes binding INTEGRATION.md shows (section 2 and the resident Gibbs calls),
+    call for call, against the oracle: the document's signatures are the library's."""
+    import ctypes as C
+    from desi_mcmc_amd import _lib, synth
+    L = C.CDLL(_lib.LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    L.cel_last_error.restype = C.c_char_p
+
+    def check(rc):
+        if rc:
+            raise (ValueError if rc == 1 else RuntimeError)(L.cel_last_error().decode())
+
+    H, W, B, S = 96, 128, 2, 5
+    bands = synth.make_bands(H, W, B)
+    src = synth.make_sources(S, H, W, bands, frac_gal=0.6, seed=12)
+    typ, radec, counts, shape = (np.ascontiguousarray(src[k]) for k in ("type", "radec", "counts", "shape"))
+    nelec = np.ascontiguousarray(np.random.RandomState(2).poisson(300.0, size=(B, H, W)).astype(np.float64))
+    ctx, img, srch = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    check(L.cel_ctx_create(0, None, C.byref(ctx)))
+    check(L.cel_images_create(ctx, B, H, W, bands.ctypes.data_as(dp), C.byref(img)))
+    check(L.cel_images_set_nelec(img, nelec.ctypes.data_as(C.c_void_p), 0))
+    check(L.cel_sources_create(ctx, C.c_int64(S), B, C.byref(srch)))
+    check(L.cel_sources_set(srch, C.c_int64(S), typ.ctypes.data_as(C.c_void_p), radec.ctypes.data_as(C.c_void_p),
+                            counts.ctypes.data_as(C.c_void_p), shape.ctypes.data_as(C.c_void_p), 0))
+    ll_band, ll = np.zeros(B), C.c_double()
+    check(L.cel_render_field(img, srch, 1, ll_band.ctypes.data_as(dp), C.byref(ll)))
+    lam = np.empty((B, H, W))
+    check(L.cel_images_get_lambda(img, lam.ctypes.data_as(C.c_void_p), 0))
+    ob = bands.copy()
+    rec = np.zeros(37)
+    for b in range(B):
+        check(L.cel_images_get_band(img, b, rec.ctypes.data_as(dp)))
+        ob[b, 36] = rec[36]
+    o_lam, o_ll, _ = orc.render_field(ob, H, W, typ, radec, counts, shape, nelec)
+    np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM)
+    np.testing.assert_allclose(ll_band, o_ll, rtol=RT_LL)
+    assert abs(ll.value - o_ll.sum()) <= 1e-11 * abs(o_ll.sum())
+    # the resident Gibbs calls
+    noise = np.zeros(B)
+    check(L.cel_photon_split(img, srch, C.c_uint64(7), None, None, 1, noise.ctypes.data_as(dp)))
+    S_, total = C.c_int64(), C.c_int64()
+    check(L.cel_samples_info(img, C.byref(S_), C.byref(total)))
+    assert S_.value == S and total.value > 0
+    sums = np.zeros((S, B))
+    check(L.cel_samples_fetch(img, None, None, None, sums.ctypes.data_as(dp)))
+    assert np.array_equal(sums.sum(axis=0) + noise, nelec.reshape(B, -1).sum(axis=1))
+    P = 2 * S
+    prop = C.c_void_p()
+    check(L.cel_sources_create(ctx, C.c_int64(P), B, C.byref(prop)))
+    rep = lambda a: np.ascontiguousarray(np.repeat(a, 2, axis=0))
+    t2, r2, c2, s2 = rep(typ), rep(radec), rep(counts), rep(shape)
+    check(L.cel_sources_set(prop, C.c_int64(P), t2.ctypes.data_as(C.c_void_p), r2.ctypes.data_as(C.c_void_p),
+                            c2.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p), 0))
+    owner = np.repeat(np.arange(S, dtype=np.int32), 2)
+    llp = np.zeros(P)
+    check(L.cel_patch_loglik_multi(img, prop, owner.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(S),
+                                   None, None, None, 1, 0, llp.ctypes.data_as(dp)))
+    assert np.all(np.isfinite(llp)) and np.array_equal(llp[0::2], llp[1::2])      # identical proposals, identical scores
+    for h in (prop, srch):
+        check(L.cel_sources_destroy(h))
+    check(L.cel_images_destroy(img))
+    check(L.cel_ctx_destroy(ctx))
