@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--layout", type=int, default=1, choices=[0, 1, 2],
                     help="render tile geometry: 0 = 64x32 (k_render), 1 = 32x64 half-wave (k_render_hw)")
     ap.add_argument("--cpu-sample", type=int, default=400, help="sources in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, what the driver runs): one field per GPU.  strong: ONE field cut into row "
+                         "strips, one per GPU (cel_images_set_window), total work fixed")
     args = ap.parse_args()
 
     import torch
@@ -104,9 +107,19 @@ def main():
     ctx.set_option(7, args.layout)   # CEL_OPT_TILE_LAYOUT
     ctx.set_option(_lib.CEL_OPT_TILE_ORDER, args.tile_order)
 
-    # one field per rank (weak scaling): same population, different seed
-    field = synth.SyntheticField.from_config(ctx, args.workload, seed=42 + 1000 * rank)
+    # weak: one field per rank (same population, different seed).  strong: every rank builds the SAME
+    # field (the catalogue is small and replicated) and keeps only its row strip of the pixels.
+    strong = (args.scaling == "strong") and world > 1
+    field = synth.SyntheticField.from_config(ctx, args.workload, seed=42 + (0 if strong else 1000 * rank))
     stats = None
+    if strong:
+        y0, y1 = dist.strip_rows(field.H, world, rank)
+        full_stats = None
+        field.images.render(field.sources, loglik=False)
+        full_stats = field.images.stats()                  # the whole field's work: what every step of the job does
+        strip = cel.ImageSet(ctx, field.bands, max(y1 - y0, 1), field.W, nelec=field.nelec[:, y0:max(y1, y0 + 1)])
+        strip.set_window(y0, field.H)
+        field.images = strip
 
     # the one collective: B per-band doubles summed over ranks.  Pipelined one step deep: the sum of
     # step k travels while step k+1 renders (the ranks' fields are independent chains; the global
@@ -126,6 +139,8 @@ def main():
     if reducer is not None:
         reducer.drain()
     stats = field.images.stats()
+    if strong:   # total work is the one field's, whoever renders which rows: count it once (rank 0)
+        stats = dict(full_stats) if rank == 0 else dict(full_stats, n_srcpix=0, n_gauss=0)
     ctx.profile(True)
 
     dist.barrier()
@@ -165,8 +180,10 @@ def main():
         # algorithmic HBM bytes of one k_render launch (DESIGN.md "Measurement"):
         #   read nelec 8 B + write lambda 8 B per image pixel, + one 128-B record per (source, band)
         alg_bytes = 16.0 * n_imgpix + 128.0 * S * B
+        if strong:   # rank 0's launch covers its strip of the pixels (and still reads every record)
+            alg_bytes = 16.0 * B * (y1 - y0) * W + 128.0 * S * B
         achieved = alg_bytes / (t_render * 1e-3) / 1e9 if t_render > 0 else 0.0
-        pmc = PMC_TRAFFIC.get((args.workload, args.kernel, args.tail_log, args.layout))
+        pmc = None if strong else PMC_TRAFFIC.get((args.workload, args.kernel, args.tail_log, args.layout))
         out = {
             # BASELINE.json's metric; `value` is its first half, `ms_per_step` its second
             "metric": "source-pixel evals/sec + full-field log-lik ms, %s sources x %d bands x %d^2"
@@ -179,7 +196,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -187,7 +204,8 @@ def main():
                        "galaxy_fraction": fg, "kernel": args.kernel, "tail_log": args.tail_log,
                        "tile_layout": {1: "32x64 half-wave", 2: "16x128 quarter-wave"}.get(args.layout, "64x%d" % args.tile_rows),
                        "tile_order": args.tile_order,
-                       "parallelism": "1 field per GPU, %d GPU(s), 1 all-reduce of %d doubles per step (overlapped with the next step's render)" % (world, B)},
+                       "parallelism": ("1 field cut into %d row strips, 1 per GPU" if strong else "1 field per GPU, %d GPU(s)") % world
+                                      + ", 1 all-reduce of %d doubles per step (overlapped with the next step's render)" % B},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc[0] if pmc else None,
                          "traffic_source": pmc[1] if pmc else None,
