@@ -40,7 +40,7 @@ __device__ inline float wave_max_f(float v) {
 // the rectangle columns [xa, xb] x rows Y0 + [ra, rb).  Returns the number of kept components;
 // `direct` comes back true when the rectangle must be evaluated without the recurrence.
 // All 64 lanes call this; it contains the two barriers that fence the table.
-__device__ inline int hw_build(CompTab &T, const LaneConst &lc, const RecU &rec, int lane, int dropmode,
+__device__ __forceinline__ int hw_build(CompTab &T, const LaneConst &lc, const RecU &rec, int lane, int dropmode,
                                double Tdrop, double log_floor /* HW_DROP_SKY: log(eps) */, int Y0, int xa,
                                int xb, int ra, int rb, bool &direct) {
     const int K = (rec.type == 0) ? K_PSF : K_GAL;
@@ -113,7 +113,9 @@ __device__ inline int hw_build(CompTab &T, const LaneConst &lc, const RecU &rec,
 // Add the table's Kk components into the tile: lanes 0..31 / 32..63 are the same 32 columns
 // (x = this lane's column, `on` = the column belongs to the rectangle) working on two groups of
 // components; rows [ra, rb) bound the direct path, the recurrence walks each group's own rows.
-__device__ inline void hw_walk(const CompTab &T, const double *__restrict__ et, int Kk, double x, int Y0,
+// (forced inline: as a called function it cost a scratch frame per chunk -- 12 GB of scratch writes
+// per 160 000-proposal launch of k_patch_ll_hw)
+__device__ __forceinline__ void hw_walk(const CompTab &T, const double *__restrict__ et, int Kk, double x, int Y0,
                                int ra, int rb, bool on, bool direct, double *__restrict__ acc, int lane) {
     const int half = lane >> 5, col = lane & 31;
     if (direct) {

@@ -61,7 +61,10 @@ __device__ inline Philox philox_init(unsigned long long seed, unsigned long long
 // uniform double in [0, 1) with 53 random bits
 __device__ inline double philox_double(Philox &g) {
     if (g.have < 2) philox_block(g);
-    unsigned a = g.out[g.have - 1] >> 5, b = g.out[g.have - 2] >> 6;
+    // words (3, 2) first, then (1, 0); selected, not indexed: a dynamically indexed register array
+    // would live in scratch memory
+    const bool first = (g.have == 4);
+    unsigned a = (first ? g.out[3] : g.out[1]) >> 5, b = (first ? g.out[2] : g.out[0]) >> 6;
     g.have -= 2;
     return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
 }
