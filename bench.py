@@ -204,6 +204,9 @@ def main():
                        "galaxy_fraction": fg, "kernel": args.kernel, "tail_log": args.tail_log,
                        "tile_layout": {1: "32x64 half-wave", 2: "16x128 quarter-wave"}.get(args.layout, "64x%d" % args.tile_rows),
                        "tile_order": args.tile_order,
+                       "tile_order_note": {0: "index order", 1: "heaviest first by the previous step's measured tile durations "
+                                           "(a launch-order hint only: every step redoes all of the work)",
+                                           2: "heaviest first by the binning pass's estimate"}[args.tile_order],
                        "parallelism": ("1 field cut into %d row strips, 1 per GPU" if strong else "1 field per GPU, %d GPU(s)") % world
                                       + ", 1 all-reduce of %d doubles per step (overlapped with the next step's render)" % B},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
