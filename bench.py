@@ -67,6 +67,61 @@ def cpu_baseline(field, nsample, orc):
                 gauss_evals_per_s=st["n_gauss"] / dt)
 
 
+def visible_gpus():
+    """Number of HIP devices, WITHOUT initialising the GPU runtime in this process (a child does it)."""
+    import subprocess
+    code = "import torch; print(torch.cuda.device_count())"
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def self_launch(n, argv, port=0):
+    """Run `python -m torch.distributed.run --nproc-per-node n bench.py <argv>` as a child process and
+    return its exit code.  Fails loudly (non-zero, message on stderr) when fewer than n GPUs are
+    visible -- never a silent 1-GPU number.  CEL_BENCH_BACKEND=gloo is the documented rehearsal mode
+    (ranks may share GPUs, the collective runs on the host); it is exempt from the device-count check."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("CEL_BENCH_BACKEND") == "gloo"
+    have = visible_gpus()
+    if have < n and not rehearsal:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) visible; refusing to run on fewer "
+                         "(set CEL_BENCH_BACKEND=gloo to rehearse the multi-rank flow on shared GPUs)\n" % (n, have))
+        return 2
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """CEL_BENCH_DRYRUN=1: rendezvous + the two collectives of the timed region on synthetic
+    numbers, no GPU and no metric -- what the CPU test of the self-launch path runs."""
+    from desi_mcmc_amd import dist
+    rank, world, local = dist.init_from_env(backend=os.environ.get("CEL_BENCH_BACKEND", "gloo"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    red = dist.LoglikReducer(5, depth=2)
+    red.submit(np.full(5, float(rank + 1)))
+    got = red.drain()[-1]
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": world, "allreduce_check": float(got[0]),
+                          "expected": world * (world + 1) / 2.0}))
+    if world > 1:
+        import torch.distributed as td
+        td.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,7 +138,18 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default, what the driver runs): one field per GPU.  strong: ONE field cut into row "
                          "strips, one per GPU (cel_images_set_window), total work fixed")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU,
+        # as children of this process -- BEFORE anything here touches the GPU (the parent never does).
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], args.master_port))
+
+    if os.environ.get("CEL_BENCH_DRYRUN") == "1":
+        return dry_run(args)
 
     import torch
 
@@ -93,10 +159,14 @@ def main():
     # CEL_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs than ranks
     # (ranks then share GPUs and the collective runs on the host); the driver's runs use RCCL.
     rank, world, local = dist.init_from_env(backend=os.environ.get("CEL_BENCH_BACKEND"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torchrun --nproc-per-node %d, or run "
+                         "`python bench.py --gpus %d` without a launcher (it starts its own ranks)"
+                         % (args.gpus, world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if world > torch.cuda.device_count() and os.environ.get("CEL_BENCH_BACKEND") != "gloo":
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible" % (world, torch.cuda.device_count()))
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     ctx = cel.Context(local)
@@ -104,7 +174,7 @@ def main():
     ctx.set_tail_log(args.tail_log)
     from desi_mcmc_amd import _lib
     ctx.set_option(_lib.CEL_OPT_TILE_ROWS, args.tile_rows)
-    ctx.set_option(7, args.layout)   # CEL_OPT_TILE_LAYOUT
+    ctx.set_option(_lib.CEL_OPT_TILE_LAYOUT, args.layout)
     ctx.set_option(_lib.CEL_OPT_TILE_ORDER, args.tile_order)
 
     # weak: one field per rank (same population, different seed).  strong: every rank builds the SAME

@@ -10,6 +10,7 @@ Divergences from the reference, all documented in DESIGN.md "Quirks":
       accumulated (the reference's gen_galaxy_psf_image ignores return_patch and breaks there);
   planck  stars given by temperature (`src.t`) need a hook: set `photons_expected_brightness`.
 """
+import collections
 import weakref
 
 import numpy as np
@@ -29,36 +30,94 @@ _DEVICE = 0
 def set_device(device):
     global _DEVICE
     _DEVICE = int(device)
-    _SETS.clear()
+    for key in list(_SETS):
+        _evict(key)
 
 
 # ---- device-resident image sets, cached per python image object ---------------------------
-_SETS = {}
+# One ImageSet (nelec + model image + split totals on the device: 24 bytes per pixel) per distinct
+# tuple of image objects, least-recently-used first.  Entries are evicted -- and their device
+# memory released at once, not at garbage collection -- when the cache holds more than
+# CACHE_MAX_BYTES or CACHE_MAX_SETS, or when one of their images has been collected.
+# Callers that touch only SOME images of a set that is already resident (a source sampled in 3
+# of a field's 5 bands) are handed that set and the positions of their images in it
+# (_image_subset) instead of a second copy of the same pixels.
+CACHE_MAX_BYTES = 16 << 30
+CACHE_MAX_SETS = 64
+_SETS = collections.OrderedDict()      # key: tuple of id(image) -> [refs, ImageSet, eps list, bytes]
+
+
+def _set_bytes(images):
+    return sum(24 * im.nelec.size for im in images)
+
+
+def _evict(key):
+    ent = _SETS.pop(key, None)
+    if ent is not None:
+        ent[1].close()                 # cel_images_destroy now
+
+
+def _cache_trim(keep=None):
+    for key in [k for k, e in _SETS.items() if any(r() is None for r in e[0])]:
+        _evict(key)
+    while _SETS and (len(_SETS) > CACHE_MAX_SETS or sum(e[3] for e in _SETS.values()) > CACHE_MAX_BYTES):
+        key = next(iter(_SETS))
+        if key == keep:
+            if len(_SETS) == 1:
+                break
+            _SETS.move_to_end(key)
+            continue
+        _evict(key)
+
+
+def _sync_epsilon(ent, images):
+    iset, eps = ent[1], ent[2]
+    for b, im in enumerate(images):          # epsilon is resampled by Gibbs (models.py:156-160)
+        if im.epsilon != eps[b]:
+            iset.set_epsilon(b, im.epsilon)
+            eps[b] = im.epsilon
 
 
 def _image_set(images):
     """ImageSet for a tuple of same-shape FitsImage objects (uploaded once, nelec is immutable)."""
+    images = tuple(images)
     key = tuple(id(im) for im in images)
     hit = _SETS.get(key)
     if hit is not None and all(r() is im for r, im in zip(hit[0], images)):
-        iset, eps = hit[1], hit[2]
-        for b, im in enumerate(images):          # epsilon is resampled by Gibbs (models.py:156-160)
-            if im.epsilon != eps[b]:
-                iset.set_epsilon(b, im.epsilon)
-                eps[b] = im.epsilon
-        return iset
+        _SETS.move_to_end(key)
+        _sync_epsilon(hit, images)
+        return hit[1]
+    if hit is not None:
+        _evict(key)                          # ids re-used by other objects
     H, W = images[0].nelec.shape
     ctx = _field.default_context(_DEVICE)
     bands = np.stack([im.band_record() for im in images])
     iset = _field.ImageSet(ctx, bands, H, W, nelec=np.stack([im.nelec for im in images]))
-    if len(_SETS) > 64:
-        _SETS.clear()
     try:
         refs = [weakref.ref(im) for im in images]
     except TypeError:
         return iset
-    _SETS[key] = (refs, iset, [im.epsilon for im in images])
+    _SETS[key] = [refs, iset, [im.epsilon for im in images], _set_bytes(images)]
+    _cache_trim(keep=key)
     return iset
+
+
+def _image_subset(images):
+    """-> (ImageSet, positions): a resident set that CONTAINS `images` and where each sits in it;
+    a new set of exactly `images` when there is none."""
+    images = tuple(images)
+    want = [id(im) for im in images]
+    for key in reversed(_SETS):
+        if set(want) <= set(key):
+            ent = _SETS[key]
+            pos = [key.index(i) for i in want]
+            if all(ent[0][p]() is im for p, im in zip(pos, images)):
+                _SETS.move_to_end(key)
+                live = [r() for r in ent[0]]
+                if all(im is not None for im in live):
+                    _sync_epsilon(ent, live)
+                    return ent[1], pos
+    return _image_set(images), list(range(len(images)))
 
 
 def _flux(src, band):

@@ -43,6 +43,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -138,7 +139,14 @@ struct cel_images {
     SrcRec *d_recs = nullptr;
     int4 *d_boxes = nullptr;
     int *d_kind = nullptr;
+    int *d_status = nullptr;       // per (band, source): 1 has a stamp, 0 empty box, -1 overlap-test miss
     int64_t recs_cap = 0;
+    // which sources the records on the device belong to (cel_sources::gen, unique per cel_sources_set),
+    // and the host copy of their boxes / status that cel_stamp_boxes / cel_source_boxes hand out:
+    // a stamp call (boxes, then stamps) runs k_prep and the D2H once, not twice
+    uint64_t recs_gen = 0, hbox_gen = 0;
+    std::vector<int4> h_boxes;
+    std::vector<int> h_status;
     int *d_tile_cnt = nullptr, *d_tile_work = nullptr, *d_order = nullptr;
     int *d_tile_cost = nullptr;   // measured duration of every tile in the last render (the next render's launch order)
     int64_t cost_S = -1;          // number of sources that render had (-1: nothing measured yet)
@@ -165,10 +173,13 @@ struct cel_images {
     double last_entries = 0;
 };
 
+static std::atomic<uint64_t> g_source_gen{0};
+
 struct cel_sources {
     cel_ctx *ctx = nullptr;
     int64_t cap = 0, S = 0;
     int B = 0;
+    uint64_t gen = 0;              // changes with every cel_sources_set (process-wide counter)
     int *d_type = nullptr;
     double *d_radec = nullptr, *d_counts = nullptr, *d_shape = nullptr;
 };
@@ -397,7 +408,7 @@ int cel_images_destroy(cel_images *im) {
     (void)hipSetDevice(im->ctx->device);
     (void)hipStreamSynchronize(im->ctx->stream);
     void *ptrs[] = {im->d_bands, im->d_nelec, im->d_lambda, im->d_partials, im->d_llband, im->d_recs,
-                    im->d_boxes, im->d_kind, im->d_tile_cnt, im->d_tile_work, im->d_tile_cost, im->d_order, im->d_tile_off, im->d_cursor, im->d_lists, im->d_stats,
+                    im->d_boxes, im->d_kind, im->d_status, im->d_tile_cnt, im->d_tile_work, im->d_tile_cost, im->d_order, im->d_tile_off, im->d_cursor, im->d_lists, im->d_stats,
                     im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff, im->d_rate, im->d_snz};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -484,11 +495,9 @@ int cel_images_set_epsilon(cel_images *im, int band, double eps) {
     if (!im || band < 0 || band >= im->B) return fail(CEL_ERR_INVALID, "cel_images_set_epsilon: bad band");
     HIP_TRY(hipSetDevice(im->ctx->device));
     im->hb[band].eps = eps;
-    im->ctx->pinned[MAX_BANDS] = eps;
-    HIP_TRY(hipStreamSynchronize(im->ctx->stream));
-    HIP_TRY(hipMemcpyAsync(&im->d_bands[band].eps, &im->ctx->pinned[MAX_BANDS], sizeof(double),
-                           hipMemcpyHostToDevice, im->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(im->ctx->stream));
+    // stream-ordered, no host synchronisation (Gibbs calls this per band per sweep)
+    hipLaunchKernelGGL(k_set_eps, dim3(1), dim3(1), 0, im->ctx->stream, im->d_bands, band, eps);
+    HIP_TRY(hipGetLastError());
     return CEL_OK;
 }
 
@@ -498,6 +507,7 @@ int cel_images_set_window(cel_images *im, int y0, int full_H) {
         return fail(CEL_ERR_INVALID, "window rows [%d, %d) do not fit a %d-row frame", y0, y0 + im->H, full_H);
     im->win_y0 = y0;
     im->full_H = full_H;
+    im->recs_gen = im->hbox_gen = 0;      // boxes are cut to the window
     return CEL_OK;
 }
 
@@ -567,6 +577,7 @@ int cel_sources_set(cel_sources *s, int64_t S, const int32_t *type, const double
         if (mem != CEL_DEVICE) HIP_TRY(hipStreamSynchronize(st));   // pageable sources must stay valid: one sync for the four
     }
     s->S = S;
+    s->gen = ++g_source_gen;
     return CEL_OK;
 }
 
@@ -577,11 +588,14 @@ static int ensure_recs(cel_images *im, int64_t n) {
     if (im->d_recs) (void)hipFree(im->d_recs);
     if (im->d_boxes) (void)hipFree(im->d_boxes);
     if (im->d_kind) (void)hipFree(im->d_kind);
-    im->d_recs = nullptr; im->d_boxes = nullptr; im->d_kind = nullptr; im->recs_cap = 0;
+    if (im->d_status) (void)hipFree(im->d_status);
+    im->d_recs = nullptr; im->d_boxes = nullptr; im->d_kind = nullptr; im->d_status = nullptr; im->recs_cap = 0;
+    im->recs_gen = im->hbox_gen = 0;
     int64_t cap = n + n / 4 + 64;
     HIP_TRY(hipMalloc((void **)&im->d_recs, sizeof(SrcRec) * cap));
     HIP_TRY(hipMalloc((void **)&im->d_boxes, sizeof(int4) * cap));
     HIP_TRY(hipMalloc((void **)&im->d_kind, sizeof(int) * cap));
+    HIP_TRY(hipMalloc((void **)&im->d_status, sizeof(int) * cap));
     im->recs_cap = cap;
     return CEL_OK;
 }
@@ -616,13 +630,35 @@ static int run_prep(cel_images *im, cel_sources *src) {
     int64_t n = src->S * im->B;
     int rc = ensure_recs(im, n > 0 ? n : 1);
     if (rc) return rc;
-    if (n == 0) return CEL_OK;
+    if (n == 0) { im->recs_gen = src->gen; im->last_S = 0; return CEL_OK; }
     int pi = prof_begin(c, CEL_K_PREP);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, im->d_bands, im->B,
                        im->full_H, im->W, im->win_y0, im->H, src->S, src->d_type, src->d_radec, src->d_counts, src->d_shape,
-                       rsq_galaxy(), im->d_recs, im->d_boxes, im->d_kind);
+                       rsq_galaxy(), im->d_recs, im->d_boxes, im->d_kind, im->d_status);
     prof_end(c, pi);
     HIP_TRY(hipGetLastError());
+    im->recs_gen = src->gen;
+    im->last_S = src->S;
+    return CEL_OK;
+}
+
+// host copies of the boxes and status of every (band, source) of `src` (20 B each, not the 128-B
+// records); reused until the sources or the window change
+static int host_boxes(cel_images *im, cel_sources *src) {
+    if (im->hbox_gen == src->gen && src->gen != 0 && im->recs_gen == src->gen) return CEL_OK;
+    int rc = CEL_OK;
+    if (im->recs_gen != src->gen || src->gen == 0) rc = run_prep(im, src);
+    if (rc) return rc;
+    const int64_t n = src->S * im->B;
+    im->h_boxes.resize((size_t)n);
+    im->h_status.resize((size_t)n);
+    if (n) {
+        hipStream_t st = im->ctx->stream;
+        HIP_TRY(hipMemcpyAsync(im->h_boxes.data(), im->d_boxes, sizeof(int4) * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(im->h_status.data(), im->d_status, sizeof(int) * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    im->hbox_gen = src->gen;
     return CEL_OK;
 }
 
@@ -770,19 +806,15 @@ int cel_stamp_boxes(cel_images *im, cel_sources *src, int band, int32_t *boxes, 
     if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
     cel_ctx *c = im->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = run_prep(im, src);
+    int rc = host_boxes(im, src);
     if (rc) return rc;
-    im->last_S = src->S;
-    int64_t S = src->S;
-    std::vector<SrcRec> h((size_t)S);
-    if (S) {
-        HIP_TRY(hipMemcpyAsync(h.data(), im->d_recs + (int64_t)band * S, sizeof(SrcRec) * S, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
+    const int64_t S = src->S;
+    const int4 *hb = im->h_boxes.data() + (int64_t)band * S;     // x0, x1, y0, y1
+    const int *hs = im->h_status.data() + (int64_t)band * S;
     for (int64_t s = 0; s < S; s++) {
-        boxes[4 * s + 0] = h[s].y0; boxes[4 * s + 1] = h[s].y1;
-        boxes[4 * s + 2] = h[s].x0; boxes[4 * s + 3] = h[s].x1;
-        status[s] = h[s].type >= 0 ? 1 : (h[s].type == -3 ? -1 : 0);
+        boxes[4 * s + 0] = hb[s].z; boxes[4 * s + 1] = hb[s].w;
+        boxes[4 * s + 2] = hb[s].x; boxes[4 * s + 3] = hb[s].y;
+        status[s] = hs[s];
     }
     return CEL_OK;
 }
@@ -801,6 +833,7 @@ int cel_render_stamps(cel_images *im, cel_sources *src, int band, int scaled, co
     if (rc) return rc;
     std::vector<int4> obox((size_t)S);
     std::vector<StampJob> jobs;
+    std::vector<int64_t> skipped;   // sources without a stamp whose slot in `out` is not empty
     const int ROWS = 64;
     const int strip_w = (c->variant == 0) ? TILE_W : HW_TW;     // the recurrence kernel works on 32 x 64 chunks
     for (int64_t s = 0; s < S; s++) {
@@ -814,7 +847,13 @@ int cel_render_stamps(cel_images *im, cel_sources *src, int band, int scaled, co
             ok = hs[s] > 0;
         }
         obox[s] = make_int4(x0, x1, y0, y1);
-        if (!ok) continue;
+        if (offsets[s + 1] < offsets[s]) return fail(CEL_ERR_INVALID, "offsets must not decrease (source %lld)", (long long)s);
+        if (!ok) {
+            // the reference returns (None, None, None) here; the slot the caller sized for it is
+            // zero-filled so that nothing stale can be read from it
+            if (offsets[s + 1] > offsets[s]) skipped.push_back(s);
+            continue;
+        }
         int64_t area = (int64_t)(y1 - y0) * (x1 - x0);
         if (offsets[s + 1] - offsets[s] != area)
             return fail(CEL_ERR_INVALID, "offsets[%lld+1]-offsets[%lld] = %lld but the stamp has %lld pixels",
@@ -823,8 +862,12 @@ int cel_render_stamps(cel_images *im, cel_sources *src, int band, int scaled, co
             for (int ys = y0; ys < y1; ys += ROWS)
                 jobs.push_back(StampJob{(int)s, xs, ys, ys + ROWS < y1 ? ys + ROWS : y1});
     }
-    if (jobs.empty()) return CEL_OK;
     int64_t total = offsets[S];
+    if (jobs.empty() && (skipped.empty() || mem != CEL_DEVICE)) {
+        if (mem != CEL_DEVICE)
+            for (int64_t s : skipped) memset(out + offsets[s], 0, sizeof(double) * (size_t)(offsets[s + 1] - offsets[s]));
+        return CEL_OK;
+    }
     StampJob *d_jobs = nullptr;
     int4 *d_obox = nullptr;
     int64_t *d_off = nullptr;
@@ -842,6 +885,9 @@ int cel_render_stamps(cel_images *im, cel_sources *src, int band, int scaled, co
         return rc;
     if (mem == CEL_DEVICE) d_out = out;
     else if ((rc = scratch_get(c, 7, sizeof(double) * (total > 0 ? total : 1), (void **)&d_out))) return rc;
+    for (int64_t s : skipped)
+        ST_TRY(hipMemsetAsync(d_out + offsets[s], 0, sizeof(double) * (size_t)(offsets[s + 1] - offsets[s]), c->stream));
+    if (jobs.empty()) goto sync;
     ST_TRY(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(StampJob) * jobs.size(), hipMemcpyHostToDevice, c->stream));
     ST_TRY(hipMemcpyAsync(d_obox, obox.data(), sizeof(int4) * S, hipMemcpyHostToDevice, c->stream));
     ST_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (S + 1), hipMemcpyHostToDevice, c->stream));
@@ -857,6 +903,7 @@ int cel_render_stamps(cel_images *im, cel_sources *src, int band, int scaled, co
     }
     ST_TRY(hipGetLastError());
     if (mem != CEL_DEVICE) ST_TRY(hipMemcpyAsync(out, d_out, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream));
+sync:
     ST_TRY(hipStreamSynchronize(c->stream));
 #undef ST_TRY
 done:
@@ -981,19 +1028,14 @@ int cel_source_boxes(cel_images *im, cel_sources *src, int32_t *boxes, int32_t *
     if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
     cel_ctx *c = im->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = run_prep(im, src);
+    int rc = host_boxes(im, src);
     if (rc) return rc;
-    im->last_S = src->S;
     const int64_t n = src->S * im->B;
-    std::vector<SrcRec> h((size_t)n);
-    if (n) {
-        HIP_TRY(hipMemcpyAsync(h.data(), im->d_recs, sizeof(SrcRec) * n, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
     for (int64_t i = 0; i < n; i++) {
-        boxes[4 * i + 0] = h[i].y0; boxes[4 * i + 1] = h[i].y1;
-        boxes[4 * i + 2] = h[i].x0; boxes[4 * i + 3] = h[i].x1;
-        status[i] = h[i].type >= 0 ? 1 : (h[i].type == -3 ? -1 : 0);
+        const int4 b = im->h_boxes[(size_t)i];
+        boxes[4 * i + 0] = b.z; boxes[4 * i + 1] = b.w;
+        boxes[4 * i + 2] = b.x; boxes[4 * i + 3] = b.y;
+        status[i] = im->h_status[(size_t)i];
     }
     return CEL_OK;
 }
@@ -1076,6 +1118,7 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         a.tile_off = im->d_tile_off; a.nelec = im->d_nelec; a.offsets = d_off; a.samp = d_samp;
         a.partials = im->d_partials; a.S = S; a.capacity = im->lists_cap; a.B = B; a.H = im->H; a.W = im->W;
         a.ntx = im->ntx; a.nty = im->nty; a.TW = im->TW; a.TH = im->TH; a.seed = seed;
+        a.win_y0 = im->win_y0; a.full_H = im->full_H;
         a.rate_img = im->d_rate; a.tail_T = c->tail_T; a.nz = fused_nz ? im->d_snz : nullptr;
         a.order = (hw && c->tile_order) ? im->d_order : nullptr;
         if (hw && (rc = scratch_get(c, 2, sizeof(double) * 2 * (size_t)T, (void **)&a.partials))) return rc;

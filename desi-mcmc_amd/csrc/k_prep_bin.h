@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256)
 k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int win_h, int64_t S,
        const int *__restrict__ type, const double *__restrict__ radec,
        const double *__restrict__ counts, const double *__restrict__ shape, double rsq_gal,
-       SrcRec *__restrict__ recs, int4 *__restrict__ boxes, int *__restrict__ kind) {
+       SrcRec *__restrict__ recs, int4 *__restrict__ boxes, int *__restrict__ kind, int *__restrict__ status) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S * B) return;
     int b = (int)(i / S);
@@ -123,7 +123,14 @@ k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int w
     recs[i] = r;
     boxes[i] = make_int4(r.x0, r.x1, r.y0, r.y1);
     kind[i] = r.type < 0 ? 0 : (r.type == 0 ? K_PSF : K_GAL);
+    // what cel_stamp_boxes / cel_source_boxes report: 1 = has a stamp, 0 = empty box, -1 = the
+    // reference's overlap test fails (celeste.py:130-135)
+    status[i] = r.type >= 0 ? 1 : (r.type == -3 ? -1 : 0);
 }
+
+// Gibbs resamples the sky level (models.py:156-160): one scalar, passed as a kernel argument so
+// that the update is ordered on the stream without a host synchronisation
+__global__ void k_set_eps(BandDev *__restrict__ bands, int band, double eps) { bands[band].eps = eps; }
 
 // work counters of one render: sum of box areas and K-weighted areas (on demand, not timed)
 __global__ void k_stats(const SrcRec *__restrict__ recs, int64_t n, double *out) {

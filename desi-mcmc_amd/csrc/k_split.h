@@ -273,6 +273,12 @@ k_binomial_draws(long long n, double p, unsigned long long seed, int64_t N, long
     out[i] = binomial_draw(n, p, g, et, lt);
 }
 
+// int(num_photons_xy) of the reference (celeste_sample_sources.pyx:105), without the undefined
+// behaviour of an out-of-range cast
+__device__ inline int photons_int(double nelec) {
+    return (int)fmin(fmax(nelec, -2147483648.0), 2147483647.0);
+}
+
 struct SplitArgs {
     const BandDev *bands;
     const SrcRec *recs;
@@ -285,6 +291,9 @@ struct SplitArgs {
     double *partials;           // per-tile noise sums
     int64_t S, capacity;
     int B, H, W, ntx, nty, TW, TH;
+    int win_y0, full_H;         // the images hold rows [win_y0, win_y0 + H) of a full_H-row frame: the random
+                                // streams are keyed on FULL-FRAME pixel indices, so a pixel draws the same
+                                // numbers whichever row strip (GPU) holds it
     unsigned long long seed;
     const double *rate_img;     // k_photon_split_hw: every pixel's total rate (strict boxes), rendered beforehand
     double tail_T;              // k_photon_split_hw: drop threshold of the per-source tiles
@@ -314,15 +323,17 @@ k_photon_split(SplitArgs a) {
     const BandDev *bd = a.bands + b;
     const double eps = bd->eps;
     const int64_t plane = (int64_t)b * a.H * a.W;
+    const int64_t key0 = (int64_t)b * a.full_H * a.W + (int64_t)a.win_y0 * a.W;   // full-frame pixel index of (x=0, y=0)
     const int cnt = a.tile_cnt[tile];
     const int64_t off = a.tile_off[tile];
     const SrcRec *recs = a.recs + (int64_t)b * a.S;
+    unsigned covered = 0u;            // bit i: pixel i of this lane lies strictly inside some source's box
 
     for (int i = 0; i < niter; i++) {
         const int y = Y0 + i * rstep + rsub;
         const bool in = (xi < a.W) && (y < a.H);
         rate[i * 64 + lane] = eps;
-        left[i * 64 + lane] = in ? (int)a.nelec[plane + (int64_t)y * a.W + xi] : 0;
+        left[i * 64 + lane] = in ? photons_int(a.nelec[plane + (int64_t)y * a.W + xi]) : 0;
     }
 
     for (int pass = 0; pass < 2; pass++) {
@@ -352,12 +363,13 @@ k_photon_split(SplitArgs a) {
                 const int li = i * 64 + lane;
                 if (pass == 0) {
                     rate[li] += F;
+                    covered |= 1u << i;
                 } else {
                     const int n = left[li];
                     double tot = rate[li];
                     long long z = 0;
                     if (n > 0) {
-                        Philox g = philox_init(a.seed, (unsigned long long)(plane + (int64_t)y * a.W + xi), (unsigned)s);
+                        Philox g = philox_init(a.seed, (unsigned long long)(key0 + (int64_t)y * a.W + xi), (unsigned)s);
                         z = binomial_draw((long long)n, F * fast_rcp(tot), g, et, lt);   // curr_prob / sum_probs (:147)
                     }
                     left[li] = n - (int)z;
@@ -367,9 +379,14 @@ k_photon_split(SplitArgs a) {
             }
         }
     }
-    // what is left belongs to the sky (:153, :91-93)
+    // what is left belongs to the sky (:153); a pixel nobody covers adds its nelec as it is, not
+    // truncated to an integer (:91-93)
     double noise = 0.0;
-    for (int i = 0; i < niter; i++) noise += (double)left[i * 64 + lane];
+    for (int i = 0; i < niter; i++) {
+        const int y = Y0 + i * rstep + rsub;
+        if ((covered >> i) & 1u) noise += (double)left[i * 64 + lane];
+        else if (xi < a.W && y < a.H) noise += a.nelec[plane + (int64_t)y * a.W + xi];
+    }
     noise = wave_sum(noise);
     if (lane == 0) a.partials[tile] = noise;
 }
@@ -408,6 +425,8 @@ k_photon_split_hw(SplitArgs a) {
     const BandDev *bd = a.bands + b;
     const double eps = bd->eps;
     const int64_t plane = (int64_t)b * a.H * a.W;
+    const int64_t key0 = (int64_t)b * a.full_H * a.W + (int64_t)a.win_y0 * a.W;   // full-frame pixel index of (x=0, y=0)
+    unsigned covered = 0u;            // bit r: this lane's pixel of row pair r lies strictly inside some source's box
     et[lane] = exp2((double)lane * (1.0 / 64.0));
     lt[lane] = c_log_ic[lane];
     lt[64 + lane] = c_log_lc[lane];
@@ -418,7 +437,7 @@ k_photon_split_hw(SplitArgs a) {
         const int64_t idx = plane + (int64_t)y * a.W + xi;
         one[r * 64 + lane] = 0.0;
         rate[r * 64 + lane] = in ? a.rate_img[idx] : eps;
-        left[r * 64 + lane] = in ? (int)a.nelec[idx] : 0;
+        left[r * 64 + lane] = in ? photons_int(a.nelec[idx]) : 0;
     }
     const int cnt = a.tile_cnt[tile];
     const int64_t off = a.tile_off[tile];
@@ -465,8 +484,9 @@ k_photon_split_hw(SplitArgs a) {
                 const int n = left[li];
                 const double tot = rate[li];
                 long long z = 0;
+                covered |= 1u << r;
                 if (n > 0) {
-                    Philox g = philox_init(a.seed, (unsigned long long)(plane + (int64_t)(Y0 + row) * a.W + xi), (unsigned)s);
+                    Philox g = philox_init(a.seed, (unsigned long long)(key0 + (int64_t)(Y0 + row) * a.W + xi), (unsigned)s);
                     z = binomial_draw((long long)n, F * fast_rcp(tot), g, et, lt);  // curr_prob / sum_probs (:147)
                 }
                 left[li] = n - (int)z;
@@ -493,10 +513,15 @@ k_photon_split_hw(SplitArgs a) {
         }
         __syncthreads();
     }
-    // what is left belongs to the sky (:153, :91-93)
+    // what is left belongs to the sky (:153); a pixel nobody covers adds its nelec as it is, not
+    // truncated to an integer (:91-93)
     double noise = 0.0;
 #pragma unroll
-    for (int r = 0; r < SP_TH / 2; r++) noise += (double)left[r * 64 + lane];
+    for (int r = 0; r < SP_TH / 2; r++) {
+        const int y = Y0 + 2 * r + half;
+        if ((covered >> r) & 1u) noise += (double)left[r * 64 + lane];
+        else if (xi < a.W && y < a.H) noise += a.nelec[plane + (int64_t)y * a.W + xi];
+    }
     noise = wave_sum(noise);
     if (lane == 0) a.partials[2 * tile + sub] = noise;
 }

@@ -143,6 +143,12 @@ class ImageSet(object):
         if nelec is not None:
             self.set_nelec(nelec)
 
+    def close(self):
+        """Release the device memory now (otherwise: when the object is collected).  Any later call
+        on this object fails with ValueError (null handle)."""
+        self._finalizer()
+        self._h = C.c_void_p(None)
+
     def set_nelec(self, nelec):
         nelec = L.f64(nelec)
         if nelec.size != self.B * self.H * self.W:
@@ -344,11 +350,14 @@ class ImageSet(object):
     def stamps(self, sources, band, scaled=False, boxes_in=None):
         """Per-source stamps in one band -> (list of 2-D arrays or None, boxes[S,4] = y0,y1,x0,x1)."""
         S = sources.S
-        if boxes_in is None:
-            boxes, status = self.stamp_boxes(sources, band)
-        else:
+        # the sources' own boxes + status (one k_prep + a 20-byte-per-source copy, shared with the
+        # render call below: the library keeps them until the sources change)
+        boxes, status = self.stamp_boxes(sources, band)
+        if boxes_in is not None:
             boxes = np.ascontiguousarray(boxes_in, dtype=np.int32).reshape(S, 4)
-            status = ((boxes[:, 1] > boxes[:, 0]) & (boxes[:, 3] > boxes[:, 2])).astype(np.int32)
+            # a star that fails the reference's overlap test is (None, None, None) whatever limits
+            # the caller imposes (celeste.py:130-135): status -1 stays a miss
+            status = (((boxes[:, 1] > boxes[:, 0]) & (boxes[:, 3] > boxes[:, 2])) & (status != -1)).astype(np.int32)
         area = np.where(status > 0, (boxes[:, 1] - boxes[:, 0]).astype(np.int64) * (boxes[:, 3] - boxes[:, 2]), 0)
         offs = np.zeros(S + 1, dtype=np.int64)
         np.cumsum(area, out=offs[1:])

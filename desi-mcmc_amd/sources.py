@@ -163,15 +163,19 @@ class Source(object):
             while j < len(imgs) and j - i < 16 and imgs[j].nelec.shape == imgs[i].nelec.shape:
                 j += 1
             group = imgs[i:j]
-            iset = _celeste._image_set(group)
-            counts = np.stack([(fluxes[:, BANDS.index(im.band)] / im.calib) * im.kappa for im in group], axis=1)
-            boxes, patches = [], []
-            for (samp, im, _) in self.sample_image_list[i:j]:
-                boxes.append([samp.y0, samp.y1, samp.x0, samp.x1])
+            # a resident set that already holds these images (the field's) is reused; its other
+            # bands get an empty box = "no sample image in that band"
+            iset, pos = _celeste._image_subset(group)
+            counts = np.zeros((P, iset.B))
+            boxes = np.zeros((iset.B, 4), dtype=np.int32)
+            patches = [None] * iset.B
+            for k, (samp, im, _) in zip(pos, self.sample_image_list[i:j]):
+                counts[:, k] = (fluxes[:, BANDS.index(im.band)] / im.calib) * im.kappa
+                boxes[k] = [samp.y0, samp.y1, samp.x0, samp.x1]
                 if isolated:
-                    patches.append(im.nelec[samp.y0:samp.y1, samp.x0:samp.x1])    # sources.py:204
+                    patches[k] = im.nelec[samp.y0:samp.y1, samp.x0:samp.x1]        # sources.py:204
                 else:
-                    patches.append(np.array(samp.data))
+                    patches[k] = np.array(samp.data)
             sset = iset._sources(typ, us, counts, shapes)
             ll += iset.patch_loglik(sset, boxes, patches, isolated=isolated)
             i = j

@@ -80,3 +80,42 @@ def test_world2_gloo_loglik_allreduce(tmp_path, mode):
         np.testing.assert_allclose(res[r][1], expect, rtol=1e-12)      # all-gather + ordered sum
         assert np.array_equal(res[r][1], res[0][1])                     # identical on every rank
     assert not np.allclose(res[0][2], res[1][2])                        # the ranks did different work
+
+
+# ---- bench.py --gpus N without a launcher ---------------------------------------------------------
+def _run_bench(extra_env, *argv):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env,
+                          capture_output=True, text=True, timeout=600)
+
+
+def test_bench_self_launch_spawns_n_ranks_gloo_dry_run():
+    """`python bench.py --gpus 2` starts its own two ranks (torch.distributed.run child), they
+    rendezvous and run the bench's collectives; rank 0 reports n_gpus = 2.  Dry run: no GPU here."""
+    import json
+    r = _run_bench({"CEL_BENCH_BACKEND": "gloo", "CEL_BENCH_DRYRUN": "1"}, "--gpus", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["ranks"] == 2
+    assert out["allreduce_check"] == out["expected"] == 3.0
+
+
+def test_bench_gpus_n_fails_loudly_with_fewer_devices():
+    """Fewer GPUs than --gpus: non-zero exit and a message, never a silent 1-GPU line."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    r = _run_bench({}, "--gpus", "2")
+    assert r.returncode != 0
+    assert "--gpus 2 requested but only" in r.stderr
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_bench_rejects_world_size_mismatch():
+    r = _run_bench({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "CEL_BENCH_DRYRUN": "1"}, "--gpus", "2")
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -270,10 +270,10 @@ def test_mixed_field_vs_oracle(cel, ctx, orc, kernel, layout):
     full-wave, 32 x 64 half-wave = default, 16 x 128 quarter-wave)"""
     from desi_mcmc_amd import synth
     ctx.set_kernel(kernel)
-    ctx.set_option(7, layout)            # read when the image set is created
+    ctx.set_option(cel._lib.CEL_OPT_TILE_LAYOUT, layout)            # read when the image set is created
     try:
         f = synth.SyntheticField(ctx, 400, 3, 333, 500, frac_gal=0.5, seed=7)
-        ctx.set_option(7, 1)
+        ctx.set_option(cel._lib.CEL_OPT_TILE_LAYOUT, 1)
         ll, llb = f.images.render(f.sources, loglik=True)
         lam = f.images.model_images()
         o_lam, o_ll, o_st = orc.render_field(oracle_bands(f), f.H, f.W, f.src["type"], f.src["radec"],
@@ -283,7 +283,7 @@ def test_mixed_field_vs_oracle(cel, ctx, orc, kernel, layout):
         assert f.images.stats()["n_srcpix"] == o_st["n_srcpix"]
     finally:
         ctx.set_kernel("recurrence")
-        ctx.set_option(7, 1)
+        ctx.set_option(cel._lib.CEL_OPT_TILE_LAYOUT, 1)
 
 
 def test_edge_cases_empty_ragged_offimage(cel, ctx, orc):
@@ -564,7 +564,7 @@ def test_crowded_field_exercises_list_chunking_and_regrowth(cel, ctx, orc):
     nelec = rs.poisson(2000.0, size=(2, H, W)).astype(float)
     for layout in (1, 0, 2):
         c2 = cel.Context(0)
-        c2.set_option(7, layout)
+        c2.set_option(cel._lib.CEL_OPT_TILE_LAYOUT, layout)
         iset = cel.ImageSet(c2, bands, H, W, nelec=nelec)
         # a 10-source render first: the list buffers get sized for it (10*2*6 + 1024 entries) ...
         small = cel.SourceSet(c2, 16, 2).set(src["type"][:10], src["radec"][:10], src["counts"][:10], src["shape"][:10])
@@ -675,7 +675,7 @@ def test_photon_split_conservation_moments_quirks(cel, ctx, orc):
     results = {}
     for layout in (1, 0, 2):
         c2 = cel.Context(0)
-        c2.set_option(7, layout)
+        c2.set_option(cel._lib.CEL_OPT_TILE_LAYOUT, layout)
         iset = cel.ImageSet(c2, bands, H, W, nelec=g["nelec"])
         sset = cel.SourceSet(c2, S, 5).set(g["is_gal"], g["radec"], counts, g["shape"])
         patches, boxes, noise = iset.photon_split(sset, seed=99)
@@ -936,11 +936,11 @@ def test_fuzz_random_fields_vs_oracle(cel, ctx, orc, seed):
     shape = np.column_stack([theta, sigma, rs.uniform(0, 180, S), rs.uniform(0.03, 1.0, S)])
     counts = np.exp(rs.uniform(0.0, np.log(1e7), size=(S, B)))
     nelec = rs.poisson(np.clip(bands[:, 0], 1.0, 1e4)[:, None, None], size=(B, H, W)).astype(float)
-    ctx.set_option(7, int(__import__("os").environ.get("CEL_TEST_LAYOUT", "1")))     # render-tile layout under test
+    ctx.set_option(cel._lib.CEL_OPT_TILE_LAYOUT, int(__import__("os").environ.get("CEL_TEST_LAYOUT", "1")))     # render-tile layout under test
     try:
         iset = cel.ImageSet(ctx, bands, H, W, nelec=nelec)
     finally:
-        ctx.set_option(7, 1)
+        ctx.set_option(cel._lib.CEL_OPT_TILE_LAYOUT, 1)
     sset = cel.SourceSet(ctx, S, B).set(typ, radec, counts, shape)
     ll, llb = iset.render(sset, loglik=True)
     ob = bands.copy()
