@@ -63,6 +63,11 @@ SYMBOLS = [
     ("cel_estep_stats", C.c_int, [C.c_void_p, C.c_void_p, c_double_p, c_double_p, c_double_p]),
     ("cel_gmm_like_2d", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p, C.c_int,
                                   C.c_void_p, C.c_int]),
+    ("cel_mog_loglike", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p, C.c_int,
+                                  C.c_void_p, C.c_int]),
+    ("cel_galaxy_mixture_params", C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_double_p, c_double_p, c_double_p,
+                                            c_double_p, C.c_int, c_double_p, c_double_p, C.c_int, c_double_p, c_double_p,
+                                            c_double_p]),
     ("cel_bounding_radius", C.c_int, [c_double_p, c_double_p, c_double_p, C.c_int, C.c_double, c_double_p, c_double_p]),
     ("cel_profile_reset", C.c_int, [C.c_void_p]),
     ("cel_profile_get", C.c_int, [C.c_void_p, C.c_int, c_double_p, c_int64_p]),

@@ -917,7 +917,7 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
                            double *ll_out) {
     if (!im || !src || !ll_out) return fail(CEL_ERR_INVALID, "cel_patch_loglik: null argument");
     if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
-    if (mode != 0 && mode != 1) return fail(CEL_ERR_INVALID, "mode must be 0 (conditional) or 1 (isolated)");
+    if (mode != 0 && mode != 1 && mode != 2) return fail(CEL_ERR_INVALID, "mode must be 0 (conditional), 1 (isolated) or 2 (patch Poisson)");
     // resident form: boxes == offsets == data == NULL -> the patches of the last resident photon
     // split (mode 0) or the observed image on those boxes (mode 1); NB must be that split's S
     const bool resident = (!boxes && !offsets && !data);
@@ -975,7 +975,7 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
         d_nz = im->d_snz;
         d_box = im->d_sbox;
         d_off = im->d_soff;
-        d_data = (mode == 0) ? im->d_samp : nullptr;      // mode 1 reads nelec on the boxes
+        d_data = (mode != 1) ? im->d_samp : nullptr;      // mode 1 reads nelec on the boxes
     } else {
         PL_TRY(hipMemcpyAsync(d_box, hbox.data(), sizeof(int4) * nb, hipMemcpyHostToDevice, c->stream));
         PL_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice, c->stream));
@@ -998,7 +998,10 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
                 hipLaunchKernelGGL(k_patch_nzbox, dim3((unsigned)nb), dim3(64), 0, c->stream, d_box, d_off, d_data, d_nz);
             hipLaunchKernelGGL(k_patch_ll_hw<0>, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
                                d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, d_nz, c->tail_T, d_out);
-        } else
+        } else if (mode == 2)
+            hipLaunchKernelGGL(k_patch_ll_hw<2>, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                               d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
+        else
             hipLaunchKernelGGL(k_patch_ll_hw<1>, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
                                d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
         prof_end(c, pi);
@@ -1290,6 +1293,80 @@ done:
         if (d_p) (void)hipFree(d_p);
     }
     return rc;
+}
+
+int cel_mog_loglike(cel_ctx *c, const double *x, int64_t N, const double *means, const double *icovs,
+                    const double *logw, int K, double *out, int mem) {
+    if (!c || !x || !means || !icovs || !logw || !out) return fail(CEL_ERR_INVALID, "cel_mog_loglike: null argument");
+    if (N < 0 || K < 1) return fail(CEL_ERR_INVALID, "cel_mog_loglike: bad sizes");
+    if (N == 0) return CEL_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<double> comp((size_t)K * 6);
+    for (int k = 0; k < K; k++) {
+        comp[6 * k + 0] = logw[k];
+        comp[6 * k + 1] = means[2 * k];
+        comp[6 * k + 2] = means[2 * k + 1];
+        comp[6 * k + 3] = icovs[4 * k];
+        comp[6 * k + 4] = icovs[4 * k + 1] + icovs[4 * k + 2];     // the einsum keeps both off-diagonal terms (mog.py:15-16)
+        comp[6 * k + 5] = icovs[4 * k + 3];
+    }
+    double *d_comp = nullptr, *d_x = nullptr, *d_o = nullptr;
+    int rc;
+    if ((rc = scratch_get(c, 4, sizeof(double) * 6 * K, (void **)&d_comp))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_comp, comp.data(), sizeof(double) * 6 * K, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));      // comp is a local
+    if (mem == CEL_DEVICE) {
+        d_x = const_cast<double *>(x);
+        d_o = out;
+    } else {
+        if ((rc = scratch_get(c, 5, sizeof(double) * 2 * N, (void **)&d_x)) ||
+            (rc = scratch_get(c, 6, sizeof(double) * N, (void **)&d_o))) return rc;
+        HIP_TRY(hipMemcpyAsync(d_x, x, sizeof(double) * 2 * N, hipMemcpyHostToDevice, c->stream));
+    }
+    int pi = prof_begin(c, CEL_K_GMM);
+    hipLaunchKernelGGL(k_mog_ll, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_x, N, d_comp, K, d_o);
+    prof_end(c, pi);
+    HIP_TRY(hipGetLastError());
+    if (mem != CEL_DEVICE) HIP_TRY(hipMemcpyAsync(out, d_o, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CEL_OK;
+}
+
+int cel_galaxy_mixture_params(cel_ctx *c, int64_t N, const double *W, const double *v_s, const double *image_ws,
+                              const double *image_means, const double *image_covars, int K_psf, const double *amp,
+                              const double *sigs, int J, double *weights, double *means, double *covars) {
+    if (!c || !W || !v_s || !image_ws || !image_means || !image_covars || !amp || !sigs || !weights || !means || !covars)
+        return fail(CEL_ERR_INVALID, "cel_galaxy_mixture_params: null argument");
+    if (N < 0 || K_psf < 1 || J < 1 || K_psf > 4096 || J > 4096) return fail(CEL_ERR_INVALID, "cel_galaxy_mixture_params: bad sizes");
+    if (N == 0) return CEL_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t K = (int64_t)K_psf * J, n = N * K;
+    // inputs in one upload: W (4N), v_s (2N), ws (Kp), means (2Kp), covars (4Kp), amp (J), sigs (J)
+    const size_t nin = (size_t)(6 * N + 7 * K_psf + 2 * J);
+    std::vector<double> hin(nin);
+    double *q = hin.data();
+    memcpy(q, W, sizeof(double) * 4 * N); q += 4 * N;
+    memcpy(q, v_s, sizeof(double) * 2 * N); q += 2 * N;
+    memcpy(q, image_ws, sizeof(double) * K_psf); q += K_psf;
+    memcpy(q, image_means, sizeof(double) * 2 * K_psf); q += 2 * K_psf;
+    memcpy(q, image_covars, sizeof(double) * 4 * K_psf); q += 4 * K_psf;
+    memcpy(q, amp, sizeof(double) * J); q += J;
+    memcpy(q, sigs, sizeof(double) * J);
+    double *d_in = nullptr, *d_out = nullptr;
+    int rc;
+    if ((rc = scratch_get(c, 4, sizeof(double) * nin, (void **)&d_in)) ||
+        (rc = scratch_get(c, 5, sizeof(double) * 7 * n, (void **)&d_out))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_in, hin.data(), sizeof(double) * nin, hipMemcpyHostToDevice, c->stream));
+    const double *dW = d_in, *dv = dW + 4 * N, *dws = dv + 2 * N, *dmu = dws + K_psf, *dcv = dmu + 2 * K_psf,
+                 *damp = dcv + 4 * K_psf, *dsig = damp + J;
+    hipLaunchKernelGGL(k_mixture_params, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, N, dW, dv, dws, dmu, dcv,
+                       K_psf, damp, dsig, J, d_out, d_out + n, d_out + 3 * n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(weights, d_out, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(means, d_out + n, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(covars, d_out + 3 * n, sizeof(double) * 4 * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CEL_OK;
 }
 
 int cel_bounding_radius(const double *w, const double *mu, const double *cov, int K, double error,

@@ -102,3 +102,38 @@ k_gmm(const double *__restrict__ x, int64_t N, const double *__restrict__ comp /
     if (n < N) probs[n] = s;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_mog_ll: mog_loglike (CelestePy/util/dists/mog.py:5-21) -- the log-domain mixture evaluator
+// ------------------------------------------------------------------------------------------
+// out[n] = logsumexp_k( -q_k(x_n)/2 + lw[k] ),  lw[k] = -log(2 pi) - log(det_k)/2 + log(pi_k) formed by
+// the caller exactly as the reference forms it (so a weight <= 0 arrives as NaN / -inf).
+// One thread per point; the components (K*6 doubles: lw, mx, my, ia, ib2 = icov01 + icov10, ic) are
+// staged through LDS 64 at a time; two sweeps (maximum, then the sum of exp(e - max)), as
+// scipy's logsumexp does.
+__global__ void __launch_bounds__(256)
+k_mog_ll(const double *__restrict__ x, int64_t N, const double *__restrict__ comp, int K, double *__restrict__ out) {
+    __shared__ double sc[64 * 6];
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double px = 0.0, py = 0.0;
+    if (n < N) { px = x[2 * n]; py = x[2 * n + 1]; }
+    double mx = -INFINITY, s = 0.0;
+    bool bad = false;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            int kn = min(64, K - k0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < kn * 6; i += blockDim.x) sc[i] = comp[(int64_t)k0 * 6 + i];
+            __syncthreads();
+            for (int k = 0; k < kn; k++) {
+                double dx = px - sc[k * 6 + 1], dy = py - sc[k * 6 + 2];
+                double q = sc[k * 6 + 3] * dx * dx + sc[k * 6 + 4] * dx * dy + sc[k * 6 + 5] * dy * dy;
+                double e = -0.5 * q + sc[k * 6 + 0];
+                if (pass == 0) { bad = bad || (e != e); mx = fmax(mx, e); }
+                else s += exp(e - mx);
+            }
+        }
+        if (pass == 0 && !(mx > -INFINITY && mx < INFINITY)) mx = 0.0;   // logsumexp: a non-finite maximum is replaced by 0
+    }
+    if (n < N) out[n] = bad ? NAN : log(s) + mx;
+}

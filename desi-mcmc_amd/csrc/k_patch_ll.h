@@ -8,6 +8,8 @@
 // component dropping) and reduces, in a fixed order,
 //   mode 0:  sum_{m>0} log(m) * z  -  counts * sum(psf weights),   m = counts * stamp
 //   mode 1:  sum log(m + eps) * z  -  sum (m + eps)
+//   mode 2:  sum_{m>0} log(m) * z  -  sum m        (galaxy_source_like, celeste_galaxy_conditionals.py:15-42,
+//            on given limits; a pixel the model does not reach contributes nothing)
 // z = the patch data (photons attributed to the source, or nelec for the isolated form).
 //
 // Two kernels with the same contract:
@@ -70,6 +72,8 @@ k_patch_ll(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__
         const double zi = z[(int64_t)yy * zpitch + xx];
         if (mode == 0) {
             if (v > 0.0) a += log(v) * zi;
+        } else if (mode == 2) {
+            if (v > 0.0) { a += log(v) * zi; m += v; }
         } else {
             v += eps;
             a += log(v) * zi;
@@ -161,7 +165,7 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     int dropmode = HW_DROP_NONE;
     double log_floor = 0.0;
     if (Tdrop > 0.0) {
-        if (MODE == 0) dropmode = HW_DROP_SELF;
+        if (MODE == 0 || MODE == 2) dropmode = HW_DROP_SELF;
         else if (eps > 0.0 && counts > 0.0) { dropmode = HW_DROP_SKY; log_floor = (double)__logf((float)(eps / counts)); }
     }
     const double *z = data ? data + offsets[ob] : nelec + (int64_t)b * H * W + (int64_t)bx.z * W + bx.x;
@@ -191,6 +195,8 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
                         double v = counts * acc[(r0 + r) * 64 + lane];
                         if (MODE == 0) {
                             if (v > 0.0) a += log_tab(v, lt) * zz[r];
+                        } else if (MODE == 2) {
+                            if (v > 0.0) { a += log_tab(v, lt) * zz[r]; m += v; }
                         } else {
                             v += eps;
                             a += log_tab(v, lt) * zz[r];

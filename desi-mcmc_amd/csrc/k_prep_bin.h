@@ -107,6 +107,35 @@ k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int w
             r.y0 = (int)clampd(fmax(0.0, floor(py - bound)), -BIG, BIG);
             r.y1 = (int)clampd(fmin((double)H, ceil(py + bound)), -BIG, BIG);
         }
+    } else if (t == 2) {
+        // The older per-profile galaxy route, gen_galaxy_prof_psf_image
+        // (celeste_galaxy_conditionals.py:134-182): the caller hands W = R R^T itself (:151; R comes
+        // from gen_galaxy_transformation with the CONSTANT img.Ups_n, :33 -- not cd_at_pixel, Q9),
+        // shape = (theta, W00, W01, W11).  theta = 1 / 0 selects the 'exp' / 'dev' profile alone.
+        // Bound: calc_bounding_radius over the convolved components that carry weight, ERROR = 1e-5
+        // (:160-161); box: the int() rule of :166-167 (as a star's); no overlap test on this route.
+        double theta = shape[4 * s], w00 = shape[4 * s + 1], w01 = shape[4 * s + 2], w11 = shape[4 * s + 3];
+        r.w00 = w00; r.w01 = w01; r.w11 = w11; r.theta = theta;
+        r.type = 1;                       // downstream kernels see an ordinary galaxy record
+        double rsq_inv = 1.0 / rsq_gal;
+        double bound = -INFINITY;
+        for (int k = 0; k < K_PSF; k++) {
+            double dist = sqrt(bd.mux[k] * bd.mux[k] + bd.muy[k] * bd.muy[k]);
+            for (int j = 0; j < K_PROF; j++) {
+                if ((j < K_EXP) ? (theta == 0.0) : (theta == 1.0)) continue;
+                double v = c_prof_var[j];
+                bound = fmax(bound, comp_radius(v * w00 + bd.cxx[k], v * w01 + bd.cxy[k], v * w11 + bd.cyy[k],
+                                                rsq_inv, dist));
+            }
+        }
+        if (!(bound == bound) || !(px == px) || !(py == py)) {
+            r.type = -1;
+        } else {
+            int lx = (int)clampd(px - bound, -BIG, BIG), hx = (int)clampd(px + bound + 1, -BIG, BIG);
+            int ly = (int)clampd(py - bound, -BIG, BIG), hy = (int)clampd(py + bound + 1, -BIG, BIG);
+            r.x0 = max(0, lx); r.x1 = min(hx, W);
+            r.y0 = max(0, ly); r.y1 = min(hy, H);
+        }
     } else {
         r.type = -1;
     }
@@ -131,6 +160,27 @@ k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int w
 // Gibbs resamples the sky level (models.py:156-160): one scalar, passed as a kernel argument so
 // that the update is ordered on the stream without a host synchronisation
 __global__ void k_set_eps(BandDev *__restrict__ bands, int band, double eps) { bands[band].eps = eps; }
+
+// gen_galaxy_prof_psf_mixture_params (CelestePy/celeste_fast.pyx:100-140) for N sources that share
+// the PSF and profile arrays: one thread per output component, PSF-major (idx = k * J + j):
+//   weights = image_ws[k] * amp[j],  means = v_s + image_means[k],  covars = image_covars[k] + sigs[j] * W
+__global__ void __launch_bounds__(256)
+k_mixture_params(int64_t N, const double *__restrict__ Wm /* N*4 */, const double *__restrict__ v_s /* N*2 */,
+                 const double *__restrict__ iw, const double *__restrict__ im, const double *__restrict__ ic, int Kp,
+                 const double *__restrict__ amp, const double *__restrict__ sigs, int J,
+                 double *__restrict__ weights, double *__restrict__ means, double *__restrict__ covars) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = Kp * J;
+    if (i >= N * K) return;
+    const int64_t n = i / K;
+    const int c = (int)(i - n * K);
+    const int k = c / J, j = c - k * J;
+    weights[i] = iw[k] * amp[j];
+    means[2 * i + 0] = v_s[2 * n + 0] + im[2 * k + 0];
+    means[2 * i + 1] = v_s[2 * n + 1] + im[2 * k + 1];
+#pragma unroll
+    for (int q = 0; q < 4; q++) covars[4 * i + q] = ic[4 * k + q] + sigs[j] * Wm[4 * n + q];
+}
 
 // work counters of one render: sum of box areas and K-weighted areas (on demand, not timed)
 __global__ void k_stats(const SrcRec *__restrict__ recs, int64_t n, double *out) {

@@ -288,7 +288,7 @@ class ImageSet(object):
         L.check(L.lib().cel_estep_stats(self._h, sources._h, L.dptr(xt), L.dptr(ms), L.dptr(nz)))
         return xt, ms, nz
 
-    def patch_loglik(self, sources, boxes, patches, isolated=False):
+    def patch_loglik(self, sources, boxes, patches, isolated=False, mode=None):
         """Conditional log-likelihood of each of the P proposals in `sources` on fixed patches.
         boxes: (B,4) int y0,y1,x0,x1 (empty box = band without a sample image);
         patches: list of B arrays (or None) of the box shapes.  -> ll[P]
@@ -309,7 +309,7 @@ class ImageSet(object):
         out = np.zeros(sources.S)
         L.check(L.lib().cel_patch_loglik(self._h, sources._h, boxes.ctypes.data_as(L.c_int32_p),
                                          offs.ctypes.data_as(L.c_int64_p), data.ctypes.data, L.CEL_HOST,
-                                         1 if isolated else 0, L.dptr(out)))
+                                         (1 if isolated else 0) if mode is None else int(mode), L.dptr(out)))
         return out
 
     def patch_loglik_multi(self, sources, owner, boxes, patches, isolated=False):

@@ -76,6 +76,17 @@ class FitsImage(object):
         # star bounding radius, 1 - 1e-3 of the PSF mass (fits_image.py:151-155)
         self.R = _field.bounding_radius(self.weights, self.means, self.covars, 0.001)
 
+    @property
+    def psf_mog(self):
+        """the PSF as a MixtureOfGaussians (fits_image.py:147); `psf` is the name
+        gen_galaxy_psf_image reads (celeste_galaxy_conditionals.py:200)"""
+        if getattr(self, "_psf_mog", None) is None:
+            from .util.dists.mog import MixtureOfGaussians
+            self._psf_mog = MixtureOfGaussians(means=self.means, covs=self.covars, pis=self.weights)
+        return self._psf_mog
+
+    psf = psf_mog
+
     # ---- constructors -------------------------------------------------------------------
     @classmethod
     def from_header(cls, band, header, img):

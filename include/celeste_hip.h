@@ -141,7 +141,12 @@ int cel_images_device_ptrs(cel_images *img, void **nelec, void **lambda);
 
 /* ---- sources ------------------------------------------------------------------------ */
 /* Replaces a python list of SrcParams (celeste_src.py:57-94) as far as the path reads them:
- *   type[s]   0 star, 1 galaxy (SrcParams.a)
+ *   type[s]   0 star, 1 galaxy (SrcParams.a);
+ *             2 = a galaxy on the older per-profile route, gen_galaxy_prof_psf_image
+ *             (celeste_galaxy_conditionals.py:134-182): shape[s] = theta, W00, W01, W11 with
+ *             W = R R^T as the caller formed it (:151, R from the constant img.Ups_n, :33);
+ *             theta = 1 / 0 is the 'exp' / 'dev' profile alone; its box is the int() box of
+ *             :166-167 from the bounding radius (ERROR 1e-5) of the components that carry weight
  *   radec[s]  (ra, dec) degrees (SrcParams.u)
  *   counts[s*B + b] expected photons of source s in band b -- the multiplier that
  *             gen_src_image applies (celeste.py:35-62; the caller picks the flux convention)
@@ -197,6 +202,8 @@ int cel_render_stamps(cel_images *img, cel_sources *src, int band, int scaled, c
  *   mode 0   ll = sum_b [ sum_{m>0} log(m) z - counts_b sum(psf weights_b) ],  m = counts_b * stamp
  *            (a star failing the overlap test contributes -counts_b sum(weights_b), :160-163)
  *   mode 1   ll = sum_b [ sum log(m + eps_b) z - sum (m + eps_b) ]
+ *   mode 2   ll = sum_b [ sum_{m>0} log(m) z - sum m ]   -- galaxy_source_like
+ *            (celeste_galaxy_conditionals.py:15-42) on given limits
  *   ll_out   P doubles (host) */
 int cel_patch_loglik(cel_images *img, cel_sources *src, const int32_t *boxes, const int64_t *offsets,
                      const double *data, int mem, int mode, double *ll_out);
@@ -254,6 +261,27 @@ int cel_estep_stats(cel_images *img, cel_sources *src, double *xtilde, double *m
  * x and probs follow `mem`; ws/mus/sigs are host arrays. */
 int cel_gmm_like_2d(cel_ctx *ctx, const double *x, int64_t N, const double *ws, const double *mus,
                     const double *sigs, int K, double *probs, int mem);
+
+/* mog_loglike (util/dists/mog.py:5-21), the log-domain evaluator MixtureOfGaussians.logpdf /
+ * evaluate_grid (:58-60, :102-112) and gen_point_source_psf_image (celeste.py:158) call:
+ *   out[n] = logsumexp_k( -(x_n - mu_k)^T icov_k (x_n - mu_k) / 2 + logw[k] )
+ * logw[k] = -log(2 pi) - log(dets[k]) / 2 + log(pis[k]), formed by the caller as the reference forms
+ * it (a weight <= 0 gives NaN / -inf there; NaN propagates to every output).
+ * x and out follow `mem`; means (K*2), icovs (K*4), logw (K) are host arrays. */
+int cel_mog_loglike(cel_ctx *ctx, const double *x, int64_t N, const double *means, const double *icovs,
+                    const double *logw, int K, double *out, int mem);
+
+/* gen_galaxy_prof_psf_mixture_params (CelestePy/celeste_fast.pyx:100-140), for N sources sharing the
+ * PSF and profile arrays: the convolved component tables, PSF-major (index k * J + j):
+ *   weights[n][k*J+j] = image_ws[k] * amp[j]
+ *   means  [n][k*J+j] = v_s[n] + image_means[k]
+ *   covars [n][k*J+j] = image_covars[k] + sigs[j] * W[n]
+ * W: N*4 (= R R^T), v_s: N*2, image_*: the PSF (K_psf components), amp/sigs: the profile (J).
+ * gen_galaxy_psf_mixture_params (:29-94) is the same call with amp = [thetas[0] * exp_amp,
+ * thetas[1] * dev_amp] and sigs = [exp_sigs, dev_sigs].  Host arrays in and out; built on the device. */
+int cel_galaxy_mixture_params(cel_ctx *ctx, int64_t N, const double *W, const double *v_s, const double *image_ws,
+                              const double *image_means, const double *image_covars, int K_psf, const double *amp,
+                              const double *sigs, int J, double *weights, double *means, double *covars);
 
 /* calc_bounding_radius (util/bound/bounding_box.py:9-31); host arithmetic, no device needed */
 int cel_bounding_radius(const double *w, const double *mu, const double *cov, int K, double error,

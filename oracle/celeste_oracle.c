@@ -495,6 +495,116 @@ double orc_patch_loglik(const orc_band *b, int H, int W, int type, const double 
     return mode == 0 ? (double)a - counts * wsum : (double)(a - msum);
 }
 
+/* ------------------------------------- the older per-profile galaxy route (A16, A18) -- */
+
+/* celeste_fast.pyx:100-140 gen_galaxy_prof_psf_mixture_params: one profile (amp[J], sigs[J])
+ * convolved with the PSF (K_psf components); PSF-major output, cnt = k * J + j (:122-139). */
+void orc_galaxy_prof_psf_mixture_params(const double W[4], const double v_s[2], const double *image_ws,
+                                        const double *image_means, const double *image_covars, int K_psf,
+                                        const double *amp, const double *sigs, int J, double *weights,
+                                        double *means, double *covars) {
+    int cnt = 0;
+    for (int k = 0; k < K_psf; k++)
+        for (int j = 0; j < J; j++) {
+            weights[cnt] = image_ws[k] * amp[j];                         /* :124 */
+            means[2 * cnt + 0] = v_s[0] + image_means[2 * k + 0];        /* :127-128 */
+            means[2 * cnt + 1] = v_s[1] + image_means[2 * k + 1];
+            for (int ii = 0; ii < 2; ii++)
+                for (int jj = 0; jj < 2; jj++)                           /* :131-134 */
+                    covars[4 * cnt + 2 * ii + jj] = image_covars[4 * k + 2 * ii + jj] + sigs[j] * W[2 * ii + jj];
+            cnt++;
+        }
+}
+
+/* celeste_fast.pyx:29-94 gen_galaxy_psf_mixture_params: for k (PSF) / for i in (exp, dev) / for j;
+ * weights = image_ws[k] * thetas[i] * amp_ij (:77), evaluated left to right. */
+void orc_galaxy_psf_mixture_params(const double thetas[2], const double W[4], const double v_s[2],
+                                   const double *image_ws, const double *image_means, const double *image_covars,
+                                   int K_psf, const double *exp_amp, const double *exp_sigs, int K_exp_,
+                                   const double *dev_amp, const double *dev_sigs, int K_dev_, double *weights,
+                                   double *means, double *covars) {
+    int cnt = 0;
+    for (int k = 0; k < K_psf; k++)
+        for (int i = 0; i < 2; i++) {
+            int Ki = (i == 0) ? K_exp_ : K_dev_;
+            for (int j = 0; j < Ki; j++) {
+                double amp_ij = (i == 0) ? exp_amp[j] : dev_amp[j];
+                double var_ij = (i == 0) ? exp_sigs[j] : dev_sigs[j];
+                weights[cnt] = image_ws[k] * thetas[i] * amp_ij;
+                means[2 * cnt + 0] = v_s[0] + image_means[2 * k + 0];
+                means[2 * cnt + 1] = v_s[1] + image_means[2 * k + 1];
+                for (int ii = 0; ii < 2; ii++)
+                    for (int jj = 0; jj < 2; jj++)
+                        covars[4 * cnt + 2 * ii + jj] = image_covars[4 * k + 2 * ii + jj] + var_ij * W[2 * ii + jj];
+                cnt++;
+            }
+        }
+}
+
+/* celeste_galaxy_conditionals.py:134-182 gen_galaxy_prof_psf_image: prof 0 = 'exp', 1 = 'dev'; R is the
+ * shape matrix (row-major 2x2), W = R R^T (:151); amplitudes / variances are the profile's normalised
+ * tables (what `.amp` / `.var[:,0,0]` of :155-156 mean).  bound with ERROR = 1e-5 about v_s (:160-161),
+ * int() box (:166-167) unless lims = {y0,y1,x0,x1} is given (:162-164); values by gmm_like_2d (:173-176).
+ * box = {y0,y1,x0,x1} out; patch may be NULL to query the box.  Returns the number of patch pixels. */
+int64_t orc_galaxy_prof_psf_image(const orc_band *b, int H, int W_, int prof, const double R[4], const double u[2],
+                                  const int *lims, int box[4], double *patch) {
+    double ea[K_EXP], ev[K_EXP], da[K_DEV], dv[K_DEV];
+    orc_profile_tables(ea, ev, da, dv);
+    const double *amp = prof == 0 ? ea : da, *sig = prof == 0 ? ev : dv;
+    const int J = prof == 0 ? K_EXP : K_DEV;
+    double v_s[2];
+    orc_equa2pixel(b, u, v_s);
+    /* np.dot(R, R.T) */
+    double Wm[4] = {R[0] * R[0] + R[1] * R[1], R[0] * R[2] + R[1] * R[3], R[2] * R[0] + R[3] * R[1], R[2] * R[2] + R[3] * R[3]};
+    double weights[K_PSF * K_DEV], means[2 * K_PSF * K_DEV], covars[4 * K_PSF * K_DEV];
+    orc_galaxy_prof_psf_mixture_params(Wm, v_s, b->w, &b->mu[0][0], &b->cov[0][0][0], K_PSF, amp, sig, J, weights, means, covars);
+    if (lims) {
+        box[0] = lims[0]; box[1] = lims[1]; box[2] = lims[2]; box[3] = lims[3];
+    } else {
+        double bound = orc_bounding_radius(weights, means, covars, K_PSF * J, 0.00001, v_s);
+        int lx = (int)(v_s[0] - bound), hx = (int)(v_s[0] + bound + 1);
+        int ly = (int)(v_s[1] - bound), hy = (int)(v_s[1] + bound + 1);
+        box[2] = lx > 0 ? lx : 0; box[3] = hx < W_ ? hx : W_;
+        box[0] = ly > 0 ? ly : 0; box[1] = hy < H ? hy : H;
+    }
+    if (box[1] <= box[0] || box[3] <= box[2]) return 0;
+    int64_t n = (int64_t)(box[1] - box[0]) * (box[3] - box[2]);
+    if (!patch) return n;
+    int nx = box[3] - box[2];
+    double *pts = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    for (int64_t i = 0; i < n; i++) {                                    /* meshgrid 'xy', C-order ravel (:170-171) */
+        pts[2 * i + 0] = (double)(box[2] + (int)(i % nx));
+        pts[2 * i + 1] = (double)(box[0] + (int)(i / nx));
+    }
+    orc_gmm_like_2d(patch, pts, n, weights, means, covars, K_PSF * J);
+    free(pts);
+    return n;
+}
+
+/* celeste_galaxy_conditionals.py:15-42 galaxy_source_like, one image's term on the photon patch's
+ * limits box = {y0,y1,x0,x1}: R_s from the CONSTANT b->ups (:33), f = theta f_exp + (1 - theta) f_dev
+ * (:34-36, both profiles on the same limits), lam = image_flux * f (:39-40),
+ * sum Z log(lam) - lam over the pixels with lam > 0 (:41; a pixel the model does not reach is skipped
+ * instead of contributing 0 * log 0).  th = {theta, sigma, phi, rho}. */
+double orc_galaxy_source_like(const orc_band *b, int H, int W_, const double th[4], const double u[2],
+                              double image_flux, const int box[4], const double *Z) {
+    int64_t n = (int64_t)(box[1] - box[0]) * (box[3] - box[2]);
+    if (n <= 0) return 0.0;
+    double R[4];
+    orc_galaxy_tinv(th[1], th[3], th[2], &b->ups[0][0], R);
+    double *fe = (double *)malloc(sizeof(double) * (size_t)n), *fd = (double *)malloc(sizeof(double) * (size_t)n);
+    int bx[4];
+    orc_galaxy_prof_psf_image(b, H, W_, 0, R, u, box, bx, fe);
+    orc_galaxy_prof_psf_image(b, H, W_, 1, R, u, box, bx, fd);
+    long double a = 0.0L, m = 0.0L;
+    for (int64_t i = 0; i < n; i++) {
+        double lam = image_flux * (th[0] * fe[i] + (1. - th[0]) * fd[i]);
+        if (lam > 0.) { a += (long double)(Z[i] * log(lam)); m += (long double)lam; }
+    }
+    free(fe); free(fd);
+    return (double)(a - m);
+}
+
 /* The reductions celeste_em.py:38-91 takes of gen_src_prob_layers (celeste.py:222-234):
  *   xtilde[s*B+b] = sum nelec * F_s / lambda, mass[s*B+b] = sum unit stamp, noise[b] = sum nelec * eps / lambda
  * lambda (B*H*W) must be the model image of exactly these sources (orc_render_field). */

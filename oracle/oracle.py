@@ -227,6 +227,76 @@ def patch_loglik(band, H, W, typ, u, shape, counts, box, data, mode=0):
                                   box.ctypes.data_as(_ip), dp, C.c_int(int(mode)))
 
 
+def galaxy_prof_psf_mixture_params(W, v_s, image_ws, image_means, image_covars, amp, sigs):
+    """celeste_fast.pyx:100-140 -> (weights, means, covars), PSF-major"""
+    W, Wp = _d(W)
+    v_s, vp = _d(v_s)
+    iw, iwp = _d(image_ws)
+    im, imp = _d(image_means)
+    ic, icp = _d(image_covars)
+    amp, ap = _d(amp)
+    sigs, sp = _d(sigs)
+    K = len(iw) * len(amp)
+    w, m, c = np.zeros(K), np.zeros((K, 2)), np.zeros((K, 2, 2))
+    lib().orc_galaxy_prof_psf_mixture_params(Wp, vp, iwp, imp, icp, C.c_int(len(iw)), ap, sp, C.c_int(len(amp)),
+                                             w.ctypes.data_as(_dp), m.ctypes.data_as(_dp), c.ctypes.data_as(_dp))
+    return w, m, c
+
+
+def galaxy_psf_mixture_params(thetas, W, v_s, image_ws, image_means, image_covars, exp_amp, exp_sigs, dev_amp, dev_sigs):
+    """celeste_fast.pyx:29-94 -> (weights, means, covars)"""
+    th, tp = _d(thetas)
+    W, Wp = _d(W)
+    v_s, vp = _d(v_s)
+    iw, iwp = _d(image_ws)
+    im, imp = _d(image_means)
+    ic, icp = _d(image_covars)
+    ea, eap = _d(exp_amp)
+    es, esp = _d(exp_sigs)
+    da, dap = _d(dev_amp)
+    ds, dsp = _d(dev_sigs)
+    K = len(iw) * (len(ea) + len(da))
+    w, m, c = np.zeros(K), np.zeros((K, 2)), np.zeros((K, 2, 2))
+    lib().orc_galaxy_psf_mixture_params(tp, Wp, vp, iwp, imp, icp, C.c_int(len(iw)), eap, esp, C.c_int(len(ea)),
+                                        dap, dsp, C.c_int(len(da)), w.ctypes.data_as(_dp), m.ctypes.data_as(_dp),
+                                        c.ctypes.data_as(_dp))
+    return w, m, c
+
+
+def galaxy_prof_psf_image(band, H, W, prof, R, u, lims=None):
+    """celeste_galaxy_conditionals.py:134-182 -> (patch or None, (y0,y1), (x0,x1)); prof 'exp' | 'dev';
+    lims = (y0, y1, x0, x1) or None (own int() box)"""
+    b, bp = _d(band)
+    R, Rp = _d(R)
+    u, up = _d(u)
+    pi = {"exp": 0, "dev": 1}[prof]
+    box = np.zeros(4, dtype=np.int32)
+    lp = None
+    if lims is not None:
+        lims = np.ascontiguousarray(lims, dtype=np.int32)
+        lp = lims.ctypes.data_as(_ip)
+    lib().orc_galaxy_prof_psf_image.restype = C.c_int64
+    n = lib().orc_galaxy_prof_psf_image(bp, C.c_int(H), C.c_int(W), C.c_int(pi), Rp, up, lp, box.ctypes.data_as(_ip), None)
+    if n <= 0:
+        return None, (int(box[0]), int(box[1])), (int(box[2]), int(box[3]))
+    patch = np.empty((box[1] - box[0], box[3] - box[2]))
+    lib().orc_galaxy_prof_psf_image(bp, C.c_int(H), C.c_int(W), C.c_int(pi), Rp, up, lp, box.ctypes.data_as(_ip),
+                                    patch.ctypes.data_as(_dp))
+    return patch, (int(box[0]), int(box[1])), (int(box[2]), int(box[3]))
+
+
+def galaxy_source_like(band, H, W, th, u, image_flux, box, Z):
+    """one image's term of celeste_galaxy_conditionals.py:15-42 on the limits box = (y0, y1, x0, x1)"""
+    b, bp = _d(band)
+    th, tp = _d(th)
+    u, up = _d(u)
+    box = np.ascontiguousarray(box, dtype=np.int32)
+    Z, zp = _d(Z)
+    lib().orc_galaxy_source_like.restype = C.c_double
+    return lib().orc_galaxy_source_like(bp, C.c_int(H), C.c_int(W), tp, up, C.c_double(float(image_flux)),
+                                        box.ctypes.data_as(_ip), zp)
+
+
 def estep_stats(bands, H, W, typ, radec, counts, shape, nelec):
     """-> (xtilde[S,B], mass[S,B], noise[B]) : celeste_em.py:38-91 reductions"""
     lam, _, _ = render_field(bands, H, W, typ, radec, counts, shape, nelec)

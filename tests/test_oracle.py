@@ -277,3 +277,115 @@ def test_estep_statistics_golden():
     np.testing.assert_allclose(nz, e["noise"], rtol=1e-12)
     # every observed photon is attributed to a source or to the sky
     np.testing.assert_allclose(xt.sum(axis=0) + nz, g["nelec"].sum(axis=(1, 2)), rtol=1e-12)
+
+
+# ---- the older per-profile galaxy route ---------------------------------------
+# The reference's celeste_fast.pyx does not build here, so these restatements are pinned through
+# goldens the reference's OWN Python produced: the convolved tables of MixtureOfGaussians (A15:
+# *_cw / *_cm / *_cc, galaxy-major) are the same table in another order -- the PSF-major A16
+# output must be a permutation of them for the same W = Tinv Tinv^T -- and the per-profile image
+# route (A18) must reproduce the reference's gen_galaxy_psf_image patches (A17) wherever the two
+# routes' shape matrices coincide (a source at the WCS reference declination).
+def _a16_perm():
+    # galaxy-major index j*3 + k  ->  PSF-major index k*14 + j
+    return np.array([(c % 14) * 3 + c // 14 for c in range(42)])
+
+
+@pytest.mark.parametrize("tag", ["s", "b"])
+def test_a16_mixture_params_are_a_permutation_of_reference_tables(bands, tag):
+    rec, B = bands
+    g = load_golden("galaxy_stamps.npz")
+    ea, ev, da, dv = orc.profile_tables()
+    perm = _a16_perm()
+    for i in range(len(g[tag + "_th"])):
+        bi = g[tag + "_band"][i]
+        th = g[tag + "_th"][i]
+        tinv = g[tag + "_tinv"][i]
+        Wm = tinv @ tinv.T
+        w, m, c = orc.galaxy_psf_mixture_params([th[0], 1. - th[0]], Wm, g[tag + "_pix"][i], rec["weights"][bi],
+                                                rec["means"][bi], rec["covars"][bi], ea, ev, da, dv)
+        np.testing.assert_allclose(w, g[tag + "_cw"][i][perm], rtol=1e-13)
+        np.testing.assert_allclose(m, g[tag + "_cm"][i][perm], rtol=1e-13)
+        np.testing.assert_allclose(c, g[tag + "_cc"][i][perm], rtol=1e-9, atol=1e-18)
+        # the one-profile form with concatenated (theta-scaled) tables is the same table
+        w2, m2, c2 = orc.galaxy_prof_psf_mixture_params(
+            Wm, g[tag + "_pix"][i], rec["weights"][bi], rec["means"][bi], rec["covars"][bi],
+            np.concatenate([th[0] * ea, (1. - th[0]) * da]), np.concatenate([ev, dv]))
+        np.testing.assert_allclose(w2, w, rtol=1e-15)
+        assert np.array_equal(m2, m) and np.array_equal(c2, c)
+
+
+def test_a18_profile_images_reproduce_reference_patches_at_the_wcs_reference_dec(bands):
+    """theta f_exp + (1-theta) f_dev through A16 + A5 + A7 with R from the CONSTANT Ups_n equals the
+    reference's gen_galaxy_psf_image patch (golden, A17 route) when the source sits at the frame's
+    reference declination, where cd_at_pixel == Ups_n; away from it the two differ at ~1e-4 (Q9)."""
+    rec, B = bands
+    g = load_golden("galaxy_stamps.npz")
+    patches = unpack_ragged(g["s_flat"], g["s_offs"], g["s_shapes"])
+    stride = int(g["s_stride"])
+    n_same = 0
+    for i in range(len(patches)):
+        bi = g["s_band"][i]
+        band = B[bi]
+        th, u = g["s_th"][i], g["s_u"][i]
+        box = [int(t) for t in g["s_box"][i]]
+        cd = orc.cd_at_pixel(band, *g["s_pix"][i])
+        R = orc.galaxy_tinv(th[1], th[3], th[2], rec["ups"][bi])
+        fe, yl, xl = orc.galaxy_prof_psf_image(band, 51, 51, "exp", R, u, lims=box)
+        fd, _, _ = orc.galaxy_prof_psf_image(band, 51, 51, "dev", R, u, lims=box)
+        assert (yl, xl) == ((box[0], box[1]), (box[2], box[3]))
+        f = th[0] * fe + (1. - th[0]) * fd
+        rel = np.max(np.abs(cd - rec["ups"][bi]) / np.abs(rec["ups"][bi]).max())
+        ref = patches[i]
+        got = f[::stride, ::stride]
+        if rel < 1e-9:
+            n_same += 1
+            np.testing.assert_allclose(got, ref, rtol=1e-7, atol=1e-300)
+        else:
+            # same mixture up to the ~1e-5..1e-3 change of the shape matrix
+            big = ref > 1e-6 * ref.max()
+            assert np.max(np.abs(got[big] / ref[big] - 1.0)) < 50 * rel + 1e-9
+        # own box of the route: int() rule about v_s with the profile's 1e-5 bound
+        pe, yle, xle = orc.galaxy_prof_psf_image(band, 51, 51, "exp", R, u)
+        ea, ev, da, dv = orc.profile_tables()
+        w, m, c = orc.galaxy_prof_psf_mixture_params(R @ R.T, g["s_pix"][i], rec["weights"][bi], rec["means"][bi],
+                                                     rec["covars"][bi], ea, ev)
+        bound = orc.bounding_radius(w, m, c, 1e-5, center=g["s_pix"][i])
+        px, py = g["s_pix"][i]
+        assert xle == (max(0, int(px - bound)), min(int(px + bound + 1), 51))
+        assert yle == (max(0, int(py - bound)), min(int(py + bound + 1), 51))
+        if pe is not None:
+            np.testing.assert_allclose(pe, orc.gmm_like_2d(
+                np.column_stack([a.ravel() for a in np.meshgrid(np.arange(xle[0], xle[1], dtype=float),
+                                                                np.arange(yle[0], yle[1], dtype=float), indexing="xy")]),
+                w, m, c).reshape(pe.shape), rtol=1e-13)
+    # exactly on the reference declination cd_at_pixel == Ups_n: the two routes give the same patch
+    for bi, th in ((2, g["s_th"][3]), (0, g["s_th"][30]), (4, g["s_th"][55])):
+        band = B[bi]
+        u = np.array([rec["phi"][bi][0] + 7e-4, rec["phi"][bi][1]])
+        p17, yl, xl = orc.source_patch(band, 51, 51, 1, u, th)
+        box = [yl[0], yl[1], xl[0], xl[1]]
+        R = orc.galaxy_tinv(th[1], th[3], th[2], rec["ups"][bi])
+        fe, _, _ = orc.galaxy_prof_psf_image(band, 51, 51, "exp", R, u, lims=box)
+        fd, _, _ = orc.galaxy_prof_psf_image(band, 51, 51, "dev", R, u, lims=box)
+        np.testing.assert_allclose(th[0] * fe + (1. - th[0]) * fd, p17, rtol=1e-9, atol=1e-300)   # cd_at_pixel is a finite difference: ~1e-12 off Ups_n
+
+
+def test_galaxy_source_like_oracle_matches_a_numpy_statement(bands):
+    rec, B = bands
+    g = load_golden("galaxy_stamps.npz")
+    rs = np.random.RandomState(5)
+    for i in (0, 7, 20, 41):
+        bi = g["s_band"][i]
+        band = B[bi]
+        th, u = g["s_th"][i], g["s_u"][i]
+        box = [5, 47, 3, 50]
+        Z = rs.poisson(3.0, size=(42, 47)).astype(float)
+        flux = 1234.5
+        R = orc.galaxy_tinv(th[1], th[3], th[2], rec["ups"][bi])
+        fe, _, _ = orc.galaxy_prof_psf_image(band, 51, 51, "exp", R, u, lims=box)
+        fd, _, _ = orc.galaxy_prof_psf_image(band, 51, 51, "dev", R, u, lims=box)
+        lam = flux * (th[0] * fe + (1. - th[0]) * fd)
+        ok = lam > 0
+        want = np.sum(Z[ok] * np.log(lam[ok])) - np.sum(lam[ok])
+        np.testing.assert_allclose(orc.galaxy_source_like(band, 51, 51, th, u, flux, box, Z), want, rtol=1e-12)
