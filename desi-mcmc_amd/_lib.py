@@ -55,6 +55,7 @@ SYMBOLS = [
     ("cel_patch_loglik", C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, c_int64_p, C.c_void_p, C.c_int, C.c_int, c_double_p]),
     ("cel_patch_loglik_multi", C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_int64, c_int32_p, c_int64_p, C.c_void_p,
                                           C.c_int, C.c_int, c_double_p]),
+    ("cel_stamp_mass", C.c_int, [C.c_void_p, C.c_void_p, c_double_p]),
     ("cel_source_boxes", C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, c_int32_p]),
     ("cel_photon_split", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, c_int64_p, C.c_void_p, C.c_int, c_double_p]),
     ("cel_samples_info", C.c_int, [C.c_void_p, c_int64_p, c_int64_p]),

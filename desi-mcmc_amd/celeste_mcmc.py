@@ -49,3 +49,186 @@ def sample_source_photons_single_image_cython(img, srcs, seed=None):
     returns (samp_imgs: list of SamplePatch (x0,x1,y0,y1,data) or None, noise_sum)"""
     samp, noise = sample_source_photons_multi_image((img,), srcs, seed)
     return samp[0], noise[0]
+
+
+# ---- the whole Gibbs sweep, catalogue-wide and device-resident -------------------------------------
+class GibbsField(object):
+    """One field's images on the device plus what the sweep needs to know about them."""
+
+    def __init__(self, iset, band_index, calib, kappa, npix, a_0=5, b_0=.005):
+        self.iset = iset
+        self.band_index = np.asarray(band_index, dtype=np.int64)      # which of u,g,r,i,z each image is
+        self.calib = np.asarray(calib, dtype=np.float64)
+        self.kappa = np.asarray(kappa, dtype=np.float64)
+        self.npix = float(npix)
+        self.a_0, self.b_0 = a_0, b_0                                  # Gamma prior of the sky level (models.py:119-121)
+        self.epsilon = np.array([iset.band(b)[0] for b in range(iset.B)])
+        self.sset = None
+        self.prop = None
+        self.has_patch = None
+
+
+class ModelGibbs(object):
+    """CelesteBase.resample_model (CelestePy/models.py:75-83) for a whole catalogue at once:
+
+        for every field:  Field.resample_photons (models.py:123-160) -- the photon split of all its
+                          images in one device pass, sample patches kept on the device, and the
+                          sky level of every image redrawn from its Gamma conditional;
+        for every source: Source.resample (sources.py:242-245) = resample_fluxes (:321-349), then
+                          resample_location (:308-319) by slice sampling -- all sources in
+                          lock-step: round k scores the k-th slice evaluation of every unfinished
+                          source in ONE launch of cel_patch_loglik_multi against the resident patches.
+
+    State lives in arrays (type[S], u[S,2], fluxes[S,5] in nanomaggies, shape[S,4]); nothing per
+    source runs in Python.  A source that has no sample patch in any image is left alone (the
+    reference asserts there, sources.py:243).
+
+    Random numbers: Philox on the device for the split (keyed by pixel and source), one SplitMix64
+    stream per source for the slice sampler, numpy's generator for the Gamma draws -- all derived
+    from `seed`; a chain is reproducible and does not depend on batching."""
+
+    BANDS = ['u', 'g', 'r', 'i', 'z']
+
+    def __init__(self, fields, typ, u, fluxes, shape, seed=0, flux_a_0=5., flux_b_0=.005, slice_args=None):
+        self.fields = list(fields)
+        self.typ = np.ascontiguousarray(typ, dtype=np.int32)
+        self.S = self.typ.shape[0]
+        self.u = np.array(u, dtype=np.float64).reshape(self.S, 2)
+        self.fluxes = np.array(fluxes, dtype=np.float64).reshape(self.S, 5)
+        self.shape = np.array(shape, dtype=np.float64).reshape(self.S, 4)
+        self.seed = int(seed)
+        self.rng = np.random.RandomState(self.seed & 0x7FFFFFFF)
+        self.flux_a_0, self.flux_b_0 = flux_a_0, flux_b_0
+        # Source.resample_location's call (sources.py:312-317): no stepping out; `step=` is not a
+        # slicesample argument, so sigma keeps its default 1.0 unless the caller sets it
+        self.slice_args = dict(step_out=False)
+        self.slice_args.update(slice_args or {})
+        self.sweeps = 0
+        self.timing = dict(split=0.0, flux=0.0, location=0.0, rounds=0, evals=0)
+        self.noise_sums = None
+        self.active = np.ones(self.S, dtype=bool)
+
+    # -- helpers ---------------------------------------------------------------------------------
+    @classmethod
+    def from_images(cls, img_dicts, params, **kw):
+        """fields given as the reference holds them: a list of {band letter: FitsImage} dicts
+        (CelesteBase.add_field) and a list of SrcParams."""
+        fields = []
+        for img_dict in img_dicts:
+            bands = [b for b in cls.BANDS if b in img_dict]
+            imgs = [img_dict[b] for b in bands]
+            iset = _celeste._image_set(tuple(imgs))
+            f = GibbsField(iset, [cls.BANDS.index(b) for b in bands], [im.calib for im in imgs],
+                           [im.kappa for im in imgs], imgs[0].nelec.size)
+            f.images = imgs
+            fields.append(f)
+        S = len(params)
+        typ = np.array([1 if p.a == 1 else 0 for p in params], dtype=np.int32)
+        u = np.array([p.u for p in params], dtype=np.float64).reshape(S, 2)
+        fl = np.array([[p.flux_dict[b] for b in cls.BANDS] for p in params], dtype=np.float64).reshape(S, 5)
+        sh = np.array([[p.theta, p.sigma, p.phi, p.rho] if p.a == 1 else [0., 0., 0., 0.] for p in params],
+                      dtype=np.float64).reshape(S, 4)
+        return cls(fields, typ, u, fl, sh, **kw)
+
+    def counts(self, f, fluxes=None, idx=None):
+        """flux in nanomaggies -> expected photons in every image of field f  (sources.py:120-129)"""
+        fl = self.fluxes if fluxes is None else fluxes
+        if idx is not None:
+            fl = fl[idx]
+        return fl[:, f.band_index] / f.calib[None, :] * f.kappa[None, :]
+
+    def _sources(self, f):
+        from . import field as _field
+        if f.sset is None or f.sset.capacity < self.S:
+            f.sset = _field.SourceSet(f.iset.ctx, max(self.S, 1), f.iset.B)
+        return f.sset.set(self.typ, self.u, self.counts(f), self.shape)
+
+    # -- Field.resample_photons: models.py:123-160 ---------------------------------------------------
+    def resample_photons(self):
+        import time
+        t0 = time.perf_counter()
+        self.noise_sums = []
+        any_patch = np.zeros(self.S, dtype=bool)
+        for k, f in enumerate(self.fields):
+            seed = (self.seed * 1000003 + self.sweeps * 8191 + k) & (2 ** 64 - 1)
+            noise = f.iset.photon_split_resident(self._sources(f), seed)
+            f.sums = f.iset.sample_sums()                              # photons per (source, image)
+            f.has_patch = f.iset.sample_box_areas() > 0
+            any_patch |= f.has_patch.any(axis=1)
+            self.noise_sums.append(noise)
+            # resample the noise parameter of every image (models.py:155-160)
+            a_n = f.a_0 + noise
+            b_n = f.b_0 + f.npix
+            f.epsilon = self.rng.gamma(a_n, 1. / b_n)
+            for b in range(f.iset.B):
+                f.iset.set_epsilon(b, f.epsilon[b])
+                if getattr(f, "images", None) is not None:
+                    f.images[b].epsilon = float(f.epsilon[b])
+        self.active = any_patch
+        self.timing["split"] += time.perf_counter() - t0
+        return self.noise_sums
+
+    # -- Source.resample_fluxes: sources.py:321-349 --------------------------------------------------
+    def resample_fluxes(self):
+        import time
+        t0 = time.perf_counter()
+        band_counts = np.zeros((self.S, 5))
+        psf_sums = np.zeros((self.S, 5))
+        for f in self.fields:
+            mass = f.iset.stamp_mass(f.sset) * f.has_patch              # sum of the unit stamp on its own box
+            for b in range(f.iset.B):
+                band_counts[:, f.band_index[b]] += f.sums[:, b]
+                psf_sums[:, f.band_index[b]] += mass[:, b] * (f.kappa[b] / f.calib[b])
+        a_n = self.flux_a_0 + band_counts
+        b_n = self.flux_b_0 + psf_sums
+        new = self.rng.gamma(a_n, 1. / b_n)
+        self.fluxes = np.where(self.active[:, None], new, self.fluxes)
+        self.timing["flux"] += time.perf_counter() - t0
+        return self.fluxes
+
+    # -- Source.resample_location: sources.py:308-319, all sources in lock-step ------------------------
+    def location_loglik(self, idx, U):
+        """Source.location_likelihood (sources.py:185-186) of chain idx[i] at U[i], summed over fields"""
+        from . import field as _field
+        idx = np.asarray(idx, dtype=np.int64)
+        P = idx.shape[0]
+        ll = np.zeros(P)
+        typ, shape = self.typ[idx], self.shape[idx]
+        owner = idx.astype(np.int32)
+        for f in self.fields:
+            if f.prop is None or f.prop.capacity < P:
+                f.prop = _field.SourceSet(f.iset.ctx, max(2 * self.S, P, 16), f.iset.B)
+            f.prop.set(typ, U, self.counts(f, idx=idx), shape)
+            ll += f.iset.patch_loglik_resident(f.prop, owner)
+        return ll
+
+    def resample_locations(self):
+        import time
+        from .util.infer.slicesample import slicesample_lockstep
+        t0 = time.perf_counter()
+        act = np.nonzero(self.active)[0]
+        if act.size:
+            st = {}
+            new_u, _ = slicesample_lockstep(self.u[act], lambda i, U: self.location_loglik(act[i], U),
+                                            seed=self.seed * 7919 + self.sweeps, chain_ids=act, stats=st,
+                                            **self.slice_args)
+            self.u[act] = new_u
+            self.timing["rounds"] += st["rounds"]
+            self.timing["evals"] += st["evals"]
+        self.timing["location"] += time.perf_counter() - t0
+        return self.u
+
+    def sweep(self):
+        """CelesteBase.resample_model: every field's photons, then every source (fluxes, location)"""
+        self.resample_photons()
+        self.resample_fluxes()
+        self.resample_locations()
+        self.sweeps += 1
+
+    def log_likelihood(self):
+        """sum of img_log_likelihood over every image of every field at the current state (models.py:104-108)"""
+        tot = 0.0
+        for f in self.fields:
+            ll, _ = f.iset.render(self._sources(f), loglik=True)
+            tot += ll
+        return tot

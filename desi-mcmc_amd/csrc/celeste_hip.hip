@@ -1025,6 +1025,27 @@ int cel_patch_loglik(cel_images *im, cel_sources *src, const int32_t *boxes, con
     return cel_patch_loglik_multi(im, src, nullptr, 1, boxes, offsets, data, mem, mode, ll_out);
 }
 
+int cel_stamp_mass(cel_images *im, cel_sources *src, double *mass) {
+    if (!im || !src || !mass) return fail(CEL_ERR_INVALID, "cel_stamp_mass: null argument");
+    if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
+    cel_ctx *c = im->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int B = im->B;
+    const int64_t S = src->S;
+    if (S == 0) return CEL_OK;
+    int rc = run_prep(im, src);
+    if (rc) return rc;
+    double *d_out = nullptr;
+    if ((rc = scratch_get(c, 2, sizeof(double) * S * B, (void **)&d_out))) return rc;
+    int pi = prof_begin(c, CEL_K_STAMPS);
+    hipLaunchKernelGGL(k_patch_ll_hw<3>, dim3((unsigned)(S * B)), dim3(64), 0, c->stream, im->d_bands, B, S, im->d_recs,
+                       (const int *)nullptr, (const int4 *)nullptr, (const int64_t *)nullptr, (const double *)nullptr,
+                       (const double *)nullptr, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
+    prof_end(c, pi);
+    HIP_TRY(hipGetLastError());
+    return copy_out(mass, d_out, sizeof(double) * S * B, CEL_HOST, c->stream);
+}
+
 // ---- photon split -------------------------------------------------------------------------------
 int cel_source_boxes(cel_images *im, cel_sources *src, int32_t *boxes, int32_t *status) {
     if (!im || !src || !boxes || !status) return fail(CEL_ERR_INVALID, "cel_source_boxes: null argument");

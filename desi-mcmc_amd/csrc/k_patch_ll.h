@@ -140,13 +140,14 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     const int64_t p = job / B;
     const BandDev *bd = bands + b;
     const int64_t ob = (int64_t)(owner ? owner[p] : 0) * B + b;
-    const int4 bx = pbox[ob];
+    RecU rec = rec_unpack(rec_fetch(recs + (int64_t)b * P, (int)p, lane));
+    // MODE 3 (mass of the unit stamp on the source's OWN box, sources.py:338-339): the box is the record's
+    const int4 bx = (MODE == 3) ? make_int4(rec.x0, rec.x1, rec.y0, rec.y1) : pbox[ob];
     const int nx = bx.y - bx.x, ny = bx.w - bx.z;
     const int4 ev = (MODE == 0 && nzbox) ? nzbox[ob] : bx;     // the rectangle that has to be evaluated
-    RecU rec = rec_unpack(rec_fetch(recs + (int64_t)b * P, (int)p, lane));
     const double counts = rec.scale;
     const double wsum = bd->w[0] + bd->w[1] + bd->w[2];
-    if (nx <= 0 || ny <= 0) {           // no sample image in this band
+    if (nx <= 0 || ny <= 0 || (MODE == 3 && rec.type < 0)) {   // no sample image in this band / no stamp
         if (lane == 0) out[job] = 0.0;
         return;
     }
@@ -161,14 +162,31 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     lt[64 + lane] = c_log_lc[lane];
     const LaneConst lc = lane_consts(lane, bd);
     const double eps = bd->eps;
+    if (MODE == 0) {
+        // A proposal so far from the patch that every component's exponent stays below -750 on the
+        // whole rectangle evaluates to exactly 0 there (exp underflows below -745.2): every pixel
+        // is masked out (model_patch > 0, sources.py:172) and only the mass term is left.  The
+        // first shrink steps of a slice sampler started from a wide interval are of this kind.
+        bool alive = false;
+        if (lane < ((rec.type == 0) ? K_PSF : K_GAL)) {
+            const Comp c = make_comp_lc(lc, rec);
+            const double qmin = quad_min_rect(c.qa, c.qb, c.qc, (double)ev.x - c.mx, (double)(ev.y - 1) - c.mx,
+                                              (double)ev.z - c.my, (double)(ev.w - 1) - c.my);
+            alive = !(0.5 * qmin > 750.0);
+        }
+        if (__ballot(alive) == 0ull) {
+            if (lane == 0) out[job] = -counts * wsum;
+            return;
+        }
+    }
     // mode 1 drops against the sky seen from the unit stamp: counts * g < eps e^-T
     int dropmode = HW_DROP_NONE;
     double log_floor = 0.0;
     if (Tdrop > 0.0) {
-        if (MODE == 0 || MODE == 2) dropmode = HW_DROP_SELF;
+        if (MODE == 0 || MODE == 2 || MODE == 3) dropmode = HW_DROP_SELF;
         else if (eps > 0.0 && counts > 0.0) { dropmode = HW_DROP_SKY; log_floor = (double)__logf((float)(eps / counts)); }
     }
-    const double *z = data ? data + offsets[ob] : nelec + (int64_t)b * H * W + (int64_t)bx.z * W + bx.x;
+    const double *z = (MODE == 3) ? nullptr : (data ? data + offsets[ob] : nelec + (int64_t)b * H * W + (int64_t)bx.z * W + bx.x);
     const int64_t zpitch = data ? nx : W;
     double a = 0.0, m = 0.0;
     for (int Y0 = ev.z; Y0 < ev.w; Y0 += HW_TH) {
@@ -182,6 +200,13 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
             const int Kk = hw_build(T, lc, rec, lane, dropmode, Tdrop, log_floor, Y0, X0, min(ev.y, X0 + HW_TW) - 1, 0, rb, direct);
             hw_walk(T, et, Kk, (double)xi, Y0, 0, rb, on, direct, acc, lane);
             __syncthreads();
+            if (MODE == 3) {
+#pragma unroll
+                for (int r = 0; r < HW_TH / 2; r++)
+                    if (on && 2 * r + half < rb) m += acc[r * 64 + lane];
+                __syncthreads();
+                continue;
+            }
             // the chunk's patch data, 16 rows of loads in flight at a time (addresses clamped into
             // the chunk instead of predicated), issued only once the walk's registers are free
             const double *zp = z + (int64_t)(Y0 - bx.z) * zpitch + (min(xi, ev.y - 1) - bx.x);
@@ -210,5 +235,5 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     }
     a = wave_sum(a);
     m = wave_sum(m);
-    if (lane == 0) out[job] = (MODE == 0) ? a - counts * wsum : a - m;
+    if (lane == 0) out[job] = (MODE == 0) ? a - counts * wsum : (MODE == 3) ? m : a - m;
 }

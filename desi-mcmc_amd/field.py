@@ -270,6 +270,14 @@ class ImageSet(object):
         L.check(L.lib().cel_samples_fetch(self._h, None, None, None, L.dptr(sums)))
         return sums
 
+    def sample_box_areas(self):
+        """pixels in the resident split's patch of every (source, band) -> (S, B) int64 (0: no patch)"""
+        S, tot = C.c_int64(0), C.c_int64(0)
+        L.check(L.lib().cel_samples_info(self._h, C.byref(S), C.byref(tot)))
+        offs = np.zeros(S.value * self.B + 1, dtype=np.int64)
+        L.check(L.lib().cel_samples_fetch(self._h, None, offs.ctypes.data_as(L.c_int64_p), None, None))
+        return np.diff(offs).reshape(S.value, self.B)
+
     def fetch_samples(self):
         """host copies of the resident split: (boxes[S,B,4] = y0,y1,x0,x1, offsets[S*B+1], data)"""
         S, tot = C.c_int64(0), C.c_int64(0)
@@ -280,6 +288,12 @@ class ImageSet(object):
         L.check(L.lib().cel_samples_fetch(self._h, boxes.ctypes.data_as(L.c_int32_p), offs.ctypes.data_as(L.c_int64_p),
                                           data.ctypes.data, None))
         return boxes, offs, data[:tot.value]
+
+    def stamp_mass(self, sources):
+        """sum of every source's unit stamp over its own box -> (S, B)  (sources.py:336-339)"""
+        out = np.zeros((sources.S, self.B))
+        L.check(L.lib().cel_stamp_mass(self._h, sources._h, L.dptr(out)))
+        return out
 
     def estep_stats(self, sources):
         """E-step reductions (celeste_em.py:38-91) -> (xtilde[S,B], mass[S,B], noise[B])."""

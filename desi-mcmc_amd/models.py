@@ -1,11 +1,15 @@
 """Catalogue-level model classes: mirror of the render / likelihood surface of CelestePy/models.py.
 
-`CelesteBase` keeps the reference's field list, source list and the two methods that sit on the
+`CelesteBase` keeps the reference's field list, source list, the two methods that sit on the
 render path -- render_model_image and img_log_likelihood (models.py:88-108) -- on top of the
-device-resident image sets, and Field.resample_photons (models.py:123-160) on top of the device
-photon split.  The per-source samplers (Source.resample*, slice sampling, Gamma draws) are host
-control flow around the path and are not reproduced here; they call Source.log_likelihood,
-which is (sources.py mirror).
+device-resident image sets, Field.resample_photons (models.py:123-160) on top of the device
+photon split, and the Gibbs sweep resample_model / resample_sources (models.py:75-83).
+
+resample_model runs the sweep for the whole catalogue on the device (celeste_mcmc.ModelGibbs: the
+photon split of every field, then every source's flux and location update in lock-step) and
+writes the new parameters back into the Source objects.  `resample_sources` alone, after
+Field.resample_photons has filled the sources' sample_image_list with host-side patches, is the
+reference's per-object loop (one Source.resample per source).
 
 Quirk Q4: the reference's render_model_image re-uses its `xlim` / `ylim` loop variables,
 so every source after the first is rendered onto the FIRST source's box and the result is
@@ -100,6 +104,52 @@ class CelesteBase(object):
         type_idx = type_idx[np.argsort(fluxes[type_idx])[::-1]][:num_srcs]
         blist = [self.srcs[i] for i in type_idx]
         return (blist, type_idx) if return_idx else blist
+
+    # ---- resample methods: models.py:75-83 ---------------------------------------------------------
+    def gibbs(self, seed=None, slice_args=None, rebuild=False):
+        """the catalogue-wide device sampler over this model's fields and sources (built once; the
+        Source objects are re-read when `rebuild` is set or their number changed)"""
+        from . import celeste_mcmc as cel_mcmc
+        g = getattr(self, "_gibbs", None)
+        if g is None or rebuild or g.S != len(self.srcs):
+            if seed is None:
+                seed = int(np.random.randint(0, 2 ** 31 - 1))
+            g = cel_mcmc.ModelGibbs.from_images([f.img_dict for f in self.field_list], [s.params for s in self.srcs],
+                                                seed=seed, slice_args=slice_args)
+            for gf, field in zip(g.fields, self.field_list):
+                gf.a_0, gf.b_0 = field.a_0, field.b_0
+            self._gibbs = g
+        return g
+
+    def sync_sources(self):
+        """write the sampler's state (locations, fluxes) back into the Source objects"""
+        g = self._gibbs
+        for i, s in enumerate(self.srcs):
+            s.params.u = g.u[i].copy()
+            s.params.fluxes = g.fluxes[i].copy()
+
+    def resample_model(self, n_sweeps=1, seed=None, slice_args=None, sync=True):
+        """resample each field's photons, then every source  -- models.py:75-79.  n_sweeps > 1 runs
+        that many sweeps back to back on the device before the Source objects are updated."""
+        if not self.srcs or not self.field_list:
+            return
+        g = self.gibbs(seed=seed, slice_args=slice_args)
+        if getattr(self, "_gibbs_dirty", True):
+            # the Source objects may have been edited since the last sweep
+            fresh = type(g).from_images([f.img_dict for f in self.field_list], [s.params for s in self.srcs], seed=g.seed)
+            g.typ, g.u, g.fluxes, g.shape = fresh.typ, fresh.u, fresh.fluxes, fresh.shape
+        for _ in range(int(n_sweeps)):
+            g.sweep()
+        self._gibbs_dirty = sync
+        if sync:
+            self.sync_sources()
+
+    def resample_sources(self, rng=None):
+        """one Source.resample per source, on the sample images Field.resample_photons stored
+        -- models.py:81-83"""
+        for src in self.srcs:
+            src.resample(rng=rng)
+        self._gibbs_dirty = True
 
     # ---- the render path -----------------------------------------------------------------------
     def render_model_image(self, fimg, xlim=None, ylim=None, exclude=None):

@@ -3,15 +3,29 @@
 `Source` keeps the reference's method names and argument meaning for the calls that sit on the
 render path -- compute_scatter_on_pixels / compute_model_patch (sources.py:351-395),
 flux_in_image (:120-129), get_bounding_box (:83-96), log_likelihood / log_likelihood_isolated /
-location_likelihood (:134-237) -- and adds log_likelihood_batch, which scores many proposals in
-one launch (the reference's slice sampler and HMC call log_likelihood 10-50 times per source per
-sweep, sources.py:308-319).  Sampling itself (resample_*, Gamma draws, slice sampling) is host
-control flow outside this path and is not reproduced here.
+location_likelihood (:134-237) -- and for the per-source Gibbs updates that drive it: resample /
+resample_fluxes / resample_location (:242-349), the star <-> galaxy move's image_like
+(:275-306), make_bbox_dict / get_active_sources / generate_background_patch (:434-483).  It adds
+log_likelihood_batch, which scores many proposals in one launch (the reference's slice sampler
+calls log_likelihood 10-50 times per source per sweep, sources.py:308-319).
+
+These per-object methods are the small-catalogue API (one device launch per likelihood call, sample
+patches on the host, as the reference holds them).  A whole catalogue is updated by
+celeste_mcmc.ModelGibbs -- the same steps for every source at once, patches resident on the device
+-- which CelesteBase.resample_model uses.
+
+Reference slips on this stretch, handled as follows:
+  * resample_location calls slicesample without importing it (NameError) and passes `step=`, which
+    slicesample does not read: sigma stays 1.0 (degrees) and the bounds are never applied.  The call
+    is reproduced as written (`sigma=` may be given to override);
+  * resample_fluxes passes the cached pixel grid as `u` (sources.py:338); the intended call -- the
+    unit stamp at the current location on the source's own box -- is what is summed here.
 """
 import numpy as np
 
 from . import celeste as _celeste
 from . import celeste_galaxy_conditionals as gal_funs
+from .util.infer.slicesample import slicesample
 
 BANDS = ['u', 'g', 'r', 'i', 'z']
 
@@ -85,9 +99,43 @@ class Source(object):
         self.params = params
         self.model = model
         self.sample_image_list = []      # (samp_img, fits_img, pixel_grid) like the reference
+        # a ~20 x 20 pixel box about the first guess (sources.py:23-27)
+        self.u_lower = np.asarray(self.params.u, dtype=np.float64) - .0025
+        self.u_upper = np.asarray(self.params.u, dtype=np.float64) + .0025
+        self.du = self.u_upper - self.u_lower
+        self.loc_samps, self.flux_samps, self.shape_samps, self.ll_samps = [], [], [], []
 
     def clear_sample_images(self):
         self.sample_image_list = []
+
+    @property
+    def object_type(self):
+        return "star" if self.is_star() else ("galaxy" if self.is_galaxy() else "none")
+
+    # ---- kept samples (sources.py:98-118) --------------------------------------------------------
+    @property
+    def location_samples(self):
+        return np.array(self.loc_samps)
+
+    @property
+    def flux_samples(self):
+        return np.array(self.flux_samps)
+
+    @property
+    def shape_samples(self):
+        return np.array(self.shape_samps)
+
+    @property
+    def loglike_samples(self):
+        return np.array(self.ll_samps)
+
+    def store_sample(self):
+        self.loc_samps.append(np.array(self.params.u, copy=True))
+        self.flux_samps.append(np.array([self.params.flux_dict[b] for b in BANDS]))
+        self.shape_samps.append(np.array(self.params.shape, copy=True))
+
+    def store_loglike(self):
+        self.ll_samps.append(self.log_likelihood())
 
     def is_star(self):
         return self.params.a == 0
@@ -193,3 +241,130 @@ class Source(object):
         """likelihood if this were the only source on its patch  -- sources.py:188-237"""
         return float(self.log_likelihood_batch(None if u is None else [u], None if fluxes is None else [fluxes],
                                                None if shape is None else [shape], isolated=True)[0])
+
+    # ---- resampling (sources.py:242-349) ---------------------------------------------------------
+    def resample(self, rng=None):
+        assert len(self.sample_image_list) != 0, "resample source needs sampled images"
+        self.resample_fluxes(rng=rng)
+        self.resample_location(rng=rng)
+
+    def resample_fluxes(self, rng=None):
+        """fluxes u,g,r,i,z given everything else: Gamma(a_0 + photons, 1 / (b_0 + sum(unit stamp) *
+        kappa / calib)) per band  -- sources.py:321-349"""
+        rng = np.random if rng is None else rng
+        a_0, b_0 = 5., .005
+        band_counts = {b: 0 for b in BANDS}
+        psf_sums = {b: 0 for b in BANDS}
+        for src_img, fits_img, pixel_grid in self.sample_image_list:
+            band_counts[fits_img.band] += np.sum(np.array(src_img.data))
+            psf_ns, ylim, xlim = self.compute_scatter_on_pixels(fits_img)     # see the module docstring
+            if psf_ns is not None:
+                psf_sums[fits_img.band] += np.sum(psf_ns) * fits_img.kappa / fits_img.calib
+        a_n = a_0 + np.array([band_counts[b] for b in BANDS])
+        b_n = b_0 + np.array([psf_sums[b] for b in BANDS])
+        self.params.fluxes = rng.gamma(a_n, 1. / b_n)
+
+    def resample_location(self, u=None, rng=None, **slice_args):
+        """conditionally resample the location by slice sampling  -- sources.py:308-319"""
+        if u is None:
+            u = np.array(self.params.u, dtype=np.float64, copy=True)
+        kw = dict(step_out=False, upper_bound=self.u_upper, lower_bound=self.u_lower)
+        kw.update(slice_args)                 # `step=self.du/5` of the reference is not a slicesample argument
+        if "seed" not in kw:
+            kw["seed"] = int((np.random if rng is None else rng).randint(0, 2 ** 31 - 1))
+        u, ll = slicesample(u, lambda uu: self.location_likelihood(uu), **kw)
+        self.params.u = u
+        return u
+
+    def resample_shape(self):
+        """shape/extent of a galaxy: not implemented in the reference either (sources.py:321-325)"""
+        return
+
+    # ---- star <-> galaxy move (sources.py:247-306) ------------------------------------------------
+    def image_like(self, src, img):
+        """Poisson log-likelihood of `img` on this source's bounding box with `src` rendered on the
+        stored background  -- the closure of calculate_acceptance_logprob, sources.py:277-291"""
+        xlim, ylim = self.bounding_boxes[img]
+        background_img = self.background_image_dict[img]
+        data_img = img.nelec[ylim[0]:ylim[1], xlim[0]:xlim[1]]
+        invvar = getattr(img, "invvar", None)
+        mask_img = np.ones(data_img.shape) if invvar is None else invvar[ylim[0]:ylim[1], xlim[0]:xlim[1]]
+        model_img, _, _ = src.compute_model_patch(img, xlim=xlim, ylim=ylim)
+        return poisson_loglike(data=data_img, model_img=background_img + model_img, mask=mask_img)
+
+    def calculate_acceptance_logprob(self, proposal, logprob_proposal, logprob_reverse, logdet, images):
+        """sources.py:275-306; the priors (model.logprior) are the caller's"""
+        curr_like = np.sum([self.image_like(self, img) for img in images])
+        curr_logprior = self.model.logprior(self.params)
+        proposal_source = self.model._source_type(proposal, self.model)
+        prop_like = np.sum([self.image_like(proposal_source, img) for img in images])
+        prop_logprior = self.model.logprior(proposal_source.params)
+        return (prop_like + prop_logprior) - (curr_like + curr_logprior) + \
+               (logprob_reverse - logprob_proposal) + logdet
+
+    def resample_type(self, proposal_fun=None, rng=None):
+        """star vs galaxy by a reversible jump  -- sources.py:247-261.  Needs model.prior_sample /
+        model.logprior (priors are outside this path) and bounding_boxes / background_image_dict."""
+        rng = np.random if rng is None else rng
+        proposal_fun = self.propose_other_type_prior if proposal_fun is None else proposal_fun
+        proposal, logpdf, logreverse, logdet = proposal_fun()
+        fimgs = [self.model.field_list[0].img_dict[b] for b in self.model.bands]
+        accept_logprob = self.calculate_acceptance_logprob(proposal, logpdf, logreverse, logdet, fimgs)
+        if np.log(rng.rand()) < accept_logprob:
+            self.params = proposal
+
+    def propose_other_type_prior(self):
+        """prior-based proposal  -- sources.py:263-273"""
+        if self.is_star():
+            params, logprob = self.model.prior_sample('galaxy', u=self.params.u)
+        elif self.is_galaxy():
+            params, logprob = self.model.prior_sample('star', u=self.params.u)
+        logreverse = self.model.logprior(self.params)
+        return params, logprob, logreverse, 0.
+
+
+# ---- source utility functions (sources.py:430-483) --------------------------------------------------
+def make_bbox_dict(params, images, pixel_radius=None):
+    """{img: (xlim, ylim)}: the area a source's model affects  -- sources.py:434-456"""
+    if pixel_radius is None:
+        raise NotImplementedError
+
+    def image_bbox(params, img):
+        img_ymax, img_xmax = img.nelec.shape
+        px, py = img.equa2pixel(params.u)
+        xlim = (np.max([0, int(np.floor(px - pixel_radius))]), np.min([img_xmax, int(np.ceil(px + pixel_radius))]))
+        ylim = (np.max([0, int(np.floor(py - pixel_radius))]), np.min([img_ymax, int(np.ceil(py + pixel_radius))]))
+        return xlim, ylim
+    return {img: image_bbox(params, img) for img in images}
+
+
+def get_active_sources(source, source_list, image):
+    """sources whose bounding box intersects `source`'s in `image`  -- sources.py:458-474"""
+    def intersect(sa, sb, image):
+        xlima, ylima = sa.bounding_boxes[image]
+        xlimb, ylimb = sb.bounding_boxes[image]
+        widtha, heighta = xlima[1] - xlima[0], ylima[1] - ylima[0]
+        widthb, heightb = xlimb[1] - xlimb[0], ylimb[1] - ylimb[0]
+        return (np.abs(xlima[0] - xlimb[0]) * 2 < (widtha + widthb)) and \
+               (np.abs(ylima[0] - ylimb[0]) * 2 < (heighta + heightb))
+    return [s for s in source_list if intersect(s, source, image) and s is not source]
+
+
+def generate_background_patch(source, source_list, image):
+    """epsilon + every active source's model patch on `source`'s bounding box  -- sources.py:476-483.
+    All active sources are rendered on the box in ONE device call."""
+    active_sources = get_active_sources(source, source_list, image)
+    xlim, ylim = source.bounding_boxes[image]
+    y0, y1, x0, x1 = int(ylim[0]), int(ylim[1]), int(xlim[0]), int(xlim[1])
+    background = np.zeros((y1 - y0, x1 - x0)) + image.epsilon
+    if active_sources:
+        iset = _celeste._image_set((image,))
+        counts_fn = lambda p, im: (p.flux_dict[im.band] / im.calib) * im.kappa      # noqa: E731  (sources.py:393-394)
+        typ, radec, counts, shape = _celeste._source_arrays([s.params for s in active_sources], (image,), counts_fn=counts_fn)
+        sset = iset._sources(typ, radec, counts, shape)
+        boxes = np.tile(np.array([[y0, y1, x0, x1]], dtype=np.int32), (len(active_sources), 1))
+        patches, _ = iset.stamps(sset, 0, scaled=True, boxes_in=boxes)
+        for p in patches:
+            if p is not None:
+                background += p
+    return background

@@ -217,6 +217,11 @@ int cel_patch_loglik_multi(cel_images *img, cel_sources *src, const int32_t *own
                            const int32_t *boxes, const int64_t *offsets, const double *data, int mem, int mode,
                            double *ll_out);
 
+/* Sum of every source's UNIT stamp over its own box, in every band: mass[s*B + b] -- what
+ * Source.resample_fluxes multiplies by kappa/calib for the rate of its Gamma conditional
+ * (CelestePy/sources.py:336-339) and celeste_em's sum_fs (celeste_em.py:89).  0 without a stamp.  Host output. */
+int cel_stamp_mass(cel_images *img, cel_sources *src, double *mass);
+
 /* ---- photon split (Gibbs step) ------------------------------------------------------------ */
 /* boxes[(b*S+s)*4..] = y0,y1,x0,x1 and status[b*S+s] (as cel_stamp_boxes) for every band at once */
 int cel_source_boxes(cel_images *img, cel_sources *src, int32_t *boxes, int32_t *status);

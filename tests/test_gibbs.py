@@ -1,0 +1,248 @@
+"""GPU tests of the Gibbs sweep (BASELINE configs[4] flavour): the catalogue-wide device sampler
+ModelGibbs (CelesteBase.resample_model, models.py:75-83) and the per-object mirrors
+Source.resample / resample_fluxes / resample_location (sources.py:242-349).
+
+RNG parity with the reference (randomkit + numpy's global MT19937) is impossible; what is checked:
+exact photon conservation, the Gamma conditionals' parameters, agreement of the batched device
+likelihood with the per-object one, and the posterior a short chain reaches for a bright star."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+BANDS = ["u", "g", "r", "i", "z"]
+
+
+@pytest.fixture(scope="module")
+def cel():
+    import desi_mcmc_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def small_scene(cel, H=96, W=112, seed=3):
+    """5 band images of one synthetic frame: a bright isolated star, a fainter star, two galaxies"""
+    from test_hip_parity import frame_images
+    rec = load_golden("bands_253.npz")
+    imgs0 = frame_images(cel, rec, H, W)
+    pix = np.array([[30.3, 40.6], [80.2, 25.7], [60.5, 70.1], [20.9, 78.4]])
+    typ = np.array([0, 0, 1, 1])
+    flux = np.array([[400., 500., 600., 550., 450.], [30., 40., 50., 45., 35.], [150., 200., 260., 240., 180.],
+                     [60., 80., 100., 90., 70.]])
+    shape = np.array([[0, 0, 0, 0], [0, 0, 0, 0], [0.4, 1.2, 35.0, 0.6], [0.7, 0.8, 120.0, 0.8]], dtype=float)
+    params = []
+    for s in range(4):
+        u = imgs0[2].pixel2equa(pix[s])
+        if typ[s]:
+            params.append(cel.SrcParams(u=u, a=1, fluxes=flux[s].copy(), theta=shape[s, 0], sigma=shape[s, 1],
+                                        phi=shape[s, 2], rho=shape[s, 3]))
+        else:
+            params.append(cel.SrcParams(u=u, a=0, fluxes=flux[s].copy()))
+    from desi_mcmc_amd import models
+    m = models.Celeste()
+    m.initialize_sources(init_src_params=params)
+    lam = np.stack([m.render_model_image(im) for im in imgs0])
+    nelec = np.random.RandomState(seed).poisson(lam).astype(np.float64)
+    imgs = frame_images(cel, rec, H, W, nelec=nelec)
+    return imgs, params, pix, flux, nelec
+
+
+def fisher_sigma_pix(cel, img, params, s):
+    """Cramer-Rao error (pixels) of source s's x and y position in one image, all else fixed"""
+    from desi_mcmc_amd import models
+    m = models.Celeste()
+    m.initialize_sources(init_src_params=params)
+    lam = m.render_model_image(img)
+    h = 1e-3
+    u0 = np.array(params[s].u, copy=True)
+    px = img.equa2pixel(u0)
+    d = []
+    for ax in range(2):
+        dp = np.zeros(2)
+        dp[ax] = h
+        params[s].u = img.pixel2equa(px + dp)
+        lp = m.render_model_image(img)
+        params[s].u = img.pixel2equa(px - dp)
+        lm = m.render_model_image(img)
+        d.append((lp - lm) / (2 * h))
+    params[s].u = u0
+    info = np.array([[np.sum(d[i] * d[j] / lam) for j in range(2)] for i in range(2)])
+    return info
+
+
+def test_stamp_mass_vs_oracle(cel, orc):
+    imgs, params, pix, flux, nelec = small_scene(cel)
+    from desi_mcmc_amd import celeste_mcmc
+    g = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params, seed=1)
+    f = g.fields[0]
+    mass = f.iset.stamp_mass(g._sources(f))
+    rec = load_golden("bands_253.npz")
+    B = orc.pack_bands(rec)
+    for b in range(5):
+        band = B[b].copy()
+        band[24:26] = [112 / 2.0, 96 / 2.0]
+        for s in range(4):
+            p, _, _ = orc.source_patch(band, 96, 112, g.typ[s], g.u[s], g.shape[s])
+            np.testing.assert_allclose(mass[s, b], p.sum(), rtol=1e-10)
+
+
+def test_lockstep_device_loglik_equals_per_object_loglik(cel):
+    """ModelGibbs.location_loglik (resident patches, one launch for all sources) == Source.log_likelihood
+    on the same photons fetched to the host"""
+    from desi_mcmc_amd import celeste_mcmc, sources
+    imgs, params, pix, flux, nelec = small_scene(cel)
+    g = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params, seed=5)
+    g.resample_photons()
+    f = g.fields[0]
+    boxes, offs, data = f.iset.fetch_samples()
+    rs = np.random.RandomState(0)
+    idx = np.array([0, 1, 2, 3, 0, 2])
+    U = g.u[idx] + rs.normal(0, 3e-5, size=(6, 2))
+    U[4] = g.u[0] + 0.5                      # half a degree off: the star fails the overlap test -> -counts * sum(w)
+    got = g.location_loglik(idx, U)
+    for i, (s, u) in enumerate(zip(idx, U)):
+        src = sources.Source(params[s])
+        for b in range(5):
+            k = s * 5 + b
+            y0, y1, x0, x1 = boxes[s, b]
+            if y1 > y0:
+                src.sample_image_list.append((sources.SamplePatch(data[offs[k]:offs[k + 1]].reshape(y1 - y0, x1 - x0),
+                                                                  (y0, y1), (x0, x1)), imgs[b], None))
+        np.testing.assert_allclose(got[i], src.log_likelihood(u=u), rtol=1e-11)
+    wsum = np.array([im.weights.sum() for im in imgs])
+    np.testing.assert_allclose(got[4], -np.sum(g.counts(f)[0] * wsum), rtol=1e-13)
+
+
+def test_model_gibbs_conserves_photons_and_draws_the_gamma_conditionals(cel):
+    from desi_mcmc_amd import celeste_mcmc
+    imgs, params, pix, flux, nelec = small_scene(cel)
+    g = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params, seed=11, slice_args=dict(sigma=1e-3))
+    f = g.fields[0]
+    for sweep in range(3):
+        noise = g.resample_photons()[0]
+        # every photon of every image goes to exactly one source or to the sky
+        np.testing.assert_array_equal(f.sums.sum(axis=0) + noise, nelec.reshape(5, -1).sum(axis=1))
+        # the sky level's Gamma conditional (models.py:155-160): mean (a_0 + noise) / (b_0 + npix)
+        assert np.all(np.abs(f.epsilon / ((5 + noise) / (.005 + 96 * 112)) - 1.0) < 0.01)
+        assert np.all([abs(im.epsilon - e) == 0 for im, e in zip(imgs, f.epsilon)])
+        # the flux Gamma conditional (sources.py:341-345), re-drawn here with the same generator state
+        state = g.rng.get_state()
+        mass = f.iset.stamp_mass(f.sset)
+        fl = g.resample_fluxes().copy()
+        chk = np.random.RandomState(0)
+        chk.set_state(state)
+        want = chk.gamma(5. + f.sums, 1. / (.005 + mass * (f.kappa / f.calib)[None, :]))
+        np.testing.assert_allclose(fl, want, rtol=1e-12)
+        g.resample_locations()
+        g.sweeps += 1
+    assert g.timing["rounds"] > 0 and g.timing["evals"] >= 4 * g.timing["rounds"] // 4
+
+
+def test_short_chain_recovers_a_bright_star(cel):
+    """the posterior of the bright star's position: mean within 4 Fisher sigma of the truth, spread
+    of the order of the Fisher sigma; fluxes within 5 sigma of their Poisson error"""
+    from desi_mcmc_amd import celeste_mcmc
+    imgs, params, pix, flux, nelec = small_scene(cel)
+    info = sum(fisher_sigma_pix(cel, im, params, 0) for im in imgs)
+    sig = np.sqrt(np.diag(np.linalg.inv(info)))                 # pixels
+    assert np.all(sig < 0.05)
+    g = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params, seed=2, slice_args=dict(sigma=1e-3))
+    # start the star a fifth of a pixel off
+    g.u[0] = imgs[2].pixel2equa(pix[0] + np.array([0.2, -0.15]))
+    burn, keep = 15, 60
+    locs, fls = [], []
+    for it in range(burn + keep):
+        g.sweep()
+        if it >= burn:
+            locs.append(imgs[2].equa2pixel(g.u[0]))
+            fls.append(g.fluxes[0].copy())
+    locs, fls = np.array(locs), np.array(fls)
+    err = locs.mean(axis=0) - pix[0]
+    assert np.all(np.abs(err) < 4 * sig), (err, sig)
+    spread = locs.std(axis=0)
+    assert np.all(spread < 4 * sig) and np.all(spread > 0.2 * sig), (spread, sig)
+    counts = flux[0] / np.array([im.calib for im in imgs]) * np.array([im.kappa for im in imgs])
+    rel = (fls.mean(axis=0) - flux[0]) / flux[0]
+    assert np.all(np.abs(rel) < 5.0 / np.sqrt(counts) + 0.01), rel
+    # the galaxies stay where their photons are, too
+    for s in (2, 3):
+        assert np.all(np.abs(imgs[2].equa2pixel(g.u[s]) - pix[s]) < 0.5)
+
+
+def test_reference_effective_call_sigma_one_degree(cel):
+    """Source.resample_location's call as the reference makes it (sigma = 1 degree, no stepping out):
+    the first shrink steps land hundreds of pixels away, where the model underflows to exactly 0
+    (the kernel's far-proposal shortcut); the chain must still end next to the photons"""
+    from desi_mcmc_amd import celeste_mcmc
+    imgs, params, pix, flux, nelec = small_scene(cel)
+    g = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params, seed=4)      # slice_args: reference default
+    assert g.slice_args == dict(step_out=False)
+    for it in range(3):
+        g.sweep()
+    assert g.timing["rounds"] / 3 > 20                         # ~log2(1 deg / posterior width) shrinks per axis
+    assert np.all(np.abs(imgs[2].equa2pixel(g.u[0]) - pix[0]) < 0.3)
+
+
+def test_celeste_base_resample_model_and_per_object_resample(cel):
+    from desi_mcmc_amd import models
+    imgs, params, pix, flux, nelec = small_scene(cel)
+    m = models.Celeste()
+    m.add_field(dict(zip(BANDS, imgs)))
+    m.initialize_sources(init_src_params=params)
+    u0 = np.array([s.params.u for s in m.srcs])
+    m.resample_model(n_sweeps=2, seed=9, slice_args=dict(sigma=1e-3))
+    u1 = np.array([s.params.u for s in m.srcs])
+    assert np.all(u1 != u0) and np.all(np.abs(u1 - u0) < 2e-4)
+    assert all(np.asarray(s.params.fluxes).shape == (5,) and np.all(np.asarray(s.params.fluxes) > 0) for s in m.srcs)
+    # the sky levels were redrawn and written to the image objects (models.py:156-160)
+    assert all(abs(im.epsilon / np.median(im.nelec) - 1) < 0.2 for im in imgs)
+    # the reference's per-object loop: photons to the host, then one Source.resample per source
+    rng = np.random.RandomState(3)
+    m.field_list[0].resample_photons(m.srcs, seed=77, rng=rng)
+    assert all(len(s.sample_image_list) == 5 for s in m.srcs)
+    before = np.array([s.params.u for s in m.srcs])
+    m.srcs[0].resample_fluxes(rng=rng)
+    z = np.array([np.sum(sp.data) for sp, _, _ in m.srcs[0].sample_image_list])
+    cnt = np.asarray(m.srcs[0].params.fluxes) / np.array([i.calib for i in imgs]) * np.array([i.kappa for i in imgs])
+    assert np.all(np.abs(cnt / (5 + z) - 1) < 6 / np.sqrt(z))            # Gamma(5 + z, ~1 / (kappa / calib))
+    m.srcs[0].resample_location(rng=rng, sigma=1e-3)
+    after = np.array(m.srcs[0].params.u)
+    assert np.all(after != before[0]) and np.all(np.abs(imgs[2].equa2pixel(after) - pix[0]) < 0.3)
+    m.resample_sources(rng=rng)                                             # every source, reference call (sigma = 1 deg)
+    assert np.all(np.abs(imgs[2].equa2pixel(m.srcs[0].params.u) - pix[0]) < 0.3)
+    m.srcs[0].store_sample()
+    m.srcs[0].store_loglike()
+    assert m.srcs[0].location_samples.shape == (1, 2) and np.isfinite(m.srcs[0].loglike_samples[0])
+
+
+def test_background_patch_and_image_like(cel, orc):
+    """generate_background_patch / get_active_sources / make_bbox_dict (sources.py:434-483) and the
+    star <-> galaxy move's image_like (:277-291)"""
+    from desi_mcmc_amd import models, sources
+    imgs, params, pix, flux, nelec = small_scene(cel)
+    m = models.Celeste()
+    m.add_field(dict(zip(BANDS, imgs)))
+    m.initialize_sources(init_src_params=params)
+    img = imgs[2]
+    for s in m.srcs:
+        s.bounding_boxes = sources.make_bbox_dict(s.params, imgs, pixel_radius=45)
+    src = m.srcs[2]
+    act = sources.get_active_sources(src, m.srcs, img)
+    assert src not in act and len(act) >= 1
+    bg = sources.generate_background_patch(src, m.srcs, img)
+    xlim, ylim = src.bounding_boxes[img]
+    want = np.zeros((ylim[1] - ylim[0], xlim[1] - xlim[0])) + img.epsilon
+    for a in act:
+        p, _, _ = a.compute_model_patch(img, xlim=xlim, ylim=ylim)
+        want += p
+    np.testing.assert_allclose(bg, want, rtol=1e-12)
+    src.background_image_dict = {img: bg}
+    ll = src.image_like(src, img)
+    model, _, _ = src.compute_model_patch(img, xlim=xlim, ylim=ylim)
+    np.testing.assert_allclose(ll, orc.poisson_loglike(img.nelec[ylim[0]:ylim[1], xlim[0]:xlim[1]], bg + model), rtol=1e-12)

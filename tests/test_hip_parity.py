@@ -420,6 +420,43 @@ def test_full_size_spot_check_vs_oracle(cel, ctx, orc, big_field):
         np.testing.assert_allclose(lam[b, y0:y0 + h, x0:x0 + w], o_lam[0, y0:y0 + h, x0:x0 + w], rtol=RT_LAM)
 
 
+def test_config3_full_vs_oracle(cel, ctx, orc, big_field):
+    """BASELINE configs[2] at full size against the CPU oracle over the WHOLE field: all 10 000
+    sources, all 5 bands, every one of the 2.1e7 model pixels at 1e-10, per-band log-likelihoods at
+    1e-11, the work counters exact; then the other two tile layouts on one band.  (The oracle needs
+    ~1 min on 16 threads; set CEL_SKIP_FULL_ORACLE=1 to skip.)"""
+    import os
+    if os.environ.get("CEL_SKIP_FULL_ORACLE") == "1":
+        pytest.skip("CEL_SKIP_FULL_ORACLE=1")
+    f = big_field
+    ll, llb = f.images.render(f.sources, loglik=True)
+    lam = f.images.model_images()
+    st = f.images.stats()
+    ob = oracle_bands(f)
+    try:
+        orc.set_threads(min(orc.max_threads(), len(os.sched_getaffinity(0))))
+    except AttributeError:
+        pass
+    o_lam, o_ll, o_st = orc.render_field(ob, f.H, f.W, f.src["type"], f.src["radec"], f.src["counts"], f.src["shape"], f.nelec)
+    assert st["n_srcpix"] == o_st["n_srcpix"] and st["n_gauss"] == o_st["n_gauss"]
+    for b in range(f.B):
+        np.testing.assert_allclose(lam[b], o_lam[b], rtol=RT_LAM)
+    np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
+    np.testing.assert_allclose(ll, o_ll.sum(), rtol=RT_LL)
+    del lam
+    # the 64 x 32 and 16 x 128 tile layouts on the r band of the same field
+    b = 2
+    for layout in (0, 2):
+        c2 = cel.Context(0)
+        c2.set_option(cel._lib.CEL_OPT_TILE_LAYOUT, layout)
+        iset = cel.ImageSet(c2, f.bands[b:b + 1], f.H, f.W, nelec=f.nelec[b:b + 1])
+        ss = cel.SourceSet(c2, f.S, 1).set(f.src["type"], f.src["radec"], f.src["counts"][:, b:b + 1], f.src["shape"])
+        l2, llb2 = iset.render(ss, loglik=True)
+        np.testing.assert_allclose(iset.model_images()[0], o_lam[b], rtol=RT_LAM)
+        np.testing.assert_allclose(llb2[0], o_ll[b], rtol=RT_LL)
+        del iset, ss, c2
+
+
 def test_full_size_gibbs_kernels_properties(cel, ctx, big_field):
     """BASELINE-size field (10 000 sources x 5 bands x 2048^2), the per-source kernels, through
     properties that do not need the oracle: photon conservation of the split, the E-step's
