@@ -1,15 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- the headline metric of BASELINE.json on MI355X.
+"""bench.py -- the headline metric of BASELINE.json on MI355X, plus the two multi-GPU configurations.
 
-Workload (config.workload): BASELINE.json configs[2], the configuration the metric is quoted
-on -- 10 000 mixed star/galaxy sources x 5 bands x 2048^2, synthetic (data "synthetic").
+Default workload (config.workload = mixed10k_2048): BASELINE.json configs[2], the configuration the
+metric is quoted on -- 10 000 mixed star/galaxy sources x 5 bands x 2048^2, synthetic.
 One step = one full-field log-likelihood evaluation with everything resident in HBM:
     k_prep (WCS, galaxy shape matrix, bounding box per source x band) -> k_bin (tile lists)
     -> k_render (model images + fused Poisson term) -> k_reduce -> 5 doubles to the host
     [-> one all-reduce of the 5 doubles across ranks when N > 1].
 value = source-pixel evaluations per second, whole job (sum over ranks / max-over-ranks time);
-ms_per_step = full-field log-lik latency.  N > 1: one field per rank ("weak"), launched by
-torchrun, one collective per step (RCCL).
+ms_per_step = full-field log-lik latency.  N > 1: one field per rank ("weak"), one collective per
+step (RCCL).  Other render workloads: stars1k_512 (configs[1]), stars10k_2048, stars2k_4096.
+
+--workload fields8_2048  configs[3] stand-in (the Stripe-82 data is not in the reference tree): 8
+    synthetic 10k-source fields dealt to the ranks (dist.field_shard), every step scores every field;
+    total work fixed ("strong"), one all-reduce of the per-band sums per step.
+--workload gibbs10k      configs[4]: Gibbs sweeps (photon split + sky level, flux Gamma conditionals,
+    lock-step slice sampling of every source's location) over the 10k-source field; one step = one
+    sweep; value = source updates (samples) per second.  N > 1: one independent chain per GPU over
+    the same field (the standard way to parallelise MCMC; "weak"), the chains' field log-likelihoods
+    all-reduced every sweep.
+
+`python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run child)
+before touching the GPU, and refuses to run on fewer than N GPUs.
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--kernel direct|recurrence]
 """
@@ -27,46 +39,24 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TF = 78.6     # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+FP64_LANE_OPS_PEAK = 3.93e13 # the same in lane-instructions per second (an fma counts once)
 FLOP_PER_GAUSS = 35.0        # SURVEY 8d accounting: 10 arithmetic + exp counted as 25
 
-# HBM bytes per k_render launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-# separate passes, gfx950 correction 2*FETCH + WRITE re-calibrated for this access pattern with
-# tools/calib_traffic.hip).  Counters cannot be read from inside this process: the number is the
-# committed measurement of exactly this command and is reported only for the configuration it
-# was taken on; any other configuration gets null.
-PMC_TRAFFIC = {   # (workload, kernel, tail_log, layout) -> (HBM bytes per k_render launch, source)
-    ("mixed10k_2048", "recurrence", 32.0, 1): (386329760.0, "profiles/r01_final_pmc.json"),
-}
-# same provenance: 2 * SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (two waves per SIMD) and SQ_INSTS_VALU of that launch
-PMC_VALU = {
-    ("mixed10k_2048", "recurrence", 32.0, 1): (0.82, 6.64e8, "profiles/r01_final_pmc.json"),
+# Per-launch PMC figures of the dominant kernel.  Counters cannot be read from inside this process
+# (rocprofv3 runs in its own passes: tools/pmc_pass.sh), so these are the committed measurements of
+# exactly this command, reported only for the configuration they were taken on (null otherwise):
+#   traffic = 2 * FETCH_SIZE + WRITE_SIZE (gfx950 correction, re-calibrated with tools/calib_traffic.hip)
+#   valu    = SQ_INSTS_VALU (wave-instructions), busy = 2 * SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES
+PMC = {   # (workload, kernel, tail_log, layout) -> dict
+    ("mixed10k_2048", "recurrence", 32.0, 1): dict(traffic=386329760.0, valu_insts=6.64e8, valu_busy=0.82,
+                                                   source="profiles/r01_final_pmc.json"),
 }
 CPU_THREADS_MAX = 16         # the GPU box's CPU share for one GPU
 
-
-def cpu_baseline(field, nsample, orc):
-    """The CPU oracle timed on a bounded sample of the SAME workload (first `nsample` sources,
-    all bands, full frame) on the host's cores.  Reported beside the GPU number; not the target."""
-    sl = slice(0, nsample)
-    bands = field.bands.copy()
-    for b in range(field.B):
-        bands[b, 36] = field.images.band(b)[36]
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    orc.set_threads(max(1, min(orc.max_threads(), avail, CPU_THREADS_MAX)))
-    t0 = time.perf_counter()
-    lam, ll, st = orc.render_field(bands, field.H, field.W, field.src["type"][sl], field.src["radec"][sl],
-                                   field.src["counts"][sl], field.src["shape"][sl], field.nelec)
-    dt = time.perf_counter() - t0
-    return dict(value=st["n_srcpix"] / dt, unit="source-pixel evals/s", cores=orc.max_threads(), kind="port",
-                sample="first %d of %d sources, %d bands, %dx%d frame, %.2e source-px in %.2f s wall "
-                       "(oracle/celeste_oracle.c, OpenMP over sources)"
-                       % (nsample, field.S, field.B, field.H, field.W, st["n_srcpix"], dt),
-                gauss_evals_per_s=st["n_gauss"] / dt)
+RENDER_WORKLOADS = ("mixed10k_2048", "stars1k_512", "stars10k_2048", "stars2k_4096", "stamp51")
 
 
+# ---- launcher ------------------------------------------------------------------------------------------
 def visible_gpus():
     """Number of HIP devices, WITHOUT initialising the GPU runtime in this process (a child does it)."""
     import subprocess
@@ -104,8 +94,8 @@ def self_launch(n, argv, port=0):
 
 
 def dry_run(args):
-    """CEL_BENCH_DRYRUN=1: rendezvous + the two collectives of the timed region on synthetic
-    numbers, no GPU and no metric -- what the CPU test of the self-launch path runs."""
+    """CEL_BENCH_DRYRUN=1: rendezvous + the collectives of the timed region on synthetic numbers, no
+    GPU and no metric -- what the CPU test of the self-launch path runs."""
     from desi_mcmc_amd import dist
     rank, world, local = dist.init_from_env(backend=os.environ.get("CEL_BENCH_BACKEND", "gloo"))
     if world != args.gpus:
@@ -113,13 +103,417 @@ def dry_run(args):
     red = dist.LoglikReducer(5, depth=2)
     red.submit(np.full(5, float(rank + 1)))
     got = red.drain()[-1]
+    shard = dist.field_shard(8, world, rank)
     dist.barrier()
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": world, "allreduce_check": float(got[0]),
-                          "expected": world * (world + 1) / 2.0}))
+                          "expected": world * (world + 1) / 2.0, "fields_of_rank0": shard}))
     if world > 1:
         import torch.distributed as td
         td.destroy_process_group()
+
+
+# ---- shared pieces -----------------------------------------------------------------------------------
+class Timer(object):
+    """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + device sync on both sides"""
+
+    def __init__(self, dist, torch):
+        self.dist, self.torch = dist, torch
+
+    def run(self, step, warmup, steps, after_warmup=None, finish=None):
+        for _ in range(warmup):
+            step()
+        if after_warmup:
+            after_warmup()
+        self.dist.barrier()
+        self.torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        if finish:
+            finish()
+        self.torch.cuda.synchronize()
+        self.dist.barrier()
+        return time.perf_counter() - t0
+
+
+def reduce_over_ranks(torch, world, local, dt, sums):
+    """max over ranks of the elapsed time, sum over ranks of the work counters"""
+    if world == 1:
+        return dt, list(sums)
+    import torch.distributed as td
+    t = torch.tensor([dt], dtype=torch.float64)
+    s = torch.tensor(list(sums), dtype=torch.float64)
+    if td.get_backend() == "nccl":
+        t, s = t.cuda(local), s.cuda(local)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    td.all_reduce(s, op=td.ReduceOp.SUM)
+    return t.item(), [float(v) for v in s.cpu()]
+
+
+def host_threads():
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, CPU_THREADS_MAX))
+
+
+def cpu_baseline(field, nsample, orc):
+    """The CPU oracle (kind "port": oracle/celeste_oracle.c, the restatement of the reference's path;
+    the reference's own Cython does not build here) timed on BOUNDED samples of the SAME workload on
+    the host's cores: (1) all threads, patch-accumulating render + log-lik of the first `nsample`
+    sources in all bands; (2) the same on ONE thread for a quarter of them; (3) the reference's
+    literal gen_model_image semantics -- a full H x W frame allocated, scaled and added per source
+    (celeste.py:203-219) -- for 100 sources in one band, which is what makes the reference O(S H W)."""
+    bands = field.bands.copy()
+    for b in range(field.B):
+        bands[b, 36] = field.images.band(b)[36]
+    nthr = max(1, min(orc.max_threads(), host_threads()))
+
+    def timed(ns, threads):
+        sl = slice(0, ns)
+        orc.set_threads(threads)
+        t0 = time.perf_counter()
+        lam, ll, st = orc.render_field(bands, field.H, field.W, field.src["type"][sl], field.src["radec"][sl],
+                                       field.src["counts"][sl], field.src["shape"][sl], field.nelec)
+        return st, time.perf_counter() - t0
+    st, dt = timed(nsample, nthr)
+    n1 = max(1, nsample // 4)
+    st1, dt1 = timed(n1, 1)
+    out = dict(value=st["n_srcpix"] / dt, unit="source-pixel evals/s", cores=nthr, kind="port",
+               sample="first %d of %d sources, %d bands, %dx%d frame, %.2e source-px in %.2f s wall "
+                      "(oracle/celeste_oracle.c, OpenMP over sources)"
+                      % (nsample, field.S, field.B, field.H, field.W, st["n_srcpix"], dt),
+               gauss_evals_per_s=st["n_gauss"] / dt,
+               one_thread={"value": st1["n_srcpix"] / dt1, "cores": 1,
+                           "sample": "first %d sources, %.2e source-px in %.2f s" % (n1, st1["n_srcpix"], dt1)})
+    stars = np.nonzero(field.src["type"] == 0)[0][:100]
+    if stars.size:
+        orc.set_threads(nthr)
+        b = min(2, field.B - 1)
+        t0 = time.perf_counter()
+        orc.gen_model_image_fullframe(bands[b], field.H, field.W, field.src["radec"][stars], field.src["counts"][stars, b])
+        dtf = time.perf_counter() - t0
+        out["reference_semantics_fullframe"] = {
+            "s_per_source": dtf / stars.size, "sources": int(stars.size), "band": int(b),
+            "note": "gen_model_image as the reference writes it (point sources; one zeros(H,W) + scale + add per "
+                    "source, celeste.py:203-219): %.1f ms per source per band at %dx%d, i.e. ~%.0f s for this "
+                    "workload's %d sources x %d bands" % (dtf / stars.size * 1e3, field.H, field.W,
+                                                        dtf / stars.size * field.S * field.B, field.S, field.B)}
+    orc.set_threads(nthr)
+    return out
+
+
+# ---- render workloads (configs[1], configs[2] and the star-only fields) ---------------------------------
+def run_render(args, env):
+    torch, cel, dist, synth, _lib = env["torch"], env["cel"], env["dist"], env["synth"], env["_lib"]
+    rank, world, local, ctx = env["rank"], env["world"], env["local"], env["ctx"]
+    # weak: one field per rank (same population, different seed).  strong: every rank builds the SAME
+    # field (the catalogue is small and replicated) and keeps only its row strip of the pixels.
+    strong = (args.scaling == "strong") and world > 1
+    field = synth.SyntheticField.from_config(ctx, args.workload, seed=42 + (0 if strong else 1000 * rank))
+    full_stats = None
+    if strong:
+        y0, y1 = dist.strip_rows(field.H, world, rank)
+        field.images.render(field.sources, loglik=False)
+        full_stats = field.images.stats()                  # the whole field's work: what every step of the job does
+        strip = cel.ImageSet(ctx, field.bands, max(y1 - y0, 1), field.W, nelec=field.nelec[:, y0:max(y1, y0 + 1)])
+        strip.set_window(y0, field.H)
+        field.images = strip
+
+    # the one collective: B per-band doubles summed over ranks.  Pipelined one step deep: the sum of
+    # step k travels while step k+1 renders (the ranks' fields are independent chains; the global
+    # log-likelihood is a diagnostic), and every sum is collected inside the timed region.
+    reducer = dist.LoglikReducer(field.B, device=local, depth=2) if world > 1 else None
+    last = {}
+
+    def step():
+        ll, llb = field.images.render(field.sources, loglik=True)
+        if reducer is not None:
+            reducer.submit(llb)
+            if len(reducer.pending) > 1:
+                llb = reducer.result()
+        last["llb"] = llb
+
+    def after_warmup():
+        if reducer is not None:
+            reducer.drain()
+        ctx.profile(True)
+
+    def finish():
+        if reducer is not None:
+            last["llb"] = reducer.drain()[-1]
+    dt = Timer(dist, torch).run(step, args.warmup, args.steps, after_warmup, finish)
+    t_render, n_render = ctx.profile_get("render")
+    t_bin, _ = ctx.profile_get("bin")
+    t_prep, _ = ctx.profile_get("prep")
+    t_red, _ = ctx.profile_get("reduce")
+    ctx.profile(False)
+    stats = field.images.stats()
+    if strong:   # total work is the one field's, whoever renders which rows: count it once (rank 0)
+        stats = dict(full_stats) if rank == 0 else dict(full_stats, n_srcpix=0, n_gauss=0)
+    dt_max, (n_srcpix_all, n_gauss_all) = reduce_over_ranks(torch, world, local, dt, [stats["n_srcpix"], stats["n_gauss"]])
+    if rank != 0:
+        return
+    S, B, H, W, fg = synth.CONFIGS[args.workload]
+    n_imgpix = B * H * W
+    # algorithmic HBM bytes of one k_render launch (DESIGN.md "Measurement"):
+    #   read nelec 8 B + write lambda 8 B per image pixel, + one 128-B record per (source, band)
+    alg_bytes = 16.0 * n_imgpix + 128.0 * S * B
+    if strong:   # rank 0's launch covers its strip of the pixels (and still reads every record)
+        alg_bytes = 16.0 * B * (y1 - y0) * W + 128.0 * S * B
+    achieved = alg_bytes / (t_render * 1e-3) / 1e9 if t_render > 0 else 0.0
+    pmc = None if strong else PMC.get((args.workload, args.kernel, args.tail_log, args.layout))
+    out = {
+        # BASELINE.json's metric; `value` is its first half, `ms_per_step` its second
+        "metric": ("source-pixel evals/sec + full-field log-lik ms, %s sources x %d bands x %d^2"
+                   % ("10k" if S == 10000 else str(S), B, H)) if H == W else
+                  "source-pixel evals/sec + full-field log-lik ms, %d sources x %d bands x %dx%d" % (S, B, H, W),
+        "value": n_srcpix_all * args.steps / dt_max,
+        "unit": "source-pixel evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt_max / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": args.workload, "sources": S, "bands": B, "frame": [H, W],
+                   "galaxy_fraction": fg, "kernel": args.kernel, "tail_log": args.tail_log,
+                   "tile_layout": {1: "32x64 half-wave", 2: "16x128 quarter-wave"}.get(args.layout, "64x%d" % args.tile_rows),
+                   "tile_order": args.tile_order,
+                   "tile_order_note": {0: "index order", 1: "heaviest first by the previous step's measured tile durations "
+                                       "(a launch-order hint only: every step redoes all of the work)",
+                                       2: "heaviest first by the binning pass's estimate"}[args.tile_order],
+                   "parallelism": ("1 field cut into %d row strips, 1 per GPU" if strong else "1 field per GPU, %d GPU(s)") % world
+                                  + ", 1 all-reduce of %d doubles per step (overlapped with the next step's render)" % B,
+                   "ranks": world, "collective_backend": env["backend"]},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic"] if pmc else None,
+                     "traffic_source": pmc["source"] if pmc else None,
+                     "kernel": "k_render", "kernel_ms": t_render, "launches": n_render,
+                     "algorithmic_bytes_per_launch": alg_bytes},
+        "work": {"n_srcpix_per_step": n_srcpix_all, "n_gauss_per_step": n_gauss_all,
+                 "gauss_evals_per_s": n_gauss_all * args.steps / dt_max,
+                 "n_tile_entries": stats["n_tile_entries"]},
+        "kernels_ms": {"k_prep": t_prep, "k_bin": t_bin, "k_render": t_render, "k_reduce": t_red},
+        "loglik": float(np.sum(last["llb"])),
+    }
+    # the roof that actually binds the mixed field's kernel is the fp64 vector ALU (SURVEY 0.6 / 8d).
+    # frac = EXECUTED lane-instructions per second / the data-sheet issue rate; the 35-flop-per-nominal-
+    # Gaussian figure of SURVEY 8d is kept only as an equivalent (the recurrence and the drop rule need
+    # ~10x fewer operations than that accounting assumes, so it exceeds the peak).
+    fp = {"peak": FP64_LANE_OPS_PEAK, "unit": "fp64 VALU lane-instructions/s",
+          "equivalent_tflops_35flop_per_nominal_gauss": FLOP_PER_GAUSS * stats["n_gauss"] / (t_render * 1e-3) / 1e12 if t_render > 0 else 0.0}
+    if pmc and t_render > 0:
+        fp.update({"achieved": pmc["valu_insts"] * 64.0 / (t_render * 1e-3), "valu_wave_instructions_per_launch_pmc": pmc["valu_insts"],
+                   "valu_busy_frac_pmc": pmc["valu_busy"], "pmc_source": pmc["source"]})
+        fp["frac"] = fp["achieved"] / FP64_LANE_OPS_PEAK
+    else:
+        fp.update({"achieved": None, "frac": None})
+    out["fp64_valu"] = fp
+    if world == 1 and not strong:
+        extra_render_legs(args, env, field, out)
+    if world == 1 and args.cpu_sample > 0:
+        from oracle import oracle as orc      # cpu_baseline leg only
+        out["cpu_baseline"] = cpu_baseline(field, min(args.cpu_sample, S), orc)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
+def extra_render_legs(args, env, field, out):
+    """Untimed-by-the-contract extras, measured after the timed region on rank 0 of a 1-GPU run: the
+    Gaussian-pixels the kernel really evaluates, the step with the catalogue uploaded from host
+    memory every time (a chain changes it before every evaluation), and the reference-API call."""
+    torch, cel, synth, _lib, ctx = env["torch"], env["cel"], env["synth"], env["_lib"], env["ctx"]
+    n = max(3, min(args.steps, 20))
+    if args.layout == 1 and args.kernel == "recurrence":
+        try:
+            ctx.set_option(_lib.CEL_OPT_TILE_TIMING, 1)
+            field.images.render(field.sources, loglik=True)
+            tt = field.images.tile_timing()
+            comprows = float(np.sum(tt[:, 2] >> np.uint64(32)))
+            # a kept component is walked over its row range on all 32 columns of the tile
+            out["work"]["n_gauss_evaluated_per_step"] = comprows * 32.0
+            out["work"]["n_gauss_evaluated_note"] = ("kept component-rows x 32 tile columns, counted by k_render_hw in an untimed "
+                                                      "launch; the rest of the nominal K x box-area count is below eps * e^-T "
+                                                      "on its tile and skipped (CEL_OPT_TAIL_LOG)")
+        finally:
+            ctx.set_option(_lib.CEL_OPT_TILE_TIMING, 0)
+    src = field.src
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        field.sources.set(src["type"], src["radec"], src["counts"], src["shape"])
+        field.images.render(field.sources, loglik=True)
+    torch.cuda.synchronize()
+    out["ms_per_step_with_source_upload"] = (time.perf_counter() - t0) / n * 1e3
+    # the drop-in Python API north_star names: celeste_likelihood_multi_image(srcs, imgs)
+    from desi_mcmc_amd import celeste
+    imgs = synth.fits_images(field)
+    cat = cel.SrcCatalog((src["type"] == 1).astype(np.int64), src["radec"], field.flux5(), src["shape"])
+    ll_api = celeste.celeste_likelihood_multi_image(cat, imgs)          # uploads the images once
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ll_api = celeste.celeste_likelihood_multi_image(cat, imgs)
+    torch.cuda.synchronize()
+    out["python_api_ms"] = (time.perf_counter() - t0) / n * 1e3
+    plist = [cel.SrcParams(u=p.u.copy(), a=p.a, fluxes=p.fluxes.copy(), theta=p.theta, sigma=p.sigma, phi=p.phi, rho=p.rho)
+             for p in cat]
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ll_list = celeste.celeste_likelihood_multi_image(plist, imgs)
+    out["python_api_list_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+    out["python_api_note"] = ("celeste_likelihood_multi_image(srcs, imgs) end to end, images resident after the first call: "
+                              "srcs = SrcCatalog (arrays; python_api_ms) / a plain list of %d SrcParams objects "
+                              "(python_api_list_ms: the per-object attribute gather dominates)" % len(plist))
+    out["python_api_loglik_rel_diff"] = float(abs(ll_api - out["loglik"]) / abs(out["loglik"])) if out["loglik"] else None
+    assert abs(ll_list - ll_api) <= 1e-12 * abs(ll_api)
+
+
+# ---- configs[3] stand-in: K fields dealt to ranks ----------------------------------------------------
+def run_fields(args, env):
+    torch, cel, dist, synth = env["torch"], env["cel"], env["dist"], env["synth"]
+    rank, world, local, ctx = env["rank"], env["world"], env["local"], env["ctx"]
+    K = args.n_fields
+    base = "mixed10k_2048"
+    mine = dist.field_shard(K, world, rank)
+    fields = [synth.SyntheticField.from_config(ctx, base, seed=42 + 1000 * k) for k in mine]
+    B = synth.CONFIGS[base][1]
+    reducer = dist.LoglikReducer(B, device=local, depth=2) if world > 1 else None
+    last = {}
+
+    def step():
+        llb = np.zeros(B)
+        for f in fields:
+            _, b = f.images.render(f.sources, loglik=True)
+            llb += b
+        if reducer is not None:
+            reducer.submit(llb)
+            if len(reducer.pending) > 1:
+                llb = reducer.result()
+        last["llb"] = llb
+
+    def after_warmup():
+        if reducer is not None:
+            reducer.drain()
+        ctx.profile(True)
+
+    def finish():
+        if reducer is not None:
+            last["llb"] = reducer.drain()[-1]
+    dt = Timer(dist, torch).run(step, args.warmup, args.steps, after_warmup, finish)
+    t_render, n_render = ctx.profile_get("render")
+    ctx.profile(False)
+    srcpix = sum(f.images.stats()["n_srcpix"] for f in fields)
+    gauss = sum(f.images.stats()["n_gauss"] for f in fields)
+    dt_max, (srcpix_all, gauss_all, nf_all) = reduce_over_ranks(torch, world, local, dt, [srcpix, gauss, len(fields)])
+    if rank != 0:
+        return
+    S, _, H, W, fg = synth.CONFIGS[base]
+    alg_bytes = 16.0 * B * H * W + 128.0 * S * B
+    achieved = alg_bytes / (t_render * 1e-3) / 1e9 if t_render > 0 else 0.0
+    print(json.dumps({
+        "metric": "source-pixel evals/sec + log-lik ms over %d fields of 10k sources x %d bands x %d^2 "
+                  "(synthetic stand-in for the Stripe-82 field set)" % (K, B, H),
+        "value": srcpix_all * args.steps / dt_max, "unit": "source-pixel evals/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "fields%d_2048" % K, "fields": K, "fields_on_rank0": mine, "fields_total_check": int(nf_all),
+                   "sources_per_field": S, "bands": B, "frame": [H, W], "galaxy_fraction": fg,
+                   "note": "BASELINE configs[3] names the Stripe-82 catalogue, which is not in the reference tree "
+                           "(.MISSING_LARGE_BLOBS); synthetic fields of the configs[2] population stand in for it",
+                   "parallelism": "fields dealt round-robin to %d GPU(s), 1 all-reduce of %d doubles per step" % (world, B),
+                   "ranks": world, "collective_backend": env["backend"]},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "k_render", "kernel_ms": t_render, "launches": n_render,
+                     "algorithmic_bytes_per_launch": alg_bytes},
+        "work": {"n_srcpix_per_step": srcpix_all, "n_gauss_per_step": gauss_all},
+        "loglik": float(np.sum(last["llb"])), "cpu_baseline": None}))
+
+
+# ---- configs[4]: Gibbs sweeps ------------------------------------------------------------------------
+def run_gibbs(args, env):
+    torch, cel, dist, synth = env["torch"], env["cel"], env["dist"], env["synth"]
+    rank, world, local, ctx = env["rank"], env["world"], env["local"], env["ctx"]
+    from desi_mcmc_amd import celeste_mcmc
+    base = "mixed10k_2048"
+    field = synth.SyntheticField.from_config(ctx, base, seed=42)          # the same sky on every rank
+    S, B, H, W, fg = synth.CONFIGS[base]
+    gf = celeste_mcmc.GibbsField(field.images, list(range(B)), field.bands[:, 2], field.bands[:, 1], H * W)
+    slice_args = dict(step_out=False, sigma=args.slice_sigma)
+    g = celeste_mcmc.ModelGibbs([gf], field.src["type"], field.src["radec"], field.flux5(), field.src["shape"],
+                                seed=1 + 1000 * rank, slice_args=slice_args)       # one independent chain per rank
+    reducer = dist.LoglikReducer(1, device=local, depth=2) if world > 1 else None
+    trace = []
+
+    def step():
+        g.sweep()
+        ll = np.array([g.log_likelihood()])          # the chain's trace (one render)
+        if reducer is not None:
+            reducer.submit(ll)
+            if len(reducer.pending) > 1:
+                ll = reducer.result()
+        trace.append(float(ll[0]))
+
+    def after_warmup():
+        if reducer is not None:
+            reducer.drain()
+        for k in g.timing:
+            g.timing[k] = 0
+        ctx.profile(True)
+
+    def finish():
+        if reducer is not None:
+            trace.append(float(reducer.drain()[-1][0]))
+    ll0 = g.log_likelihood()
+    dt = Timer(dist, torch).run(step, args.warmup, args.steps, after_warmup, finish)
+    t_ll, n_ll = ctx.profile_get("stamps")          # cel_patch_loglik_multi + split + mass launches
+    t_render, n_render = ctx.profile_get("render")
+    ctx.profile(False)
+    dt_max, (updates,) = reduce_over_ranks(torch, world, local, dt, [float(g.active.sum()) * args.steps])
+    if rank != 0:
+        return
+    areas = gf.iset.sample_box_areas()
+    # algorithmic HBM bytes of one conditional-likelihood launch: the photon patches of the scored
+    # proposals (8 B per patch pixel) + one 128-B record per (proposal, band)
+    evals_per_launch = g.timing["evals"] / max(g.timing["rounds"], 1)
+    alg_bytes = evals_per_launch * (8.0 * float(areas.sum()) / S + 128.0 * B)
+    ms_launch = g.timing["location"] / max(g.timing["rounds"], 1) * 1e3
+    achieved = alg_bytes / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
+    print(json.dumps({
+        "metric": "end-to-end samples/sec, slice-sampling Gibbs sweeps over the 10k-source x %d-band x %d^2 synthetic field" % (B, H),
+        "value": updates / dt_max, "unit": "source updates (samples)/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "gibbs10k", "sources": S, "bands": B, "frame": [H, W], "galaxy_fraction": fg,
+                   "sweep": "photon split of all bands + sky level (models.py:123-160), then per source: flux Gamma "
+                            "conditionals (sources.py:321-349) and location by slice sampling (sources.py:308-319), "
+                            "all sources in lock-step; + one field log-likelihood per sweep (the trace)",
+                   "slice": dict(slice_args, compwise=True,
+                                 note="sigma in degrees.  The reference's call passes step=du/5=0.001 deg, which its "
+                                      "slicesample ignores (sigma stays 1.0 deg); 0.001 is the call's intent and this "
+                                      "bench's default, --slice-sigma 1.0 runs the literal behaviour"),
+                   "parallelism": "%d independent chain(s), 1 per GPU, over the same field; 1 all-reduce of the chains' "
+                                  "log-likelihood per sweep" % world,
+                   "ranks": world, "collective_backend": env["backend"]},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "k_patch_ll_hw (one slice round: host + launch, wall clock)",
+                     "kernel_ms": ms_launch, "launches": g.timing["rounds"], "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "fp64-issue-bound like k_render (DESIGN.md 5); the HBM fraction is reported because the contract asks for it"},
+        "work": {"slice_rounds_per_sweep": g.timing["rounds"] / args.steps, "loglik_evals_per_sweep": g.timing["evals"] / args.steps,
+                 "sources_updated_per_sweep": float(g.active.sum())},
+        "sweep_ms": {"photon_split_and_sky": g.timing["split"] / args.steps * 1e3, "flux": g.timing["flux"] / args.steps * 1e3,
+                     "location_slice": g.timing["location"] / args.steps * 1e3,
+                     "trace_render": dt / args.steps * 1e3 - (g.timing["split"] + g.timing["flux"] + g.timing["location"]) / args.steps * 1e3},
+        "device_ms_per_sweep": {"per_source_kernels (split, mass, conditional ll)": t_ll * n_ll / args.steps,
+                                "k_render (split totals + trace)": t_render * n_render / args.steps},
+        "loglik_before": ll0, "loglik_trace_tail": trace[-3:], "cpu_baseline": None}))
 
 
 def main():
@@ -136,8 +530,10 @@ def main():
                     help="render tile geometry: 0 = 64x32 (k_render), 1 = 32x64 half-wave (k_render_hw)")
     ap.add_argument("--cpu-sample", type=int, default=400, help="sources in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak (default, what the driver runs): one field per GPU.  strong: ONE field cut into row "
-                         "strips, one per GPU (cel_images_set_window), total work fixed")
+                    help="render workloads.  weak (default, what the driver runs): one field per GPU.  strong: ONE "
+                         "field cut into row strips, one per GPU (cel_images_set_window), total work fixed")
+    ap.add_argument("--n-fields", type=int, default=8, help="fields8_2048: number of fields dealt to the ranks")
+    ap.add_argument("--slice-sigma", type=float, default=0.001, help="gibbs10k: slice-sampler interval width in degrees")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
     args = ap.parse_args()
 
@@ -147,14 +543,16 @@ def main():
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU,
         # as children of this process -- BEFORE anything here touches the GPU (the parent never does).
         raise SystemExit(self_launch(args.gpus, sys.argv[1:], args.master_port))
-
     if os.environ.get("CEL_BENCH_DRYRUN") == "1":
         return dry_run(args)
+    kind = "gibbs" if args.workload == "gibbs10k" else ("fields" if args.workload.startswith("fields") else "render")
+    if kind == "render" and args.workload not in RENDER_WORKLOADS:
+        raise SystemExit("unknown workload %r (render: %s; also fields8_2048, gibbs10k)" % (args.workload, ", ".join(RENDER_WORKLOADS)))
 
     import torch
 
     import desi_mcmc_amd as cel
-    from desi_mcmc_amd import dist, synth
+    from desi_mcmc_amd import _lib, dist, synth
 
     # CEL_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs than ranks
     # (ranks then share GPUs and the collective runs on the host); the driver's runs use RCCL.
@@ -172,140 +570,16 @@ def main():
     ctx = cel.Context(local)
     ctx.set_kernel(args.kernel)
     ctx.set_tail_log(args.tail_log)
-    from desi_mcmc_amd import _lib
     ctx.set_option(_lib.CEL_OPT_TILE_ROWS, args.tile_rows)
     ctx.set_option(_lib.CEL_OPT_TILE_LAYOUT, args.layout)
     ctx.set_option(_lib.CEL_OPT_TILE_ORDER, args.tile_order)
-
-    # weak: one field per rank (same population, different seed).  strong: every rank builds the SAME
-    # field (the catalogue is small and replicated) and keeps only its row strip of the pixels.
-    strong = (args.scaling == "strong") and world > 1
-    field = synth.SyntheticField.from_config(ctx, args.workload, seed=42 + (0 if strong else 1000 * rank))
-    stats = None
-    if strong:
-        y0, y1 = dist.strip_rows(field.H, world, rank)
-        full_stats = None
-        field.images.render(field.sources, loglik=False)
-        full_stats = field.images.stats()                  # the whole field's work: what every step of the job does
-        strip = cel.ImageSet(ctx, field.bands, max(y1 - y0, 1), field.W, nelec=field.nelec[:, y0:max(y1, y0 + 1)])
-        strip.set_window(y0, field.H)
-        field.images = strip
-
-    # the one collective: B per-band doubles summed over ranks.  Pipelined one step deep: the sum of
-    # step k travels while step k+1 renders (the ranks' fields are independent chains; the global
-    # log-likelihood is a diagnostic), and every sum is collected inside the timed region.
-    reducer = dist.LoglikReducer(field.B, device=local, depth=2) if world > 1 else None
-
-    def step():
-        ll, llb = field.images.render(field.sources, loglik=True)
-        if reducer is not None:
-            reducer.submit(llb)
-            if len(reducer.pending) > 1:
-                llb = reducer.result()
-        return llb
-
-    for _ in range(args.warmup):
-        step()
-    if reducer is not None:
-        reducer.drain()
-    stats = field.images.stats()
-    if strong:   # total work is the one field's, whoever renders which rows: count it once (rank 0)
-        stats = dict(full_stats) if rank == 0 else dict(full_stats, n_srcpix=0, n_gauss=0)
-    ctx.profile(True)
-
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        llb = step()
-    if reducer is not None:
-        llb = reducer.drain()[-1]
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
-
-    t_render, n_render = ctx.profile_get("render")
-    t_bin, _ = ctx.profile_get("bin")
-    t_prep, _ = ctx.profile_get("prep")
-    t_red, _ = ctx.profile_get("reduce")
-    ctx.profile(False)
-
-    # max over ranks of the elapsed time, sum over ranks of the work
-    agg = torch.tensor([dt, stats["n_srcpix"], stats["n_gauss"]], dtype=torch.float64)
+    backend = "none"
     if world > 1:
         import torch.distributed as td
-        if td.get_backend() == "nccl":
-            agg = agg.cuda(local)
-        tmax = agg[:1].clone()
-        td.all_reduce(tmax, op=td.ReduceOp.MAX)
-        tsum = agg[1:].clone()
-        td.all_reduce(tsum, op=td.ReduceOp.SUM)
-        dt_max, n_srcpix_all, n_gauss_all = tmax.item(), tsum[0].item(), tsum[1].item()
-    else:
-        dt_max, n_srcpix_all, n_gauss_all = dt, stats["n_srcpix"], stats["n_gauss"]
-
-    if rank == 0:
-        S, B, H, W, fg = synth.CONFIGS[args.workload]
-        n_imgpix = B * H * W
-        # algorithmic HBM bytes of one k_render launch (DESIGN.md "Measurement"):
-        #   read nelec 8 B + write lambda 8 B per image pixel, + one 128-B record per (source, band)
-        alg_bytes = 16.0 * n_imgpix + 128.0 * S * B
-        if strong:   # rank 0's launch covers its strip of the pixels (and still reads every record)
-            alg_bytes = 16.0 * B * (y1 - y0) * W + 128.0 * S * B
-        achieved = alg_bytes / (t_render * 1e-3) / 1e9 if t_render > 0 else 0.0
-        pmc = None if strong else PMC_TRAFFIC.get((args.workload, args.kernel, args.tail_log, args.layout))
-        out = {
-            # BASELINE.json's metric; `value` is its first half, `ms_per_step` its second
-            "metric": "source-pixel evals/sec + full-field log-lik ms, %s sources x %d bands x %d^2"
-                      % ("10k" if S == 10000 else str(S), B, H) if H == W else
-                      "source-pixel evals/sec + full-field log-lik ms, %d sources x %d bands x %dx%d" % (S, B, H, W),
-            "value": n_srcpix_all * args.steps / dt_max,
-            "unit": "source-pixel evals/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong" if strong else "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": args.workload, "sources": S, "bands": B, "frame": [H, W],
-                       "galaxy_fraction": fg, "kernel": args.kernel, "tail_log": args.tail_log,
-                       "tile_layout": {1: "32x64 half-wave", 2: "16x128 quarter-wave"}.get(args.layout, "64x%d" % args.tile_rows),
-                       "tile_order": args.tile_order,
-                       "tile_order_note": {0: "index order", 1: "heaviest first by the previous step's measured tile durations "
-                                           "(a launch-order hint only: every step redoes all of the work)",
-                                           2: "heaviest first by the binning pass's estimate"}[args.tile_order],
-                       "parallelism": ("1 field cut into %d row strips, 1 per GPU" if strong else "1 field per GPU, %d GPU(s)") % world
-                                      + ", 1 all-reduce of %d doubles per step (overlapped with the next step's render)" % B},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc[0] if pmc else None,
-                         "traffic_source": pmc[1] if pmc else None,
-                         "kernel": "k_render", "kernel_ms": t_render, "launches": n_render,
-                         "algorithmic_bytes_per_launch": alg_bytes},
-            # the roof that actually binds this kernel: fp64 vector ALU
-            "fp64_valu": {"achieved": FLOP_PER_GAUSS * stats["n_gauss"] / (t_render * 1e-3) / 1e12 if t_render > 0 else 0.0,
-                          "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s (35 flop per Gaussian-eval accounting)"},
-            "work": {"n_srcpix_per_step": n_srcpix_all, "n_gauss_per_step": n_gauss_all,
-                     "gauss_evals_per_s": n_gauss_all * args.steps / dt_max,
-                     "n_tile_entries": stats["n_tile_entries"]},
-            "kernels_ms": {"k_prep": t_prep, "k_bin": t_bin, "k_render": t_render, "k_reduce": t_red},
-            "loglik": float(np.sum(llb)),
-        }
-        out["fp64_valu"]["frac"] = out["fp64_valu"]["achieved"] / FP64_VALU_PEAK_TF
-        vp = PMC_VALU.get((args.workload, args.kernel, args.tail_log, args.layout))
-        if vp:
-            # how busy the vector ALUs really are, and the executed instruction stream, from the
-            # committed PMC profile of this configuration (not re-measured here)
-            out["fp64_valu"].update({"valu_busy_frac_pmc": vp[0], "valu_wave_instructions_per_launch_pmc": vp[1],
-                                     "pmc_source": vp[2]})
-        if world == 1 and args.cpu_sample > 0:
-            from oracle import oracle as orc      # cpu_baseline leg only
-            out["cpu_baseline"] = cpu_baseline(field, min(args.cpu_sample, S), orc)
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
+        backend = {"nccl": "rccl (torch.distributed nccl)"}.get(td.get_backend(), td.get_backend())
+    env = dict(torch=torch, cel=cel, dist=dist, synth=synth, _lib=_lib, rank=rank, world=world, local=local, ctx=ctx,
+               backend=backend)
+    {"render": run_render, "fields": run_fields, "gibbs": run_gibbs}[kind](args, env)
     if world > 1:
         import torch.distributed as td
         td.barrier()

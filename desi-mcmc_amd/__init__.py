@@ -15,8 +15,8 @@ All arithmetic runs in hand-written HIP kernels (csrc/celeste_hip.hip) behind th
 include/celeste_hip.h.  There is no CPU fallback.
 """
 from . import _lib  # noqa: F401
-from .celeste_src import SrcParams  # noqa: F401
+from .celeste_src import SrcCatalog, SrcParams  # noqa: F401
 from .field import Context, ImageSet, SourceSet, default_context  # noqa: F401
 from .fits_image import FitsImage  # noqa: F401
 
-__all__ = ["SrcParams", "FitsImage", "Context", "ImageSet", "SourceSet", "default_context"]
+__all__ = ["SrcParams", "SrcCatalog", "FitsImage", "Context", "ImageSet", "SourceSet", "default_context"]

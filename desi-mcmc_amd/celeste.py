@@ -143,16 +143,63 @@ def expected_photons(src, image):
     raise Exception("No way to compute expected photons without at least fluxes or brightness")
 
 
-def _source_arrays(srcs, images, counts_fn=expected_photons):
+def _gather_fluxes(srcs, images, bidx):
+    """(S, B) fluxes in the images' bands: one pass over the sources, not S x B calls"""
     S = len(srcs)
-    typ = np.zeros(S, dtype=np.int32)
+    fls = [s.fluxes for s in srcs]
+    if all(isinstance(f, dict) for f in fls):
+        names = [im.band for im in images]
+        return np.array([[f[n] for n in names] for f in fls], dtype=np.float64).reshape(S, len(images))
+    if not any(isinstance(f, dict) for f in fls):
+        return np.array(fls, dtype=np.float64).reshape(S, -1)[:, bidx]
+    return np.array([[_flux(s, im.band) for im in images] for s in srcs], dtype=np.float64).reshape(S, len(images))
+
+
+def _source_arrays(srcs, images, counts_fn=expected_photons):
+    """(type[S], radec[S,2], counts[S,B], shape[S,4]) of a sequence of SrcParams for the device.
+    A SrcCatalog hands its arrays over without any per-source work; a plain list is gathered with
+    one pass per attribute (no S x B nest of Python calls) when every source takes the same flux
+    convention, and source by source otherwise."""
+    from .celeste_src import SrcCatalog
+    B = len(images)
+    bidx = [list(BANDS).index(im.band) for im in images]
+    calib = np.array([im.calib for im in images])
+    kappa = np.array([im.kappa for im in images])
+    if isinstance(srcs, SrcCatalog):
+        a, fl = srcs.a, srcs.fluxes[:, bidx]
+        if counts_fn is expected_photons:
+            # celeste.py:35-62: stars / galaxies flux / calib * kappa, untyped rows kappa * flux
+            counts = np.where((a >= 0)[:, None], fl / calib[None, :] * kappa[None, :], kappa[None, :] * fl)
+        else:
+            counts = (fl / calib[None, :]) * kappa[None, :]          # flux_dict convention (celeste.py:80-81,94)
+        typ = (a == 1).astype(np.int32)
+        return typ, srcs.u, counts, np.where((a == 1)[:, None], srcs.shape, 0.0)
+    S = len(srcs)
+    typ = np.fromiter((1 if s.a == 1 else 0 for s in srcs), dtype=np.int32, count=S)
     radec = np.zeros((S, 2))
     shape = np.zeros((S, 4))
-    counts = np.zeros((S, len(images)))
+    counts = np.zeros((S, B))
+    simple = counts_fn is not expected_photons or not any(getattr(s, "t", None) for s in srcs)
+    if S and simple:
+        radec[:] = np.array([s.u for s in srcs], dtype=np.float64).reshape(S, 2)
+        gal = np.nonzero(typ)[0]
+        if gal.size:
+            shape[gal] = [[srcs[i].theta, srcs[i].sigma, srcs[i].phi, srcs[i].rho] for i in gal]
+        if counts_fn is expected_photons:
+            for s in srcs:
+                if s.a is None and s.fluxes is None:
+                    raise Exception("No way to compute expected photons without at least fluxes or brightness")
+            fl = _gather_fluxes(srcs, images, bidx)
+            untyped = np.fromiter((s.a is None for s in srcs), dtype=bool, count=S)
+            counts = np.where(untyped[:, None], kappa[None, :] * fl, fl / calib[None, :] * kappa[None, :])
+        else:
+            fd = [s.flux_dict for s in srcs]
+            fl = np.array([[d[im.band] for im in images] for d in fd], dtype=np.float64).reshape(S, B)
+            counts = (fl / calib[None, :]) * kappa[None, :]
+        return typ, radec, counts, shape
     for s, src in enumerate(srcs):
         radec[s] = src.u
         if src.a == 1:
-            typ[s] = 1
             shape[s] = [src.theta, src.sigma, src.phi, src.rho]
         for b, im in enumerate(images):
             counts[s, b] = counts_fn(src, im)

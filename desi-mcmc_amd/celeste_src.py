@@ -70,3 +70,84 @@ class SrcParams(object):
     def __str__(self):
         kind = {0: "StrSrc", 1: "GalSrc"}.get(self.a, "NoType")
         return "%s: u=(%2.2f, %2.2f)" % (kind, self.u[0], self.u[1])
+
+
+class SrcCatalog(object):
+    """A catalogue of sources held as arrays (structure of arrays) that still reads as a sequence
+    of SrcParams: `len(cat)`, `cat[i]`, iteration -- each element is a view whose attributes read
+    and write the arrays.  The render / likelihood functions (celeste.gen_model_image,
+    celeste_likelihood[_multi_image], ...) take it wherever the reference takes a list of
+    SrcParams and hand its arrays to the device without touching the sources one by one: at
+    10 000 sources the per-object gather of a plain list costs more than the render itself.
+
+        a        (S,) int: 0 star, 1 galaxy, -1 = None (untyped catalogue row, celeste.py:52-62)
+        u        (S, 2) ra, dec in degrees
+        fluxes   (S, 5) nanomaggies in u, g, r, i, z
+        shape    (S, 4) theta, sigma, phi (degrees), rho
+    """
+
+    def __init__(self, a, u, fluxes, shape=None):
+        self.a = np.array([-1 if v is None else int(v) for v in a] if not isinstance(a, np.ndarray) else a, dtype=np.int64)
+        S = self.a.shape[0]
+        self.u = np.array(u, dtype=np.float64).reshape(S, 2)
+        self.fluxes = np.array(fluxes, dtype=np.float64).reshape(S, 5)
+        self.shape = np.zeros((S, 4)) if shape is None else np.array(shape, dtype=np.float64).reshape(S, 4)
+
+    @classmethod
+    def from_params(cls, params):
+        """pack a list of SrcParams (fluxes as a dict or a ugriz array)"""
+        params = list(params)
+        a = [p.a for p in params]
+        u = [p.u for p in params]
+        fl = [[p.flux(b) for b in BANDS] for p in params]
+        sh = [[p.theta, p.sigma, p.phi, p.rho] if p.a == 1 else [0., 0., 0., 0.] for p in params]
+        return cls(a, u, fl, sh)
+
+    def __len__(self):
+        return self.a.shape[0]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return SrcCatalog(self.a[i], self.u[i], self.fluxes[i], self.shape[i])
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return _SrcView(self, i)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield _SrcView(self, i)
+
+
+class _SrcView(object):
+    """one row of a SrcCatalog with the attribute names of SrcParams"""
+    __slots__ = ("_c", "_i")
+    t = b = v = ell = d = header = None
+
+    def __init__(self, cat, i):
+        self._c, self._i = cat, i
+
+    a = property(lambda s: None if s._c.a[s._i] < 0 else int(s._c.a[s._i]),
+                 lambda s, v: s._c.a.__setitem__(s._i, -1 if v is None else int(v)))
+    u = property(lambda s: s._c.u[s._i], lambda s, v: s._c.u.__setitem__(s._i, v))
+    fluxes = property(lambda s: s._c.fluxes[s._i], lambda s, v: s._c.fluxes.__setitem__(
+        s._i, [v[b] for b in BANDS] if isinstance(v, dict) else v))
+    shape = property(lambda s: s._c.shape[s._i], lambda s, v: s._c.shape.__setitem__(s._i, v))
+    theta = property(lambda s: s._c.shape[s._i, 0], lambda s, v: s._c.shape.__setitem__((s._i, 0), v))
+    sigma = property(lambda s: s._c.shape[s._i, 1], lambda s, v: s._c.shape.__setitem__((s._i, 1), v))
+    phi = property(lambda s: s._c.shape[s._i, 2], lambda s, v: s._c.shape.__setitem__((s._i, 2), v))
+    rho = property(lambda s: s._c.shape[s._i, 3], lambda s, v: s._c.shape.__setitem__((s._i, 3), v))
+
+    def flux(self, band):
+        return self._c.fluxes[self._i, BANDS.index(band)]
+
+    @property
+    def flux_dict(self):
+        return dict(zip(BANDS, self._c.fluxes[self._i]))
+
+    def is_star(self):
+        return self.a == 0
+
+    def is_galaxy(self):
+        return self.a == 1

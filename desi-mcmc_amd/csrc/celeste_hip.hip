@@ -147,7 +147,7 @@ struct cel_images {
     uint64_t recs_gen = 0, hbox_gen = 0;
     std::vector<int4> h_boxes;
     std::vector<int> h_status;
-    int *d_tile_cnt = nullptr, *d_tile_work = nullptr, *d_order = nullptr;
+    int *d_tile_cnt = nullptr, *d_tile_nstar = nullptr, *d_tile_work = nullptr, *d_order = nullptr;
     int *d_tile_cost = nullptr;   // measured duration of every tile in the last render (the next render's launch order)
     int64_t cost_S = -1;          // number of sources that render had (-1: nothing measured yet)
     int64_t *d_tile_off = nullptr;
@@ -408,7 +408,7 @@ int cel_images_destroy(cel_images *im) {
     (void)hipSetDevice(im->ctx->device);
     (void)hipStreamSynchronize(im->ctx->stream);
     void *ptrs[] = {im->d_bands, im->d_nelec, im->d_lambda, im->d_partials, im->d_llband, im->d_recs,
-                    im->d_boxes, im->d_kind, im->d_status, im->d_tile_cnt, im->d_tile_work, im->d_tile_cost, im->d_order, im->d_tile_off, im->d_cursor, im->d_lists, im->d_stats,
+                    im->d_boxes, im->d_kind, im->d_status, im->d_tile_cnt, im->d_tile_nstar, im->d_tile_work, im->d_tile_cost, im->d_order, im->d_tile_off, im->d_cursor, im->d_lists, im->d_stats,
                     im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff, im->d_rate, im->d_snz};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -466,6 +466,7 @@ int cel_images_create(cel_ctx *c, int B, int H, int W, const cel_band *bands, ce
     IM_TRY(hipMalloc((void **)&im->d_partials, sizeof(double) * T));
     IM_TRY(hipMalloc((void **)&im->d_llband, sizeof(double) * MAX_BANDS));
     IM_TRY(hipMalloc((void **)&im->d_tile_cnt, sizeof(int) * T));
+    IM_TRY(hipMalloc((void **)&im->d_tile_nstar, sizeof(int) * T));
     IM_TRY(hipMalloc((void **)&im->d_tile_work, sizeof(int) * T));
     IM_TRY(hipMalloc((void **)&im->d_tile_cost, sizeof(int) * T));
     IM_TRY(hipMalloc((void **)&im->d_order, sizeof(int) * T));
@@ -706,7 +707,7 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
                            im->d_sup_off, im->d_cursor + 2, im->d_clist, im->clist_cap, (int *)(im->d_cursor + 3));
         hipLaunchKernelGGL(k_bin_fine_blk, dim3(NS), dim3(256), 0, st, im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
                            im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
-                           im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
+                           im->d_tile_nstar, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
                            (int *)(im->d_cursor + 1));
         if (c->tile_order)
             // heaviest first: by the durations the tiles had in the previous render when that was
@@ -717,6 +718,7 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         prof_end(c, pi);
         RenderArgs a;
         a.bands = im->d_bands; a.recs = im->d_recs; a.lists = im->d_lists; a.tile_cnt = im->d_tile_cnt;
+        a.tile_nstar = im->d_tile_nstar;
         a.tile_off = im->d_tile_off; a.nelec = im->d_nelec; a.lambda = lambda_out ? lambda_out : im->d_lambda; a.partials = im->d_partials;
         a.S = S; a.capacity = im->lists_cap; a.B = im->B; a.H = im->H; a.W = im->W; a.ntx = im->ntx; a.nty = im->nty;
         a.flags = flags; a.variant = c->variant; a.tail_T = c->tail_T; a.order = c->tile_order ? im->d_order : nullptr;

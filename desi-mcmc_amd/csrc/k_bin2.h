@@ -5,8 +5,10 @@
 // Level 2 (k_bin_fine_blk): one block per super-tile stages its candidates (a few hundred instead
 //   of S) in LDS and writes, for each of its 64 x TH render tiles, the ordered source list, its
 //   length and a work estimate for the heaviest-first launch order.
-// Both levels compact with ballot + prefix popcount, so every list is in ascending source index:
-// the accumulation order in k_render -- and with it every output bit -- is reproducible.
+// Both levels compact with ballot + prefix popcount, so every list is ordered: a render tile's list
+// holds its STARS first (ascending source index), then its galaxies (ascending source index) -- the
+// render kernel takes the stars of a tile through a batched 3-component path -- and the
+// accumulation order in k_render, and with it every output bit, is reproducible.
 // List SEGMENTS are placed with one atomicAdd per list (segment order in the buffer is
 // arbitrary and irrelevant); no atomics touch list contents.
 #pragma once
@@ -83,7 +85,7 @@ k_bin_coarse(const int4 *__restrict__ boxes, int64_t S, int nsx, int nsy, int *_
 __global__ void __launch_bounds__(256)
 k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int64_t S, int ntx, int nty, int TH,
                int TW, int nsx, int nsy, const int *__restrict__ sup_cnt, const int64_t *__restrict__ sup_off,
-               const int *__restrict__ clist, int64_t ccap, int *__restrict__ tile_cnt,
+               const int *__restrict__ clist, int64_t ccap, int *__restrict__ tile_cnt, int *__restrict__ tile_nstar,
                int *__restrict__ tile_work, int64_t *__restrict__ tile_off, unsigned long long *cursor,
                int *__restrict__ lists, int64_t capacity, int *overflow) {
     __shared__ int4 sbox[BIN_CH];
@@ -103,10 +105,10 @@ k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int
     int n = sup_cnt[st];
     const int64_t coff = sup_off[st];
     if (coff + n > ccap) n = (int)((ccap > coff) ? (ccap - coff) : 0);   // truncated coarse list (overflow is flagged)
-    int cnt[BIN_TPW], work[BIN_TPW], run[BIN_TPW];
+    int cnt[BIN_TPW], nst[BIN_TPW], work[BIN_TPW], run[BIN_TPW], rung[BIN_TPW];
     long long base[BIN_TPW];
 #pragma unroll
-    for (int j = 0; j < BIN_TPW; j++) { cnt[j] = 0; work[j] = 0; run[j] = 0; base[j] = 0; }
+    for (int j = 0; j < BIN_TPW; j++) { cnt[j] = 0; nst[j] = 0; work[j] = 0; run[j] = 0; rung[j] = 0; base[j] = 0; }
 
     for (int pass = 0; pass < 2; pass++) {
         for (int c0 = 0; c0 < n || (c0 == 0 && n == 0 && pass == 0); c0 += BIN_CH) {
@@ -130,19 +132,25 @@ k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int
                 const int X0 = tx * TW, X1 = X0 + TW, Y0 = ty * TH, Y1 = Y0 + TH;
                 for (int i0 = 0; i0 < m; i0 += 64) {
                     const int i = i0 + lane;
-                    bool hit = false;
+                    bool hit = false, star = false;
                     int4 q = make_int4(0, 0, 0, 0);
-                    if (i < m) { q = sbox[i]; hit = box_hits(q, X0, X1, Y0, Y1); }
+                    if (i < m) { q = sbox[i]; hit = box_hits(q, X0, X1, Y0, Y1); star = hit && (skind[i] == K_PSF); }
                     const unsigned long long mk = __ballot(hit);
+                    const unsigned long long ms = __ballot(star);
                     if (pass == 0) {
                         if (hit) work[j] += skind[i] * (min(q.w, Y1) - max(q.z, Y0) + 18);
                         cnt[j] += __popcll(mk);
+                        nst[j] += __popcll(ms);
                     } else {
                         if (hit) {
-                            int64_t at = base[j] + run[j] + __popcll(mk & ((1ull << lane) - 1ull));
+                            const unsigned long long below = (1ull << lane) - 1ull;
+                            // stars fill the head of the segment, everything else follows them
+                            int64_t at = star ? base[j] + run[j] + __popcll(ms & below)
+                                              : base[j] + nst[j] + rung[j] + __popcll((mk & ~ms) & below);
                             if (at < capacity) lists[at] = sid[i]; else *overflow = 1;
                         }
-                        run[j] += __popcll(mk);
+                        run[j] += __popcll(ms);
+                        rung[j] += __popcll(mk & ~ms);
                     }
                 }
             }
@@ -176,6 +184,7 @@ k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int
                 for (int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o);
                 if (lane == 0) {
                     tile_cnt[tile] = cnt[j];
+                    tile_nstar[tile] = nst[j];
                     tile_work[tile] = w;
                     tile_off[tile] = base[j];
                 }

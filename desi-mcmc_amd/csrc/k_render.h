@@ -316,6 +316,7 @@ struct RenderArgs {
     const SrcRec *recs;
     const int *lists;
     const int *tile_cnt;
+    const int *tile_nstar; // how many of a tile's entries are stars: they come first in its list (k_bin2.h)
     const int64_t *tile_off;
     const int *order;     // tile launch order (heaviest first) or nullptr
     unsigned long long *timing;   // diagnostic: per-tile {start, end} wall clock (100 MHz) + XCC/CU id, or nullptr

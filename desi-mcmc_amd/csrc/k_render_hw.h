@@ -17,6 +17,15 @@
 #define HW_TH 64
 #define HW_PAD 12   // zero components behind the compacted table: a half's group may read past the end
 
+// largest value of the convex form a x^2 + 2 b x y + c y^2 on a rectangle: at one of the corners
+__device__ inline double quad_max_rect_hw(double a, double b, double c, double x1, double x2, double y1, double y2) {
+    double m = a * x1 * x1 + (2.0 * b * x1 + c * y1) * y1;
+    m = fmax(m, a * x2 * x2 + (2.0 * b * x2 + c * y1) * y1);
+    m = fmax(m, a * x1 * x1 + (2.0 * b * x1 + c * y2) * y2);
+    m = fmax(m, a * x2 * x2 + (2.0 * b * x2 + c * y2) * y2);
+    return m * 1.00001;
+}
+
 template <int G, int STRIDE = HW_TW>   // STRIDE = doubles between consecutive rows of the accumulator tile
 __device__ inline void rec_group_hw(const CompTab &T, const double *__restrict__ et, int k0, double x,
                                     int Y0, int ra, int rb, int L, bool on, double *__restrict__ acc_col) {
@@ -69,6 +78,26 @@ __device__ inline void rec_group_hw(const CompTab &T, const double *__restrict__
         }
     }
 }
+
+// ---- the stars of a tile, batched ---------------------------------------------------------------
+// A star's three components are the band's PSF components shifted to the star: inverse covariance,
+// normaliser, row-to-row ratio are BAND constants (computed once per tile by lanes 0..2); a star
+// brings only its position, counts and box.  So the stars of a tile (they come first in its list,
+// k_bin2.h) need no per-source component table, no division, no drop test and no barrier pair per
+// source: up to 64 of them are staged in LDS per batch (40 bytes each, one lane per star), and the
+// two halves of the wave then walk TWO stars at a time -- lanes 0..31 star 2i, lanes 32..63 star
+// 2i+1, each all three components in one group over the star's rows on this tile.  One segment per
+// star: legal when no component's exponent can exceed 600 anywhere on a star's box (checked per
+// tile from the band's bounding radius; otherwise the stars take the general path below).
+// Nothing is dropped here, so a star's pixels carry all three components (the general path skips
+// components below eps * e^-T on the tile): both agree with the reference to the test tolerances.
+struct StarTab {           // lives in the component table's LDS while the stars are processed
+    double px[64], py[64], scale[64];
+    int4 box[64];          // x0, x1, y0, y1
+    double qa[K_PSF], qb[K_PSF], qc[K_PSF], eq[K_PSF], A0[K_PSF], mux[K_PSF], muy[K_PSF];
+};
+static_assert(sizeof(StarTab) <= sizeof(CompTab), "the star table must fit the component table's storage");
+#define STAR_EMAX 600.0
 
 __global__ void __launch_bounds__(64)
 k_render_hw(RenderArgs a) {
@@ -149,17 +178,102 @@ k_render_hw(RenderArgs a) {
     const int strict = (a.flags >> 2) & 1;   // photon-split totals: boxes open on the low side (internal flag)
 
     unsigned dbg_pairrows = 0, dbg_comprows = 0, dbg_pairs = 0;   // only counted under CEL_OPT_TILE_TIMING
+    const int nent_all = (int)min((int64_t)cnt, a.capacity > off ? a.capacity - off : (int64_t)0);
+    int nstar = min(a.tile_nstar ? a.tile_nstar[tile] : 0, nent_all);
+    if (a.variant == 0) nstar = 0;             // the direct evaluator takes every source through the general path
+    if (nstar > 0) {
+        StarTab &ST = *reinterpret_cast<StarTab *>(&T);
+        __syncthreads();                       // et[] is written
+        bool bad = false;
+        if (lane < K_PSF) {
+            const double cxx = bd->cxx[lane], cxy = bd->cxy[lane], cyy = bd->cyy[lane];
+            const double inv = 1.0 / (cxx * cyy - cxy * cxy);
+            const double qa = cyy * inv, qb = -cxy * inv, qc = cxx * inv;
+            ST.qa[lane] = qa * EXP_SCALE; ST.qb[lane] = qb * EXP_SCALE; ST.qc[lane] = qc * EXP_SCALE;
+            ST.eq[lane] = exp_tab64(-qc * EXP_SCALE, et);
+            ST.A0[lane] = bd->w[lane] * (0.5 / PI_D) * sqrt(inv);
+            ST.mux[lane] = bd->mux[lane]; ST.muy[lane] = bd->muy[lane];
+            // largest exponent of this component anywhere on a star's box (half-width R + 2 about the star)
+            const double rb_ = bd->R + 2.0;
+            const double emax = 0.5 * quad_max_rect_hw(qa, qb, qc, -rb_ - bd->mux[lane], rb_ - bd->mux[lane],
+                                                       -rb_ - bd->muy[lane], rb_ - bd->muy[lane]);
+            bad = !(emax <= STAR_EMAX);
+        }
+        if (__ballot(bad) != 0ull) nstar = 0;  // a very sharp PSF component: general path (segments, direct fallback)
+        __syncthreads();
+    }
+    if (nstar > 0) {
+        StarTab &ST = *reinterpret_cast<StarTab *>(&T);
+        double cqa[K_PSF], cqb[K_PSF], cqc[K_PSF], ceq[K_PSF], cA0[K_PSF], cmx[K_PSF], cmy[K_PSF];
+#pragma unroll
+        for (int k = 0; k < K_PSF; k++) {
+            cqa[k] = ST.qa[k]; cqb[k] = ST.qb[k]; cqc[k] = ST.qc[k]; ceq[k] = ST.eq[k];
+            cA0[k] = ST.A0[k]; cmx[k] = ST.mux[k]; cmy[k] = ST.muy[k];
+        }
+        double *colp = acc + col;
+        for (int base = 0; base < nstar; base += 64) {
+            const int nb = min(64, nstar - base);
+            __syncthreads();                   // the previous batch has been read
+            if (lane < nb) {
+                const SrcRec *rp = recs + a.lists[off + base + lane];
+                const double2 pp = *reinterpret_cast<const double2 *>(&rp->px);
+                ST.px[lane] = pp.x; ST.py[lane] = pp.y; ST.scale[lane] = rp->scale;
+                ST.box[lane] = *reinterpret_cast<const int4 *>(&rp->x0);
+            }
+            __syncthreads();
+            if (a.timing) { dbg_pairs += (unsigned)nb; }
+            for (int it = 0; 2 * it < nb; it++) {
+                const bool valid = (2 * it + half) < nb;
+                const int j = min(2 * it + half, nb - 1);
+                const double px = ST.px[j], py = ST.py[j];
+                const int4 bx = ST.box[j];
+                const int bx0 = bx.x + strict, by0 = bx.z + strict;
+                const int ra = max(by0, Y0) - Y0;
+                const int rb = valid ? min(bx.w, Y0 + HW_TH) - Y0 : ra;
+                const bool on = (xi >= bx0) && (xi < bx.y);
+                const double amp = on ? ST.scale[j] : 0.0;
+                if (a.timing && rb > ra) dbg_comprows += (unsigned)(rb - ra) * K_PSF / 2;   // per half: halves add up
+                double g[K_PSF], r[K_PSF];
+                const double y0 = (double)(Y0 + ra);
+#pragma unroll
+                for (int k = 0; k < K_PSF; k++) {
+                    const double dx = x - (px + cmx[k]), dy = y0 - (py + cmy[k]);
+                    const double hx = cqb[k] * dx + cqc[k] * dy;
+                    const double e = -0.5 * (cqa[k] * dx * dx + (cqb[k] * dx + hx) * dy);
+                    const double er = fmin(fmax(-(hx + 0.5 * cqc[k]), -REC_EMAX * EXP_SCALE), REC_EMAX * EXP_SCALE);
+                    g[k] = (cA0[k] * amp) * exp_tab64(e, et);
+                    r[k] = exp_tab64(er, et);
+                }
+                int row = ra;
+                for (; row + 1 < rb; row += 2) {
+#pragma clang fp contract(off)
+                    const double s0 = (g[0] + g[1]) + g[2];
+                    double g1[K_PSF], r1[K_PSF];
+#pragma unroll
+                    for (int k = 0; k < K_PSF; k++) { g1[k] = g[k] * r[k]; r1[k] = r[k] * ceq[k]; }
+                    const double s1 = (g1[0] + g1[1]) + g1[2];
+#pragma unroll
+                    for (int k = 0; k < K_PSF; k++) { g[k] = g1[k] * r1[k]; r[k] = r1[k] * ceq[k]; }
+                    lds_add(&colp[row * HW_TW], s0);
+                    lds_add(&colp[(row + 1) * HW_TW], s1);
+                }
+                if (row < rb) lds_add(&colp[row * HW_TW], (g[0] + g[1]) + g[2]);
+            }
+        }
+    }
+
     const LaneConst lc = lane_consts(lane, bd);
-    // the tile's list, 64 indices per coalesced load; the next source's record is in flight while
-    // the current one is evaluated
-    const int nent = (int)min((int64_t)cnt, a.capacity > off ? a.capacity - off : (int64_t)0);
-    int idx64 = (lane < nent) ? a.lists[off + lane] : 0;
+    // the rest of the tile's list (everything when there was no star pass), 64 indices per coalesced
+    // load; the next source's record is in flight while the current one is evaluated
+    const int64_t off2 = off + nstar;
+    const int nent = nent_all - nstar;
+    int idx64 = (lane < nent) ? a.lists[off2 + lane] : 0;
     int recw_next = (nent > 0) ? rec_fetch(recs, __builtin_amdgcn_readlane(idx64, 0), lane) : 0;
 
     for (int e = 0; e < nent; e++) {
         const int recw = recw_next;
         if (e + 1 < nent) {
-            if (((e + 1) & 63) == 0) idx64 = (e + 1 + lane < nent) ? a.lists[off + e + 1 + lane] : 0;
+            if (((e + 1) & 63) == 0) idx64 = (e + 1 + lane < nent) ? a.lists[off2 + e + 1 + lane] : 0;
             recw_next = rec_fetch(recs, __builtin_amdgcn_readlane(idx64, (e + 1) & 63), lane);
         }
         const RecU rec = rec_unpack(recw);

@@ -205,6 +205,15 @@ class ImageSet(object):
         L.check(L.lib().cel_field_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(n_srcpix=a.value, n_gauss=b.value, n_tile_entries=c.value)
 
+    def tile_timing(self):
+        """diagnostic stamps of the last render under CEL_OPT_TILE_TIMING -> (T, 3) uint64: start, end
+        (100 MHz ticks), packed work counters (include/celeste_hip.h: cel_debug_tile_timing)"""
+        n = C.c_int64(0)
+        L.check(L.lib().cel_debug_tile_timing(self._h, None, C.byref(n)))
+        buf = np.zeros((n.value, 3), dtype=np.uint64)
+        L.check(L.lib().cel_debug_tile_timing(self._h, buf.ctypes.data, C.byref(n)))
+        return buf
+
     def source_boxes(self, sources):
         """(boxes[B,S,4] = y0,y1,x0,x1, status[B,S]) for every band."""
         S = sources.S

@@ -77,7 +77,26 @@ class SyntheticField(object):
             self.nelec = np.random.RandomState(seed + 1).poisson(lam).astype(np.float64)
             self.images.set_nelec(self.nelec)
 
+    def flux5(self):
+        """(S, 5) fluxes in nanomaggies by band letter u,g,r,i,z (band b of this field is letter b % 5)"""
+        out = np.zeros((self.S, 5))
+        for b in range(self.B):
+            out[:, b % 5] = self.src["flux"][:, b]
+        return out
+
     @classmethod
     def from_config(cls, ctx, name, seed=42, with_nelec=True):
         S, B, H, W, fg = CONFIGS[name]
         return cls(ctx, S, B, H, W, fg, seed, with_nelec)
+
+
+def fits_images(field):
+    """The field's band images as FitsImage objects (what the reference-API functions take)."""
+    from .fits_image import FitsImage
+    out = []
+    for b in range(field.B):
+        r = field.bands[b]
+        out.append(FitsImage("ugriz"[b % 5], field.nelec[b] if field.nelec is not None else np.zeros((field.H, field.W)),
+                             epsilon=r[0], kappa=r[1], calib=r[2], weights=r[3:6], means=r[6:12].reshape(3, 2),
+                             covars=r[12:24].reshape(3, 2, 2), rho_n=r[24:26], phi_n=r[26:28], Ups_n=r[28:32].reshape(2, 2)))
+    return out

@@ -169,7 +169,7 @@ void orc_gmm_like_2d(double *probs, const double *x, int64_t N, const double *ws
                      const double *sigs, int K) {
     const double log2pi = log(2.0 * M_PI);
     int64_t n;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (N >= 16384)
     for (n = 0; n < N; n++) probs[n] = 0.0;
     for (int k = 0; k < K; k++) {
         const double *s = sigs + 4 * k;
@@ -178,7 +178,7 @@ void orc_gmm_like_2d(double *probs, const double *x, int64_t N, const double *ws
         double invk_11 = s[0] / detk;
         double invk_01 = -1 * s[1] / detk;
         double m0 = mus[2 * k], m1 = mus[2 * k + 1], wk = ws[k];
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (N >= 16384)   /* small grids: a parallel region per component costs more than it saves */
         for (n = 0; n < N; n++) {
             double x0 = x[2 * n] - m0;
             double x1 = x[2 * n + 1] - m1;
@@ -212,7 +212,7 @@ static inline double mog_loglike_pt(double px, double py, const double *means, c
 void orc_mog_loglike(double *out, const double *x, int64_t N, const double *means, const double *icovs,
                      const double *dets, const double *pis, int K) {
     int64_t n;
-#pragma omp parallel
+#pragma omp parallel if (N >= 4096)
     {
         double *scratch = (double *)malloc(sizeof(double) * (size_t)(K > 0 ? K : 1));
 #pragma omp for schedule(static)

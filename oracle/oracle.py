@@ -44,6 +44,13 @@ def lib():
         L.orc_galaxy_box.restype = C.c_double
         L.orc_source_patch.restype = C.c_int64
         L.orc_poisson_loglike.restype = C.c_double
+        # never more threads than this process may run on (the GPU boxes report every core of the host
+        # but grant a share of 16): an oversubscribed OpenMP team turns every barrier into a scheduler wait
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        L.orc_set_threads(C.c_int(max(1, min(L.orc_max_threads(), avail, int(os.environ.get("ORC_MAX_THREADS", "16"))))))
         _lib = L
     return _lib
 

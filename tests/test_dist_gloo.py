@@ -36,8 +36,10 @@ def _worker(rank, world, port, mode, out_dir):
     if mode == "strips":
         y0, y1 = dist.strip_rows(H, world, rank)
         part = np.array([orc.poisson_loglike(g["nelec"][b, y0:y1], lam[b, y0:y1]) for b in range(5)])
-    else:  # fields: rank r owns field r (field 1 = the same sky observed with +1 electron per pixel)
-        mine = dist.field_shard(world, world, rank)
+    else:  # fields: 8 fields dealt to the ranks as bench.py --workload fields8_2048 deals them
+        # (field k = the same sky observed with +k electrons per pixel)
+        mine = dist.field_shard(8, world, rank)
+        assert len(mine) == 8 // world and sorted(sum((dist.field_shard(8, world, r) for r in range(world)), [])) == list(range(8))
         part = np.zeros(5)
         for f in mine:
             part += np.array([orc.poisson_loglike(g["nelec"][b] + f, lam[b]) for b in range(5)])
@@ -74,7 +76,7 @@ def test_world2_gloo_loglik_allreduce(tmp_path, mode):
         expect = g["ll_band"]
     else:
         from oracle import oracle as orc
-        expect = g["ll_band"] + np.array([orc.poisson_loglike(g["nelec"][b] + 1, g["lam"][b]) for b in range(5)])
+        expect = sum(np.array([orc.poisson_loglike(g["nelec"][b] + k, g["lam"][b]) for b in range(5)]) for k in range(8))
     for r in range(world):
         np.testing.assert_allclose(res[r][0], expect, rtol=1e-12)      # all-reduce
         np.testing.assert_allclose(res[r][1], expect, rtol=1e-12)      # all-gather + ordered sum

@@ -1070,3 +1070,26 @@ def test_integration_md_ctypes_binding(cel, orc):
         check(L.cel_sources_destroy(h))
     check(L.cel_images_destroy(img))
     check(L.cel_ctx_destroy(ctx))
+
+
+def test_multi_field_standin_dealt_to_one_rank(cel, ctx, orc):
+    """BASELINE configs[3] stand-in at world size 1: K synthetic fields dealt by dist.field_shard, every
+    field's log-likelihood against the oracle, and the job's sum (what bench.py --workload fields8_2048
+    all-reduces) -- the world-2 deal is covered on CPU by tests/test_dist_gloo.py."""
+    from desi_mcmc_amd import dist, synth
+    K = 3
+    mine = dist.field_shard(K, 1, 0)
+    assert mine == [0, 1, 2]
+    total = np.zeros(5)
+    want = np.zeros(5)
+    for k in mine:
+        f = synth.SyntheticField(ctx, 150, 5, 200, 240, frac_gal=0.5, seed=42 + 1000 * k)
+        _, llb = f.images.render(f.sources, loglik=True)
+        _, o_ll, _ = orc.render_field(oracle_bands(f), f.H, f.W, f.src["type"], f.src["radec"], f.src["counts"],
+                                      f.src["shape"], f.nelec)
+        np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
+        total += llb
+        want += o_ll
+    np.testing.assert_allclose(dist.allreduce_loglik(total), want, rtol=RT_LL)
+    fields = [synth.SyntheticField(ctx, 150, 5, 200, 240, frac_gal=0.5, seed=42 + 1000 * k).src["radec"][0] for k in mine]
+    assert len({tuple(r) for r in fields}) == K          # different fields, not one field K times
