@@ -15,7 +15,7 @@ CEL_OK, CEL_ERR_INVALID, CEL_ERR_HIP, CEL_ERR_NOMEM, CEL_ERR_NO_DEVICE = 0, 1, 2
 CEL_HOST, CEL_DEVICE = 0, 1
 CEL_RENDER_LOGLIK, CEL_RENDER_NO_STORE = 1, 2
 CEL_OPT_KERNEL, CEL_OPT_TAIL_LOG, CEL_OPT_PROFILE, CEL_OPT_TILE_ORDER, CEL_OPT_TILE_ROWS = 1, 2, 3, 4, 5
-CEL_OPT_TILE_TIMING, CEL_OPT_TILE_LAYOUT = 6, 7
+CEL_OPT_TILE_TIMING, CEL_OPT_TILE_LAYOUT, CEL_OPT_DEBUG = 6, 7, 8
 KERNELS = {"prep": 0, "bin": 1, "render": 2, "reduce": 3, "stamps": 4, "gmm": 5}
 BAND_DOUBLES = 37
 MAX_BANDS = 16

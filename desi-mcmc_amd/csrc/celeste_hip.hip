@@ -102,6 +102,7 @@ struct cel_ctx {
     int tile_order = 1;       // 0 = launch k_render tiles in index order, 1 = heaviest first by the last render's measured tile durations (estimate when none), 2 = heaviest first by the estimate only
     int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created
     bool tile_timing = false; // diagnostic: k_render stamps each tile's start/end wall clock
+    int debug = 0;            // CEL_OPT_DEBUG: timing-only ablation bits handed to the render kernel (results are wrong when set)
     int tile_layout = 1;      // 0: 64 x tile_rows tiles, one lane per column (k_render)
                               // 1: 32 x 64 tiles, two component groups per column (k_render_hw)
     Prof prof;
@@ -384,6 +385,10 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         if (v != 0.0 && v != 1.0 && v != 2.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TILE_LAYOUT must be 0, 1 or 2");
         c->tile_layout = (int)v;
         return CEL_OK;
+    case CEL_OPT_DEBUG:
+        if (!(v >= 0.0) || v > 255.0) return fail(CEL_ERR_INVALID, "CEL_OPT_DEBUG must be in [0, 255]");
+        c->debug = (int)v;
+        return CEL_OK;
     }
     return fail(CEL_ERR_INVALID, "unknown option %d", key);
 }
@@ -398,6 +403,7 @@ int cel_ctx_get_option(cel_ctx *c, int key, double *v) {
     case CEL_OPT_TILE_ROWS: *v = c->tile_rows; return CEL_OK;
     case CEL_OPT_TILE_TIMING: *v = c->tile_timing ? 1.0 : 0.0; return CEL_OK;
     case CEL_OPT_TILE_LAYOUT: *v = c->tile_layout; return CEL_OK;
+    case CEL_OPT_DEBUG: *v = c->debug; return CEL_OK;
     }
     return fail(CEL_ERR_INVALID, "unknown option %d", key);
 }
@@ -721,7 +727,7 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         a.tile_nstar = im->d_tile_nstar;
         a.tile_off = im->d_tile_off; a.nelec = im->d_nelec; a.lambda = lambda_out ? lambda_out : im->d_lambda; a.partials = im->d_partials;
         a.S = S; a.capacity = im->lists_cap; a.B = im->B; a.H = im->H; a.W = im->W; a.ntx = im->ntx; a.nty = im->nty;
-        a.flags = flags; a.variant = c->variant; a.tail_T = c->tail_T; a.order = c->tile_order ? im->d_order : nullptr;
+        a.flags = flags | (c->debug << 8); a.variant = c->variant; a.tail_T = c->tail_T; a.order = c->tile_order ? im->d_order : nullptr;
         a.timing = nullptr;
         a.cost = (im->TW == HW_TW || im->TW == QW_TW) ? im->d_tile_cost : nullptr;
         if (c->tile_timing) {

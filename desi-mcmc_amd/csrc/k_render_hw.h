@@ -99,6 +99,190 @@ struct StarTab {           // lives in the component table's LDS while the stars
 static_assert(sizeof(StarTab) <= sizeof(CompTab), "the star table must fit the component table's storage");
 #define STAR_EMAX 600.0
 
+
+// band constants of the three PSF components into the star table (lanes 0..2) and the check that a
+// star may take the one-segment path; contains one barrier, all 64 lanes call it
+__device__ __forceinline__ bool star_setup(StarTab &ST, const BandDev *__restrict__ bd, const double *__restrict__ et, int lane) {
+    bool bad = false;
+    if (lane < K_PSF) {
+        const double cxx = bd->cxx[lane], cxy = bd->cxy[lane], cyy = bd->cyy[lane];
+        const double inv = 1.0 / (cxx * cyy - cxy * cxy);
+        const double qa = cyy * inv, qb = -cxy * inv, qc = cxx * inv;
+        ST.qa[lane] = qa * EXP_SCALE; ST.qb[lane] = qb * EXP_SCALE; ST.qc[lane] = qc * EXP_SCALE;
+        ST.eq[lane] = exp_tab64(-qc * EXP_SCALE, et);
+        ST.A0[lane] = bd->w[lane] * (0.5 / PI_D) * sqrt(inv);
+        ST.mux[lane] = bd->mux[lane]; ST.muy[lane] = bd->muy[lane];
+        // largest exponent of this component anywhere on a star's box (half-width R + 2 about the star)
+        const double rb_ = bd->R + 2.0;
+        const double emax = 0.5 * quad_max_rect_hw(qa, qb, qc, -rb_ - bd->mux[lane], rb_ - bd->mux[lane],
+                                                   -rb_ - bd->muy[lane], rb_ - bd->muy[lane]);
+        bad = !(emax <= STAR_EMAX);
+    }
+    const bool ok = (__ballot(bad) == 0ull);
+    __syncthreads();
+    return ok;
+}
+
+struct StarBatch {         // lane j's star of a tile's first batch, already in registers (k_render_stars prefetches it)
+    double2 pp;
+    double sc;
+    int4 bx;
+    bool valid;
+};
+
+// the first nstar entries of the tile's list (its stars) into the accumulator tile
+__device__ __forceinline__ void star_pass(const RenderArgs &a, StarTab &ST, const double *__restrict__ et, double *__restrict__ acc,
+                                          const SrcRec *__restrict__ recs, int64_t off, int nstar, int lane, int xi, int Y0,
+                                          int strict, unsigned &dbg_halfrows, unsigned &dbg_pairs, const StarBatch *first = nullptr) {
+    const int half = lane >> 5, col = lane & 31;
+    const double x = (double)xi;
+    {
+        double cqa[K_PSF], cqb[K_PSF], cqc[K_PSF], ceq[K_PSF], cA0[K_PSF], cmx[K_PSF], cmy[K_PSF];
+#pragma unroll
+        for (int k = 0; k < K_PSF; k++) {
+            cqa[k] = ST.qa[k]; cqb[k] = ST.qb[k]; cqc[k] = ST.qc[k]; ceq[k] = ST.eq[k];
+            cA0[k] = ST.A0[k]; cmx[k] = ST.mux[k]; cmy[k] = ST.muy[k];
+        }
+        double *colp = acc + col;
+        for (int base = 0; base < nstar; base += 64) {
+            const int nb = min(64, nstar - base);
+            __syncthreads();                   // the previous batch has been read
+            // One lane per star loads it; the batch is then SORTED by the number of rows the star has
+            // on this tile (descending; ties by list position), so that the two stars a wave walks
+            // together are of nearly equal length -- unsorted, a step lasts as long as the longer
+            // of two unrelated row counts (+25 % on a dense star field).  The rank of a star is a
+            // count over the batch (<= 64 LDS broadcasts), and depends only on the data.
+            double2 pp = make_double2(0.0, 0.0);
+            double sc = 0.0;
+            int4 bx4 = make_int4(0, 0, 0, 0);
+            int nrows = -1;
+            if (lane < nb) {
+                if (first && base == 0) {
+                    pp = first->pp; sc = first->sc; bx4 = first->bx;
+                } else {
+                    const SrcRec *rp = recs + a.lists[off + base + lane];
+                    pp = *reinterpret_cast<const double2 *>(&rp->px);
+                    sc = rp->scale;
+                    bx4 = *reinterpret_cast<const int4 *>(&rp->x0);
+                }
+                nrows = max(min(bx4.w, Y0 + HW_TH) - max(bx4.z + strict, Y0), 0);
+            }
+            int *srows = reinterpret_cast<int *>(ST.scale);      // scratch until the sorted table is written
+            srows[lane] = nrows;
+            __syncthreads();
+            int rank = 0;
+            for (int j = 0; j < nb; j++) {
+                const int rj = srows[j];
+                rank += (rj > nrows || (rj == nrows && j < lane)) ? 1 : 0;
+            }
+            __syncthreads();
+            if (lane < nb) {
+                ST.px[rank] = pp.x; ST.py[rank] = pp.y; ST.scale[rank] = sc;
+                ST.box[rank] = bx4;
+            }
+            __syncthreads();
+            if (a.timing) { dbg_pairs += (unsigned)nb; }
+            const int dbg = a.flags >> 8;
+            for (int it = 0; 2 * it < nb && !(dbg & 2); it++) {
+                const bool valid = (2 * it + half) < nb;
+                const int j = min(2 * it + half, nb - 1);
+                const double px = ST.px[j], py = ST.py[j];
+                const int4 bx = ST.box[j];
+                const int bx0 = bx.x + strict, by0 = bx.z + strict;
+                const int ra = max(by0, Y0) - Y0;
+                const int rb = (valid && !(dbg & 1)) ? min(bx.w, Y0 + HW_TH) - Y0 : ra;
+                const bool on = (xi >= bx0) && (xi < bx.y);
+                const double amp = on ? ST.scale[j] : 0.0;
+                if (a.timing) {      // kept component-rows of the step = both halves' rows x 3; counted as half-tile widths
+                    const int rows_lo = __builtin_amdgcn_readlane(max(rb - ra, 0), 0), rows_hi = __builtin_amdgcn_readlane(max(rb - ra, 0), 32);
+                    dbg_halfrows += (unsigned)(rows_lo + rows_hi) * K_PSF;
+                }
+                double g[K_PSF], r[K_PSF];
+                const double y0 = (double)(Y0 + ra);
+#pragma unroll
+                for (int k = 0; k < K_PSF; k++) {
+                    const double dx = x - (px + cmx[k]), dy = y0 - (py + cmy[k]);
+                    const double hx = cqb[k] * dx + cqc[k] * dy;
+                    const double e = -0.5 * (cqa[k] * dx * dx + (cqb[k] * dx + hx) * dy);
+                    const double er = fmin(fmax(-(hx + 0.5 * cqc[k]), -REC_EMAX * EXP_SCALE), REC_EMAX * EXP_SCALE);
+                    g[k] = (cA0[k] * amp) * exp_tab64(e, et);
+                    r[k] = exp_tab64(er, et);
+                }
+                int row = ra;
+                double *rowp = colp + ra * HW_TW;
+                for (; row + 3 < rb; row += 4, rowp += 4 * HW_TW) {       // four rows per trip: one address update, one bound test
+#pragma clang fp contract(off)
+                    double g1[K_PSF], r1[K_PSF];
+                    const double s0 = (g[0] + g[1]) + g[2];
+#pragma unroll
+                    for (int k = 0; k < K_PSF; k++) { g1[k] = g[k] * r[k]; r1[k] = r[k] * ceq[k]; }
+                    const double s1 = (g1[0] + g1[1]) + g1[2];
+#pragma unroll
+                    for (int k = 0; k < K_PSF; k++) { g[k] = g1[k] * r1[k]; r[k] = r1[k] * ceq[k]; }
+                    const double s2 = (g[0] + g[1]) + g[2];
+#pragma unroll
+                    for (int k = 0; k < K_PSF; k++) { g1[k] = g[k] * r[k]; r1[k] = r[k] * ceq[k]; }
+                    const double s3 = (g1[0] + g1[1]) + g1[2];
+#pragma unroll
+                    for (int k = 0; k < K_PSF; k++) { g[k] = g1[k] * r1[k]; r[k] = r1[k] * ceq[k]; }
+                    lds_add(&rowp[0], s0);
+                    lds_add(&rowp[HW_TW], s1);
+                    lds_add(&rowp[2 * HW_TW], s2);
+                    lds_add(&rowp[3 * HW_TW], s3);
+                }
+                for (; row < rb; row++, rowp += HW_TW) {
+#pragma clang fp contract(off)
+                    lds_add(&rowp[0], (g[0] + g[1]) + g[2]);
+#pragma unroll
+                    for (int k = 0; k < K_PSF; k++) { g[k] = g[k] * r[k]; r[k] = r[k] * ceq[k]; }
+                }
+            }
+        }
+    }
+}
+
+
+// epilogue of a tile: lambda = eps + acc written once, the Poisson term reduced to one partial.
+// One wave-instruction covers two 256-B row segments (rows 2r and 2r+1).  `lt` is the component /
+// star table's LDS, dead by now: it takes the log table (128 doubles).  All 32 nelec loads of a lane
+// are issued before the first use (16 KB in flight per wave); PRE (nelec already in registers) is
+// kept for experiments.
+template <bool PRE>
+__device__ __forceinline__ void hw_epilogue(const RenderArgs &a, const double *__restrict__ acc, double *__restrict__ lt,
+                                            const BandDev *__restrict__ bd, int tile, int b, int xi, int Y0, int lane,
+                                            const double *ne_pre) {
+    const int half = lane >> 5;
+    __syncthreads();
+    lt[lane] = c_log_ic[lane];
+    lt[64 + lane] = c_log_lc[lane];
+    __syncthreads();
+    const double eps = bd->eps;
+    const bool store = !(a.flags & CEL_RENDER_NO_STORE);
+    const bool ll = (a.flags & CEL_RENDER_LOGLIK) != 0;
+    double part = 0.0;
+    const int64_t plane = (int64_t)b * a.H * a.W;
+    if (xi < a.W && !((a.flags >> 8) & 16)) {
+        const int64_t base = plane + (int64_t)(Y0 + half) * a.W + xi;
+        double ne[HW_TH / 2];
+#pragma unroll
+        for (int r = 0; r < HW_TH / 2; r++)
+            ne[r] = PRE ? ne_pre[r] : ((ll && Y0 + 2 * r + half < a.H) ? a.nelec[base + (int64_t)(2 * r) * a.W] : 0.0);
+#pragma unroll
+        for (int r = 0; r < HW_TH / 2; r++) {
+            if (Y0 + 2 * r + half < a.H) {
+                double lam = eps + acc[r * 64 + lane];
+                if (store) a.lambda[base + (int64_t)(2 * r) * a.W] = lam;
+                if (ll) part += ((a.flags >> 8) & 4) ? ne[r] - lam : ne[r] * log_tab(lam, lt) - lam;
+            }
+        }
+    }
+    if (ll) {
+        part = wave_sum(part);
+        if (lane == 0) a.partials[tile] = part;
+    }
+}
+
+static_assert(sizeof(CompTab) >= 128 * sizeof(double), "log table must fit the component table");
 __global__ void __launch_bounds__(64)
 k_render_hw(RenderArgs a) {
     __shared__ double acc[HW_TH * HW_TW];
@@ -118,6 +302,7 @@ k_render_hw(RenderArgs a) {
     const BandDev *bd = a.bands + b;
 
     const int cnt = a.tile_cnt[tile];
+    if ((a.flags >> 8) & 8) return;             // ablation: launch + header load only
     if (cnt == 0 && !a.timing) {
         // empty sky: lambda = eps on the whole tile -- pure streaming (nelec in, eps out), one log
         // per wave instead of one per pixel, no LDS.  Same arithmetic per pixel as the general
@@ -178,95 +363,27 @@ k_render_hw(RenderArgs a) {
     const int strict = (a.flags >> 2) & 1;   // photon-split totals: boxes open on the low side (internal flag)
 
     unsigned dbg_pairrows = 0, dbg_comprows = 0, dbg_pairs = 0;   // only counted under CEL_OPT_TILE_TIMING
+    unsigned dbg_halfrows = 0;                                   // star path: component-rows (each walked on 32 lanes, like the general path's)
     const int nent_all = (int)min((int64_t)cnt, a.capacity > off ? a.capacity - off : (int64_t)0);
     int nstar = min(a.tile_nstar ? a.tile_nstar[tile] : 0, nent_all);
+    if ((a.flags >> 8) & 32) nstar = 0;         // ablation: no star pass at all (and no general pass: see below)
     if (a.variant == 0) nstar = 0;             // the direct evaluator takes every source through the general path
     if (nstar > 0) {
         StarTab &ST = *reinterpret_cast<StarTab *>(&T);
         __syncthreads();                       // et[] is written
-        bool bad = false;
-        if (lane < K_PSF) {
-            const double cxx = bd->cxx[lane], cxy = bd->cxy[lane], cyy = bd->cyy[lane];
-            const double inv = 1.0 / (cxx * cyy - cxy * cxy);
-            const double qa = cyy * inv, qb = -cxy * inv, qc = cxx * inv;
-            ST.qa[lane] = qa * EXP_SCALE; ST.qb[lane] = qb * EXP_SCALE; ST.qc[lane] = qc * EXP_SCALE;
-            ST.eq[lane] = exp_tab64(-qc * EXP_SCALE, et);
-            ST.A0[lane] = bd->w[lane] * (0.5 / PI_D) * sqrt(inv);
-            ST.mux[lane] = bd->mux[lane]; ST.muy[lane] = bd->muy[lane];
-            // largest exponent of this component anywhere on a star's box (half-width R + 2 about the star)
-            const double rb_ = bd->R + 2.0;
-            const double emax = 0.5 * quad_max_rect_hw(qa, qb, qc, -rb_ - bd->mux[lane], rb_ - bd->mux[lane],
-                                                       -rb_ - bd->muy[lane], rb_ - bd->muy[lane]);
-            bad = !(emax <= STAR_EMAX);
-        }
-        if (__ballot(bad) != 0ull) nstar = 0;  // a very sharp PSF component: general path (segments, direct fallback)
-        __syncthreads();
+        if (!star_setup(ST, bd, et, lane)) nstar = 0;   // a very sharp PSF component: general path (segments, direct fallback)
     }
-    if (nstar > 0) {
-        StarTab &ST = *reinterpret_cast<StarTab *>(&T);
-        double cqa[K_PSF], cqb[K_PSF], cqc[K_PSF], ceq[K_PSF], cA0[K_PSF], cmx[K_PSF], cmy[K_PSF];
-#pragma unroll
-        for (int k = 0; k < K_PSF; k++) {
-            cqa[k] = ST.qa[k]; cqb[k] = ST.qb[k]; cqc[k] = ST.qc[k]; ceq[k] = ST.eq[k];
-            cA0[k] = ST.A0[k]; cmx[k] = ST.mux[k]; cmy[k] = ST.muy[k];
-        }
-        double *colp = acc + col;
-        for (int base = 0; base < nstar; base += 64) {
-            const int nb = min(64, nstar - base);
-            __syncthreads();                   // the previous batch has been read
-            if (lane < nb) {
-                const SrcRec *rp = recs + a.lists[off + base + lane];
-                const double2 pp = *reinterpret_cast<const double2 *>(&rp->px);
-                ST.px[lane] = pp.x; ST.py[lane] = pp.y; ST.scale[lane] = rp->scale;
-                ST.box[lane] = *reinterpret_cast<const int4 *>(&rp->x0);
-            }
-            __syncthreads();
-            if (a.timing) { dbg_pairs += (unsigned)nb; }
-            for (int it = 0; 2 * it < nb; it++) {
-                const bool valid = (2 * it + half) < nb;
-                const int j = min(2 * it + half, nb - 1);
-                const double px = ST.px[j], py = ST.py[j];
-                const int4 bx = ST.box[j];
-                const int bx0 = bx.x + strict, by0 = bx.z + strict;
-                const int ra = max(by0, Y0) - Y0;
-                const int rb = valid ? min(bx.w, Y0 + HW_TH) - Y0 : ra;
-                const bool on = (xi >= bx0) && (xi < bx.y);
-                const double amp = on ? ST.scale[j] : 0.0;
-                if (a.timing && rb > ra) dbg_comprows += (unsigned)(rb - ra) * K_PSF / 2;   // per half: halves add up
-                double g[K_PSF], r[K_PSF];
-                const double y0 = (double)(Y0 + ra);
-#pragma unroll
-                for (int k = 0; k < K_PSF; k++) {
-                    const double dx = x - (px + cmx[k]), dy = y0 - (py + cmy[k]);
-                    const double hx = cqb[k] * dx + cqc[k] * dy;
-                    const double e = -0.5 * (cqa[k] * dx * dx + (cqb[k] * dx + hx) * dy);
-                    const double er = fmin(fmax(-(hx + 0.5 * cqc[k]), -REC_EMAX * EXP_SCALE), REC_EMAX * EXP_SCALE);
-                    g[k] = (cA0[k] * amp) * exp_tab64(e, et);
-                    r[k] = exp_tab64(er, et);
-                }
-                int row = ra;
-                for (; row + 1 < rb; row += 2) {
-#pragma clang fp contract(off)
-                    const double s0 = (g[0] + g[1]) + g[2];
-                    double g1[K_PSF], r1[K_PSF];
-#pragma unroll
-                    for (int k = 0; k < K_PSF; k++) { g1[k] = g[k] * r[k]; r1[k] = r[k] * ceq[k]; }
-                    const double s1 = (g1[0] + g1[1]) + g1[2];
-#pragma unroll
-                    for (int k = 0; k < K_PSF; k++) { g[k] = g1[k] * r1[k]; r[k] = r1[k] * ceq[k]; }
-                    lds_add(&colp[row * HW_TW], s0);
-                    lds_add(&colp[(row + 1) * HW_TW], s1);
-                }
-                if (row < rb) lds_add(&colp[row * HW_TW], (g[0] + g[1]) + g[2]);
-            }
-        }
-    }
+    // (Requesting a star-only tile's nelec BEFORE the star pass, so that the loads land under the
+    // arithmetic, was tried both here and in a persistent, software-pipelined star kernel: slower in
+    // both forms, 0.179 / 0.205 against 0.171 ms on the dense star field -- DESIGN.md 5.)
+    if (nstar > 0)
+        star_pass(a, *reinterpret_cast<StarTab *>(&T), et, acc, recs, off, nstar, lane, xi, Y0, strict, dbg_halfrows, dbg_pairs);
 
     const LaneConst lc = lane_consts(lane, bd);
     // the rest of the tile's list (everything when there was no star pass), 64 indices per coalesced
     // load; the next source's record is in flight while the current one is evaluated
     const int64_t off2 = off + nstar;
-    const int nent = nent_all - nstar;
+    const int nent = ((a.flags >> 8) & 32) ? 0 : nent_all - nstar;
     int idx64 = (lane < nent) ? a.lists[off2 + lane] : 0;
     int recw_next = (nent > 0) ? rec_fetch(recs, __builtin_amdgcn_readlane(idx64, 0), lane) : 0;
 
@@ -369,47 +486,14 @@ k_render_hw(RenderArgs a) {
         }
     }
 
-    // epilogue: one wave-instruction covers two 256-B row segments (rows 2r and 2r+1).
-    // The component table is dead now: its LDS holds the log table (128 doubles) instead.
-    __syncthreads();
-    double *lt = reinterpret_cast<double *>(&T);
-    static_assert(sizeof(CompTab) >= 128 * sizeof(double), "log table must fit the component table");
-    lt[lane] = c_log_ic[lane];
-    lt[64 + lane] = c_log_lc[lane];
-    __syncthreads();
-    const double eps = bd->eps;
-    const bool store = !(a.flags & CEL_RENDER_NO_STORE);
-    const bool ll = (a.flags & CEL_RENDER_LOGLIK) != 0;
-    double part = 0.0;
-    const int64_t plane = (int64_t)b * a.H * a.W;
-    if (xi < a.W) {
-        // all of the tile's nelec loads are issued before the first use: 16 KB in flight per
-        // wave (an empty-sky tile is pure streaming, and 8 waves per CU must cover HBM latency)
-        double ne[HW_TH / 2];
-        const int64_t base = plane + (int64_t)(Y0 + half) * a.W + xi;
-#pragma unroll
-        for (int r = 0; r < HW_TH / 2; r++)
-            ne[r] = (ll && Y0 + 2 * r + half < a.H) ? a.nelec[base + (int64_t)(2 * r) * a.W] : 0.0;
-#pragma unroll
-        for (int r = 0; r < HW_TH / 2; r++) {
-            if (Y0 + 2 * r + half < a.H) {
-                double lam = eps + acc[r * 64 + lane];
-                if (store) a.lambda[base + (int64_t)(2 * r) * a.W] = lam;
-                if (ll) part += ne[r] * log_tab(lam, lt) - lam;
-            }
-        }
-    }
-    if (ll) {
-        part = wave_sum(part);
-        if (lane == 0) a.partials[tile] = part;
-    }
+    hw_epilogue<false>(a, acc, reinterpret_cast<double *>(&T), bd, tile, b, xi, Y0, lane, nullptr);
     if (a.cost && lane == 0) a.cost[tile] = (int)min(wall_clock64() - t_start, 0x3fffffffull) + 1;
     if (a.timing && lane == 0) {
         a.timing[3 * (size_t)blockIdx.x + 0] = t_start;
         a.timing[3 * (size_t)blockIdx.x + 1] = wall_clock64();
         // work counters of this tile (diagnostic): sources | pairs of groups << 12 | kept component-rows << 32
         a.timing[3 * (size_t)blockIdx.x + 2] = (unsigned long long)(unsigned)cnt | ((unsigned long long)dbg_pairs << 12) |
-                                               ((unsigned long long)dbg_comprows << 32);
+                                               ((unsigned long long)(dbg_comprows + dbg_halfrows) << 32);
         (void)dbg_pairrows;
     }
 }

@@ -72,12 +72,16 @@ enum {
                               is none), 2 = heaviest first by the estimate only                         */
     CEL_OPT_TILE_ROWS = 5, /* rows per render tile, 32 (default) or 64; read by cel_images_create  */
     CEL_OPT_TILE_TIMING = 6,/* diagnostic: 1 = k_render stamps every tile's start/end wall clock   */
-    CEL_OPT_TILE_LAYOUT = 7 /* render tile geometry, read by cel_images_create:
+    CEL_OPT_TILE_LAYOUT = 7,/* render tile geometry, read by cel_images_create:
                                0 = 64 columns x TILE_ROWS rows, one lane per column;
                                1 (default) = 32 columns x 64 rows, two component groups per column;
                                2 = 16 columns x 128 rows, four component groups per column (fewer
                                recurrence seeds, more per-tile set-up: measured 4 % slower than 1
                                on the benchmark field, kept for fields of tall narrow boxes)      */
+    CEL_OPT_DEBUG = 8       /* diagnostic, timing-only: ablation bits for the render kernel (1 = skip the star
+                               walk, 2 = the star seeds + walk, 4 = the epilogue's log, 8 = everything after the
+                               tile header, 16 = the epilogue's global loads / stores, 32 = every source).
+                               Results are WRONG when non-zero; never set outside tools/ablate_render.py */
 };
 
 /* kernels reported by cel_profile_get */
