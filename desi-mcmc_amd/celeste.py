@@ -71,11 +71,10 @@ def _cache_trim(keep=None):
 
 
 def _sync_epsilon(ent, images):
-    iset, eps = ent[1], ent[2]
+    iset = ent[1]
     for b, im in enumerate(images):          # epsilon is resampled by Gibbs (models.py:156-160)
-        if im.epsilon != eps[b]:
+        if im.epsilon != iset.eps[b]:        # iset.eps mirrors what the device holds, whoever set it
             iset.set_epsilon(b, im.epsilon)
-            eps[b] = im.epsilon
 
 
 def _image_set(images):

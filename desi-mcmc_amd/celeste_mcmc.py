@@ -62,7 +62,7 @@ class GibbsField(object):
         self.kappa = np.asarray(kappa, dtype=np.float64)
         self.npix = float(npix)
         self.a_0, self.b_0 = a_0, b_0                                  # Gamma prior of the sky level (models.py:119-121)
-        self.epsilon = np.array([iset.band(b)[0] for b in range(iset.B)])
+        self.epsilon = np.array(iset.eps, copy=True)
         self.sset = None
         self.prop = None
         self.has_patch = None
@@ -89,7 +89,7 @@ class ModelGibbs(object):
 
     BANDS = ['u', 'g', 'r', 'i', 'z']
 
-    def __init__(self, fields, typ, u, fluxes, shape, seed=0, flux_a_0=5., flux_b_0=.005, slice_args=None):
+    def __init__(self, fields, typ, u, fluxes, shape, seed=0, flux_a_0=5., flux_b_0=.005, slice_args=None, engine="auto"):
         self.fields = list(fields)
         self.typ = np.ascontiguousarray(typ, dtype=np.int32)
         self.S = self.typ.shape[0]
@@ -103,6 +103,13 @@ class ModelGibbs(object):
         # slicesample argument, so sigma keeps its default 1.0 unless the caller sets it
         self.slice_args = dict(step_out=False)
         self.slice_args.update(slice_args or {})
+        # where the slice sampler's state machine runs: "device" (cel_slice_locations: nothing but a
+        # counter crosses PCIe per round; one field, the reference call's options), "host" (the numpy
+        # engine of util/infer/slicesample.py: every option, any number of fields), "auto" = device
+        # when it applies.  Both draw the same per-chain streams: a chain takes the same trajectory.
+        if engine not in ("auto", "device", "host"):
+            raise ValueError("engine must be auto, device or host")
+        self.engine = engine
         self.sweeps = 0
         self.timing = dict(split=0.0, flux=0.0, location=0.0, rounds=0, evals=0)
         self.noise_sums = None
@@ -198,15 +205,35 @@ class ModelGibbs(object):
         for f in self.fields:
             if f.prop is None or f.prop.capacity < P:
                 f.prop = _field.SourceSet(f.iset.ctx, max(2 * self.S, P, 16), f.iset.B)
-            f.prop.set(typ, U, self.counts(f, idx=idx), shape)
+            cts = getattr(f, "_counts", None)            # (S, B), fixed while the locations are sampled
+            f.prop.set(typ, U, self.counts(f, idx=idx) if cts is None else cts[idx], shape)
             ll += f.iset.patch_loglik_resident(f.prop, owner)
         return ll
+
+    def _device_engine_applies(self):
+        a = self.slice_args
+        return (len(self.fields) == 1 and not a.get("step_out", True) and a.get("compwise", True)
+                and set(a) <= {"step_out", "compwise", "sigma"})
 
     def resample_locations(self):
         import time
         from .util.infer.slicesample import slicesample_lockstep
         t0 = time.perf_counter()
+        use_device = self.engine == "device" or (self.engine == "auto" and self._device_engine_applies())
+        if use_device:
+            if not self._device_engine_applies():
+                raise ValueError("the device slice sampler runs one field with step_out=False, compwise=True")
+            f = self.fields[0]
+            sset = self._sources(f)                        # the catalogue with the fluxes just drawn
+            new_u, _, st = f.iset.slice_locations(sset, self.slice_args.get("sigma", 1.0), self.seed * 7919 + self.sweeps)
+            self.u = new_u
+            self.timing["rounds"] += st["rounds"]
+            self.timing["evals"] += st["evals"]
+            self.timing["location"] += time.perf_counter() - t0
+            return self.u
         act = np.nonzero(self.active)[0]
+        for f in self.fields:
+            f._counts = self.counts(f)
         if act.size:
             st = {}
             new_u, _ = slicesample_lockstep(self.u[act], lambda i, U: self.location_loglik(act[i], U),
@@ -215,6 +242,8 @@ class ModelGibbs(object):
             self.u[act] = new_u
             self.timing["rounds"] += st["rounds"]
             self.timing["evals"] += st["evals"]
+        for f in self.fields:
+            f._counts = None
         self.timing["location"] += time.perf_counter() - t0
         return self.u
 

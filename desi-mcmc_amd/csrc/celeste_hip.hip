@@ -80,6 +80,7 @@ static int fail(int code, const char *fmt, ...) {
 #include "k_patch_ll.h"
 #include "k_estep.h"
 #include "k_split.h"
+#include "k_slice.h"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -170,6 +171,10 @@ struct cel_images {
     int64_t *d_soff = nullptr;
     int64_t slay_cap = 0, samp_S = 0, samp_total = 0;
     double *d_stats = nullptr;
+    // device-resident slice sampler (cel_slice_locations): chain state, proposal set, per-round outputs
+    void *d_slice = nullptr;
+    size_t slice_cap = 0;
+    cel_sources *slice_prop = nullptr;
     int64_t last_S = 0;
     double last_entries = 0;
 };
@@ -418,6 +423,8 @@ int cel_images_destroy(cel_images *im) {
                     im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff, im->d_rate, im->d_snz};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (im->d_slice) (void)hipFree(im->d_slice);
+    if (im->slice_prop) cel_sources_destroy(im->slice_prop);
     delete im;
     return CEL_OK;
 }
@@ -1052,6 +1059,109 @@ int cel_stamp_mass(cel_images *im, cel_sources *src, double *mass) {
     prof_end(c, pi);
     HIP_TRY(hipGetLastError());
     return copy_out(mass, d_out, sizeof(double) * S * B, CEL_HOST, c->stream);
+}
+
+// ---- lock-step slice sampling of the locations, on the device -----------------------------------
+int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_ids, double sigma, uint64_t seed,
+                        int max_rounds, double *radec_out, double *llh_out, int64_t *stats) {
+    if (!im || !src) return fail(CEL_ERR_INVALID, "cel_slice_locations: null argument");
+    if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
+    if (im->samp_S <= 0 || im->samp_S != src->S)
+        return fail(CEL_ERR_INVALID, "cel_slice_locations needs a resident photon split of these %lld sources (have %lld)",
+                    (long long)src->S, (long long)im->samp_S);
+    if (!(sigma > 0.0) || max_rounds < 1) return fail(CEL_ERR_INVALID, "cel_slice_locations: sigma and max_rounds must be positive");
+    cel_ctx *c = im->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int B = im->B;
+    const int64_t S = src->S;
+    // one allocation, carved: 2 x u64, 10 x f64 (x and x0 are 2 per chain), 4 x i32 per chain + owner + ll (S*B) + chain ids + 2 ints
+    const size_t per_chain = 2 * 8 + 10 * 8 + 4 * 4 + 4 + (size_t)B * 8 + 4;
+    const size_t need = per_chain * (size_t)S + 64;
+    if (need > im->slice_cap) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (im->d_slice) (void)hipFree(im->d_slice);
+        im->d_slice = nullptr; im->slice_cap = 0;
+        HIP_TRY(hipMalloc(&im->d_slice, need + need / 4));
+        im->slice_cap = need + need / 4;
+    }
+    if (!im->slice_prop || im->slice_prop->cap < S) {
+        if (im->slice_prop) cel_sources_destroy(im->slice_prop);
+        im->slice_prop = nullptr;
+        int rc0 = cel_sources_create(c, S + S / 4 + 16, B, &im->slice_prop);
+        if (rc0) return rc0;
+    }
+    cel_sources *prop = im->slice_prop;
+    char *p = (char *)im->d_slice;
+    SliceState ss;
+    ss.key = (unsigned long long *)p; p += 8 * S;
+    ss.count = (unsigned long long *)p; p += 8 * S;
+    ss.x = (double *)p; p += 16 * S;
+    ss.x0 = (double *)p; p += 16 * S;
+    ss.lower = (double *)p; p += 8 * S;
+    ss.upper = (double *)p; p += 8 * S;
+    ss.log_u = (double *)p; p += 8 * S;
+    ss.llh_s = (double *)p; p += 8 * S;
+    ss.new_z = (double *)p; p += 8 * S;
+    ss.new_llh = (double *)p; p += 8 * S;
+    double *d_ll = (double *)p; p += 8 * S * B;
+    ss.phase = (int *)p; p += 4 * S;
+    ss.kdir = (int *)p; p += 4 * S;
+    ss.first = (int *)p; p += 4 * S;
+    ss.steps = (int *)p; p += 4 * S;
+    int *d_owner = (int *)p; p += 4 * S;
+    int *d_ids = (int *)p; p += 4 * S;
+    int *d_flags = (int *)p;            // [0] chains still running, [1] error bits, [2] likelihood evaluations so far
+    // the proposal set: this catalogue with the locations rewritten every round
+    HIP_TRY(hipMemcpyAsync(prop->d_type, src->d_type, sizeof(int) * S, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(prop->d_counts, src->d_counts, sizeof(double) * B * S, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(prop->d_shape, src->d_shape, sizeof(double) * 4 * S, hipMemcpyDeviceToDevice, st));
+    prop->S = S;
+    if (chain_ids) {
+        HIP_TRY(hipMemcpyAsync(d_ids, chain_ids, sizeof(int) * S, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(int) * 3, st));
+    const unsigned g256 = (unsigned)((S + 255) / 256);
+    hipLaunchKernelGGL(k_slice_init, dim3(g256), dim3(256), 0, st, ss, S, src->d_radec, chain_ids ? d_ids : (const int *)nullptr,
+                       im->d_soff, B, (unsigned long long)seed, sigma, d_owner);
+    int64_t rounds = 0, evals = 0;
+    int *h_flags = reinterpret_cast<int *>(c->pinned + MAX_BANDS + 2);
+    int rc = CEL_OK;
+    // how many chains start: those with a patch
+    hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags);
+    for (;;) {
+        prop->gen = ++g_source_gen;
+        if ((rc = run_prep(im, prop))) return rc;
+        int pi = prof_begin(c, CEL_K_STAMPS);
+        if (c->variant == 0)
+            hipLaunchKernelGGL(k_patch_ll, dim3((unsigned)(S * B)), dim3(256), 0, st, im->d_bands, B, S, im->d_recs,
+                               d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, 0, d_ll);
+        else
+            hipLaunchKernelGGL(k_patch_ll_hw<0>, dim3((unsigned)(S * B)), dim3(64), 0, st, im->d_bands, B, S, im->d_recs,
+                               d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll);
+        prof_end(c, pi);
+        hipLaunchKernelGGL(k_slice_consume, dim3(g256), dim3(256), 0, st, ss, S, B, d_ll, sigma, d_flags, d_flags + 1);
+        HIP_TRY(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+        rounds++;
+        const int running = h_flags[0], err = h_flags[1];
+        if (err & 1) return fail(CEL_ERR_INVALID, "Slice sampler got a NaN");
+        if (err & 2) return fail(CEL_ERR_INVALID, "Slice sampler shrank to zero!");
+        evals = h_flags[2];
+        if (running == 0) break;
+        if (rounds >= max_rounds) return fail(CEL_ERR_INVALID, "cel_slice_locations: %d rounds without every chain finishing", max_rounds);
+        hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags);
+    }
+    // the new locations replace the catalogue's
+    HIP_TRY(hipMemcpyAsync(src->d_radec, ss.x, sizeof(double) * 2 * S, hipMemcpyDeviceToDevice, st));
+    src->gen = ++g_source_gen;
+    if (radec_out) HIP_TRY(hipMemcpyAsync(radec_out, ss.x, sizeof(double) * 2 * S, hipMemcpyDeviceToHost, st));
+    if (llh_out) HIP_TRY(hipMemcpyAsync(llh_out, ss.new_llh, sizeof(double) * S, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (stats) { stats[0] = rounds; stats[1] = evals; }
+    return CEL_OK;
 }
 
 // ---- photon split -------------------------------------------------------------------------------

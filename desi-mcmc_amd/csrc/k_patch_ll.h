@@ -139,6 +139,10 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     const int b = (int)(job % B);
     const int64_t p = job / B;
     const BandDev *bd = bands + b;
+    if (owner && owner[p] < 0) {        // a retired proposal slot (the device-resident slice sampler's finished chains)
+        if (lane == 0) out[job] = 0.0;
+        return;
+    }
     const int64_t ob = (int64_t)(owner ? owner[p] : 0) * B + b;
     RecU rec = rec_unpack(rec_fetch(recs + (int64_t)b * P, (int)p, lane));
     // MODE 3 (mass of the unit stamp on the source's OWN box, sources.py:338-339): the box is the record's

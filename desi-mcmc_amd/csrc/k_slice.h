@@ -1,0 +1,145 @@
+// k_slice.h -- lock-step slice sampling of source locations, state machine on the device
+//
+// Source.resample_location (CelestePy/sources.py:308-319) = slicesample(u, location_likelihood, ...)
+// (CelestePy/util/infer/slicesample.py:89-227) with the options that call uses: component-wise,
+// no stepping out.  One chain per source; every round each unfinished chain names the point it
+// needs next (k_slice_propose writes it into the proposal set's radec), cel_patch_loglik's kernels
+// score all of them against the resident photon patches, and k_slice_consume advances the chains.
+// Nothing but one counter crosses PCIe per round.
+//
+// The arithmetic and the random streams are those of the host engine
+// (desi-mcmc_amd/util/infer/slicesample.py: one SplitMix64 stream per chain keyed by (seed, chain id),
+// drawn in the reference's order), so a chain takes the same trajectory on either engine.
+#pragma once
+#include "device_common.h"
+
+#define SL_LEVEL 0
+#define SL_SHRINK 4
+#define SL_FINAL 7
+
+struct SliceState {            // SoA over chains
+    unsigned long long *key, *count;
+    double *x;                 // current location (ra, dec), 2 per chain
+    double *x0;                // location the current direction started from, 2 per chain
+    double *lower, *upper, *log_u, *llh_s, *new_z, *new_llh;
+    int *phase, *kdir, *first; // first = axis of the chain's first direction (0 or 1)
+    int *steps;                // shrink steps taken (diagnostic)
+};
+
+__device__ inline unsigned long long sl_mix(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ inline double sl_uniform(const SliceState &st, int64_t s) {
+    const unsigned long long c = st.count[s];
+    st.count[s] = c + 1ull;
+    const unsigned long long z = sl_mix(st.key[s] + c * 0x9E3779B97F4A7C15ull);
+    return ((double)(z >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// slicesample.py:142-146: the interval about the current point and the random part of the level
+__device__ inline void sl_start_direction(const SliceState &st, int64_t s, double sigma) {
+#pragma clang fp contract(off)
+    st.x0[2 * s] = st.x[2 * s];
+    st.x0[2 * s + 1] = st.x[2 * s + 1];
+    const double up = sigma * sl_uniform(st, s);
+    st.upper[s] = up;
+    st.lower[s] = up - sigma;
+    st.log_u[s] = log(sl_uniform(st, s));
+    st.phase[s] = SL_LEVEL;
+}
+
+__global__ void __launch_bounds__(256)
+k_slice_init(SliceState st, int64_t S, const double *__restrict__ radec, const int *__restrict__ chain_ids,
+             const int64_t *__restrict__ soff, int B, unsigned long long seed, double sigma, int *__restrict__ owner) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const unsigned long long id = (unsigned long long)(chain_ids ? chain_ids[s] : (int)s);
+    st.key[s] = sl_mix(seed ^ (id * 0xD1342543DE82EF95ull));
+    st.count[s] = 0ull;
+    st.x[2 * s] = radec[2 * s];
+    st.x[2 * s + 1] = radec[2 * s + 1];
+    st.steps[s] = 0;
+    st.new_llh[s] = NAN;
+    // a random order of the two axes: argsort (stable) of two uniforms (slicesample.py:214-221)
+    const double u0 = sl_uniform(st, s), u1 = sl_uniform(st, s);
+    st.first[s] = (u1 < u0) ? 1 : 0;
+    st.kdir[s] = 0;
+    // a source without any sample patch is left alone (the reference asserts there, sources.py:243)
+    const bool has_patch = soff[(s + 1) * B] > soff[s * B];
+    if (has_patch) sl_start_direction(st, s, sigma);
+    else st.phase[s] = SL_FINAL;
+    owner[s] = has_patch ? (int)s : -1;
+}
+
+// the point every unfinished chain needs next -> the proposal set's radec; owner[s] = -1 retires a chain
+__global__ void __launch_bounds__(256)
+k_slice_propose(SliceState st, int64_t S, double *__restrict__ prop_radec, int *__restrict__ owner, int *__restrict__ n_active) {
+#pragma clang fp contract(off)
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0) *n_active = 0;
+    if (s >= S) return;
+    const int ph = st.phase[s];
+    if (ph == SL_FINAL) { owner[s] = -1; return; }
+    double z = 0.0;
+    if (ph == SL_SHRINK) {
+        z = (st.upper[s] - st.lower[s]) * sl_uniform(st, s) + st.lower[s];      // slicesample.py:172
+        st.new_z[s] = z;
+        st.steps[s] += 1;
+    }
+    const int axis = st.kdir[s] == 0 ? st.first[s] : 1 - st.first[s];
+    const double d0 = axis == 0 ? 1.0 : 0.0, d1 = axis == 1 ? 1.0 : 0.0;
+    prop_radec[2 * s] = st.x0[2 * s] + z * d0;
+    prop_radec[2 * s + 1] = st.x0[2 * s + 1] + z * d1;
+    owner[s] = (int)s;
+}
+
+// consume the round's log-likelihoods (per (chain, band), summed in band order as the host sums them)
+__global__ void __launch_bounds__(256)
+k_slice_consume(SliceState st, int64_t S, int B, const double *__restrict__ ll_pb, double sigma, int *__restrict__ n_active,
+                int *__restrict__ err) {
+#pragma clang fp contract(off)
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = false, scored = false;
+    if (s < S) {
+        const int ph = st.phase[s];
+        if (ph != SL_FINAL) {
+            scored = true;
+            double v = 0.0;
+            for (int b = 0; b < B; b++) v += ll_pb[s * B + b];
+            if (ph == SL_LEVEL) {
+                st.llh_s[s] = st.log_u[s] + v;                                   // slicesample.py:146
+                st.phase[s] = SL_SHRINK;
+            } else {
+                if (v != v) atomicOr(err, 1);                                    // "Slice sampler got a NaN"
+                const double z = st.new_z[s];
+                if (v > st.llh_s[s]) {                                           // accepted (:177; no doubling, nothing to test)
+                    st.new_llh[s] = v;
+                    const int axis = st.kdir[s] == 0 ? st.first[s] : 1 - st.first[s];
+                    const double d0 = axis == 0 ? 1.0 : 0.0, d1 = axis == 1 ? 1.0 : 0.0;
+                    st.x[2 * s] = st.x0[2 * s] + z * d0;                        // :203
+                    st.x[2 * s + 1] = st.x0[2 * s + 1] + z * d1;
+                    const int k = st.kdir[s] + 1;
+                    st.kdir[s] = k;
+                    if (k >= 2) st.phase[s] = SL_FINAL;
+                    else sl_start_direction(st, s, sigma);
+                } else if (z < 0.0) {
+                    st.lower[s] = z;
+                } else if (z > 0.0) {
+                    st.upper[s] = z;
+                } else {
+                    atomicOr(err, 2);                                            // "Slice sampler shrank to zero!"
+                    st.phase[s] = SL_FINAL;
+                }
+            }
+            active = st.phase[s] != SL_FINAL;
+        }
+    }
+    const unsigned long long m = __ballot(active), me = __ballot(scored);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_active, __popcll(m));
+    if ((threadIdx.x & 63) == 0 && me) atomicAdd(err + 1, __popcll(me));         // evaluations so far (int: < 2^31 per call)
+}

@@ -63,6 +63,8 @@ class Context(object):
         self.set_option(L.CEL_OPT_KERNEL, {"direct": 0, "recurrence": 1}[name])
 
     def set_tail_log(self, T):
+        """drop threshold T of CEL_OPT_TAIL_LOG; "default" (32) or "fast" (20, 1e-6 parity only) name the presets"""
+        T = {"default": L.TAIL_LOG_DEFAULT, "fast": L.TAIL_LOG_FAST}.get(T, T)
         self.set_option(L.CEL_OPT_TAIL_LOG, T)
 
     def profile(self, on=True):
@@ -140,6 +142,7 @@ class ImageSet(object):
         L.check(L.lib().cel_images_create(ctx._h, self.B, self.H, self.W, L.dptr(bands), C.byref(self._h)))
         self._finalizer = weakref.finalize(self, L.lib().cel_images_destroy, self._h)
         self._srcs = None
+        self.eps = bands[:, 0].copy()          # host mirror of the sky levels on the device
         if nelec is not None:
             self.set_nelec(nelec)
 
@@ -164,6 +167,7 @@ class ImageSet(object):
 
     def set_epsilon(self, band, eps):
         L.check(L.lib().cel_images_set_epsilon(self._h, int(band), float(eps)))
+        self.eps[int(band)] = float(eps)
 
     def band(self, b):
         out = np.zeros(L.BAND_DOUBLES)
@@ -270,6 +274,27 @@ class ImageSet(object):
         L.check(L.lib().cel_patch_loglik_multi(self._h, proposals._h, owner.ctypes.data_as(L.c_int32_p), S.value,
                                                None, None, None, L.CEL_DEVICE, 1 if isolated else 0, L.dptr(out)))
         return out
+
+    def slice_locations(self, sources, sigma, seed, chain_ids=None, max_rounds=4000):
+        """Source.resample_location for every source at once, on the device (cel_slice_locations).
+        The sources' locations are updated in place on the device.  -> (radec[S,2], llh[S], dict(rounds, evals))"""
+        S = sources.S
+        radec, llh = np.zeros((S, 2)), np.zeros(S)
+        stats = np.zeros(2, dtype=np.int64)
+        ids = None
+        if chain_ids is not None:
+            ids = np.ascontiguousarray(chain_ids, dtype=np.int32)
+            if ids.shape != (S,):
+                raise ValueError("chain_ids must have one entry per source")
+        try:
+            L.check(L.lib().cel_slice_locations(self._h, sources._h, None if ids is None else ids.ctypes.data_as(L.c_int32_p),
+                                                float(sigma), C.c_uint64(int(seed) & (2 ** 64 - 1)), int(max_rounds),
+                                                L.dptr(radec), L.dptr(llh), stats.ctypes.data_as(L.c_int64_p)))
+        except ValueError as e:
+            if "Slice sampler" in str(e):
+                raise Exception(str(e))          # the sampler's own failures are plain Exceptions in the reference
+            raise
+        return radec, llh, dict(rounds=int(stats[0]), evals=int(stats[1]))
 
     def sample_sums(self):
         """photons attributed to every (source, band) by the resident split -> (S, B)"""

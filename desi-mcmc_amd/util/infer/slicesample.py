@@ -6,7 +6,8 @@ The reference calls its log-probability one point at a time; Source.resample_loc
 source's conditional likelihood.  Here S chains (one per source) advance together: in every
 round each unfinished chain names the point(s) it needs next, ALL of them are evaluated by one
 call of `logprob_batch` (one device launch of cel_patch_loglik_multi for a whole catalogue),
-and the chains consume their values.  There is no per-chain Python.
+and the chains consume their values; a chain that has finished one direction starts its next in the
+following round without waiting for the others.  There is no per-chain Python.
 
 Algorithm per chain (slicesample.py:114-203, component-wise or random directions):
     for each direction:                                   upper = sigma * U;  lower = upper - sigma
@@ -60,7 +61,7 @@ class ChainStreams(object):
 
 
 # phases of a chain inside one direction
-_P_LEVEL, _P_OUT_DOUBLE, _P_OUT_LEFT, _P_OUT_RIGHT, _P_SHRINK, _P_ACCEPT, _P_DONE = 0, 1, 2, 3, 4, 5, 6
+_P_LEVEL, _P_OUT_DOUBLE, _P_OUT_LEFT, _P_OUT_RIGHT, _P_SHRINK, _P_ACCEPT, _P_DONE, _P_FINAL = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 def slicesample_lockstep(init_x, logprob_batch, sigma=1.0, step_out=True, max_steps_out=1000, compwise=True,
@@ -92,137 +93,159 @@ def slicesample_lockstep(init_x, logprob_batch, sigma=1.0, step_out=True, max_st
     else:
         ndir = int(numdir)
     new_llh = np.full(S, np.nan)
-    n_rounds = n_evals = max_in = 0
+    n_rounds = n_evals = 0
+    # per-chain state of the direction a chain is working on.  Chains do NOT wait for each other
+    # between directions: one that has finished its first axis starts its second in the next
+    # round, so an update takes max over chains of (evaluations of the chain) rounds, not the sum
+    # over directions of the slowest chain of each.
+    kdir = np.zeros(S, dtype=np.int64)
+    direction = np.zeros((S, D))
+    x0 = X.copy()
+    upper, lower, log_u, llh_s = np.zeros(S), np.zeros(S), np.zeros(S), np.zeros(S)
+    phase = np.full(S, _P_LEVEL)
+    l_out = np.zeros(S, dtype=np.int64)
+    u_out = np.zeros(S, dtype=np.int64)
+    start_lower, start_upper = np.zeros(S), np.zeros(S)
+    new_z, acc_L, acc_U = np.zeros(S), np.zeros(S), np.zeros(S)
+    steps_in = np.zeros(S, dtype=np.int64)
+    max_in = 0
 
-    for k in range(ndir):
+    def start_direction(idx):
+        if idx.size == 0:
+            return
         if compwise:
-            direction = np.zeros((S, D))
-            direction[every, order[:, k]] = 1.0
+            direction[idx] = 0.0
+            direction[idx, order[idx, kdir[idx]]] = 1.0
         else:
-            direction = np.stack([rng.normal(every) for _ in range(D)], axis=1)
-            direction /= np.sqrt(np.sum(direction ** 2, axis=1, keepdims=True))
-        x0 = X.copy()
-        upper = sigma * rng.uniform(every)                    # :142-143
-        lower = upper - sigma
-        log_u = np.log(rng.uniform(every))                    # :146, the level's random part
-        llh_s = np.zeros(S)
-        phase = np.full(S, _P_LEVEL)
-        l_out = np.zeros(S, dtype=np.int64)
-        u_out = np.zeros(S, dtype=np.int64)
-        start_lower = lower.copy()
-        start_upper = upper.copy()
-        new_z = np.zeros(S)
-        acc_L = np.zeros(S)                                   # `acceptable` interval (:119-131)
-        acc_U = np.zeros(S)
-        steps_in = np.zeros(S, dtype=np.int64)
+            dr = np.stack([rng.normal(idx) for _ in range(D)], axis=1)
+            direction[idx] = dr / np.sqrt(np.sum(dr ** 2, axis=1, keepdims=True))
+        x0[idx] = X[idx]
+        upper[idx] = sigma * rng.uniform(idx)              # :142-143
+        lower[idx] = upper[idx] - sigma
+        log_u[idx] = np.log(rng.uniform(idx))              # :146, the level's random part
+        phase[idx] = _P_LEVEL
+        l_out[idx] = 0
+        u_out[idx] = 0
+        steps_in[idx] = 0
 
-        def enter_shrink(idx):
-            start_lower[idx] = lower[idx]
-            start_upper[idx] = upper[idx]
-            phase[idx] = _P_SHRINK
+    def enter_shrink(idx):
+        start_lower[idx] = lower[idx]
+        start_upper[idx] = upper[idx]
+        phase[idx] = _P_SHRINK
 
-        while True:
-            act = np.nonzero(phase != _P_DONE)[0]
-            if act.size == 0:
-                break
-            ph = phase[act]
-            # ---- which points does every chain need this round? --------------------------------
-            single = act[(ph == _P_LEVEL) | (ph == _P_OUT_LEFT) | (ph == _P_OUT_RIGHT) | (ph == _P_SHRINK)]
-            double = act[(ph == _P_OUT_DOUBLE) | (ph == _P_ACCEPT)]
-            zs = np.zeros(single.size)
-            p1 = phase[single]
-            zs[p1 == _P_OUT_LEFT] = lower[single[p1 == _P_OUT_LEFT]]
-            zs[p1 == _P_OUT_RIGHT] = upper[single[p1 == _P_OUT_RIGHT]]
-            sh = single[p1 == _P_SHRINK]
-            if sh.size:
-                new_z[sh] = (upper[sh] - lower[sh]) * rng.uniform(sh) + lower[sh]     # :172
-                steps_in[sh] += 1
-                zs[p1 == _P_SHRINK] = new_z[sh]
-            p2 = phase[double]
-            za = np.where(p2 == _P_OUT_DOUBLE, lower[double], acc_L[double])
-            zb = np.where(p2 == _P_OUT_DOUBLE, upper[double], acc_U[double])
-            idx = np.concatenate([single, double, double])
-            z = np.concatenate([zs, za, zb])
-            vals = np.asarray(logprob_batch(idx, x0[idx] + z[:, None] * direction[idx]), dtype=np.float64)
-            n_rounds += 1
-            n_evals += idx.size
-            v1 = vals[:single.size]
-            va = vals[single.size:single.size + double.size]
-            vb = vals[single.size + double.size:]
+    if ndir > 0:
+        start_direction(every)
+    else:
+        phase[:] = _P_FINAL
+    while True:
+        act = np.nonzero(phase != _P_FINAL)[0]
+        if act.size == 0:
+            break
+        ph = phase[act]
+        # ---- which points does every chain need this round? --------------------------------
+        single = act[(ph == _P_LEVEL) | (ph == _P_OUT_LEFT) | (ph == _P_OUT_RIGHT) | (ph == _P_SHRINK)]
+        double = act[(ph == _P_OUT_DOUBLE) | (ph == _P_ACCEPT)]
+        zs = np.zeros(single.size)
+        p1 = phase[single]
+        zs[p1 == _P_OUT_LEFT] = lower[single[p1 == _P_OUT_LEFT]]
+        zs[p1 == _P_OUT_RIGHT] = upper[single[p1 == _P_OUT_RIGHT]]
+        sh = single[p1 == _P_SHRINK]
+        if sh.size:
+            new_z[sh] = (upper[sh] - lower[sh]) * rng.uniform(sh) + lower[sh]     # :172
+            steps_in[sh] += 1
+            zs[p1 == _P_SHRINK] = new_z[sh]
+        p2 = phase[double]
+        za = np.where(p2 == _P_OUT_DOUBLE, lower[double], acc_L[double])
+        zb = np.where(p2 == _P_OUT_DOUBLE, upper[double], acc_U[double])
+        idx = np.concatenate([single, double, double]) if double.size else single
+        z = np.concatenate([zs, za, zb]) if double.size else zs
+        vals = np.asarray(logprob_batch(idx, x0[idx] + z[:, None] * direction[idx]), dtype=np.float64)
+        n_rounds += 1
+        n_evals += idx.size
+        v1 = vals[:single.size]
+        va = vals[single.size:single.size + double.size]
+        vb = vals[single.size + double.size:]
 
-            # ---- consume ------------------------------------------------------------------------
-            m = p1 == _P_LEVEL                                 # llh_s = log(U) + logprob(x)   (:146)
-            c = single[m]
-            if c.size:
-                llh_s[c] = log_u[c] + v1[m]
-                if step_out:
-                    phase[c] = _P_OUT_DOUBLE if doubling_step else _P_OUT_LEFT
-                else:
-                    enter_shrink(c)
-            m = p1 == _P_OUT_LEFT                              # :159-161
-            c = single[m]
-            if c.size:
-                go = (v1[m] > llh_s[c]) & (l_out[c] < max_steps_out)
-                l_out[c[go]] += 1
-                lower[c[go]] -= sigma
-                phase[c[~go]] = _P_OUT_RIGHT
-            m = p1 == _P_OUT_RIGHT                             # :162-164
-            c = single[m]
-            if c.size:
-                go = (v1[m] > llh_s[c]) & (u_out[c] < max_steps_out)
-                u_out[c[go]] += 1
-                upper[c[go]] += sigma
-                enter_shrink(c[~go])
-            m = p2 == _P_OUT_DOUBLE                            # :151-157
-            c = double[m]
-            if c.size:
-                go = ((va[m] > llh_s[c]) | (vb[m] > llh_s[c])) & ((l_out[c] + u_out[c]) < max_steps_out)
-                g = c[go]
-                if g.size:
-                    left = rng.uniform(g) < 0.5
-                    width = upper[g] - lower[g]
-                    l_out[g[left]] += 1
-                    lower[g[left]] -= width[left]
-                    u_out[g[~left]] += 1
-                    upper[g[~left]] += width[~left]
-                enter_shrink(c[~go])
-            m = p1 == _P_SHRINK                                # :173-190
-            c = single[m]
-            if c.size:
-                v = v1[m]
-                if np.any(np.isnan(v)):
-                    raise Exception("Slice sampler got a NaN")
-                inside = v > llh_s[c]
-                # accepted unless the doubled interval has to be tested (:177, :119-131)
-                need = inside & ((start_upper[c] - start_lower[c]) > 1.1 * sigma)
-                ok = inside & ~need
-                new_llh[c[ok]] = v[ok]
-                phase[c[ok]] = _P_DONE
-                t = c[need]
-                if t.size:
-                    new_llh[t] = v[need]
-                    acc_L[t] = start_lower[t]
-                    acc_U[t] = start_upper[t]
-                    phase[t] = _P_ACCEPT
-                    _accept_advance(t, new_z, llh_s, acc_L, acc_U, sigma, phase, None, None)
-                r = c[~inside]
-                if r.size:
-                    if np.any(new_z[r] == 0.0):
-                        raise Exception("Slice sampler shrank to zero!")
-                    neg = new_z[r] < 0
-                    lower[r[neg]] = new_z[r[neg]]
-                    upper[r[~neg]] = new_z[r[~neg]]
-            m = p2 == _P_ACCEPT                                # the halving test of `acceptable`
-            c = double[m]
-            if c.size:
-                _accept_advance(c, new_z, llh_s, acc_L, acc_U, sigma, phase, va[m], vb[m])
-                rej = c[phase[c] == _P_SHRINK]
-                if rej.size:                                   # not acceptable: shrink as a rejection (:180-183)
-                    neg = new_z[rej] < 0
-                    lower[rej[neg]] = new_z[rej[neg]]
-                    upper[rej[~neg]] = new_z[rej[~neg]]
-        X = x0 + new_z[:, None] * direction                    # :203
-        max_in = max(max_in, int(steps_in.max()) if S else 0)
+        # ---- consume ------------------------------------------------------------------------
+        m = p1 == _P_LEVEL                                 # llh_s = log(U) + logprob(x)   (:146)
+        c = single[m]
+        if c.size:
+            llh_s[c] = log_u[c] + v1[m]
+            if step_out:
+                phase[c] = _P_OUT_DOUBLE if doubling_step else _P_OUT_LEFT
+            else:
+                enter_shrink(c)
+        m = p1 == _P_OUT_LEFT                              # :159-161
+        c = single[m]
+        if c.size:
+            go = (v1[m] > llh_s[c]) & (l_out[c] < max_steps_out)
+            l_out[c[go]] += 1
+            lower[c[go]] -= sigma
+            phase[c[~go]] = _P_OUT_RIGHT
+        m = p1 == _P_OUT_RIGHT                             # :162-164
+        c = single[m]
+        if c.size:
+            go = (v1[m] > llh_s[c]) & (u_out[c] < max_steps_out)
+            u_out[c[go]] += 1
+            upper[c[go]] += sigma
+            enter_shrink(c[~go])
+        m = p2 == _P_OUT_DOUBLE                            # :151-157
+        c = double[m]
+        if c.size:
+            go = ((va[m] > llh_s[c]) | (vb[m] > llh_s[c])) & ((l_out[c] + u_out[c]) < max_steps_out)
+            g = c[go]
+            if g.size:
+                left = rng.uniform(g) < 0.5
+                width = upper[g] - lower[g]
+                l_out[g[left]] += 1
+                lower[g[left]] -= width[left]
+                u_out[g[~left]] += 1
+                upper[g[~left]] += width[~left]
+            enter_shrink(c[~go])
+        m = p1 == _P_SHRINK                                # :173-190
+        c = single[m]
+        if c.size:
+            v = v1[m]
+            if np.any(np.isnan(v)):
+                raise Exception("Slice sampler got a NaN")
+            inside = v > llh_s[c]
+            # accepted unless the doubled interval has to be tested (:177, :119-131)
+            need = inside & ((start_upper[c] - start_lower[c]) > 1.1 * sigma)
+            ok = inside & ~need
+            new_llh[c[ok]] = v[ok]
+            phase[c[ok]] = _P_DONE
+            t = c[need]
+            if t.size:
+                new_llh[t] = v[need]
+                acc_L[t] = start_lower[t]
+                acc_U[t] = start_upper[t]
+                phase[t] = _P_ACCEPT
+                _accept_advance(t, new_z, llh_s, acc_L, acc_U, sigma, phase, None, None)
+            r = c[~inside]
+            if r.size:
+                if np.any(new_z[r] == 0.0):
+                    raise Exception("Slice sampler shrank to zero!")
+                neg = new_z[r] < 0
+                lower[r[neg]] = new_z[r[neg]]
+                upper[r[~neg]] = new_z[r[~neg]]
+        m = p2 == _P_ACCEPT                                # the halving test of `acceptable`
+        c = double[m]
+        if c.size:
+            _accept_advance(c, new_z, llh_s, acc_L, acc_U, sigma, phase, va[m], vb[m])
+            rej = c[phase[c] == _P_SHRINK]
+            if rej.size:                                   # not acceptable: shrink as a rejection (:180-183)
+                neg = new_z[rej] < 0
+                lower[rej[neg]] = new_z[rej[neg]]
+                upper[rej[~neg]] = new_z[rej[~neg]]
+        # ---- chains that finished a direction: move, then on to their next one ---------------
+        fin = act[phase[act] == _P_DONE]
+        if fin.size:
+            X[fin] = x0[fin] + new_z[fin, None] * direction[fin]          # :203
+            max_in = max(max_in, int(steps_in[fin].max()))
+            kdir[fin] += 1
+            last = kdir[fin] >= ndir
+            phase[fin[last]] = _P_FINAL
+            start_direction(fin[~last])
     if stats is not None:
         stats.update(rounds=n_rounds, evals=n_evals, max_steps_in=max_in)
     return X, new_llh

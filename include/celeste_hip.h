@@ -226,6 +226,21 @@ int cel_patch_loglik_multi(cel_images *img, cel_sources *src, const int32_t *own
  * (CelestePy/sources.py:336-339) and celeste_em's sum_fs (celeste_em.py:89).  0 without a stamp.  Host output. */
 int cel_stamp_mass(cel_images *img, cel_sources *src, double *mass);
 
+/* Source.resample_location (CelestePy/sources.py:308-319) for EVERY source of `src` at once: slicesample
+ * (CelestePy/util/infer/slicesample.py:89-227) with the options of that call -- component-wise, no stepping
+ * out, interval width sigma (degrees) -- run as a lock-step state machine on the device against the
+ * resident photon split of exactly these sources (cel_photon_split with offsets = NULL): every round each
+ * unfinished chain's next point is scored by the conditional-likelihood kernel (mode 0 of
+ * cel_patch_loglik_multi, resident form) and the chains advance; one counter crosses PCIe per round.
+ * A source without any sample patch is left where it is.  Random numbers: one SplitMix64 stream per
+ * chain keyed by (seed, chain_ids[s] or s), in the reference's draw order -- the same streams and
+ * arithmetic as the host engine of the Python mirror (util/infer/slicesample.py), chain for chain.
+ *   radec_out  S*2 (host, may be NULL): the new locations; they also REPLACE src's locations on the device
+ *   llh_out    S (host, may be NULL): log-likelihood at the new location (NaN for a source left alone)
+ *   stats      2 (host, may be NULL): rounds, likelihood evaluations */
+int cel_slice_locations(cel_images *img, cel_sources *src, const int32_t *chain_ids, double sigma, uint64_t seed,
+                        int max_rounds, double *radec_out, double *llh_out, int64_t *stats);
+
 /* ---- photon split (Gibbs step) ------------------------------------------------------------ */
 /* boxes[(b*S+s)*4..] = y0,y1,x0,x1 and status[b*S+s] (as cel_stamp_boxes) for every band at once */
 int cel_source_boxes(cel_images *img, cel_sources *src, int32_t *boxes, int32_t *status);

@@ -246,3 +246,42 @@ def test_background_patch_and_image_like(cel, orc):
     ll = src.image_like(src, img)
     model, _, _ = src.compute_model_patch(img, xlim=xlim, ylim=ylim)
     np.testing.assert_allclose(ll, orc.poisson_loglike(img.nelec[ylim[0]:ylim[1], xlim[0]:xlim[1]], bg + model), rtol=1e-12)
+
+
+def test_device_slice_sampler_follows_the_host_engine_chain_by_chain(cel):
+    """cel_slice_locations (state machine on the device) and the numpy engine draw the same per-chain
+    streams and do the same arithmetic: after a sweep's location update every source sits at the same
+    place, to the last bit, whichever engine ran -- also with the reference's 1-degree interval."""
+    from desi_mcmc_amd import celeste_mcmc
+    imgs, params, pix, flux, nelec = small_scene(cel)
+    eps0 = [im.epsilon for im in imgs]
+    for sa in (dict(sigma=1e-3), None):
+        gs = {}
+        for eng in ("host", "device"):
+            for im, e in zip(imgs, eps0):          # a sweep redraws the images' sky levels: both engines start from the same
+                im.epsilon = e
+            g = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params, seed=21, slice_args=sa, engine=eng)
+            for _ in range(3):
+                g.sweep()
+            gs[eng] = g
+        assert gs["host"].timing["rounds"] == gs["device"].timing["rounds"]
+        assert gs["host"].timing["evals"] == gs["device"].timing["evals"]
+        assert np.array_equal(gs["host"].u, gs["device"].u)
+        assert np.array_equal(gs["host"].fluxes, gs["device"].fluxes)
+    # a source without any patch (off the frame) is left alone by both
+    far = cel.SrcParams(u=imgs[2].pixel2equa(np.array([5000.0, 40.0])), a=0, fluxes=np.full(5, 50.0))
+    for eng in ("host", "device"):
+        for im, e in zip(imgs, eps0):
+            im.epsilon = e
+        g = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params + [far], seed=3, slice_args=dict(sigma=1e-3), engine=eng)
+        g.sweep()
+        assert not g.active[4] and np.array_equal(g.u[4], np.asarray(far.u)) and np.array_equal(g.fluxes[4], np.full(5, 50.0))
+    # options the device engine does not run fall back to the host engine under "auto" and are refused under "device"
+    g = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params, seed=1, slice_args=dict(sigma=1e-4, step_out=True))
+    assert not g._device_engine_applies()
+    g.sweep()
+    g2 = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params, seed=1, slice_args=dict(sigma=1e-4, step_out=True), engine="device")
+    g2.resample_photons()
+    g2.resample_fluxes()
+    with pytest.raises(ValueError):
+        g2.resample_locations()

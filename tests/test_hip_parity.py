@@ -1093,3 +1093,35 @@ def test_multi_field_standin_dealt_to_one_rank(cel, ctx, orc):
     np.testing.assert_allclose(dist.allreduce_loglik(total), want, rtol=RT_LL)
     fields = [synth.SyntheticField(ctx, 150, 5, 200, 240, frac_gal=0.5, seed=42 + 1000 * k).src["radec"][0] for k in mine]
     assert len({tuple(r) for r in fields}) == K          # different fields, not one field K times
+
+
+def test_tail_log_fast_preset_meets_the_1e6_bar(cel, orc, big_field):
+    """CEL_OPT_TAIL_LOG = 20 (the documented fast preset, bench.py's second line): model pixels within
+    1e-6 of the oracle on a mixed field, and within 1e-6 of the default threshold's pixels over the
+    whole BASELINE-size field; log-likelihoods within 1e-8."""
+    from desi_mcmc_amd import _lib, synth
+    c2 = cel.Context(0)
+    c2.set_tail_log("fast")
+    assert c2.get_option(_lib.CEL_OPT_TAIL_LOG) == _lib.TAIL_LOG_FAST == 20.0
+    f = synth.SyntheticField(c2, 400, 5, 300, 333, frac_gal=0.6, seed=77)
+    ll, llb = f.images.render(f.sources, loglik=True)
+    o_lam, o_ll, _ = orc.render_field(oracle_bands(f), f.H, f.W, f.src["type"], f.src["radec"], f.src["counts"],
+                                      f.src["shape"], f.nelec)
+    lam = f.images.model_images()
+    np.testing.assert_allclose(lam, o_lam, rtol=1e-6)
+    assert np.max(np.abs(lam / o_lam - 1.0)) > 1e-13          # the preset does skip more than the default
+    np.testing.assert_allclose(llb, o_ll, rtol=1e-8)
+    # the BASELINE-size field: fast preset against the default threshold
+    bf = big_field
+    bf.images.render(bf.sources, loglik=True)
+    ll32, llb32 = bf.images.render(bf.sources, loglik=True)
+    lam32 = bf.images.model_images()
+    ctx0 = bf.images.ctx
+    ctx0.set_tail_log("fast")
+    try:
+        ll20, llb20 = bf.images.render(bf.sources, loglik=True)
+        lam20 = bf.images.model_images()
+    finally:
+        ctx0.set_tail_log("default")
+    assert np.max(np.abs(lam20 / lam32 - 1.0)) < 1e-6
+    np.testing.assert_allclose(llb20, llb32, rtol=1e-8)
