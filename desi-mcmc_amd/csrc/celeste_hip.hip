@@ -1076,7 +1076,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     const int B = im->B;
     const int64_t S = src->S;
     // one allocation, carved: 2 x u64, 10 x f64 (x and x0 are 2 per chain), 4 x i32 per chain + owner + ll (S*B) + chain ids + 2 ints
-    const size_t per_chain = 2 * 8 + 10 * 8 + 4 * 4 + 4 + (size_t)B * 8 + 4;
+    const size_t per_chain = 2 * 8 + 10 * 8 + 4 * 4 + 4 + (size_t)B * 8 + 4 + (size_t)B * 8;
     const size_t need = per_chain * (size_t)S + 64;
     if (need > im->slice_cap) {
         HIP_TRY(hipStreamSynchronize(st));
@@ -1111,6 +1111,8 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     ss.steps = (int *)p; p += 4 * S;
     int *d_owner = (int *)p; p += 4 * S;
     int *d_ids = (int *)p; p += 4 * S;
+    int *d_work = (int *)p; p += 4 * S * B;
+    int *d_jobs = (int *)p; p += 4 * S * B;
     int *d_flags = (int *)p;            // [0] chains still running, [1] error bits, [2] likelihood evaluations so far
     // the proposal set: this catalogue with the locations rewritten every round
     HIP_TRY(hipMemcpyAsync(prop->d_type, src->d_type, sizeof(int) * S, hipMemcpyDeviceToDevice, st));
@@ -1125,6 +1127,9 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     const unsigned g256 = (unsigned)((S + 255) / 256);
     hipLaunchKernelGGL(k_slice_init, dim3(g256), dim3(256), 0, st, ss, S, src->d_radec, chain_ids ? d_ids : (const int *)nullptr,
                        im->d_soff, B, (unsigned long long)seed, sigma, d_owner);
+    // the (chain, band) jobs of a round, heaviest first (the photon rectangles are fixed for the call)
+    hipLaunchKernelGGL(k_job_work, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, src->d_type, im->d_snz, S, B, d_work);
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, d_work, (int)(S * B), d_jobs);
     int64_t rounds = 0, evals = 0;
     int *h_flags = reinterpret_cast<int *>(c->pinned + MAX_BANDS + 2);
     int rc = CEL_OK;
@@ -1139,7 +1144,8 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
                                d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, 0, d_ll);
         else
             hipLaunchKernelGGL(k_patch_ll_hw<0>, dim3((unsigned)(S * B)), dim3(64), 0, st, im->d_bands, B, S, im->d_recs,
-                               d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll);
+                               d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll,
+                               (const int *)d_jobs);
         prof_end(c, pi);
         hipLaunchKernelGGL(k_slice_consume, dim3(g256), dim3(256), 0, st, ss, S, B, d_ll, sigma, d_flags, d_flags + 1);
         HIP_TRY(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 3, hipMemcpyDeviceToHost, st));

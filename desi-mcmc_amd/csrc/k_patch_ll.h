@@ -128,14 +128,15 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
               const int *__restrict__ owner, const int4 *__restrict__ pbox, const int64_t *__restrict__ offsets,
               const double *__restrict__ data, const double *__restrict__ nelec, int H, int W,
               const int4 *__restrict__ nzbox /* NB*B from k_patch_nzbox, or nullptr: evaluate the whole patch */,
-              double Tdrop, double *__restrict__ out /* P*B */) {
+              double Tdrop, double *__restrict__ out /* P*B */,
+              const int *__restrict__ job_order = nullptr /* P*B: launch order of the (proposal, band) jobs, heaviest first */) {
     __shared__ double acc[HW_TH * HW_TW];
     __shared__ CompTab T;
     __shared__ double et[64];
     __shared__ double lt[128];
     const int lane = threadIdx.x;
     const int half = lane >> 5, col = lane & 31;
-    const int64_t job = blockIdx.x;
+    const int64_t job = job_order ? job_order[blockIdx.x] : blockIdx.x;
     const int b = (int)(job % B);
     const int64_t p = job / B;
     const BandDev *bd = bands + b;
@@ -240,4 +241,18 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     a = wave_sum(a);
     m = wave_sum(m);
     if (lane == 0) out[job] = (MODE == 0) ? a - counts * wsum : (MODE == 3) ? m : a - m;
+}
+
+// work estimate of every (chain, band) job of the device slice sampler: components x pixels of the
+// photon rectangle its likelihood evaluates; k_order turns it into a heaviest-first launch order
+// (a round's 50 000 one-wave jobs differ by two orders of magnitude: in index order the launch
+// ends on a few late galaxies)
+__global__ void __launch_bounds__(256)
+k_job_work(const int *__restrict__ type, const int4 *__restrict__ nzbox, int64_t S, int B, int *__restrict__ work) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * B) return;
+    const int4 q = nzbox[i];
+    const long long area = (q.y > q.x && q.w > q.z) ? (long long)(q.y - q.x) * (q.w - q.z) : 0;
+    const long long w = area * ((type[i / B] == 0) ? K_PSF : K_GAL) + 64;
+    work[i] = (int)min(w, (long long)0x3fffffff);
 }
