@@ -133,7 +133,9 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     __shared__ double acc[HW_TH * HW_TW];
     __shared__ CompTab T;
     __shared__ double et[64];
-    __shared__ double lt[128];
+    // the log table lives in the component table's LDS between a chunk's walk and the next chunk's
+    // build (20 184 B per wave: 8 waves per CU; with a table of its own 21 208 B: 7)
+    double *lt = reinterpret_cast<double *>(&T);
     const int lane = threadIdx.x;
     const int half = lane >> 5, col = lane & 31;
     const int64_t job = job_order ? job_order[blockIdx.x] : blockIdx.x;
@@ -163,8 +165,7 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     if (rec.type < 0) rec.type = (rec.type == -2) ? 1 : 0;    // imposed limits: the kind still renders
     rec.scale = 1.0;                                          // the tile holds the unit stamp
     et[lane] = exp2((double)lane * (1.0 / 64.0));
-    lt[lane] = c_log_ic[lane];
-    lt[64 + lane] = c_log_lc[lane];
+    const double lt_ic = c_log_ic[lane], lt_lc = c_log_lc[lane];      // this lane's two entries of the log table
     const LaneConst lc = lane_consts(lane, bd);
     const double eps = bd->eps;
     if (MODE == 0) {
@@ -205,6 +206,11 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
             const int Kk = hw_build(T, lc, rec, lane, dropmode, Tdrop, log_floor, Y0, X0, min(ev.y, X0 + HW_TW) - 1, 0, rb, direct);
             hw_walk(T, et, Kk, (double)xi, Y0, 0, rb, on, direct, acc, lane);
             __syncthreads();
+            if (MODE != 3) {
+                lt[lane] = lt_ic;
+                lt[64 + lane] = lt_lc;
+                __syncthreads();
+            }
             if (MODE == 3) {
 #pragma unroll
                 for (int r = 0; r < HW_TH / 2; r++)

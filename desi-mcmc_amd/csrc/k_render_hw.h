@@ -374,8 +374,9 @@ k_render_hw(RenderArgs a) {
         if (!star_setup(ST, bd, et, lane)) nstar = 0;   // a very sharp PSF component: general path (segments, direct fallback)
     }
     // (Requesting a star-only tile's nelec BEFORE the star pass, so that the loads land under the
-    // arithmetic, was tried both here and in a persistent, software-pipelined star kernel: slower in
-    // both forms, 0.179 / 0.205 against 0.171 ms on the dense star field -- DESIGN.md 5.)
+    // arithmetic, was tried here -- before and after the first batch's record loads: a wave's loads
+    // return in order -- and in a persistent, software-pipelined star kernel: slower in every form,
+    // 0.179 / 0.180 / 0.205 against 0.171 ms on the dense star field -- DESIGN.md 5.)
     if (nstar > 0)
         star_pass(a, *reinterpret_cast<StarTab *>(&T), et, acc, recs, off, nstar, lane, xi, Y0, strict, dbg_halfrows, dbg_pairs);
 
