@@ -187,3 +187,67 @@ def test_strip_partition_covers_frame_once(built):
                 assert a1 == b0 and a0 <= a1
                 assert a1 % 32 == 0 or a1 == H
     assert dist.field_shard(8, 4, 1) == [1, 5]
+
+
+# ---- host-side containers added in round 2 (no device call) ------------------------------------------
+def test_src_catalog_reads_as_a_sequence_of_srcparams(built):
+    cel = built
+    ps = [cel.SrcParams(u=np.array([10.0 + i, 20.0 - i]), a=(i % 2), fluxes=np.arange(5.0) + i, theta=.3, sigma=1. + i,
+                        phi=30., rho=.5) for i in range(4)]
+    ps.append(cel.SrcParams(u=np.array([1.0, 2.0]), a=None, fluxes={"u": 1., "g": 2., "r": 3., "i": 4., "z": 5.}))
+    cat = cel.SrcCatalog.from_params(ps)
+    assert len(cat) == 5 and [p.a for p in cat] == [0, 1, 0, 1, None]
+    assert np.array_equal(cat[1].u, ps[1].u) and cat[3].sigma == 4.0 and cat[4].flux("r") == 3.0
+    assert cat[4].flux_dict == {"u": 1., "g": 2., "r": 3., "i": 4., "z": 5.}
+    assert np.array_equal(cat.shape[0], np.zeros(4)) and np.array_equal(cat.shape[1], [.3, 2., 30., .5])
+    v = cat[2]
+    v.u = [7., 8.]
+    v.fluxes = {"u": 9., "g": 9., "r": 9., "i": 9., "z": 9.}
+    v.rho = 0.25
+    assert np.array_equal(cat.u[2], [7., 8.]) and np.all(cat.fluxes[2] == 9.) and cat.shape[2, 3] == 0.25
+    assert len(cat[1:3]) == 2 and cat[-1].a is None
+    with pytest.raises(IndexError):
+        cat[5]
+
+
+def test_source_arrays_list_and_catalog_agree_for_every_flux_convention(built):
+    """celeste._source_arrays: the vectorised gathers (SrcCatalog, list of arrays, list of dicts) and the
+    source-by-source fallback give the same device inputs (celeste.py:35-62, the three conventions)"""
+    from desi_mcmc_amd import celeste, models
+
+    class Im(object):
+        def __init__(self, band, calib, kappa):
+            self.band, self.calib, self.kappa = band, calib, kappa
+
+        def nmgy2counts(self, f):
+            return (f / self.calib) * self.kappa
+    ims = [Im(b, 0.004 + 0.001 * k, 4.0 + 0.2 * k) for k, b in enumerate("gri")]
+    rs = np.random.RandomState(0)
+    ps = []
+    for i in range(40):
+        a = [0, 1, None][i % 3]
+        fl = rs.rand(5) * 10 + 1
+        ps.append(built.SrcParams(u=rs.rand(2), a=a, fluxes=fl if i % 2 else dict(zip("ugriz", fl)), theta=.4, sigma=1.5,
+                                  phi=10. * i, rho=.6))
+    slow = [np.zeros(40, np.int32), np.zeros((40, 2)), np.zeros((40, 3)), np.zeros((40, 4))]
+    for s, p in enumerate(ps):                               # the reference's own loop
+        slow[0][s] = 1 if p.a == 1 else 0
+        slow[1][s] = p.u
+        if p.a == 1:
+            slow[3][s] = [p.theta, p.sigma, p.phi, p.rho]
+        for b, im in enumerate(ims):
+            slow[2][s, b] = celeste.expected_photons(p, im)
+    for srcs in (ps, built.SrcCatalog.from_params(ps),
+                 [built.SrcParams(u=p.u, a=p.a, fluxes=np.array([p.flux(b) for b in "ugriz"]), theta=p.theta, sigma=p.sigma,
+                                  phi=p.phi, rho=p.rho) for p in ps]):
+        got = celeste._source_arrays(srcs, ims)
+        for g, w in zip(got, slow):
+            np.testing.assert_allclose(g, w, rtol=1e-15)
+    # the flux_dict convention of the newer callers (sources.py:390-395)
+    got = celeste._source_arrays(ps, ims, counts_fn=models._flux_counts)
+    want = np.array([[(p.flux_dict[im.band] / im.calib) * im.kappa for im in ims] for p in ps])
+    np.testing.assert_allclose(got[2], want, rtol=1e-15)
+    # a star given by temperature needs the planck hook: the per-source path raises, vectorised gathers do not hide it
+    ps[0].t, ps[0].a = 5000.0, 0
+    with pytest.raises(NotImplementedError):
+        celeste._source_arrays(ps, ims)

@@ -1125,3 +1125,41 @@ def test_tail_log_fast_preset_meets_the_1e6_bar(cel, orc, big_field):
         ctx0.set_tail_log("default")
     assert np.max(np.abs(lam20 / lam32 - 1.0)) < 1e-6
     np.testing.assert_allclose(llb20, llb32, rtol=1e-8)
+
+
+def test_image_set_cache_lru_budget_and_superset_reuse(cel, stamp_images):
+    """the mirror's device image-set cache: least recently used sets are evicted -- and their device
+    memory released at once -- beyond the byte / count budget; a caller touching SOME images of a
+    resident set is handed that set, not a second copy; an evicted set fails loudly"""
+    from desi_mcmc_amd import celeste
+    rec, imgs = stamp_images
+    for key in list(celeste._SETS):
+        celeste._evict(key)
+    full = celeste._image_set(tuple(imgs))
+    assert len(celeste._SETS) == 1
+    sub, pos = celeste._image_subset((imgs[3], imgs[1]))
+    assert sub is full and pos == [3, 1] and len(celeste._SETS) == 1          # no second copy of the same pixels
+    one = celeste._image_set((imgs[2],))
+    assert one is not full and len(celeste._SETS) == 2
+    # Gibbs changes an image's sky level: the next fetch pushes it to whichever set holds the image
+    old = imgs[1].epsilon
+    try:
+        imgs[1].epsilon = old * 1.25
+        again = celeste._image_set(tuple(imgs))
+        assert again is full and full.eps[1] == old * 1.25 and full.band(1)[0] == old * 1.25
+    finally:
+        imgs[1].epsilon = old
+        celeste._image_set(tuple(imgs))
+    budget = celeste.CACHE_MAX_BYTES
+    try:
+        celeste.CACHE_MAX_BYTES = 24 * 51 * 51 * 5 + 1                          # room for the 5-band set only
+        celeste._cache_trim()
+        assert list(celeste._SETS) == [tuple(id(i) for i in imgs)] or len(celeste._SETS) == 1
+        newest = celeste._image_set((imgs[0],))                                  # the new set is kept, the older one goes
+        assert len(celeste._SETS) == 1 and celeste._SETS[(id(imgs[0]),)][1] is newest
+        with pytest.raises(ValueError):
+            full.band(0)                                                         # closed: null handle, not a stale pointer
+    finally:
+        celeste.CACHE_MAX_BYTES = budget
+    ll = celeste.celeste_likelihood_multi_image([], imgs)                        # re-created on demand
+    np.testing.assert_allclose(ll, sum(np.sum(i.nelec * np.log(i.epsilon) - i.epsilon) for i in imgs), rtol=1e-13)
