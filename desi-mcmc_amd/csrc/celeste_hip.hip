@@ -1345,7 +1345,10 @@ int cel_estep_stats(cel_images *im, cel_sources *src, double *xtilde, double *ma
     const int B = im->B;
     const int64_t S = src->S;
     const int nblk = im->ntx * im->nty;                 // d_partials holds B * nblk doubles
-    double *d_x = nullptr, *d_m = nullptr;
+    double *d_x = nullptr, *d_m = nullptr, *d_part = nullptr;
+    // recurrence evaluator on the 32 x 64 layout: the tile-walking form (the render above left the
+    // lists and boxes of exactly these sources on the device); CEL_OPT_DEBUG bit 64 keeps the per-source form
+    const bool tiles = (c->variant != 0) && (im->TW == HW_TW) && !(c->debug & 64) && S > 0;
     std::vector<double> hx((size_t)(S * B)), hm((size_t)(S * B));
     hipError_t e;
 #define ES_TRY(expr)                                                                     \
@@ -1357,19 +1360,34 @@ int cel_estep_stats(cel_images *im, cel_sources *src, double *xtilde, double *ma
         // the context's scratch arena (slots 4/5), not a hipMalloc per call: EM iterates this
         if ((rc = scratch_get(c, 4, sizeof(double) * S * B, (void **)&d_x)) ||
             (rc = scratch_get(c, 5, sizeof(double) * S * B, (void **)&d_m))) goto done;
+        if (tiles && (rc = scratch_get(c, 6, sizeof(double) * 2 * (size_t)im->lists_cap, (void **)&d_part))) goto done;
         int pi = prof_begin(c, CEL_K_STAMPS);
         if (c->variant == 0)
             hipLaunchKernelGGL(k_estep_src, dim3((unsigned)(S * B)), dim3(256), 0, c->stream, im->d_bands, B, im->H, im->W,
                                S, im->d_recs, im->d_nelec, im->d_lambda, d_x, d_m);
-        else
+        else if (tiles) {
+            // walk the render tiles: nelec / lambda are read once, every list entry gets its pair of sums,
+            // the gather adds a source's entries in tile order
+            EstepArgs ea;
+            ea.bands = im->d_bands; ea.recs = im->d_recs; ea.lists = im->d_lists; ea.tile_cnt = im->d_tile_cnt;
+            ea.tile_off = im->d_tile_off; ea.order = c->tile_order ? im->d_order : nullptr;
+            ea.nelec = im->d_nelec; ea.lambda = im->d_lambda; ea.partial = d_part; ea.noise_partial = im->d_partials;
+            ea.S = S; ea.capacity = im->lists_cap; ea.B = B; ea.H = im->H; ea.W = im->W; ea.ntx = im->ntx; ea.nty = im->nty;
+            ea.tail_T = c->tail_T;
+            hipLaunchKernelGGL(k_estep_tiles, dim3((unsigned)(B * nblk)), dim3(64), 0, c->stream, ea);
+            hipLaunchKernelGGL(k_estep_gather, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, c->stream, im->d_boxes, im->d_kind,
+                               S, B, im->ntx, im->nty, im->d_tile_cnt, im->d_tile_nstar, im->d_tile_off, im->d_lists, im->lists_cap,
+                               d_part, d_x, d_m);
+        } else
             hipLaunchKernelGGL(k_estep_src_hw, dim3((unsigned)(S * B)), dim3(64), 0, c->stream, im->d_bands, B, im->H, im->W,
                                S, im->d_recs, im->d_nelec, im->d_lambda, c->tail_T, d_x, d_m);
         prof_end(c, pi);
         ES_TRY(hipMemcpyAsync(hx.data(), d_x, sizeof(double) * S * B, hipMemcpyDeviceToHost, c->stream));
         ES_TRY(hipMemcpyAsync(hm.data(), d_m, sizeof(double) * S * B, hipMemcpyDeviceToHost, c->stream));
     }
-    hipLaunchKernelGGL(k_estep_noise, dim3(B * nblk), dim3(256), 0, c->stream, im->d_bands, (int64_t)im->H * im->W, nblk,
-                       im->d_nelec, im->d_lambda, im->d_partials);
+    if (!tiles)      // the tile walk has left the sky term's per-tile sums in d_partials
+        hipLaunchKernelGGL(k_estep_noise, dim3(B * nblk), dim3(256), 0, c->stream, im->d_bands, (int64_t)im->H * im->W, nblk,
+                           im->d_nelec, im->d_lambda, im->d_partials);
     hipLaunchKernelGGL(k_reduce, dim3(B), dim3(256), 0, c->stream, im->d_partials, nblk, im->d_llband);
     ES_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
     ES_TRY(hipGetLastError());

@@ -144,3 +144,144 @@ k_estep_noise(const BandDev *__restrict__ bands, int64_t npix, int nblk, const d
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
+
+// ---- the same reductions, walking TILES (round 2) ---------------------------------------------------
+// k_estep_src_hw re-reads nelec and lambda under every source: 16 B x (sum of box areas) = 6.4 GB at
+// config 3 where the images hold 0.34 GB (2.5 TB/s for 3.6 ms; 0.44 of the fp64 issue rate).  Here a
+// wave owns a render tile, as in k_render_hw: it loads the tile's nelec / lambda ONCE (32 quotients
+// per lane, in registers), then renders each source of the tile's list as a unit stamp into the LDS
+// tile and reduces it against the quotients -- one (sum stamp * nelec / lambda, sum stamp) pair per list
+// entry, written at the entry's position.  k_estep_gather then sums, for every (source, band), the
+// entries of the tiles its box touches in tile order (the source is found in a tile's list by
+// bisection: lists are ascending inside their star and galaxy parts), so the result is reproducible.
+// The sky term (sum nelec * eps / lambda) falls out of the same pass.
+struct EstepArgs {
+    const BandDev *bands;
+    const SrcRec *recs;
+    const int *lists;
+    const int *tile_cnt;
+    const int64_t *tile_off;
+    const int *order;
+    const double *nelec, *lambda;
+    double *partial;            // 2 per list entry: counts * sum(u * ne / lam), sum(u)
+    double *noise_partial;      // per tile
+    int64_t S, capacity;
+    int B, H, W, ntx, nty;
+    double tail_T;
+};
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+k_estep_tiles(EstepArgs a) {
+    __shared__ double acc[HW_TH * HW_TW];
+    __shared__ CompTab T;
+    __shared__ double et[64];
+    const int lane = threadIdx.x;
+    const int half = lane >> 5, col = lane & 31;
+    const int tile = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const int per_band = a.ntx * a.nty;
+    const int b = tile / per_band;
+    const int t = tile - b * per_band;
+    const int ty = t / a.ntx, tx = t - ty * a.ntx;
+    const int X0 = tx * HW_TW, Y0 = ty * HW_TH;
+    const int xi = X0 + col;
+    const BandDev *bd = a.bands + b;
+    const double eps = bd->eps;
+    // the tile's nelec / lambda, once
+    double w[HW_TH / 2];
+    double noise = 0.0;
+    {
+        const int64_t base = (int64_t)b * a.H * a.W + (int64_t)(Y0 + half) * a.W + xi;
+        double ne[HW_TH / 2], la[HW_TH / 2];
+#pragma unroll
+        for (int r = 0; r < HW_TH / 2; r++) {
+            const bool in = (xi < a.W) && (Y0 + 2 * r + half < a.H);
+            ne[r] = in ? a.nelec[base + (int64_t)(2 * r) * a.W] : 0.0;
+            la[r] = in ? a.lambda[base + (int64_t)(2 * r) * a.W] : 1.0;
+        }
+#pragma unroll
+        for (int r = 0; r < HW_TH / 2; r++) {
+            w[r] = ne[r] / la[r];
+            noise += ne[r] * eps / la[r];
+        }
+    }
+    noise = wave_sum(noise);
+    if (lane == 0) a.noise_partial[tile] = noise;
+    const int cnt = a.tile_cnt[tile];
+    const int64_t off = a.tile_off[tile];
+    const int nent = (int)min((int64_t)cnt, a.capacity > off ? a.capacity - off : (int64_t)0);
+    if (nent == 0) return;
+    et[lane] = exp2((double)lane * (1.0 / 64.0));
+#pragma unroll
+    for (int r = 0; r < HW_TH / 2; r++) acc[r * 64 + lane] = 0.0;
+    const SrcRec *recs = a.recs + (int64_t)b * a.S;
+    const LaneConst lc = lane_consts(lane, bd);
+    const int dropmode = (a.tail_T > 0.0) ? HW_DROP_SELF : HW_DROP_NONE;
+    int idx64 = (lane < nent) ? a.lists[off + lane] : 0;
+    int recw_next = rec_fetch(recs, __builtin_amdgcn_readlane(idx64, 0), lane);
+    for (int e = 0; e < nent; e++) {
+        const int recw = recw_next;
+        if (e + 1 < nent) {
+            if (((e + 1) & 63) == 0) idx64 = (e + 1 + lane < nent) ? a.lists[off + e + 1 + lane] : 0;
+            recw_next = rec_fetch(recs, __builtin_amdgcn_readlane(idx64, (e + 1) & 63), lane);
+        }
+        RecU rec = rec_unpack(recw);
+        const double counts = rec.scale;
+        rec.scale = 1.0;                                    // the tile holds the unit stamp
+        const int ra = max(rec.y0, Y0) - Y0, rb = min(rec.y1, Y0 + HW_TH) - Y0;
+        const int xa = max(rec.x0, X0), xb = min(rec.x1, X0 + HW_TW) - 1;
+        const bool on = (xi >= rec.x0) && (xi < rec.x1);
+        bool direct;
+        const int Kk = hw_build(T, lc, rec, lane, dropmode, a.tail_T, 0.0, Y0, xa, xb, ra, rb, direct);
+        hw_walk(T, et, Kk, (double)xi, Y0, ra, rb, on, direct, acc, lane);
+        __syncthreads();
+        double xt = 0.0, ms = 0.0;
+#pragma unroll
+        for (int r = 0; r < HW_TH / 2; r++) {               // static indices: w[] stays in registers
+            if (2 * r + 1 >= ra && 2 * r < rb) {            // (wave-uniform) the row pair meets the box
+                const double u = acc[r * 64 + lane];        // 0 outside the box's rows and columns
+                acc[r * 64 + lane] = 0.0;                   // clean for the next source
+                xt = fma(u, w[r], xt);
+                ms += u;
+            }
+        }
+        xt = wave_sum(xt);
+        ms = wave_sum(ms);
+        if (lane == 0) {
+            a.partial[2 * (off + e)] = counts * xt;
+            a.partial[2 * (off + e) + 1] = ms;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_estep_gather(const int4 *__restrict__ boxes /* B*S: x0, x1, y0, y1 */, const int *__restrict__ kind, int64_t S, int B, int ntx,
+               int nty, const int *__restrict__ tile_cnt, const int *__restrict__ tile_nstar, const int64_t *__restrict__ tile_off,
+               const int *__restrict__ lists, int64_t capacity, const double *__restrict__ partial,
+               double *__restrict__ xt /* S*B */, double *__restrict__ mass /* S*B */) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // band-major, like the boxes
+    if (i >= S * B) return;
+    const int b = (int)(i / S);
+    const int s = (int)(i - (int64_t)b * S);
+    const int4 q = boxes[i];
+    double a = 0.0, m = 0.0;
+    if (q.y > q.x && q.w > q.z) {
+        const bool star = (kind[i] == K_PSF);
+        for (int ty = q.z / HW_TH; ty <= (q.w - 1) / HW_TH; ty++)
+            for (int tx = q.x / HW_TW; tx <= (q.y - 1) / HW_TW; tx++) {
+                const int tile = (b * nty + ty) * ntx + tx;
+                const int64_t off = tile_off[tile];
+                const int cnt = (int)min((int64_t)tile_cnt[tile], capacity > off ? capacity - off : (int64_t)0);
+                const int ns = min(tile_nstar[tile], cnt);
+                int lo = star ? 0 : ns, hi = star ? ns : cnt;         // the part of the list the source is in, ascending
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (lists[off + mid] < s) lo = mid + 1; else hi = mid;
+                }
+                const int64_t e = off + lo;
+                a += partial[2 * e];
+                m += partial[2 * e + 1];
+            }
+    }
+    xt[(int64_t)s * B + b] = a;
+    mass[(int64_t)s * B + b] = m;
+}
