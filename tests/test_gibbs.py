@@ -285,3 +285,46 @@ def test_device_slice_sampler_follows_the_host_engine_chain_by_chain(cel):
     g2.resample_fluxes()
     with pytest.raises(ValueError):
         g2.resample_locations()
+
+
+def test_celeste_em_driver_increases_the_likelihood(cel):
+    """celeste_em (celeste_em.py:17-180) on the device reductions, with a stand-in for the black-body
+    photometry (planck.py is outside the path): EM must not decrease the marginal likelihood, and
+    it recovers the brightness of stars whose photons it is given."""
+    from desi_mcmc_amd import celeste, celeste_em
+    from test_hip_parity import frame_images
+
+    class Planck(object):          # a smooth, band-dependent photons-per-joule law (the reference's needs filter curves)
+        lens_area, exposure_duration, sun_wattage, m_per_ly = 3.68, 54.0, 3.846e26, 9.4607e15
+        centre = dict(u=3500., g=4800., r=6200., i=7600., z=9000.)
+
+        @classmethod
+        def photons_per_joule(cls, t, band):
+            x = cls.centre[band] / 1e4
+            return 1e18 * x * np.exp(-1.4388 / (x * (t / 1e4))) / (1.0 + x)
+    rec = load_golden("bands_253.npz")
+    H, W = 72, 80
+    imgs0 = frame_images(cel, rec, H, W)
+    pix = np.array([[20.5, 30.2], [55.1, 44.8], [38.0, 12.3]])
+    truth = [(5200.0, 2.0e-9), (7800.0, 6.0e-10), (3900.0, 9.0e-9)]
+    srcs = [cel.SrcParams(u=imgs0[2].pixel2equa(p), a=0, t=t, b=b) for p, (t, b) in zip(pix, truth)]
+    celeste.photons_expected_brightness = celeste_em._expected_brightness(Planck)
+    try:
+        lam = np.stack([celeste.gen_model_image(srcs, im) for im in imgs0])
+    finally:
+        celeste.photons_expected_brightness = None
+    assert lam.max() > 5 * lam.min()
+    nelec = np.random.RandomState(8).poisson(lam).astype(np.float64)
+    imgs = frame_images(cel, rec, H, W, nelec=nelec)
+    for s in srcs:                                     # start away from the truth
+        s.t, s.b = 6000.0, s.b * 1.6
+    trace, converged = celeste_em.celeste_em(srcs, imgs, maxiter=12, verbose=False, planck=Planck)
+    assert len(trace) >= 3 and all(b >= a - 1e-6 * abs(a) for a, b in zip(trace, trace[1:]))
+    assert trace[-1] > trace[0]
+    for s, (t, b) in zip(srcs, truth):
+        counts = sum(celeste_em._expected_brightness(Planck)(s.t, s.b, band) for band in BANDS)
+        want = sum(celeste_em._expected_brightness(Planck)(t, b, band) for band in BANDS)
+        assert abs(counts / want - 1.0) < 0.05          # total photons recovered to a few Poisson sigmas
+    assert celeste.photons_expected_brightness is None  # the hook is restored
+    with pytest.raises(NotImplementedError):
+        celeste_em.celeste_em(srcs, imgs, maxiter=1, verbose=False)
