@@ -328,3 +328,43 @@ def test_celeste_em_driver_increases_the_likelihood(cel):
     assert celeste.photons_expected_brightness is None  # the hook is restored
     with pytest.raises(NotImplementedError):
         celeste_em.celeste_em(srcs, imgs, maxiter=1, verbose=False)
+
+
+def test_device_and_host_engines_agree_on_a_crowded_field(cel):
+    """500 mixed sources on 5 x 512^2 (thousands of one-wave jobs of very unequal length per round, retired
+    slots, the heaviest-first job order): the device state machine and the numpy engine leave every
+    source at the same place, bit for bit, after two full sweeps"""
+    from desi_mcmc_amd import celeste_mcmc, synth
+    ctx = cel.default_context(0)
+    out = {}
+    for eng in ("host", "device"):
+        f = synth.SyntheticField(ctx, 500, 5, 512, 512, frac_gal=0.5, seed=9)
+        gf = celeste_mcmc.GibbsField(f.images, list(range(5)), f.bands[:, 2], f.bands[:, 1], 512 * 512)
+        g = celeste_mcmc.ModelGibbs([gf], f.src["type"], f.src["radec"], f.flux5(), f.src["shape"], seed=4,
+                                    slice_args=dict(step_out=False, sigma=1e-3), engine=eng)
+        for _ in range(2):
+            g.sweep()
+        out[eng] = g
+    h, d = out["host"], out["device"]
+    assert h.timing["rounds"] == d.timing["rounds"] and h.timing["evals"] == d.timing["evals"]
+    assert np.array_equal(h.u, d.u) and np.array_equal(h.fluxes, d.fluxes)
+    moved = np.abs(h.u - f.src["radec"]).max(axis=1)
+    assert np.all(moved[h.active] > 0) and np.all(moved < 5e-4)          # every sampled source moved, none ran away
+
+
+def test_slice_locations_error_paths(cel):
+    from desi_mcmc_amd import synth
+    ctx = cel.default_context(0)
+    f = synth.SyntheticField(ctx, 20, 5, 128, 128, frac_gal=0.5, seed=2)
+    with pytest.raises(ValueError, match="resident photon split"):
+        f.images.slice_locations(f.sources, 1e-3, seed=1)                 # no split yet
+    f.images.photon_split_resident(f.sources, seed=3)
+    with pytest.raises(ValueError):
+        f.images.slice_locations(f.sources, 0.0, seed=1)                  # sigma must be positive
+    other = cel.SourceSet(ctx, 7, 5).set(f.src["type"][:7], f.src["radec"][:7], f.src["counts"][:7], f.src["shape"][:7])
+    with pytest.raises(ValueError, match="resident photon split"):
+        f.images.slice_locations(other, 1e-3, seed=1)                     # not the split's sources
+    with pytest.raises(ValueError, match="rounds"):
+        f.images.slice_locations(f.sources, 1e-3, seed=1, max_rounds=1)
+    radec, llh, st = f.images.slice_locations(f.sources, 1e-3, seed=1)
+    assert st["rounds"] >= 4 and st["evals"] >= 4 * 20 and np.all(np.isfinite(llh))

@@ -1163,3 +1163,42 @@ def test_image_set_cache_lru_budget_and_superset_reuse(cel, stamp_images):
         celeste.CACHE_MAX_BYTES = budget
     ll = celeste.celeste_likelihood_multi_image([], imgs)                        # re-created on demand
     np.testing.assert_allclose(ll, sum(np.sum(i.nelec * np.log(i.epsilon) - i.epsilon) for i in imgs), rtol=1e-13)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_star_fields_vs_oracle(cel, ctx, orc, seed):
+    """random STAR-ONLY fields through the batched star pass: odd frame sizes, crowded tiles (more than
+    one 64-star batch), stars on and off every edge, a PSF so sharp that the one-segment path must
+    hand over to the general one, a caller-supplied huge bounding radius -- model pixels 1e-10,
+    log-likelihoods 1e-11, and the photon split's strict-box totals through the same lists"""
+    from desi_mcmc_amd import synth
+    rs = np.random.RandomState(100 + seed)
+    H, W = int(rs.randint(40, 300)), int(rs.randint(40, 300))
+    S = int(rs.choice([1, 7, 150, 900]))
+    f_bands = synth.make_bands(H, W, 5)
+    if seed == 3:       # a very sharp first component: exponents beyond the one-segment bound
+        f_bands[:, 12:16] = np.array([0.02, 0.0, 0.0, 0.025])[None, :]
+    if seed == 4:       # a caller-imposed radius far beyond the PSF's own
+        f_bands[:, 36] = 60.0
+    pix = np.column_stack([rs.uniform(-30, W + 30, S), rs.uniform(-30, H + 30, S)])
+    if seed == 5:       # everything on one tile: several batches of 64
+        pix = np.column_stack([rs.uniform(10, 30, S), rs.uniform(5, 60, S)])
+    typ = np.zeros(S, dtype=np.int32)
+    counts = np.exp(rs.uniform(np.log(50.0), np.log(5e4), size=(S, 5)))
+    radec = synth.pixel2equa(f_bands[0], pix)
+    iset = cel.ImageSet(ctx, f_bands, H, W)
+    ss = cel.SourceSet(ctx, S, 5).set(typ, radec, counts)
+    iset.render(ss)
+    ob = f_bands.copy()
+    for b in range(5):
+        ob[b, 36] = iset.band(b)[36]
+    nelec = rs.poisson(iset.model_images()).astype(np.float64)
+    iset.set_nelec(nelec)
+    ll, llb = iset.render(ss, loglik=True)
+    o_lam, o_ll, o_st = orc.render_field(ob, H, W, typ, radec, counts, np.zeros((S, 4)), nelec)
+    np.testing.assert_allclose(iset.model_images(), o_lam, rtol=RT_LAM)
+    np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
+    assert iset.stats()["n_srcpix"] == o_st["n_srcpix"]
+    # the split conserves every photon on the same (stars-first) lists
+    noise = iset.photon_split_resident(ss, seed=seed)
+    np.testing.assert_array_equal(iset.sample_sums().sum(axis=0) + noise, nelec.reshape(5, -1).sum(axis=1))
