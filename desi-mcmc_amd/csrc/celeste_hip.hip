@@ -37,6 +37,7 @@
 // All arithmetic is fp64 on the vector ALU; MFMA is not used (no contraction in this path).
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -211,6 +212,36 @@ static int prof_begin(cel_ctx *c, int k) {
 static void prof_end(cel_ctx *c, int i) {
     if (i >= 0) (void)hipEventRecord(c->prof.ev[i + 1], c->stream);
 }
+// The step's own kernels (prep, binning, render, reduce) are timed WITHOUT marker packets: an event
+// pair is reserved here and handed to hipExtLaunchKernelGGL, which stamps it from the dispatch's own
+// start / completion signals.  A hipEventRecord between two kernels opens a ~10 us bubble in the
+// queue (rocprofv3 kernel trace): four of them per 1.6 ms step were 2 % of what was being measured.
+static int prof_slot(cel_ctx *c, int k) {
+    if (!c->profile) return -1;
+    Prof &p = c->prof;
+    if (p.used + 2 > p.cap) {
+        int ncap = p.cap ? p.cap * 2 : 256;
+        hipEvent_t *ne = (hipEvent_t *)realloc(p.ev, sizeof(hipEvent_t) * ncap);
+        if (!ne) return -1;
+        p.ev = ne;
+        for (int i = p.cap; i < ncap; i++)
+            if (hipEventCreate(&p.ev[i]) != hipSuccess) return -1;
+        p.cap = ncap;
+    }
+    int i = p.used;
+    p.used += 2;
+    p.kid.push_back(k);
+    return i;
+}
+#define EV0(c, i) ((i) >= 0 ? (c)->prof.ev[(i)] : (hipEvent_t) nullptr)
+#define EV1(c, i) ((i) >= 0 ? (c)->prof.ev[(i) + 1] : (hipEvent_t) nullptr)
+// launch with optional start / stop events attached to the dispatch
+#define LAUNCH_EV(kernel, grid, block, st, e0, e1, ...)                                              \
+    do {                                                                                             \
+        hipEvent_t e0_ = (e0), e1_ = (e1);                                                           \
+        if (e0_ || e1_) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, e0_, e1_, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                            \
+    } while (0)
 static void prof_collect(cel_ctx *c) {
     Prof &p = c->prof;
     for (int i = 0; i < p.used; i += 2) {
@@ -645,11 +676,10 @@ static int run_prep(cel_images *im, cel_sources *src) {
     int rc = ensure_recs(im, n > 0 ? n : 1);
     if (rc) return rc;
     if (n == 0) { im->recs_gen = src->gen; im->last_S = 0; return CEL_OK; }
-    int pi = prof_begin(c, CEL_K_PREP);
-    hipLaunchKernelGGL(k_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, im->d_bands, im->B,
-                       im->full_H, im->W, im->win_y0, im->H, src->S, src->d_type, src->d_radec, src->d_counts, src->d_shape,
-                       rsq_galaxy(), im->d_recs, im->d_boxes, im->d_kind, im->d_status);
-    prof_end(c, pi);
+    int pi = prof_slot(c, CEL_K_PREP);
+    LAUNCH_EV(k_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), c->stream, EV0(c, pi), EV1(c, pi), im->d_bands, im->B,
+              im->full_H, im->W, im->win_y0, im->H, src->S, src->d_type, src->d_radec, src->d_counts, src->d_shape,
+              rsq_galaxy(), im->d_recs, im->d_boxes, im->d_kind, im->d_status);
     HIP_TRY(hipGetLastError());
     im->recs_gen = src->gen;
     im->last_S = src->S;
@@ -715,20 +745,21 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
     for (int attempt = 0; attempt < 8; attempt++) {
         // d_cursor: [0] fine cursor, [1] fine overflow, [2] coarse cursor, [3] coarse overflow
         HIP_TRY(hipMemsetAsync(im->d_cursor, 0, sizeof(unsigned long long) * 4, st));
-        int pi = prof_begin(c, CEL_K_BIN);
-        hipLaunchKernelGGL(k_bin_coarse, dim3(NS), dim3(64 * COARSE_WAVES), 0, st, im->d_boxes, S, im->nsx, im->nsy, im->d_sup_cnt,
-                           im->d_sup_off, im->d_cursor + 2, im->d_clist, im->clist_cap, (int *)(im->d_cursor + 3));
-        hipLaunchKernelGGL(k_bin_fine_blk, dim3(NS), dim3(256), 0, st, im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
-                           im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
-                           im->d_tile_nstar, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
-                           (int *)(im->d_cursor + 1));
+        // one event pair over the binning kernels: start on the first, stop on the last
+        int pi = prof_slot(c, CEL_K_BIN);
+        LAUNCH_EV(k_bin_coarse, dim3(NS), dim3(64 * COARSE_WAVES), st, EV0(c, pi), (hipEvent_t) nullptr, im->d_boxes, S, im->nsx, im->nsy,
+                  im->d_sup_cnt, im->d_sup_off, im->d_cursor + 2, im->d_clist, im->clist_cap, (int *)(im->d_cursor + 3));
+        LAUNCH_EV(k_bin_fine_blk, dim3(NS), dim3(256), st, (hipEvent_t) nullptr, c->tile_order ? (hipEvent_t) nullptr : EV1(c, pi),
+                  im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
+                  im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
+                  im->d_tile_nstar, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
+                  (int *)(im->d_cursor + 1));
         if (c->tile_order)
             // heaviest first: by the durations the tiles had in the previous render when that was
             // of the same source count (an MCMC chain changes little from one evaluation to the
             // next), by the binning pass's estimate otherwise.  The order never changes results.
-            hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (im->cost_S == S && c->tile_order == 1) ? im->d_tile_cost : im->d_tile_work,
-                               T, im->d_order);
-        prof_end(c, pi);
+            LAUNCH_EV(k_order, dim3(1), dim3(1024), st, (hipEvent_t) nullptr, EV1(c, pi),
+                      (const int *)((im->cost_S == S && c->tile_order == 1) ? im->d_tile_cost : im->d_tile_work), T, im->d_order);
         RenderArgs a;
         a.bands = im->d_bands; a.recs = im->d_recs; a.lists = im->d_lists; a.tile_cnt = im->d_tile_cnt;
         a.tile_nstar = im->d_tile_nstar;
@@ -741,20 +772,18 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
             if (!im->d_timing) HIP_TRY(hipMalloc((void **)&im->d_timing, sizeof(unsigned long long) * 3 * T));
             a.timing = im->d_timing;
         }
-        pi = prof_begin(c, CEL_K_RENDER);
+        pi = prof_slot(c, CEL_K_RENDER);
         if (im->TW == QW_TW)
-            hipLaunchKernelGGL(k_render_qw, dim3(T), dim3(64), 0, st, a);
+            LAUNCH_EV(k_render_qw, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
         else if (im->TW == HW_TW)
-            hipLaunchKernelGGL(k_render_hw, dim3(T), dim3(64), 0, st, a);
+            LAUNCH_EV(k_render_hw, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
         else if (im->TH == 64)
-            hipLaunchKernelGGL((k_render<64>), dim3(T), dim3(64), 0, st, a);
+            LAUNCH_EV((k_render<64>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
         else
-            hipLaunchKernelGGL((k_render<32>), dim3(T), dim3(64), 0, st, a);
-        prof_end(c, pi);
+            LAUNCH_EV((k_render<32>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
         if (flags & CEL_RENDER_LOGLIK) {
-            pi = prof_begin(c, CEL_K_REDUCE);
-            hipLaunchKernelGGL(k_reduce, dim3(im->B), dim3(256), 0, st, im->d_partials, im->ntx * im->nty, im->d_llband);
-            prof_end(c, pi);
+            pi = prof_slot(c, CEL_K_REDUCE);
+            LAUNCH_EV(k_reduce, dim3(im->B), dim3(256), st, EV0(c, pi), EV1(c, pi), (const double *)im->d_partials, im->ntx * im->nty, im->d_llband);
             HIP_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * im->B, hipMemcpyDeviceToHost, st));
         }
         // total list length + overflow flag ride back with the result
