@@ -450,7 +450,7 @@ int cel_images_destroy(cel_images *im) {
     (void)hipSetDevice(im->ctx->device);
     (void)hipStreamSynchronize(im->ctx->stream);
     void *ptrs[] = {im->d_bands, im->d_nelec, im->d_lambda, im->d_partials, im->d_llband, im->d_recs,
-                    im->d_boxes, im->d_kind, im->d_status, im->d_tile_cnt, im->d_tile_nstar, im->d_tile_work, im->d_tile_cost, im->d_order, im->d_tile_off, im->d_cursor, im->d_lists, im->d_stats,
+                    im->d_boxes, im->d_kind, im->d_status, im->d_tile_cnt, im->d_tile_nstar, im->d_tile_work, im->d_tile_cost, im->d_order, im->d_tile_off, im->d_lists, im->d_stats,
                     im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff, im->d_rate, im->d_snz};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -508,14 +508,15 @@ int cel_images_create(cel_ctx *c, int B, int H, int W, const cel_band *bands, ce
     IM_TRY(hipMalloc((void **)&im->d_nelec, sizeof(double) * npix));
     IM_TRY(hipMalloc((void **)&im->d_lambda, sizeof(double) * npix));
     IM_TRY(hipMalloc((void **)&im->d_partials, sizeof(double) * T));
-    IM_TRY(hipMalloc((void **)&im->d_llband, sizeof(double) * MAX_BANDS));
+    // per-band sums and the binning cursors share one buffer: they ride back to the host in one copy
+    IM_TRY(hipMalloc((void **)&im->d_llband, sizeof(double) * MAX_BANDS + sizeof(unsigned long long) * 4));
+    im->d_cursor = reinterpret_cast<unsigned long long *>(im->d_llband + MAX_BANDS);
     IM_TRY(hipMalloc((void **)&im->d_tile_cnt, sizeof(int) * T));
     IM_TRY(hipMalloc((void **)&im->d_tile_nstar, sizeof(int) * T));
     IM_TRY(hipMalloc((void **)&im->d_tile_work, sizeof(int) * T));
     IM_TRY(hipMalloc((void **)&im->d_tile_cost, sizeof(int) * T));
     IM_TRY(hipMalloc((void **)&im->d_order, sizeof(int) * T));
     IM_TRY(hipMalloc((void **)&im->d_tile_off, sizeof(int64_t) * T));
-    IM_TRY(hipMalloc((void **)&im->d_cursor, sizeof(unsigned long long) * 4));
     IM_TRY(hipMalloc((void **)&im->d_sup_cnt, sizeof(int) * B * im->nsx * im->nsy));
     IM_TRY(hipMalloc((void **)&im->d_sup_off, sizeof(int64_t) * B * im->nsx * im->nsy));
     IM_TRY(hipMalloc((void **)&im->d_stats, sizeof(double) * 2));
@@ -679,7 +680,7 @@ static int run_prep(cel_images *im, cel_sources *src) {
     int pi = prof_slot(c, CEL_K_PREP);
     LAUNCH_EV(k_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), c->stream, EV0(c, pi), EV1(c, pi), im->d_bands, im->B,
               im->full_H, im->W, im->win_y0, im->H, src->S, src->d_type, src->d_radec, src->d_counts, src->d_shape,
-              rsq_galaxy(), im->d_recs, im->d_boxes, im->d_kind, im->d_status);
+              rsq_galaxy(), im->d_recs, im->d_boxes, im->d_kind, im->d_status, im->d_cursor);
     HIP_TRY(hipGetLastError());
     im->recs_gen = src->gen;
     im->last_S = src->S;
@@ -743,8 +744,9 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
     }
     const int NS = im->B * im->nsx * im->nsy;
     for (int attempt = 0; attempt < 8; attempt++) {
-        // d_cursor: [0] fine cursor, [1] fine overflow, [2] coarse cursor, [3] coarse overflow
-        HIP_TRY(hipMemsetAsync(im->d_cursor, 0, sizeof(unsigned long long) * 4, st));
+        // d_cursor: [0] fine cursor, [1] fine overflow, [2] coarse cursor, [3] coarse overflow;
+        // zeroed by k_prep (no memset in the queue), by hand only when that did not run or on a retry
+        if (attempt > 0 || S * im->B == 0) HIP_TRY(hipMemsetAsync(im->d_cursor, 0, sizeof(unsigned long long) * 4, st));
         // one event pair over the binning kernels: start on the first, stop on the last
         int pi = prof_slot(c, CEL_K_BIN);
         LAUNCH_EV(k_bin_coarse, dim3(NS), dim3(64 * COARSE_WAVES), st, EV0(c, pi), (hipEvent_t) nullptr, im->d_boxes, S, im->nsx, im->nsy,
@@ -784,16 +786,15 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         if (flags & CEL_RENDER_LOGLIK) {
             pi = prof_slot(c, CEL_K_REDUCE);
             LAUNCH_EV(k_reduce, dim3(im->B), dim3(256), st, EV0(c, pi), EV1(c, pi), (const double *)im->d_partials, im->ntx * im->nty, im->d_llband);
-            HIP_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * im->B, hipMemcpyDeviceToHost, st));
         }
-        // total list length + overflow flag ride back with the result
-        HIP_TRY(hipMemcpyAsync(c->pinned + MAX_BANDS + 2, im->d_cursor, sizeof(unsigned long long) * 4,
+        // the per-band sums, the total list length and the overflow flags ride back in ONE copy
+        HIP_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * MAX_BANDS + sizeof(unsigned long long) * 4,
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipGetLastError());
         im->last_S = S;
         HIP_TRY(hipStreamSynchronize(st));
         unsigned long long cur[4];
-        memcpy(cur, c->pinned + MAX_BANDS + 2, sizeof(cur));
+        memcpy(cur, c->pinned + MAX_BANDS, sizeof(cur));
         const bool fine_ok = (cur[1] & 0xffffffffull) == 0 && (int64_t)cur[0] <= im->lists_cap;
         const bool coarse_ok = (cur[3] & 0xffffffffull) == 0 && (int64_t)cur[2] <= im->clist_cap;
         if (coarse_ok) im->last_entries = (double)cur[0];
