@@ -126,7 +126,14 @@ k_slice_consume(SliceState st, int64_t S, int B, const double *__restrict__ ll_p
                     const int k = st.kdir[s] + 1;
                     st.kdir[s] = k;
                     if (k >= 2) st.phase[s] = SL_FINAL;
-                    else sl_start_direction(st, s, sigma);
+                    else {
+                        // the second axis starts where the first ended: its level needs the log-likelihood
+                        // of a point that has just been scored (the reference evaluates it again and gets
+                        // the same number), so the chain goes straight to shrinking
+                        sl_start_direction(st, s, sigma);
+                        st.llh_s[s] = st.log_u[s] + v;
+                        st.phase[s] = SL_SHRINK;
+                    }
                 } else if (z < 0.0) {
                     st.lower[s] = z;
                 } else if (z > 0.0) {

@@ -245,7 +245,16 @@ def slicesample_lockstep(init_x, logprob_batch, sigma=1.0, step_out=True, max_st
             kdir[fin] += 1
             last = kdir[fin] >= ndir
             phase[fin[last]] = _P_FINAL
-            start_direction(fin[~last])
+            nxt = fin[~last]
+            if nxt.size:
+                # the next direction starts where this one ended: its level needs logprob at a point
+                # that has just been scored (the reference evaluates it again and gets the same number)
+                start_direction(nxt)
+                llh_s[nxt] = log_u[nxt] + new_llh[nxt]
+                if step_out:
+                    phase[nxt] = _P_OUT_DOUBLE if doubling_step else _P_OUT_LEFT
+                else:
+                    enter_shrink(nxt)
     if stats is not None:
         stats.update(rounds=n_rounds, evals=n_evals, max_steps_in=max_in)
     return X, new_llh
