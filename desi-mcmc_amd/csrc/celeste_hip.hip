@@ -166,6 +166,8 @@ struct cel_images {
     // device-resident sample patches of the last resident photon split (source-major, index s*B+b)
     double *d_samp = nullptr;
     int4 *d_snz = nullptr;      // nonzero rectangles of the resident sample patches (k_patch_nzbox)
+    double *d_ssum = nullptr;   // photons per (source, band) of the resident split, summed by the split kernel itself
+    bool ssum_valid = false;
     double *d_rate = nullptr;   // per-pixel total rates of the photon split (strict boxes), B*H*W, on first use
     int64_t samp_cap = 0;
     int4 *d_sbox = nullptr;
@@ -451,7 +453,7 @@ int cel_images_destroy(cel_images *im) {
     (void)hipStreamSynchronize(im->ctx->stream);
     void *ptrs[] = {im->d_bands, im->d_nelec, im->d_lambda, im->d_partials, im->d_llband, im->d_recs,
                     im->d_boxes, im->d_kind, im->d_status, im->d_tile_cnt, im->d_tile_nstar, im->d_tile_work, im->d_tile_cost, im->d_order, im->d_tile_off, im->d_lists, im->d_stats,
-                    im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff, im->d_rate, im->d_snz};
+                    im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff, im->d_rate, im->d_snz, im->d_ssum};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (im->d_slice) (void)hipFree(im->d_slice);
@@ -1254,11 +1256,13 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
             if (im->d_sbox) (void)hipFree(im->d_sbox);
             if (im->d_soff) (void)hipFree(im->d_soff);
             if (im->d_snz) (void)hipFree(im->d_snz);
-            im->d_sbox = nullptr; im->d_soff = nullptr; im->d_snz = nullptr; im->slay_cap = 0;
+            if (im->d_ssum) (void)hipFree(im->d_ssum);
+            im->d_sbox = nullptr; im->d_soff = nullptr; im->d_snz = nullptr; im->d_ssum = nullptr; im->slay_cap = 0;
             int64_t cap = n + n / 4 + 64;
             HIP_TRY(hipMalloc((void **)&im->d_sbox, sizeof(int4) * cap));
             HIP_TRY(hipMalloc((void **)&im->d_snz, sizeof(int4) * cap));
             HIP_TRY(hipMalloc((void **)&im->d_soff, sizeof(int64_t) * cap));
+            HIP_TRY(hipMalloc((void **)&im->d_ssum, sizeof(double) * cap));
             im->slay_cap = cap;
         }
         hipLaunchKernelGGL(k_samp_layout, dim3(1), dim3(1024), 0, c->stream, im->d_recs, S, B, im->d_sbox, im->d_soff);
@@ -1286,6 +1290,8 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
     // resident + recurrence form: the kernel writes every interior pixel and reduces the photon
     // rectangles itself; otherwise zero the buffer and (resident) find the rectangles afterwards
     const bool fused_nz = resident && hw && n > 0;
+    if (resident) im->ssum_valid = fused_nz;
+    if (fused_nz) HIP_TRY(hipMemsetAsync(im->d_ssum, 0, sizeof(double) * n, c->stream));
     if (fused_nz)
         hipLaunchKernelGGL(k_samp_prepare, dim3((unsigned)n), dim3(64), 0, c->stream, im->d_sbox, im->d_soff, d_samp, im->d_snz);
     else if (total > 0)
@@ -1299,6 +1305,7 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         a.win_y0 = im->win_y0; a.full_H = im->full_H;
         a.rate_img = im->d_rate; a.tail_T = c->tail_T; a.nz = fused_nz ? im->d_snz : nullptr;
         a.order = (hw && c->tile_order) ? im->d_order : nullptr;
+        a.sums = fused_nz ? im->d_ssum : nullptr;
         if (hw && (rc = scratch_get(c, 2, sizeof(double) * 2 * (size_t)T, (void **)&a.partials))) return rc;
         int pi = prof_begin(c, CEL_K_STAMPS);
         if (hw) hipLaunchKernelGGL(k_photon_split_hw, dim3(2 * T), dim3(64), 0, c->stream, a);
@@ -1342,10 +1349,14 @@ int cel_samples_fetch(cel_images *im, int32_t *boxes, int64_t *offsets, double *
     if (data && im->samp_total > 0 &&
         (rc = copy_out(data, im->d_samp, sizeof(double) * im->samp_total, CEL_HOST, c->stream))) return rc;
     if (sums) {
-        double *d_sums = nullptr;
-        if ((rc = scratch_get(c, 2, sizeof(double) * n, (void **)&d_sums))) return rc;
-        hipLaunchKernelGGL(k_patch_sums, dim3((unsigned)n), dim3(256), 0, c->stream, im->d_soff, im->d_samp, d_sums);
-        if ((rc = copy_out(sums, d_sums, sizeof(double) * n, CEL_HOST, c->stream))) return rc;
+        if (im->ssum_valid) {       // the split kernel summed them itself (exact: integer-valued)
+            if ((rc = copy_out(sums, im->d_ssum, sizeof(double) * n, CEL_HOST, c->stream))) return rc;
+        } else {
+            double *d_sums = nullptr;
+            if ((rc = scratch_get(c, 2, sizeof(double) * n, (void **)&d_sums))) return rc;
+            hipLaunchKernelGGL(k_patch_sums, dim3((unsigned)n), dim3(256), 0, c->stream, im->d_soff, im->d_samp, d_sums);
+            if ((rc = copy_out(sums, d_sums, sizeof(double) * n, CEL_HOST, c->stream))) return rc;
+        }
     }
     return CEL_OK;
 }

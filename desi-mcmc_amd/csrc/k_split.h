@@ -299,6 +299,8 @@ struct SplitArgs {
     double tail_T;              // k_photon_split_hw: drop threshold of the per-source tiles
     int4 *nz;                   // k_photon_split_hw: per patch, the rectangle holding its photons (min/max by atomics), or nullptr
     const int *order;           // k_photon_split_hw: tile launch order (heaviest first, from the totals render), or nullptr
+    double *sums;               // k_photon_split_hw: photons per (source, band), index s*B + b, zeroed by the caller, or nullptr.
+                                // Integer-valued doubles: the atomic sums are exact, so their order does not matter
 };
 
 __global__ void __launch_bounds__(64)
@@ -473,6 +475,7 @@ k_photon_split_hw(SplitArgs a) {
         hw_walk(T, et, Kk, x, Y0, ra, rb, on, direct, one, lane);
         __syncthreads();
         int zlo = INT_MAX, zhi = -1;                  // rows of this lane's column that received photons
+        double zsum = 0.0;
         if (on) {
             const int nx = rec.x1 - rec.x0;
             double *patch = a.samp + poff + (int64_t)(Y0 - rec.y0) * nx + (xi - rec.x0);
@@ -492,7 +495,7 @@ k_photon_split_hw(SplitArgs a) {
                 left[li] = n - (int)z;
                 rate[li] = tot - F;                                       // sum_probs -= curr_prob (:152)
                 patch[(int64_t)row * nx] = (double)z;
-                if (z > 0) { zlo = min(zlo, row); zhi = max(zhi, row); }
+                if (z > 0) { zlo = min(zlo, row); zhi = max(zhi, row); zsum += (double)z; }
             }
         }
         if (a.nz && __ballot(zhi >= 0)) {
@@ -505,10 +508,12 @@ k_photon_split_hw(SplitArgs a) {
                 zlo = min(zlo, __shfl_xor(zlo, o)); zhi = max(zhi, __shfl_xor(zhi, o));
                 xlo = min(xlo, __shfl_xor(xlo, o)); xhi = max(xhi, __shfl_xor(xhi, o));
             }
+            if (a.sums) zsum = wave_sum(zsum);
             if (lane == 0) {
                 int *q = reinterpret_cast<int *>(a.nz + ((int64_t)s * a.B + b));
                 atomicMin(q + 0, xlo); atomicMax(q + 1, xhi + 1);
                 atomicMin(q + 2, Y0 + zlo); atomicMax(q + 3, Y0 + zhi + 1);
+                if (a.sums) atomicAdd(a.sums + ((int64_t)s * a.B + b), zsum);
             }
         }
         __syncthreads();
