@@ -11,6 +11,7 @@ Divergences from the reference, all documented in DESIGN.md "Quirks":
   planck  stars given by temperature (`src.t`) need a hook: set `photons_expected_brightness`.
 """
 import collections
+import sys
 import weakref
 
 import numpy as np
@@ -57,15 +58,20 @@ def _evict(key):
         ent[1].close()                 # cel_images_destroy now
 
 
+def _in_use(ent):
+    """someone outside the cache holds the ImageSet (a ModelGibbs over these images, a caller in the
+    middle of a call): closing it under them would turn their next call into an error"""
+    return sys.getrefcount(ent[1]) > 2          # the entry's list + getrefcount's argument
+
+
 def _cache_trim(keep=None):
     for key in [k for k, e in _SETS.items() if any(r() is None for r in e[0])]:
         _evict(key)
-    while _SETS and (len(_SETS) > CACHE_MAX_SETS or sum(e[3] for e in _SETS.values()) > CACHE_MAX_BYTES):
-        key = next(iter(_SETS))
-        if key == keep:
-            if len(_SETS) == 1:
-                break
-            _SETS.move_to_end(key)
+    over = lambda: len(_SETS) > CACHE_MAX_SETS or sum(e[3] for e in _SETS.values()) > CACHE_MAX_BYTES   # noqa: E731
+    for key in list(_SETS):                      # least recently used first
+        if not over():
+            break
+        if key == keep or _in_use(_SETS[key]):
             continue
         _evict(key)
 

@@ -1154,11 +1154,27 @@ def test_image_set_cache_lru_budget_and_superset_reuse(cel, stamp_images):
     try:
         celeste.CACHE_MAX_BYTES = 24 * 51 * 51 * 5 + 1                          # room for the 5-band set only
         celeste._cache_trim()
-        assert list(celeste._SETS) == [tuple(id(i) for i in imgs)] or len(celeste._SETS) == 1
-        newest = celeste._image_set((imgs[0],))                                  # the new set is kept, the older one goes
-        assert len(celeste._SETS) == 1 and celeste._SETS[(id(imgs[0]),)][1] is newest
+        # sets somebody still holds (this test's `full` and `one`) are never closed under their holder
+        assert len(celeste._SETS) == 2 and full.band(0)[0] == imgs[0].epsilon
+        del sub, again, one
+        celeste._cache_trim()
+        assert list(celeste._SETS) == [tuple(id(i) for i in imgs)]               # the unreferenced one-band set went
+        newest = celeste._image_set((imgs[0],))
+        assert len(celeste._SETS) == 2                                           # `full` is held: over budget, but kept
+        import weakref
+        gone = weakref.ref(full)
+        handle = full
+        del full
+        celeste._cache_trim(keep=(id(imgs[0]),))
+        assert len(celeste._SETS) == 2                                           # `handle` still holds it
+        del handle
+        celeste._cache_trim(keep=(id(imgs[0]),))
+        assert list(celeste._SETS) == [(id(imgs[0]),)] and gone() is None        # released at once, newest kept
+        assert celeste._SETS[(id(imgs[0]),)][1] is newest
+        closed = cel.ImageSet(cel.default_context(0), np.stack([imgs[0].band_record()]), 51, 51)
+        closed.close()
         with pytest.raises(ValueError):
-            full.band(0)                                                         # closed: null handle, not a stale pointer
+            closed.band(0)                                                       # closed: null handle, not a stale pointer
     finally:
         celeste.CACHE_MAX_BYTES = budget
     ll = celeste.celeste_likelihood_multi_image([], imgs)                        # re-created on demand
@@ -1202,3 +1218,37 @@ def test_fuzz_star_fields_vs_oracle(cel, ctx, orc, seed):
     # the split conserves every photon on the same (stars-first) lists
     noise = iset.photon_split_resident(ss, seed=seed)
     np.testing.assert_array_equal(iset.sample_sums().sum(axis=0) + noise, nelec.reshape(5, -1).sum(axis=1))
+
+
+def test_bench_line_contract_on_the_small_star_workload():
+    """bench.py end to end on BASELINE configs[1] (stars1k_512): one JSON line with the contract's keys,
+    a roofline object measured live, the extra legs, and a bounded cpu_baseline"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "stars1k_512", "--steps", "10", "--warmup", "2",
+                        "--cpu-sample", "50"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["config"]["workload"] == "stars1k_512" and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["launches"] == 10
+    np.testing.assert_allclose(rf["frac"], rf["achieved"] / rf["peak"], rtol=1e-12)
+    np.testing.assert_allclose(rf["achieved"], rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9, rtol=1e-9)
+    assert 0 < rf["kernel_ms"] < d["ms_per_step"]
+    assert d["value"] > 1e9 and d["work"]["n_gauss_evaluated_per_step"] > 0
+    assert d["ms_per_step_with_source_upload"] > 0 and d["python_api_ms"] > 0 and d["python_api_loglik_rel_diff"] < 1e-12
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["one_thread"]["cores"] == 1
+    assert "reference_semantics_fullframe" in cb
