@@ -1,87 +1,13 @@
-"""CPU tests of the lock-step slice sampler (desi-mcmc_amd/util/infer/slicesample.py) against a
-scalar restatement of the reference's algorithm (CelestePy/util/infer/slicesample.py:89-227) fed
-with the same per-chain random stream, and for the distribution it leaves invariant."""
+"""CPU tests of the lock-step slice sampler (desi-mcmc_amd/util/infer/slicesample.py) against the
+oracle's scalar restatement of the reference's algorithm (oracle/slicesample_oracle.py, following
+CelestePy/util/infer/slicesample.py:89-227) fed with the same per-chain random stream, and for the
+distribution it leaves invariant."""
 import numpy as np
 import pytest
 
 import desi_mcmc_amd  # noqa: F401
 from desi_mcmc_amd.util.infer.slicesample import ChainStreams, slicesample, slicesample_lockstep
-
-
-def scalar_slicesample(init_x, logprob, stream, chain, sigma=1.0, step_out=True, max_steps_out=1000, compwise=True,
-                       numdir=2, doubling_step=True):
-    """slicesample.py:114-228, one chain, uniforms taken from stream `chain` in the reference's order"""
-    one = np.array([chain])
-
-    def rand():
-        return stream.uniform(one)[0]
-
-    def randn():
-        return stream.normal(one)[0]
-
-    def direction_slice(direction, init_x):
-        def dir_logprob(z):
-            return logprob(direction * z + init_x)
-
-        def acceptable(z, llh_s, L, U):
-            while (U - L) > 1.1 * sigma:
-                middle = 0.5 * (L + U)
-                splits = (middle > 0 and z >= middle) or (middle <= 0 and z < middle)
-                if z < middle:
-                    U = middle
-                else:
-                    L = middle
-                if splits and llh_s >= dir_logprob(U) and llh_s >= dir_logprob(L):
-                    return False
-            return True
-        upper = sigma * rand()
-        lower = upper - sigma
-        llh_s = np.log(rand()) + dir_logprob(0.0)
-        l_steps_out = u_steps_out = 0
-        if step_out:
-            if doubling_step:
-                while (dir_logprob(lower) > llh_s or dir_logprob(upper) > llh_s) and (l_steps_out + u_steps_out) < max_steps_out:
-                    if rand() < 0.5:
-                        l_steps_out += 1
-                        lower -= (upper - lower)
-                    else:
-                        u_steps_out += 1
-                        upper += (upper - lower)
-            else:
-                while dir_logprob(lower) > llh_s and l_steps_out < max_steps_out:
-                    l_steps_out += 1
-                    lower -= sigma
-                while dir_logprob(upper) > llh_s and u_steps_out < max_steps_out:
-                    u_steps_out += 1
-                    upper += sigma
-        start_upper, start_lower = upper, lower
-        while True:
-            new_z = (upper - lower) * rand() + lower
-            new_llh = dir_logprob(new_z)
-            if new_llh > llh_s and acceptable(new_z, llh_s, start_lower, start_upper):
-                break
-            elif new_z < 0:
-                lower = new_z
-            elif new_z > 0:
-                upper = new_z
-            else:
-                raise Exception("Slice sampler shrank to zero!")
-        return new_z * direction + init_x, new_llh
-    dims = init_x.shape[0]
-    if compwise:
-        ordering = np.argsort([rand() for _ in range(dims)], kind="stable")
-        new_x = init_x.copy()
-        for d in ordering:
-            direction = np.zeros(dims)
-            direction[d] = 1.0
-            new_x, new_llh = direction_slice(direction, new_x)
-    else:
-        new_x = init_x
-        for d in range(numdir):
-            direction = np.array([randn() for _ in range(dims)])
-            direction = direction / np.sqrt(np.sum(direction ** 2))
-            new_x, new_llh = direction_slice(direction, new_x)
-    return new_x, new_llh
+from oracle.slicesample_oracle import scalar_slicesample
 
 
 def _targets():
