@@ -54,7 +54,7 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-def allreduce_loglik(ll_band, device=None, deterministic=False):
+def allreduce_loglik(ll_band, device=None, deterministic=False, force=False):
     """Sum per-band log-likelihoods over ranks.  ll_band: (B,) float64 numpy -> (B,) numpy.
 
     deterministic=False: one all-reduce (sum) of B doubles -- the collective north_star names.
@@ -62,7 +62,7 @@ def allreduce_loglik(ll_band, device=None, deterministic=False):
                          any topology."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return np.asarray(ll_band, dtype=np.float64).copy()
     t = torch.from_numpy(np.ascontiguousarray(ll_band, dtype=np.float64).copy())
     if dist.get_backend() == "nccl":
@@ -87,11 +87,12 @@ class LoglikReducer(object):
     against a 1.9 ms step) to every step.  Buffers are allocated once: a ring of `depth` device
     tensors and pinned host mirrors."""
 
-    def __init__(self, B, device=None, depth=2):
+    def __init__(self, B, device=None, depth=2, force=False):
         import torch
         import torch.distributed as dist
         self.B, self.depth = int(B), int(depth)
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # force: run the collective even in a one-rank group (a rehearsal of the RCCL path on one GPU)
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
         self.pending = []          # (slot, work handle)
         self.slot = 0
         self.gpu = self.active and dist.get_backend() == "nccl"

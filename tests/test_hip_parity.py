@@ -1252,3 +1252,40 @@ def test_bench_line_contract_on_the_small_star_workload():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["one_thread"]["cores"] == 1
     assert "reference_semantics_fullframe" in cb
+
+
+def test_rccl_collective_path_in_a_one_rank_group():
+    """No multi-GPU box is available to these tests; this at least runs the RCCL code path itself --
+    process-group init with backend nccl (= RCCL on ROCm), the B-double all-reduce on device tensors,
+    the all-gather variant and the pipelined reducer bench.py uses -- in a one-rank group on the GPU."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import os, sys
+sys.path.insert(0, %r)
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517",
+                  HSA_ENABLE_IPC_MODE_LEGACY="0")
+import numpy as np, torch, torch.distributed as td
+from desi_mcmc_amd import dist
+torch.cuda.set_device(0)
+td.init_process_group(backend="nccl", rank=0, world_size=1)
+x = np.array([1.5, -2.0, 3.25, 4.0, 1e9])
+assert np.array_equal(dist.allreduce_loglik(x, device=0, force=True), x)
+assert np.array_equal(dist.allreduce_loglik(x, device=0, deterministic=True, force=True), x)
+red = dist.LoglikReducer(5, device=0, depth=2, force=True)
+assert red.active and red.gpu
+got = []
+for k in range(4):
+    red.submit(x * (k + 1))
+    if len(red.pending) > 1:
+        got.append(red.result())
+got += red.drain()
+assert len(got) == 4 and all(np.array_equal(g, x * (k + 1)) for k, g in enumerate(got))
+td.barrier()
+td.destroy_process_group()
+print("rccl one-rank ok")
+''' % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
