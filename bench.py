@@ -544,8 +544,8 @@ def run_gibbs(args, env):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="mixed10k_2048")
     ap.add_argument("--kernel", default="recurrence", choices=["direct", "recurrence"])
     ap.add_argument("--tail-log", type=float, default=32.0)

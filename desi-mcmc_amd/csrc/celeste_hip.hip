@@ -87,9 +87,12 @@ static int fail(int code, const char *fmt, ...) {
 // host side
 // ------------------------------------------------------------------------------------------
 struct Prof {
-    hipEvent_t *ev = nullptr;   // pairs
-    int cap = 0, used = 0;
-    std::vector<int> kid;
+    // a ring of event pairs, created once when profiling is switched on: nothing is allocated inside
+    // a timed loop, and finished pairs are read back a few at a time as new ones are handed out
+    static const int PAIRS = 1024;
+    hipEvent_t *ev = nullptr;   // 2 * PAIRS events; pair i = ev[2i], ev[2i+1]
+    int kid[PAIRS];
+    int head = 0, count = 0;    // next pair to hand out; pairs handed out and not yet read
     double sum_ms[CEL_K_COUNT] = {0};
     int64_t n[CEL_K_COUNT] = {0};
 };
@@ -193,22 +196,44 @@ struct cel_sources {
     double *d_radec = nullptr, *d_counts = nullptr, *d_shape = nullptr;
 };
 
-static int prof_begin(cel_ctx *c, int k) {
+static bool prof_alloc(Prof &p) {
+    if (p.ev) return true;
+    p.ev = (hipEvent_t *)calloc(2 * Prof::PAIRS, sizeof(hipEvent_t));
+    if (!p.ev) return false;
+    for (int i = 0; i < 2 * Prof::PAIRS; i++)
+        if (hipEventCreate(&p.ev[i]) != hipSuccess) return false;
+    return true;
+}
+// read the oldest outstanding pair; `wait`: block until it has completed
+static bool prof_harvest_one(Prof &p, bool wait) {
+    if (p.count == 0) return false;
+    const int t = (p.head - p.count + Prof::PAIRS) % Prof::PAIRS;
+    if (wait) (void)hipEventSynchronize(p.ev[2 * t + 1]);
+    else if (hipEventQuery(p.ev[2 * t + 1]) != hipSuccess) return false;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.ev[2 * t], p.ev[2 * t + 1]) == hipSuccess) {
+        p.sum_ms[p.kid[t]] += ms;
+        p.n[p.kid[t]] += 1;
+    }
+    p.count--;
+    return true;
+}
+// reserve a pair for kernel k; returns the index of its first event, -1 when profiling is off
+static int prof_slot(cel_ctx *c, int k) {
     if (!c->profile) return -1;
     Prof &p = c->prof;
-    if (p.used + 2 > p.cap) {
-        int ncap = p.cap ? p.cap * 2 : 256;
-        hipEvent_t *ne = (hipEvent_t *)realloc(p.ev, sizeof(hipEvent_t) * ncap);
-        if (!ne) return -1;
-        p.ev = ne;
-        for (int i = p.cap; i < ncap; i++)
-            if (hipEventCreate(&p.ev[i]) != hipSuccess) return -1;
-        p.cap = ncap;
-    }
-    int i = p.used;
-    p.used += 2;
-    p.kid.push_back(k);
-    (void)hipEventRecord(p.ev[i], c->stream);
+    if (!prof_alloc(p)) return -1;
+    if (p.count == Prof::PAIRS) prof_harvest_one(p, true);
+    else if (p.count > Prof::PAIRS / 2) { if (prof_harvest_one(p, false)) prof_harvest_one(p, false); }
+    const int t = p.head;
+    p.head = (p.head + 1) % Prof::PAIRS;
+    p.count++;
+    p.kid[t] = k;
+    return 2 * t;
+}
+static int prof_begin(cel_ctx *c, int k) {
+    const int i = prof_slot(c, k);
+    if (i >= 0) (void)hipEventRecord(c->prof.ev[i], c->stream);
     return i;
 }
 static void prof_end(cel_ctx *c, int i) {
@@ -218,23 +243,6 @@ static void prof_end(cel_ctx *c, int i) {
 // pair is reserved here and handed to hipExtLaunchKernelGGL, which stamps it from the dispatch's own
 // start / completion signals.  A hipEventRecord between two kernels opens a ~10 us bubble in the
 // queue (rocprofv3 kernel trace): four of them per 1.6 ms step were 2 % of what was being measured.
-static int prof_slot(cel_ctx *c, int k) {
-    if (!c->profile) return -1;
-    Prof &p = c->prof;
-    if (p.used + 2 > p.cap) {
-        int ncap = p.cap ? p.cap * 2 : 256;
-        hipEvent_t *ne = (hipEvent_t *)realloc(p.ev, sizeof(hipEvent_t) * ncap);
-        if (!ne) return -1;
-        p.ev = ne;
-        for (int i = p.cap; i < ncap; i++)
-            if (hipEventCreate(&p.ev[i]) != hipSuccess) return -1;
-        p.cap = ncap;
-    }
-    int i = p.used;
-    p.used += 2;
-    p.kid.push_back(k);
-    return i;
-}
 #define EV0(c, i) ((i) >= 0 ? (c)->prof.ev[(i)] : (hipEvent_t) nullptr)
 #define EV1(c, i) ((i) >= 0 ? (c)->prof.ev[(i) + 1] : (hipEvent_t) nullptr)
 // launch with optional start / stop events attached to the dispatch
@@ -244,18 +252,8 @@ static int prof_slot(cel_ctx *c, int k) {
         if (e0_ || e1_) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, e0_, e1_, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                            \
     } while (0)
-static void prof_collect(cel_ctx *c) {
-    Prof &p = c->prof;
-    for (int i = 0; i < p.used; i += 2) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]) == hipSuccess) {
-            int k = p.kid[i / 2];
-            p.sum_ms[k] += ms;
-            p.n[k] += 1;
-        }
-    }
-    p.used = 0;
-    p.kid.clear();
+static void prof_collect(cel_ctx *c) {   // after a stream synchronise: everything outstanding has completed
+    while (prof_harvest_one(c->prof, true)) {}
 }
 
 static double host_bounding_radius(const double *mu, const double *cov, int K, double error,
@@ -365,7 +363,9 @@ int cel_ctx_destroy(cel_ctx *c) {
     if (!c) return CEL_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (int i = 0; i < c->prof.cap; i++) (void)hipEventDestroy(c->prof.ev[i]);
+    if (c->prof.ev)
+        for (int i = 0; i < 2 * Prof::PAIRS; i++)
+            if (c->prof.ev[i]) (void)hipEventDestroy(c->prof.ev[i]);
     free(c->prof.ev);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (void *p : c->scratch)
@@ -406,6 +406,7 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         c->tail_T = v;
         return CEL_OK;
     case CEL_OPT_PROFILE:
+        if (v != 0.0 && !prof_alloc(c->prof)) return fail(CEL_ERR_HIP, "CEL_OPT_PROFILE: cannot create the timing events");
         c->profile = (v != 0.0);
         return CEL_OK;
     case CEL_OPT_TILE_ORDER:
@@ -424,7 +425,7 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         c->tile_layout = (int)v;
         return CEL_OK;
     case CEL_OPT_DEBUG:
-        if (!(v >= 0.0) || v > 255.0) return fail(CEL_ERR_INVALID, "CEL_OPT_DEBUG must be in [0, 255]");
+        if (!(v >= 0.0) || v > 4095.0) return fail(CEL_ERR_INVALID, "CEL_OPT_DEBUG must be in [0, 4095]");
         c->debug = (int)v;
         return CEL_OK;
     }
@@ -1586,8 +1587,8 @@ int cel_bounding_radius(const double *w, const double *mu, const double *cov, in
 int cel_profile_reset(cel_ctx *c) {
     if (!c) return fail(CEL_ERR_INVALID, "null context");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->prof.used = 0;
-    c->prof.kid.clear();
+    c->prof.head = 0;
+    c->prof.count = 0;
     for (int k = 0; k < CEL_K_COUNT; k++) { c->prof.sum_ms[k] = 0.0; c->prof.n[k] = 0; }
     return CEL_OK;
 }

@@ -88,8 +88,9 @@ __device__ __forceinline__ int hw_build(CompTab &T, const LaneConst &lc, const R
     direct = (__ballot(far) != 0ull);
     __syncthreads();   // the previous table's reads are done
     if (lane < 4) { T.gL[lane] = 4096; T.gr0[lane] = HW_TH; T.gr1[lane] = 0; }
+    const int slot = slot_by_rows(keep, rlo, rhi);
     if (keep) {
-        int p = __popcll(km & ((1ull << lane) - 1ull));
+        const int p = slot;
         T.A[p] = c.A; T.mx[p] = c.mx; T.my[p] = c.my;
         T.qa[p] = c.qa * EXP_SCALE; T.qb[p] = c.qb * EXP_SCALE; T.qc[p] = c.qc * EXP_SCALE;
         T.eq[p] = exp(-c.qc);
