@@ -85,8 +85,9 @@ __device__ inline void rec_group_hw(const CompTab &T, const double *__restrict__
 // component-rows at config 3, k_render_hw -10 %.  (An exact rank by counting over the kept lanes
 // groups no better and costs 3 VALU + a scalar loop trip per component: 1.36 against 1.32 ms; 16
 // classes of four rows 1.34.)  Depends on the data only; all 64 lanes call it.
+template <int SHIFT = 3>   // 8 << SHIFT = rows of the tile
 __device__ __forceinline__ int slot_by_rows(bool keep, int rlo, int rhi) {
-    const int cls = keep ? 7 - min((rhi - rlo - 1) >> 3, 7) : 8;
+    const int cls = keep ? 7 - min((rhi - rlo - 1) >> SHIFT, 7) : 8;
     int slot = 0, base = 0;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
@@ -529,6 +530,7 @@ k_render_hw(RenderArgs a) {
         // work counters of this tile (diagnostic): sources | pairs of groups << 12 | kept component-rows << 32
         a.timing[3 * (size_t)blockIdx.x + 2] = (unsigned long long)(unsigned)cnt | ((unsigned long long)dbg_pairs << 12) |
                                                ((unsigned long long)(dbg_comprows + dbg_halfrows) << 32);
-        if ((a.flags >> 8) & 128) a.timing[3 * (size_t)blockIdx.x + 2] = (unsigned long long)dbg_pairrows | ((unsigned long long)(unsigned)(dbg_area / 32.f) << 32);
+        if ((a.flags >> 8) & 128)   // diagnostic (tools/row_waste.py): what the kept components need one by one
+            a.timing[3 * (size_t)blockIdx.x + 2] = (unsigned long long)dbg_pairrows | ((unsigned long long)(unsigned)(dbg_area / 32.f) << 32);
     }
 }

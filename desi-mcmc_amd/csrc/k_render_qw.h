@@ -130,8 +130,9 @@ k_render_qw(RenderArgs a) {
         const int Kk = __popcll(km);
         __syncthreads();   // previous source's table reads are done
         if (lane < 4) { T.gL[lane] = 4096; T.gr0[lane] = QW_TH; T.gr1[lane] = 0; }
+        const int slot = slot_by_rows<4>(keep, rlo, rhi);
         if (keep) {
-            int p = __popcll(km & ((1ull << lane) - 1ull));
+            const int p = slot;
             T.A[p] = c.A; T.mx[p] = c.mx; T.my[p] = c.my;
             T.qa[p] = c.qa * EXP_SCALE; T.qb[p] = c.qb * EXP_SCALE; T.qc[p] = c.qc * EXP_SCALE;
             T.eq[p] = exp_tab64(-c.qc * EXP_SCALE, et);

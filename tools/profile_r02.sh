@@ -13,9 +13,9 @@ stats() {   # tag, bench args
   cp "$f" $root/gpurun_out/r02_${tag}_kernel_stats.csv
   echo "== $tag"; head -12 $root/gpurun_out/r02_${tag}_kernel_stats.csv
 }
-stats final --steps 20 --warmup 3 --cpu-sample 0 --legs none
-stats stars --workload stars10k_2048 --steps 20 --warmup 3 --cpu-sample 0 --legs none
-stats stars1k --workload stars1k_512 --steps 50 --warmup 3 --cpu-sample 0 --legs none
+stats final --steps 200 --warmup 30 --cpu-sample 0 --legs none
+stats stars --workload stars10k_2048 --steps 200 --warmup 30 --cpu-sample 0 --legs none
+stats stars1k --workload stars1k_512 --steps 200 --warmup 30 --cpu-sample 0 --legs none
 stats gibbs --workload gibbs10k --steps 5 --warmup 2
 cd $root
 PMC_PROG="bench.py --steps 3 --warmup 1 --cpu-sample 0 --legs none" tools/pmc_pass.sh r02_final "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE" > gpurun_out/r02_final_pmc.txt 2>&1
