@@ -1146,7 +1146,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     int *d_ids = (int *)p; p += 4 * S;
     int *d_work = (int *)p; p += 4 * S * B;
     int *d_jobs = (int *)p; p += 4 * S * B;
-    int *d_flags = (int *)p;            // [0] chains still running, [1] error bits, [2] likelihood evaluations so far
+    int *d_flags = (int *)p;            // [0] chains still running, [1] error bits, [2] likelihood evaluations so far, [3] rounds with work
     // the proposal set: this catalogue with the locations rewritten every round
     HIP_TRY(hipMemcpyAsync(prop->d_type, src->d_type, sizeof(int) * S, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(prop->d_counts, src->d_counts, sizeof(double) * B * S, hipMemcpyDeviceToDevice, st));
@@ -1156,42 +1156,48 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         HIP_TRY(hipMemcpyAsync(d_ids, chain_ids, sizeof(int) * S, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(int) * 3, st));
+    HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(int) * 4, st));
     const unsigned g256 = (unsigned)((S + 255) / 256);
     hipLaunchKernelGGL(k_slice_init, dim3(g256), dim3(256), 0, st, ss, S, src->d_radec, chain_ids ? d_ids : (const int *)nullptr,
                        im->d_soff, B, (unsigned long long)seed, sigma, d_owner);
     // the (chain, band) jobs of a round, heaviest first (the photon rectangles are fixed for the call)
     hipLaunchKernelGGL(k_job_work, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, src->d_type, im->d_snz, S, B, d_work);
     hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, d_work, (int)(S * B), d_jobs);
-    int64_t rounds = 0, evals = 0;
+    int64_t rounds = 0, evals = 0, queued = 0;
     int *h_flags = reinterpret_cast<int *>(c->pinned + MAX_BANDS + 2);
     int rc = CEL_OK;
-    // how many chains start: those with a patch
-    hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags);
+    // The chains advance on the device alone (propose -> records -> likelihoods -> consume), so rounds
+    // are queued SLICE_BATCH at a time and the flags read once per batch: the queue does not drain
+    // while the host takes its turn.  A round queued after the last chain has finished scores nothing
+    // (every job retires at its first instruction) and is not counted.
+    const int SLICE_BATCH = 4;
     for (;;) {
-        prop->gen = ++g_source_gen;
-        if ((rc = run_prep(im, prop))) return rc;
-        int pi = prof_begin(c, CEL_K_STAMPS);
-        if (c->variant == 0)
-            hipLaunchKernelGGL(k_patch_ll, dim3((unsigned)(S * B)), dim3(256), 0, st, im->d_bands, B, S, im->d_recs,
-                               d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, 0, d_ll);
-        else
-            hipLaunchKernelGGL(k_patch_ll_hw<0>, dim3((unsigned)(S * B)), dim3(64), 0, st, im->d_bands, B, S, im->d_recs,
-                               d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll,
-                               (const int *)d_jobs);
-        prof_end(c, pi);
-        hipLaunchKernelGGL(k_slice_consume, dim3(g256), dim3(256), 0, st, ss, S, B, d_ll, sigma, d_flags, d_flags + 1);
-        HIP_TRY(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
+        const int nb = (int)std::min<int64_t>(SLICE_BATCH, (int64_t)max_rounds - queued);
+        for (int k = 0; k < nb; k++) {
+            hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags, queued == 0 ? 1 : 0);
+            prop->gen = ++g_source_gen;
+            if ((rc = run_prep(im, prop))) return rc;
+            int pi = prof_slot(c, CEL_K_STAMPS);
+            if (c->variant == 0)
+                LAUNCH_EV(k_patch_ll, dim3((unsigned)(S * B)), dim3(256), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
+                          d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, 0, d_ll);
+            else
+                LAUNCH_EV(k_patch_ll_hw<0>, dim3((unsigned)(S * B)), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
+                          d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll,
+                          (const int *)d_jobs);
+            hipLaunchKernelGGL(k_slice_consume, dim3(g256), dim3(256), 0, st, ss, S, B, d_ll, sigma, d_flags, d_flags + 1);
+            queued++;
+        }
+        HIP_TRY(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
-        rounds++;
         const int running = h_flags[0], err = h_flags[1];
         if (err & 1) return fail(CEL_ERR_INVALID, "Slice sampler got a NaN");
         if (err & 2) return fail(CEL_ERR_INVALID, "Slice sampler shrank to zero!");
         evals = h_flags[2];
+        rounds = h_flags[3];
         if (running == 0) break;
-        if (rounds >= max_rounds) return fail(CEL_ERR_INVALID, "cel_slice_locations: %d rounds without every chain finishing", max_rounds);
-        hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags);
+        if (queued >= max_rounds) return fail(CEL_ERR_INVALID, "cel_slice_locations: %d rounds without every chain finishing", max_rounds);
     }
     // the new locations replace the catalogue's
     HIP_TRY(hipMemcpyAsync(src->d_radec, ss.x, sizeof(double) * 2 * S, hipMemcpyDeviceToDevice, st));

@@ -78,10 +78,16 @@ k_slice_init(SliceState st, int64_t S, const double *__restrict__ radec, const i
 
 // the point every unfinished chain needs next -> the proposal set's radec; owner[s] = -1 retires a chain
 __global__ void __launch_bounds__(256)
-k_slice_propose(SliceState st, int64_t S, double *__restrict__ prop_radec, int *__restrict__ owner, int *__restrict__ n_active) {
+k_slice_propose(SliceState st, int64_t S, double *__restrict__ prop_radec, int *__restrict__ owner, int *__restrict__ n_active,
+                int first) {
 #pragma clang fp contract(off)
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s == 0) *n_active = 0;
+    if (s == 0) {
+        // n_active[3] counts the rounds that had a chain to score: the host queues rounds in batches and
+        // reads the flags once per batch, so it cannot count them itself
+        if (first || *n_active > 0) n_active[3] += 1;
+        *n_active = 0;
+    }
     if (s >= S) return;
     const int ph = st.phase[s];
     if (ph == SL_FINAL) { owner[s] = -1; return; }
