@@ -1313,6 +1313,7 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         a.rate_img = im->d_rate; a.tail_T = c->tail_T; a.nz = fused_nz ? im->d_snz : nullptr;
         a.order = (hw && c->tile_order) ? im->d_order : nullptr;
         a.sums = fused_nz ? im->d_ssum : nullptr;
+        a.debug = c->debug;
         if (hw && (rc = scratch_get(c, 2, sizeof(double) * 2 * (size_t)T, (void **)&a.partials))) return rc;
         int pi = prof_begin(c, CEL_K_STAMPS);
         if (hw) hipLaunchKernelGGL(k_photon_split_hw, dim3(2 * T), dim3(64), 0, c->stream, a);

@@ -299,6 +299,7 @@ struct SplitArgs {
     double tail_T;              // k_photon_split_hw: drop threshold of the per-source tiles
     int4 *nz;                   // k_photon_split_hw: per patch, the rectangle holding its photons (min/max by atomics), or nullptr
     const int *order;           // k_photon_split_hw: tile launch order (heaviest first, from the totals render), or nullptr
+    int debug;                  // CEL_OPT_DEBUG bits (timing-only ablations; results are wrong when set)
     double *sums;               // k_photon_split_hw: photons per (source, band), index s*B + b, zeroed by the caller, or nullptr.
                                 // Integer-valued doubles: the atomic sums are exact, so their order does not matter
 };
@@ -412,6 +413,10 @@ k_photon_split_hw(SplitArgs a) {
     __shared__ double rate[SP_TH * HW_TW];
     __shared__ int left[SP_TH * HW_TW];
     __shared__ CompTab T;
+    // pixels of the current source whose draw needs the sampler proper: queued in the component table's
+    // LDS, which is dead between a source's walk and the next source's table (a barrier either side)
+    static_assert(sizeof(CompTab) >= sizeof(unsigned short) * SP_TH * HW_TW, "the draw queue lives in the component table");
+    unsigned short *queue = reinterpret_cast<unsigned short *>(&T);
     __shared__ double et[64], lt[128];
     const int lane = threadIdx.x;
     const int half = lane >> 5, col = lane & 31;
@@ -472,30 +477,65 @@ k_photon_split_hw(SplitArgs a) {
         const bool on = (xi >= xa) && (xi <= xb);
         bool direct;
         const int Kk = hw_build(T, lc, rec, lane, dropmode, a.tail_T, log_sky, Y0, xa, xb, ra, rb, direct);
-        hw_walk(T, et, Kk, x, Y0, ra, rb, on, direct, one, lane);
+        if (!(a.debug & 4)) hw_walk(T, et, Kk, x, Y0, ra, rb, on, direct, one, lane);
         __syncthreads();
-        int zlo = INT_MAX, zhi = -1;                  // rows of this lane's column that received photons
+        // Two passes over the source's pixels on this half-tile.  Most draws are decided by ONE
+        // uniform (U <= 1 - n p gives 0: a pixel in the source's tail); the few that are not would
+        // each hold their whole wave in the sampler's loops.  Pass 1 settles the easy pixels and
+        // queues the others (a ballot + prefix count per step); pass 2 runs the sampler on the queue,
+        // 64 pixels per trip.  A pixel's draw takes the same numbers of its Philox stream either way.
+        int zlo = INT_MAX, zhi = -1, xlo = INT_MAX, xhi = -1;   // where this lane's draws left photons
         double zsum = 0.0;
-        if (on) {
-            const int nx = rec.x1 - rec.x0;
-            double *patch = a.samp + poff + (int64_t)(Y0 - rec.y0) * nx + (xi - rec.x0);
-            for (int r = (ra - half + 1) >> 1; 2 * r + half < rb; r++) {
-                const int row = 2 * r + half;
-                const int li = r * 64 + lane;
+        const int nx = rec.x1 - rec.x0;
+        double *patch0 = a.samp + poff + (int64_t)(Y0 - rec.y0) * nx - rec.x0;   // + row * nx + x
+        int nq = 0;
+        for (int r = ra >> 1; 2 * r < rb; r++) {
+            const int row = 2 * r + half;
+            const int li = r * 64 + lane;
+            bool slow = false;
+            if (on && row >= ra && row < rb) {
                 const double F = one[li];
-                one[li] = 0.0;                        // the scratch tile is clean again for the next source
                 const int n = left[li];
                 const double tot = rate[li];
-                long long z = 0;
                 covered |= 1u << r;
-                if (n > 0) {
-                    Philox g = philox_init(a.seed, (unsigned long long)(key0 + (int64_t)(Y0 + row) * a.W + xi), (unsigned)s);
-                    z = binomial_draw((long long)n, F * fast_rcp(tot), g, et, lt);  // curr_prob / sum_probs (:147)
+                if (n > 0 && !(a.debug & 1)) {
+                    const double pr = F * fast_rcp(tot);                  // curr_prob / sum_probs (:147)
+                    if (pr > 0.0) {
+                        slow = true;
+                        if (pr <= 0.5) {                                  // binomial_draw's first test, on the same uniform
+                            Philox g = philox_init(a.seed, (unsigned long long)(key0 + (int64_t)(Y0 + row) * a.W + xi), (unsigned)s);
+                            slow = !(philox_double(g) <= 1.0 - (double)n * pr);
+                        }
+                    }
                 }
+                if (!slow) {
+                    one[li] = 0.0;                    // the scratch tile is clean again for the next source
+                    rate[li] = tot - F;               // sum_probs -= curr_prob (:152)
+                    patch0[(int64_t)row * nx + xi] = 0.0;
+                }
+            }
+            const unsigned long long sm = __ballot(slow);
+            if (slow) queue[nq + __builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0))] = (unsigned short)li;
+            nq += __popcll(sm);
+        }
+        __syncthreads();
+        for (int q0 = 0; q0 < nq; q0 += 64) {
+            if (q0 + lane < nq) {
+                const int li = queue[q0 + lane];
+                const int row = 2 * (li >> 6) + ((li >> 5) & 1), xq = X0 + (li & 31);
+                const double F = one[li];
+                one[li] = 0.0;
+                const int n = left[li];
+                const double tot = rate[li];
+                Philox g = philox_init(a.seed, (unsigned long long)(key0 + (int64_t)(Y0 + row) * a.W + xq), (unsigned)s);
+                const long long z = (a.debug & 2) ? 1 : binomial_draw((long long)n, F * fast_rcp(tot), g, et, lt);
                 left[li] = n - (int)z;
-                rate[li] = tot - F;                                       // sum_probs -= curr_prob (:152)
-                patch[(int64_t)row * nx] = (double)z;
-                if (z > 0) { zlo = min(zlo, row); zhi = max(zhi, row); zsum += (double)z; }
+                rate[li] = tot - F;
+                patch0[(int64_t)row * nx + xq] = (double)z;
+                if (z > 0) {
+                    zlo = min(zlo, row); zhi = max(zhi, row); xlo = min(xlo, xq); xhi = max(xhi, xq);
+                    zsum += (double)z;
+                }
             }
         }
         if (a.nz && __ballot(zhi >= 0)) {
@@ -503,7 +543,6 @@ k_photon_split_hw(SplitArgs a) {
             // wave reduction per (source, half-tile), four atomics by one lane.  (Tracking it in
             // scalar registers from a ballot per step needs a wave-uniform step loop and measured
             // slower: 10.7 against 10.4 ms; a separate pass over the 3.2 GB of patches costs 1.1 ms.)
-            int xlo = (zhi >= 0) ? xi : INT_MAX, xhi = (zhi >= 0) ? xi : -1;
             for (int o = 32; o > 0; o >>= 1) {
                 zlo = min(zlo, __shfl_xor(zlo, o)); zhi = max(zhi, __shfl_xor(zhi, o));
                 xlo = min(xlo, __shfl_xor(xlo, o)); xhi = max(xhi, __shfl_xor(xhi, o));
