@@ -112,6 +112,7 @@ class ModelGibbs(object):
         self.engine = engine
         self.sweeps = 0
         self.timing = dict(split=0.0, flux=0.0, location=0.0, rounds=0, evals=0)
+        self._pool = None               # one worker thread: device calls that run beside host-side draws
         self.noise_sums = None
         self.active = np.ones(self.S, dtype=bool)
 
@@ -180,15 +181,25 @@ class ModelGibbs(object):
         import time
         t0 = time.perf_counter()
         band_counts = np.zeros((self.S, 5))
-        psf_sums = np.zeros((self.S, 5))
         for f in self.fields:
-            mass = f.iset.stamp_mass(f.sset) * f.has_patch              # sum of the unit stamp on its own box
             for b in range(f.iset.B):
                 band_counts[:, f.band_index[b]] += f.sums[:, b]
-                psf_sums[:, f.band_index[b]] += mass[:, b] * (f.kappa[b] / f.calib[b])
         a_n = self.flux_a_0 + band_counts
-        b_n = self.flux_b_0 + psf_sums
-        new = self.rng.gamma(a_n, 1. / b_n)
+
+        def rates():        # the device's part (a ctypes call: runs beside the host's draws below)
+            psf_sums = np.zeros((self.S, 5))
+            for f in self.fields:
+                mass = f.iset.stamp_mass(f.sset) * f.has_patch          # sum of the unit stamp on its own box
+                for b in range(f.iset.B):
+                    psf_sums[:, f.band_index[b]] += mass[:, b] * (f.kappa[b] / f.calib[b])
+            return self.flux_b_0 + psf_sums
+
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1)
+        fut = self._pool.submit(rates)
+        g = self.rng.standard_gamma(a_n)            # Gamma(a_n, 1 / b_n) = standard_gamma(a_n) * (1 / b_n), the same draws
+        new = g * (1. / fut.result())
         self.fluxes = np.where(self.active[:, None], new, self.fluxes)
         self.timing["flux"] += time.perf_counter() - t0
         return self.fluxes
