@@ -156,6 +156,8 @@ struct cel_images {
     int *d_tile_cnt = nullptr, *d_tile_nstar = nullptr, *d_tile_work = nullptr, *d_order = nullptr;
     int *d_tile_cost = nullptr;   // measured duration of every tile in the last render (the next render's launch order)
     int64_t cost_S = -1;          // number of sources that render had (-1: nothing measured yet)
+    int64_t order_S = -1;         // d_order already holds the heaviest-first order of those costs (sorted behind that render's readback)
+    hipEvent_t ev_step = nullptr; // marks a step's readback copy: the host waits for it, not for the sort queued behind it
     int64_t *d_tile_off = nullptr;
     unsigned long long *d_cursor = nullptr;   // fine cursor, fine overflow, coarse cursor, coarse overflow
     int *d_lists = nullptr;
@@ -459,6 +461,7 @@ int cel_images_destroy(cel_images *im) {
         if (p) (void)hipFree(p);
     if (im->d_slice) (void)hipFree(im->d_slice);
     if (im->slice_prop) cel_sources_destroy(im->slice_prop);
+    if (im->ev_step) (void)hipEventDestroy(im->ev_step);
     delete im;
     return CEL_OK;
 }
@@ -754,12 +757,15 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         int pi = prof_slot(c, CEL_K_BIN);
         LAUNCH_EV(k_bin_coarse, dim3(NS), dim3(64 * COARSE_WAVES), st, EV0(c, pi), (hipEvent_t) nullptr, im->d_boxes, S, im->nsx, im->nsy,
                   im->d_sup_cnt, im->d_sup_off, im->d_cursor + 2, im->d_clist, im->clist_cap, (int *)(im->d_cursor + 3));
-        LAUNCH_EV(k_bin_fine_blk, dim3(NS), dim3(256), st, (hipEvent_t) nullptr, c->tile_order ? (hipEvent_t) nullptr : EV1(c, pi),
+        // the order by the previous render's measured durations was sorted behind that render's readback
+        // (below): nothing to do here then
+        const bool order_ready = (c->tile_order == 1 && im->order_S == S && im->cost_S == S);
+        LAUNCH_EV(k_bin_fine_blk, dim3(NS), dim3(256), st, (hipEvent_t) nullptr, (c->tile_order && !order_ready) ? (hipEvent_t) nullptr : EV1(c, pi),
                   im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
                   im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
                   im->d_tile_nstar, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
                   (int *)(im->d_cursor + 1));
-        if (c->tile_order)
+        if (c->tile_order && !order_ready)
             // heaviest first: by the durations the tiles had in the previous render when that was
             // of the same source count (an MCMC chain changes little from one evaluation to the
             // next), by the binning pass's estimate otherwise.  The order never changes results.
@@ -795,14 +801,26 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipGetLastError());
         im->last_S = S;
-        HIP_TRY(hipStreamSynchronize(st));
+        // An MCMC chain renders the same number of sources again: sort this render's tile durations into
+        // the next render's launch order NOW, behind the readback the host is waiting for, instead of
+        // in front of the next render (13 us + a launch gap per step).  The host waits for the copy only.
+        const bool post_order = (c->tile_order == 1 && a.cost != nullptr);
+        if (post_order) {
+            if (!im->ev_step) HIP_TRY(hipEventCreateWithFlags(&im->ev_step, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(im->ev_step, st));
+            hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const int *)im->d_tile_cost, T, im->d_order);
+            HIP_TRY(hipEventSynchronize(im->ev_step));
+        } else {
+            HIP_TRY(hipStreamSynchronize(st));
+        }
         unsigned long long cur[4];
         memcpy(cur, c->pinned + MAX_BANDS, sizeof(cur));
         const bool fine_ok = (cur[1] & 0xffffffffull) == 0 && (int64_t)cur[0] <= im->lists_cap;
         const bool coarse_ok = (cur[3] & 0xffffffffull) == 0 && (int64_t)cur[2] <= im->clist_cap;
         if (coarse_ok) im->last_entries = (double)cur[0];
-        if (fine_ok && coarse_ok) { im->cost_S = a.cost ? S : -1; break; }
+        if (fine_ok && coarse_ok) { im->cost_S = a.cost ? S : -1; im->order_S = post_order ? S : -1; break; }
         im->cost_S = -1;
+        im->order_S = -1;
         // rerun with room (a truncated coarse list also truncates the fine counts)
         if (!coarse_ok) rc = ensure_clist(im, (int64_t)cur[2] + (int64_t)cur[2] / 4 + 1024);
         if (!rc && !fine_ok) rc = ensure_lists(im, (int64_t)cur[0] + (int64_t)cur[0] / 4 + 1024);
