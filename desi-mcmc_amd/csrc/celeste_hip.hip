@@ -156,6 +156,7 @@ struct cel_images {
     int *d_tile_cnt = nullptr, *d_tile_nstar = nullptr, *d_tile_work = nullptr, *d_order = nullptr;
     int *d_tile_cost = nullptr;   // measured duration of every tile in the last render (the next render's launch order)
     int64_t cost_S = -1;          // number of sources that render had (-1: nothing measured yet)
+    bool bin_two_level = false;   // a super-tile once held more than BIN_CH candidates: coarse lists in global memory from then on
     int64_t order_S = -1;         // d_order already holds the heaviest-first order of those costs (sorted behind that render's readback)
     hipEvent_t ev_step = nullptr; // marks a step's readback copy: the host waits for it, not for the sort queued behind it
     int64_t *d_tile_off = nullptr;
@@ -755,16 +756,26 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         if (attempt > 0 || S * im->B == 0) HIP_TRY(hipMemsetAsync(im->d_cursor, 0, sizeof(unsigned long long) * 4, st));
         // one event pair over the binning kernels: start on the first, stop on the last
         int pi = prof_slot(c, CEL_K_BIN);
-        LAUNCH_EV(k_bin_coarse, dim3(NS), dim3(64 * COARSE_WAVES), st, EV0(c, pi), (hipEvent_t) nullptr, im->d_boxes, S, im->nsx, im->nsy,
-                  im->d_sup_cnt, im->d_sup_off, im->d_cursor + 2, im->d_clist, im->clist_cap, (int *)(im->d_cursor + 3));
+        // one binning kernel while no super-tile holds more than BIN_CH candidates; the two-level form after that
+        if (im->bin_two_level)
+            LAUNCH_EV(k_bin_coarse, dim3(NS), dim3(64 * COARSE_WAVES), st, EV0(c, pi), (hipEvent_t) nullptr, im->d_boxes, S, im->nsx, im->nsy,
+                      im->d_sup_cnt, im->d_sup_off, im->d_cursor + 2, im->d_clist, im->clist_cap, (int *)(im->d_cursor + 3));
         // the order by the previous render's measured durations was sorted behind that render's readback
         // (below): nothing to do here then
         const bool order_ready = (c->tile_order == 1 && im->order_S == S && im->cost_S == S);
-        LAUNCH_EV(k_bin_fine_blk, dim3(NS), dim3(256), st, (hipEvent_t) nullptr, (c->tile_order && !order_ready) ? (hipEvent_t) nullptr : EV1(c, pi),
-                  im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
-                  im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
-                  im->d_tile_nstar, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
-                  (int *)(im->d_cursor + 1));
+        const hipEvent_t bin_ev1 = (c->tile_order && !order_ready) ? (hipEvent_t) nullptr : EV1(c, pi);
+        if (im->bin_two_level)
+            LAUNCH_EV(k_bin_fine_blk<false>, dim3(NS), dim3(64 * FINE_WAVES), st, (hipEvent_t) nullptr, bin_ev1,
+                      im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
+                      im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
+                      im->d_tile_nstar, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
+                      (int *)(im->d_cursor + 1), (int *)(im->d_cursor + 3));
+        else
+            LAUNCH_EV(k_bin_fine_blk<true>, dim3(NS), dim3(64 * FINE_WAVES), st, EV0(c, pi), bin_ev1,
+                      im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
+                      im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
+                      im->d_tile_nstar, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
+                      (int *)(im->d_cursor + 1), (int *)(im->d_cursor + 3));
         if (c->tile_order && !order_ready)
             // heaviest first: by the durations the tiles had in the previous render when that was
             // of the same source count (an MCMC chain changes little from one evaluation to the
@@ -816,12 +827,14 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         unsigned long long cur[4];
         memcpy(cur, c->pinned + MAX_BANDS, sizeof(cur));
         const bool fine_ok = (cur[1] & 0xffffffffull) == 0 && (int64_t)cur[0] <= im->lists_cap;
+        const bool too_dense = (cur[3] & 2ull) != 0;        // a super-tile with more candidates than the one-kernel form stages
         const bool coarse_ok = (cur[3] & 0xffffffffull) == 0 && (int64_t)cur[2] <= im->clist_cap;
         if (coarse_ok) im->last_entries = (double)cur[0];
         if (fine_ok && coarse_ok) { im->cost_S = a.cost ? S : -1; im->order_S = post_order ? S : -1; break; }
         im->cost_S = -1;
         im->order_S = -1;
         // rerun with room (a truncated coarse list also truncates the fine counts)
+        if (too_dense) { im->bin_two_level = true; continue; }
         if (!coarse_ok) rc = ensure_clist(im, (int64_t)cur[2] + (int64_t)cur[2] / 4 + 1024);
         if (!rc && !fine_ok) rc = ensure_lists(im, (int64_t)cur[0] + (int64_t)cur[0] / 4 + 1024);
         if (rc) return rc;

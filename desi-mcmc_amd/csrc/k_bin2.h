@@ -74,24 +74,31 @@ k_bin_coarse(const int4 *__restrict__ boxes, int64_t S, int nsx, int nsy, int *_
     }
 }
 
-// Level 2: one 256-thread block per super-tile stages the super-tile's candidates
-// (box, component count, source index) through LDS in chunks of BIN_CH and its four waves bin
-// them into the super-tile's render tiles (wave w takes tiles w, w+4, ...).  Pass 0 counts and
+// Level 2: one block per super-tile stages the super-tile's candidates
+// (box, component count, source index) through LDS in chunks of BIN_CH and its FINE_WAVES waves bin
+// them into the super-tile's render tiles (wave w takes tiles w, w + FINE_WAVES, ...).  Pass 0 counts and
 // reserves each tile's list segment, pass 1 fills it; with n <= BIN_CH (the usual case) the
 // candidates are read from global memory once; every box test reads LDS.
 #define BIN_CH 1024
-#define BIN_TPW 8      // max tiles per wave: (256/64) * (256/32) / 4
+#define FINE_WAVES 16  // waves per block: a block is latency-bound (one per CU), so its tiles are spread over many waves
+#define BIN_TPW 2      // max tiles per wave: (256/64) * (256/32) / FINE_WAVES
 
-__global__ void __launch_bounds__(256)
+// FUSED: the block finds its candidates itself -- its 16 waves scan the band's S boxes (each wave a
+// contiguous slice, so the compacted list stays ordered) straight into the LDS staging arrays -- and
+// k_bin_coarse, its list in global memory and a launch drop out of the step.  Possible while a
+// super-tile has at most BIN_CH candidates (265 at config 3); a block that finds more raises bit 1 of
+// the coarse overflow flag and the host goes back to the two-level form for these images.
+template <bool FUSED>
+__global__ void __launch_bounds__(64 * FINE_WAVES)
 k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int64_t S, int ntx, int nty, int TH,
                int TW, int nsx, int nsy, const int *__restrict__ sup_cnt, const int64_t *__restrict__ sup_off,
                const int *__restrict__ clist, int64_t ccap, int *__restrict__ tile_cnt, int *__restrict__ tile_nstar,
                int *__restrict__ tile_work, int64_t *__restrict__ tile_off, unsigned long long *cursor,
-               int *__restrict__ lists, int64_t capacity, int *overflow) {
+               int *__restrict__ lists, int64_t capacity, int *overflow, int *coarse_overflow) {
     __shared__ int4 sbox[BIN_CH];
     __shared__ int skind[BIN_CH];
     __shared__ int sid[BIN_CH];
-    __shared__ int stcnt[4 * BIN_TPW], stoff[4 * BIN_TPW];
+    __shared__ int stcnt[FINE_WAVES * BIN_TPW], stoff[FINE_WAVES * BIN_TPW];
     __shared__ long long sbase;
     const int st = blockIdx.x;
     const int per_band_s = nsx * nsy;
@@ -102,9 +109,62 @@ k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int
     const int tpx = SUPER_W / TW, tpy = SUPER_H / TH;          // tiles per super-tile in x / y (<= 32 in all)
     const int4 *bx = boxes + (int64_t)b * S;
     const int *kd = kind + (int64_t)b * S;
-    int n = sup_cnt[st];
-    const int64_t coff = sup_off[st];
-    if (coff + n > ccap) n = (int)((ccap > coff) ? (ccap - coff) : 0);   // truncated coarse list (overflow is flagged)
+    int n = 0;
+    int64_t coff = 0;
+    if (FUSED) {
+        __shared__ int wcnt[FINE_WAVES];
+        const int SX0 = sx * SUPER_W, SX1 = SX0 + SUPER_W, SY0 = sy * SUPER_H, SY1 = SY0 + SUPER_H;
+        const int64_t per = ((S + 64 * FINE_WAVES - 1) / (64 * FINE_WAVES)) * 64;
+        const int64_t lo = per * wave, hi = (lo + per < S) ? lo + per : S;
+        // both scans issue SCAN_U box loads per lane before the first is used: the boxes come from L2 and a
+        // block is alone on its CU, so a load per trip would be a latency per trip
+        constexpr int SCAN_U = 8;
+        int count = 0;
+        for (int64_t s0 = lo; s0 < hi; s0 += 64 * SCAN_U) {
+            int4 q[SCAN_U];
+#pragma unroll
+            for (int u = 0; u < SCAN_U; u++) {
+                const int64_t s = s0 + 64 * u + lane;
+                q[u] = (s < hi) ? bx[s] : make_int4(0, 0, 0, 0);          // an empty box hits nothing
+            }
+#pragma unroll
+            for (int u = 0; u < SCAN_U; u++) count += __popcll(__ballot(box_hits(q[u], SX0, SX1, SY0, SY1)));
+        }
+        if (lane == 0) wcnt[wave] = count;
+        __syncthreads();
+        int at0 = 0;
+        for (int w = 0; w < FINE_WAVES; w++) { if (w < wave) at0 += wcnt[w]; n += wcnt[w]; }
+        if (n > BIN_CH) {                       // wave-uniform and block-uniform
+            if (threadIdx.x == 0) atomicOr(coarse_overflow, 2);
+            n = 0;                              // this attempt's lists of the super-tile stay empty; the host reruns
+        } else if (count > 0) {
+            int run = 0;
+            for (int64_t s0 = lo; s0 < hi; s0 += 64 * SCAN_U) {
+                int4 q[SCAN_U];
+#pragma unroll
+                for (int u = 0; u < SCAN_U; u++) {
+                    const int64_t s = s0 + 64 * u + lane;
+                    q[u] = (s < hi) ? bx[s] : make_int4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < SCAN_U; u++) {
+                    const int64_t s = s0 + 64 * u + lane;
+                    const bool hit = box_hits(q[u], SX0, SX1, SY0, SY1);
+                    const unsigned long long mk = __ballot(hit);
+                    if (hit) {
+                        const int at = at0 + run + __popcll(mk & ((1ull << lane) - 1ull));
+                        sid[at] = (int)s; sbox[at] = q[u]; skind[at] = kd[s];
+                    }
+                    run += __popcll(mk);
+                }
+            }
+        }
+        __syncthreads();
+    } else {
+        n = sup_cnt[st];
+        coff = sup_off[st];
+        if (coff + n > ccap) n = (int)((ccap > coff) ? (ccap - coff) : 0);   // truncated coarse list (overflow is flagged)
+    }
     int cnt[BIN_TPW], nst[BIN_TPW], work[BIN_TPW], run[BIN_TPW], rung[BIN_TPW];
     long long base[BIN_TPW];
 #pragma unroll
@@ -113,9 +173,9 @@ k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int
     for (int pass = 0; pass < 2; pass++) {
         for (int c0 = 0; c0 < n || (c0 == 0 && n == 0 && pass == 0); c0 += BIN_CH) {
             const int m = min(BIN_CH, n - c0);
-            if (pass == 0 || n > BIN_CH) {
+            if (!FUSED && (pass == 0 || n > BIN_CH)) {
                 __syncthreads();
-                for (int i = threadIdx.x; i < m; i += 256) {
+                for (int i = threadIdx.x; i < m; i += 64 * FINE_WAVES) {
                     int s = clist[coff + c0 + i];
                     sid[i] = s;
                     sbox[i] = bx[s];
@@ -125,7 +185,7 @@ k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int
             }
 #pragma unroll
             for (int j = 0; j < BIN_TPW; j++) {
-                const int tl = wave + 4 * j;                   // local tile index
+                const int tl = wave + FINE_WAVES * j;          // local tile index
                 if (tl >= tpx * tpy) continue;
                 const int tx = sx * tpx + (tl % tpx), ty = sy * tpy + (tl / tpx);
                 if (tx >= ntx || ty >= nty) continue;
@@ -162,19 +222,19 @@ k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int
             // consecutive segments by an LDS prefix sum
 #pragma unroll
             for (int j = 0; j < BIN_TPW; j++) {
-                const int tl = wave + 4 * j;
-                if (lane == 0 && tl < 4 * BIN_TPW) stcnt[tl] = (tl < tpx * tpy) ? cnt[j] : 0;
+                const int tl = wave + FINE_WAVES * j;
+                if (lane == 0 && tl < FINE_WAVES * BIN_TPW) stcnt[tl] = (tl < tpx * tpy) ? cnt[j] : 0;
             }
             __syncthreads();
             if (threadIdx.x == 0) {
                 int tot = 0;
-                for (int k = 0; k < 4 * BIN_TPW; k++) { int c = stcnt[k]; stoff[k] = tot; tot += c; }
+                for (int k = 0; k < FINE_WAVES * BIN_TPW; k++) { int c = stcnt[k]; stoff[k] = tot; tot += c; }
                 sbase = (long long)atomicAdd(cursor, (unsigned long long)tot);
             }
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < BIN_TPW; j++) {
-                const int tl = wave + 4 * j;
+                const int tl = wave + FINE_WAVES * j;
                 if (tl >= tpx * tpy) continue;
                 base[j] = sbase + stoff[tl];
                 const int tx = sx * tpx + (tl % tpx), ty = sy * tpy + (tl / tpx);
