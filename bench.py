@@ -408,16 +408,27 @@ def run_fields(args, env):
     K = args.n_fields
     base = "mixed10k_2048"
     mine = dist.field_shard(K, world, rank)
-    fields = [synth.SyntheticField.from_config(ctx, base, seed=42 + 1000 * k) for k in mine]
+    # The fields of a rank are independent: with --streams n they are dealt to n contexts (one HIP stream each),
+    # every context driven by its own host thread, so that one field's binning, launch gaps and ragged last
+    # round of tiles run under another field's render (measured: 11.65 -> 11.26 ms for 8 fields with 2, slower
+    # with 3 or 4).  The per-field results are summed in field order either way.
+    from concurrent.futures import ThreadPoolExecutor
+    n_str = max(1, min(args.streams, len(mine)))
+    ctxs = [ctx] + [cel.Context(local) for _ in range(n_str - 1)]
+    fields = [synth.SyntheticField.from_config(ctxs[i % n_str], base, seed=42 + 1000 * k) for i, k in enumerate(mine)]
     B = synth.CONFIGS[base][1]
     reducer = dist.LoglikReducer(B, device=local, depth=2) if world > 1 else None
     last = {}
+    pool = ThreadPoolExecutor(max_workers=n_str) if n_str > 1 else None
+
+    def lane(j):        # the fields of context j, one after the other
+        return [f.images.render(f.sources, loglik=True)[1] for f in fields[j::n_str]]
 
     def step():
         llb = np.zeros(B)
-        for f in fields:
-            _, b = f.images.render(f.sources, loglik=True)
-            llb += b
+        per = [lane(0)] if pool is None else list(pool.map(lane, range(n_str)))
+        for i in range(len(fields)):
+            llb += per[i % n_str][i // n_str]
         if reducer is not None:
             reducer.submit(llb)
             if len(reducer.pending) > 1:
@@ -427,14 +438,20 @@ def run_fields(args, env):
     def after_warmup():
         if reducer is not None:
             reducer.drain()
-        ctx.profile(True)
+        for cx in ctxs:
+            cx.profile(True)
 
     def finish():
         if reducer is not None:
             last["llb"] = reducer.drain()[-1]
     dt = Timer(dist, torch).run(step, args.warmup, args.steps, after_warmup, finish)
-    t_render, n_render = ctx.profile_get("render")
-    ctx.profile(False)
+    tn = [cx.profile_get("render") for cx in ctxs]
+    n_render = sum(n for _, n in tn)
+    t_render = sum(t * n for t, n in tn) / max(n_render, 1)
+    for cx in ctxs:
+        cx.profile(False)
+    if pool is not None:
+        pool.shutdown()
     srcpix = sum(f.images.stats()["n_srcpix"] for f in fields)
     gauss = sum(f.images.stats()["n_gauss"] for f in fields)
     dt_max, (srcpix_all, gauss_all, nf_all) = reduce_over_ranks(torch, world, local, dt, [srcpix, gauss, len(fields)])
@@ -453,7 +470,9 @@ def run_fields(args, env):
                    "sources_per_field": S, "bands": B, "frame": [H, W], "galaxy_fraction": fg,
                    "note": "BASELINE configs[3] names the Stripe-82 catalogue, which is not in the reference tree "
                            "(.MISSING_LARGE_BLOBS); synthetic fields of the configs[2] population stand in for it",
-                   "parallelism": "fields dealt round-robin to %d GPU(s), 1 all-reduce of %d doubles per step" % (world, B),
+                   "parallelism": "fields dealt round-robin to %d GPU(s), 1 all-reduce of %d doubles per step; on a GPU "
+                                  "the fields run on %d streams (a context and a host thread each)" % (world, B, n_str),
+                   "streams_per_gpu": n_str,
                    "ranks": world, "collective_backend": env["backend"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": "k_render", "kernel_ms": t_render, "launches": n_render,
@@ -558,6 +577,9 @@ def main():
                     help="render workloads.  weak (default, what the driver runs): one field per GPU.  strong: ONE "
                          "field cut into row strips, one per GPU (cel_images_set_window), total work fixed")
     ap.add_argument("--n-fields", type=int, default=8, help="fields8_2048: number of fields dealt to the ranks")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="fields8_2048: contexts (HIP streams, a host thread each) per GPU the rank's fields run on; 2 is 3 %% faster, "
+                         "but the kernels' event times then include each other")
     ap.add_argument("--slice-sigma", type=float, default=0.001, help="gibbs10k: slice-sampler interval width in degrees")
     ap.add_argument("--legs", default="all", choices=["all", "none"],
                     help="render workloads at N=1: 'all' (default) adds the untimed-by-the-contract extras after the timed region "
