@@ -72,9 +72,12 @@ __device__ __forceinline__ int hw_build(CompTab &T, const LaneConst &lc, const R
         } else if (Tk == Tk && Tk < 1e30) {
             double qmin = quad_min_rect(c.qa, c.qb, c.qc, xad - c.mx, xbd - c.mx, yad - c.my, ybd - c.my);
             keep = (0.5 * qmin <= Tk);
-            float hw = __fsqrt_rn(2.0f * (float)fmax(Tk, 0.0) / (float)c.iyy) + 1.0f;
-            rlo = max(ra, (int)floorf(fmaxf((float)(c.my - (double)Y0) - hw, -1.0f)));
-            rhi = min(rb, (int)ceilf(fminf((float)(c.my - (double)Y0) + hw, 4096.0f)) + 1);
+            // rows on which the component can matter on THIS rectangle's columns
+            float ylo, yhi;
+            quad_rows_on_columns(c.qa, c.qb, c.qc, 2.0 * fmax(Tk, 0.0), xad - c.mx, xbd - c.mx, ylo, yhi);
+            const float cy = (float)(c.my - (double)Y0);
+            rlo = max(ra, (int)floorf(fmaxf(cy + ylo - 0.02f, -1.0f)));
+            rhi = min(rb, (int)ceilf(fminf(cy + yhi + 0.02f, 4096.0f)) + 1);
             keep = keep && (rhi > rlo);
             far = keep && (Tk > 300.0);
         } else {

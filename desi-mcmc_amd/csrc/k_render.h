@@ -157,6 +157,24 @@ __device__ inline double quad_min_rect(double a, double b, double c, double x1, 
     return best * 0.99999;
 }
 
+// Rows on which a x^2 + 2 b x y + c y^2 <= R for SOME x in [x1, x2] (all relative to the component's
+// centre): at fixed x the form's y-interval is (-b x -+ sqrt(c R - det x^2)) / c, det = a c - b^2; its
+// upper end is concave in x with its maximum at x = -b sqrt(R / (det a)), the lower end convex with its
+// minimum at +b sqrt(R / (det a)) -- on an interval, at those points clamped into it.  A tile on the
+// flank of a wide component needs fewer rows than the component's full height (config 3: 9 % fewer
+// component-rows).  fp32 reciprocal / square roots: the callers round outwards by more than their error.
+__device__ inline void quad_rows_on_columns(double a, double b, double c, double R, double x1, double x2,
+                                            float &ylo, float &yhi) {
+    const double det = a * c - b * b;
+    const double xs = b * (double)__fsqrt_rn((float)R * __frcp_rn((float)(det * a)));
+    const double xt = fmin(fmax(-xs, x1), x2), xb = fmin(fmax(xs, x1), x2);
+    const float rc = __frcp_rn((float)c);
+    const float st = __fsqrt_rn(fmaxf((float)(c * R - det * xt * xt), 0.0f));
+    const float sb = __fsqrt_rn(fmaxf((float)(c * R - det * xb * xb), 0.0f));
+    yhi = ((float)(-b * xt) + st) * rc;
+    ylo = ((float)(-b * xb) - sb) * rc;
+}
+
 // ---- exp() for the recurrence seeds -----------------------------------------------------------
 // exp(x) = 2^e * 2^(j/64) * exp(r), x = (64 e + j) ln2/64 + r, |r| <= ln2/128: a 64-entry table
 // of 2^(j/64) in LDS and a degree-5 polynomial (truncation r^6/720 < 4e-17), ~9 fp64 ops against

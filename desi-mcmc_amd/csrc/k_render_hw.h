@@ -434,9 +434,12 @@ k_render_hw(RenderArgs a) {
             if (dropping) {
                 double qmin = quad_min_rect(c.qa, c.qb, c.qc, xa - c.mx, xb - c.mx, ya - c.my, yb - c.my);
                 keep = (0.5 * qmin <= Tk);
-                float hw = __fsqrt_rn(2.0f * (float)fmax(Tk, 0.0) / (float)c.iyy) + 1.0f;
-                rlo = max(ra, (int)floorf((float)(c.my - (double)Y0) - hw));
-                rhi = min(rb, (int)ceilf((float)(c.my - (double)Y0) + hw) + 1);
+                // rows on which the component can matter on THIS tile's columns
+                float ylo, yhi;
+                quad_rows_on_columns(c.qa, c.qb, c.qc, 2.0 * fmax(Tk, 0.0), xa - c.mx, xb - c.mx, ylo, yhi);
+                const float cy = (float)(c.my - (double)Y0);
+                rlo = max(ra, (int)floorf(cy + ylo - 0.02f));
+                rhi = min(rb, (int)ceilf(cy + yhi + 0.02f) + 1);
                 keep = keep && (rhi > rlo);
             } else {
                 keep = true;
