@@ -122,7 +122,12 @@ class Timer(object):
     def __init__(self, dist, torch):
         self.dist, self.torch = dist, torch
 
-    def run(self, step, warmup, steps, after_warmup=None, finish=None):
+    def run(self, step, warmup, steps, after_warmup=None, finish=None, prime=0):
+        # set-up, before the W warm-up steps: `prime` untimed steps (the same number on every rank: a step may
+        # hold a collective), so that the GPU is at its running clocks whatever W is -- the first steps after
+        # start-up ran ~5 % slow (1.54 against 1.47 ms per step with W = 3)
+        for _ in range(prime):
+            step()
         for _ in range(warmup):
             step()
         if after_warmup:
@@ -246,7 +251,7 @@ def run_render(args, env):
     def finish():
         if reducer is not None:
             last["llb"] = reducer.drain()[-1]
-    dt = Timer(dist, torch).run(step, args.warmup, args.steps, after_warmup, finish)
+    dt = Timer(dist, torch).run(step, args.warmup, args.steps, after_warmup, finish, prime=100)
     t_render, n_render = ctx.profile_get("render")
     t_bin, _ = ctx.profile_get("bin")
     t_prep, _ = ctx.profile_get("prep")
@@ -444,7 +449,7 @@ def run_fields(args, env):
     def finish():
         if reducer is not None:
             last["llb"] = reducer.drain()[-1]
-    dt = Timer(dist, torch).run(step, args.warmup, args.steps, after_warmup, finish)
+    dt = Timer(dist, torch).run(step, args.warmup, args.steps, after_warmup, finish, prime=max(2, 100 // max(K // world, 1)))
     tn = [cx.profile_get("render") for cx in ctxs]
     n_render = sum(n for _, n in tn)
     t_render = sum(t * n for t, n in tn) / max(n_render, 1)
@@ -516,7 +521,7 @@ def run_gibbs(args, env):
         if reducer is not None:
             trace.append(float(reducer.drain()[-1][0]))
     ll0 = g.log_likelihood()
-    dt = Timer(dist, torch).run(step, args.warmup, args.steps, after_warmup, finish)
+    dt = Timer(dist, torch).run(step, args.warmup, args.steps, after_warmup, finish, prime=3)
     t_ll, n_ll = ctx.profile_get("stamps")          # cel_patch_loglik_multi + split + mass launches
     t_render, n_render = ctx.profile_get("render")
     ctx.profile(False)
