@@ -231,7 +231,8 @@ int cel_stamp_mass(cel_images *img, cel_sources *src, double *mass);
  * out, interval width sigma (degrees) -- run as a lock-step state machine on the device against the
  * resident photon split of exactly these sources (cel_photon_split with offsets = NULL): every round each
  * unfinished chain's next point is scored by the conditional-likelihood kernel (mode 0 of
- * cel_patch_loglik_multi, resident form) and the chains advance; one counter crosses PCIe per round.
+ * cel_patch_loglik_multi, resident form) and the chains advance; rounds are queued four at a time and
+ * four counters (chains running, error bits, evaluations, rounds that had work) cross PCIe per batch.
  * A source without any sample patch is left where it is.  Random numbers: one SplitMix64 stream per
  * chain keyed by (seed, chain_ids[s] or s), in the reference's draw order -- the same streams and
  * arithmetic as the host engine of the Python mirror (util/infer/slicesample.py), chain for chain.
