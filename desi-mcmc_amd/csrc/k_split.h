@@ -173,13 +173,16 @@ __device__ inline long long binom_btpe(long long n, double r, Philox &g) {
     return m;   // unreachable in practice (acceptance > 0.8 per trial); keeps the loop bounded
 }
 
+#ifndef BINV_MAX_NP
+#define BINV_MAX_NP 30.0
+#endif
 __device__ inline long long binomial_draw(long long n, double p, Philox &g, const double *__restrict__ et,
                                           const double *__restrict__ lt) {
     if (n <= 0 || !(p > 0.0)) return 0;
     if (p >= 1.0) return n;
     const bool flip = p > 0.5;
     const double r = flip ? 1.0 - p : p;
-    long long y = (r * (double)n <= 30.0) ? binom_inversion(n, r, g, et, lt) : binom_btpe(n, r, g);
+    long long y = (r * (double)n <= BINV_MAX_NP) ? binom_inversion(n, r, g, et, lt) : binom_btpe(n, r, g);
     return flip ? n - y : y;
 }
 
