@@ -33,12 +33,15 @@ k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int w
        const double *__restrict__ counts, const double *__restrict__ shape, double rsq_gal,
        SrcRec *__restrict__ recs, int4 *__restrict__ boxes, int *__restrict__ kind, int *__restrict__ status,
        unsigned long long *__restrict__ cursor /* the binning pass's 4 cursors / flags, zeroed here (a memset of
-                                                  its own cost 15 us of queue time per step), or nullptr */) {
+                                                  its own cost 15 us of queue time per step), or nullptr */,
+       const int *__restrict__ live /* [S] or nullptr: a source with live[s] < 0 is skipped (a retired slice chain:
+                                       nothing reads its records this round) */) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 4 && cursor) cursor[i] = 0ull;
     if (i >= S * B) return;
     int b = (int)(i / S);
     int64_t s = i - (int64_t)b * S;
+    if (live && live[s] < 0) return;
     const BandDev &bd = bands[b];
     SrcRec r;
     memset(&r, 0, sizeof(r));
