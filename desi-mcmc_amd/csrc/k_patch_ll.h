@@ -230,7 +230,12 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
                     if (on && 2 * (r0 + r) + half < rb) {
                         double v = counts * acc[(r0 + r) * 64 + lane];
                         if (MODE == 0) {
+#ifndef PLL_NO_ZSKIP
+                            // a pixel without photons adds 0 * log(v) = 0: skipped (a step of 64 such pixels skips the log)
+                            if (v > 0.0 && zz[r] != 0.0) a += log_tab(v, lt) * zz[r];
+#else
                             if (v > 0.0) a += log_tab(v, lt) * zz[r];
+#endif
                         } else if (MODE == 2) {
                             if (v > 0.0) { a += log_tab(v, lt) * zz[r]; m += v; }
                         } else {
