@@ -42,14 +42,15 @@ __device__ inline float wave_max_f(float v) {
 // All 64 lanes call this; it contains the two barriers that fence the table.
 __device__ __forceinline__ int hw_build(CompTab &T, const LaneConst &lc, const RecU &rec, int lane, int dropmode,
                                double Tdrop, double log_floor /* HW_DROP_SKY: log(eps) */, int Y0, int xa,
-                               int xb, int ra, int rb, bool &direct) {
+                               int xb, int ra, int rb, bool &direct,
+                               const Comp *pre = nullptr /* this lane's component, when the caller has it already */) {
     const int K = (rec.type == 0) ? K_PSF : K_GAL;
     const double xad = (double)xa, xbd = (double)xb;
     const double yad = (double)(Y0 + ra), ybd = (double)(Y0 + rb - 1);
     Comp c;
     float logA = -INFINITY;
     if (lane < K) {
-        c = make_comp_lc(lc, rec);
+        c = pre ? *pre : make_comp_lc(lc, rec);
         logA = __logf((float)fabs(c.A));
     }
     if (dropmode == HW_DROP_SELF) {

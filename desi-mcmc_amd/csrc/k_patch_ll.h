@@ -168,6 +168,9 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     const double lt_ic = c_log_ic[lane], lt_lc = c_log_lc[lane];      // this lane's two entries of the log table
     const LaneConst lc = lane_consts(lane, bd);
     const double eps = bd->eps;
+    // the job's components do not depend on the chunk: one per lane, kept for every chunk's table
+    Comp cj;
+    if (lane < ((rec.type == 0) ? K_PSF : K_GAL)) cj = make_comp_lc(lc, rec);
     if (MODE == 0) {
         // A proposal so far from the patch that every component's exponent stays below -750 on the
         // whole rectangle evaluates to exactly 0 there (exp underflows below -745.2): every pixel
@@ -175,7 +178,7 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
         // first shrink steps of a slice sampler started from a wide interval are of this kind.
         bool alive = false;
         if (lane < ((rec.type == 0) ? K_PSF : K_GAL)) {
-            const Comp c = make_comp_lc(lc, rec);
+            const Comp &c = cj;
             const double qmin = quad_min_rect(c.qa, c.qb, c.qc, (double)ev.x - c.mx, (double)(ev.y - 1) - c.mx,
                                               (double)ev.z - c.my, (double)(ev.w - 1) - c.my);
             alive = !(0.5 * qmin > 750.0);
@@ -203,7 +206,7 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
 #pragma unroll
             for (int r = 0; r < HW_TH / 2; r++) acc[r * 64 + lane] = 0.0;
             bool direct;
-            const int Kk = hw_build(T, lc, rec, lane, dropmode, Tdrop, log_floor, Y0, X0, min(ev.y, X0 + HW_TW) - 1, 0, rb, direct);
+            const int Kk = hw_build(T, lc, rec, lane, dropmode, Tdrop, log_floor, Y0, X0, min(ev.y, X0 + HW_TW) - 1, 0, rb, direct, &cj);
             hw_walk(T, et, Kk, (double)xi, Y0, 0, rb, on, direct, acc, lane);
             __syncthreads();
             if (MODE != 3) {
