@@ -1,10 +1,12 @@
-// k_bin2.h -- two-level tile binning: per-tile source lists, in source order
+// k_bin2.h -- tile binning: per-tile source lists, in source order
 //
-// Level 1 (k_bin_coarse): one 256-thread block per 256 x 256-pixel super-tile scans the band's S
-//   boxes and writes the ordered list of sources whose box touches the super-tile.
-// Level 2 (k_bin_fine_blk): one block per super-tile stages its candidates (a few hundred instead
-//   of S) in LDS and writes, for each of its 64 x TH render tiles, the ordered source list, its
-//   length and a work estimate for the heaviest-first launch order.
+// k_bin_fine_blk<true> (the usual form): one 16-wave block per 256 x 256-pixel super-tile scans the band's S
+//   boxes itself, keeps the ordered list of sources whose box touches the super-tile in LDS and writes,
+//   for each of its 32-column x TH-row render tiles, the ordered source list, its length and a work
+//   estimate for the heaviest-first launch order.
+// Two-level form (a super-tile with more than BIN_CH candidates; sticky per image set):
+//   k_bin_coarse writes the super-tile lists to global memory, k_bin_fine_blk<false> streams them through
+//   LDS in chunks of BIN_CH.
 // Both levels compact with ballot + prefix popcount, so every list is ordered: a render tile's list
 // holds its STARS first (ascending source index), then its galaxies (ascending source index) -- the
 // render kernel takes the stars of a tile through a batched 3-component path -- and the
