@@ -110,6 +110,19 @@ __device__ inline int rec_fetch(const SrcRec *__restrict__ recs, int s, int lane
     return reinterpret_cast<const int *>(recs + s)[lane & 31];
 }
 
+// 1/d and 1/sqrt(d) for the component tables: fp32 seed + two Newton steps (relative error ~1e-7 ->
+// 1e-14 -> rounding), a dozen independent-ish instructions against the ~35 of a correctly rounded
+// fp64 division followed by a correctly rounded square root, whose last bit nothing here needs.
+// d is a covariance determinant: positive, far inside fp32's range.
+__device__ inline void rcp_rsqrt(double d, double &inv, double &rsq) {
+    double y = (double)__frcp_rn((float)d);
+    y = fma(y, fma(-d, y, 1.0), y);
+    inv = fma(y, fma(-d, y, 1.0), y);
+    double z = (double)__frsqrt_rn((float)d);
+    z = z * fma(-0.5 * d * z, z, 1.5);
+    rsq = z * fma(-0.5 * d * z, z, 1.5);
+}
+
 __device__ inline Comp make_comp_lc(const LaneConst &lc, const RecU &r) {
     double cxx, cxy, cyy, wt, mux, muy;
     if (r.type == 1) {
@@ -120,10 +133,15 @@ __device__ inline Comp make_comp_lc(const LaneConst &lc, const RecU &r) {
         cxx = lc.s_cxx; cxy = lc.s_cxy; cyy = lc.s_cyy; wt = lc.s_w; mux = lc.s_mux; muy = lc.s_muy;
     }
     double det = cxx * cyy - cxy * cxy;
-    double inv = 1.0 / det;
+#ifdef COMP_IEEE_DIV
+    double inv = 1.0 / det, rsq = sqrt(inv);
+#else
+    double inv, rsq;
+    rcp_rsqrt(det, inv, rsq);
+#endif
     Comp c;
     c.qa = cyy * inv; c.qb = -cxy * inv; c.qc = cxx * inv;
-    c.A = r.scale * wt * (0.5 / PI_D) * sqrt(inv);
+    c.A = r.scale * wt * (0.5 / PI_D) * rsq;
     c.mx = r.px + mux;
     c.my = r.py + muy;
     c.ixx = (double)(__frcp_rn((float)cxx) * 0.999999f);
