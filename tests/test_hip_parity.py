@@ -1289,3 +1289,46 @@ print("rccl one-rank ok")
 ''' % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_patch_loglik_vs_oracle(cel, ctx, orc, seed):
+    """random sources, random patch rectangles around and beside them, SPARSE photon patches (most pixels hold
+    no photon, some rows and whole chunks none: the conditional form skips their logs and crops to the photon
+    rectangle): both forms of cel_patch_loglik against the oracle"""
+    from desi_mcmc_amd import synth
+    rs = np.random.RandomState(500 + seed)
+    H, W = 260, 330
+    B = 2
+    bands = synth.make_bands(H, W, B)
+    P = 6
+    pix = np.column_stack([rs.uniform(40, W - 40, P), rs.uniform(40, H - 40, P)])
+    typ = (rs.rand(P) < 0.6).astype(np.int32)
+    radec = synth.pixel2equa(bands[0], pix)
+    shape = np.column_stack([rs.uniform(0.05, 0.95, P), rs.uniform(0.5, 4.0, P), rs.uniform(0, 180, P), rs.uniform(0.2, 1.0, P)])
+    counts = 10.0 ** rs.uniform(2.5, 5.0, size=(P, B))
+    nelec = rs.poisson(150.0, size=(B, H, W)).astype(float)
+    iset = cel.ImageSet(ctx, bands, H, W, nelec=nelec)
+    sset = cel.SourceSet(ctx, P, B).set(typ, radec, counts, shape)
+    ob = bands.copy()
+    ob[:, 36] = [iset.band(b)[36] for b in range(B)]
+    for case in range(3):
+        # one rectangle per band, placed near a random source, of a random size (up to several chunks)
+        boxes = np.zeros((B, 4), dtype=np.int64)
+        data = []
+        for b in range(B):
+            c = pix[rs.randint(P)] + rs.uniform(-15, 15, 2)
+            hh, ww = rs.randint(3, 110), rs.randint(3, 90)
+            y0 = int(np.clip(c[1] - hh // 2, 0, H - hh)); x0 = int(np.clip(c[0] - ww // 2, 0, W - ww))
+            boxes[b] = [y0, y0 + hh, x0, x0 + ww]
+            z = rs.poisson(0.15 if case else 2.0, size=(hh, ww)).astype(float)
+            if case == 2:                       # photons in a few rows only
+                keep = np.zeros(hh, dtype=bool); keep[rs.randint(0, hh, size=max(1, hh // 8))] = True
+                z[~keep] = 0.0
+            data.append(z)
+        for isolated in (False, True):
+            got = iset.patch_loglik(sset, boxes, data, isolated=isolated)
+            for s in range(P):
+                want = sum(orc.patch_loglik(ob[b], H, W, typ[s], radec[s], shape[s], counts[s, b], boxes[b], data[b],
+                                            1 if isolated else 0) for b in range(B))
+                np.testing.assert_allclose(got[s], want, rtol=RT_LL, err_msg="seed %d case %d src %d iso %s" % (seed, case, s, isolated))
