@@ -43,7 +43,8 @@ __device__ inline float wave_max_f(float v) {
 __device__ __forceinline__ int hw_build(CompTab &T, const LaneConst &lc, const RecU &rec, int lane, int dropmode,
                                double Tdrop, double log_floor /* HW_DROP_SKY: log(eps) */, int Y0, int xa,
                                int xb, int ra, int rb, bool &direct,
-                               const Comp *pre = nullptr /* this lane's component, when the caller has it already */) {
+                               const Comp *pre = nullptr /* this lane's component, when the caller has it already */,
+                               const double *__restrict__ et = nullptr /* the 2^(j/64) table in LDS: exp(-qc) by table */) {
     const int K = (rec.type == 0) ? K_PSF : K_GAL;
     const double xad = (double)xa, xbd = (double)xb;
     const double yad = (double)(Y0 + ra), ybd = (double)(Y0 + rb - 1);
@@ -97,7 +98,7 @@ __device__ __forceinline__ int hw_build(CompTab &T, const LaneConst &lc, const R
         const int p = slot;
         T.A[p] = c.A; T.mx[p] = c.mx; T.my[p] = c.my;
         T.qa[p] = c.qa * EXP_SCALE; T.qb[p] = c.qb * EXP_SCALE; T.qc[p] = c.qc * EXP_SCALE;
-        T.eq[p] = exp(-c.qc);
+        T.eq[p] = et ? exp_tab64(-c.qc * EXP_SCALE, et) : exp(-c.qc);
         T.L[p] = Lk;
         T.r0[p] = rlo; T.r1[p] = rhi;
         const int gi = p / (2 * REC_G);     // per pair of groups: shortest segment, union of the row ranges

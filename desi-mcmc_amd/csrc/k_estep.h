@@ -95,7 +95,7 @@ k_estep_src_hw(const BandDev *__restrict__ bands, int B, int H, int W, int64_t S
 #pragma unroll
             for (int r = 0; r < HW_TH / 2; r++) acc[r * 64 + lane] = 0.0;
             bool direct;
-            const int Kk = hw_build(T, lc, rec, lane, dropmode, Tdrop, 0.0, Y0, X0, min(rec.x1, X0 + HW_TW) - 1, 0, rb, direct);
+            const int Kk = hw_build(T, lc, rec, lane, dropmode, Tdrop, 0.0, Y0, X0, min(rec.x1, X0 + HW_TW) - 1, 0, rb, direct, nullptr, et);
             hw_walk(T, et, Kk, (double)xi, Y0, 0, rb, on, direct, acc, lane);
             __syncthreads();
             const int64_t base = plane + (int64_t)Y0 * W + min(xi, rec.x1 - 1);
@@ -231,7 +231,7 @@ k_estep_tiles(EstepArgs a) {
         const int xa = max(rec.x0, X0), xb = min(rec.x1, X0 + HW_TW) - 1;
         const bool on = (xi >= rec.x0) && (xi < rec.x1);
         bool direct;
-        const int Kk = hw_build(T, lc, rec, lane, dropmode, a.tail_T, 0.0, Y0, xa, xb, ra, rb, direct);
+        const int Kk = hw_build(T, lc, rec, lane, dropmode, a.tail_T, 0.0, Y0, xa, xb, ra, rb, direct, nullptr, et);
         hw_walk(T, et, Kk, (double)xi, Y0, ra, rb, on, direct, acc, lane);
         __syncthreads();
         double xt = 0.0, ms = 0.0;

@@ -66,7 +66,7 @@ k_stamps_hw(const BandDev *__restrict__ bands, int band, const SrcRec *__restric
     const int rb = jb.y1 - jb.y0;
     bool direct;
     const int Kk = hw_build(T, lc, rec, lane, (Tdrop > 0.0) ? HW_DROP_SELF : HW_DROP_NONE, Tdrop, 0.0, jb.y0, jb.x0,
-                            min(ob.y, jb.x0 + HW_TW) - 1, 0, rb, direct);
+                            min(ob.y, jb.x0 + HW_TW) - 1, 0, rb, direct, nullptr, et);
     hw_walk(T, et, Kk, (double)xi, jb.y0, 0, rb, on, direct, acc, lane);
     __syncthreads();
     if (!on) return;

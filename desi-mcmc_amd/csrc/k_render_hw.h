@@ -380,6 +380,7 @@ k_render_hw(RenderArgs a) {
     const double Tdrop = a.tail_T;
     const double eps_sky = bd->eps;
     const bool dropping = (a.variant != 0) && (Tdrop > 0.0) && (eps_sky > 0.0);
+    const float log_eps = dropping ? __logf((float)eps_sky) : 0.0f;
     const int strict = (a.flags >> 2) & 1;   // photon-split totals: boxes open on the low side (internal flag)
 
     unsigned dbg_pairrows = 0, dbg_comprows = 0, dbg_pairs = 0;   // only counted under CEL_OPT_TILE_TIMING
@@ -430,7 +431,7 @@ k_render_hw(RenderArgs a) {
         int Lk = 0, rlo = ra, rhi = rb;
         if (lane < K) {
             c = make_comp_lc(lc, rec);
-            double Tk = dropping ? Tdrop + (double)__logf((float)(fabs(c.A) / eps_sky)) : 100.0;
+            double Tk = dropping ? Tdrop + (double)(__logf((float)fabs(c.A)) - log_eps) : 100.0;   // T + log(A / eps), no fp64 division
             if (dropping) {
                 double qmin = quad_min_rect(c.qa, c.qb, c.qc, xa - c.mx, xb - c.mx, ya - c.my, yb - c.my);
                 keep = (0.5 * qmin <= Tk);

@@ -479,7 +479,7 @@ k_photon_split_hw(SplitArgs a) {
         if (ra >= rb || xa > xb) continue;          // touches the tile's other half only (wave-uniform)
         const bool on = (xi >= xa) && (xi <= xb);
         bool direct;
-        const int Kk = hw_build(T, lc, rec, lane, dropmode, a.tail_T, log_sky, Y0, xa, xb, ra, rb, direct);
+        const int Kk = hw_build(T, lc, rec, lane, dropmode, a.tail_T, log_sky, Y0, xa, xb, ra, rb, direct, nullptr, et);
         if (!(a.debug & 4)) hw_walk(T, et, Kk, x, Y0, ra, rb, on, direct, one, lane);
         __syncthreads();
         // Two passes over the source's pixels on this half-tile.  Most draws are decided by ONE
