@@ -99,8 +99,6 @@ __device__ __forceinline__ int hw_build(CompTab &T, const LaneConst &lc, const R
         T.A[p] = c.A; T.mx[p] = c.mx; T.my[p] = c.my;
         T.qa[p] = c.qa * EXP_SCALE; T.qb[p] = c.qb * EXP_SCALE; T.qc[p] = c.qc * EXP_SCALE;
         T.eq[p] = et ? exp_tab64(-c.qc * EXP_SCALE, et) : exp(-c.qc);
-        T.L[p] = Lk;
-        T.r0[p] = rlo; T.r1[p] = rhi;
         const int gi = p / (2 * REC_G);     // per pair of groups: shortest segment, union of the row ranges
         atomicMin(&T.gL[gi], Lk);
         atomicMin(&T.gr0[gi], rlo);

@@ -470,8 +470,6 @@ k_render_hw(RenderArgs a) {
             T.A[p] = c.A; T.mx[p] = c.mx; T.my[p] = c.my;
             T.qa[p] = c.qa * EXP_SCALE; T.qb[p] = c.qb * EXP_SCALE; T.qc[p] = c.qc * EXP_SCALE;
             T.eq[p] = exp_tab64(-c.qc * EXP_SCALE, et);
-            T.L[p] = Lk;
-            T.r0[p] = rlo; T.r1[p] = rhi;
             // LDS operations of one wave execute in order: the min/max below land after the resets above
             const int gi = p / (2 * REC_G);
             atomicMin(&T.gL[gi], Lk);

@@ -140,8 +140,6 @@ k_render_qw(RenderArgs a) {
             T.A[p] = c.A; T.mx[p] = c.mx; T.my[p] = c.my;
             T.qa[p] = c.qa * EXP_SCALE; T.qb[p] = c.qb * EXP_SCALE; T.qc[p] = c.qc * EXP_SCALE;
             T.eq[p] = exp_tab64(-c.qc * EXP_SCALE, et);
-            T.L[p] = Lk;
-            T.r0[p] = rlo; T.r1[p] = rhi;
             const int gi = p / (4 * REC_G);       // one pass = four groups of <= REC_G components
             atomicMin(&T.gL[gi], Lk);
             atomicMin(&T.gr0[gi], rlo);
