@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
-"""One Gibbs sweep of CelestePy's runnable sampler on a synthetic field, entirely on the HIP path.
+"""Gibbs sweeps of CelestePy's runnable sampler on a synthetic field, entirely on the HIP path.
 
 What CelesteBase.resample_model does (CelestePy/models.py:75-83):
-    for every field:   Field.resample_photons(srcs)           -> device photon split
-    for every source:  Source.resample()                       -> here: a flux Gibbs step and a
-                                                                  grid "slice" over the location,
-                                                                  scored by log_likelihood_batch
-The samplers themselves (slice sampling with step-out, HMC) are host control flow outside the
-build's scope; this script only shows the device-side calls they make, with timings.
+    for every field:   Field.resample_photons(srcs)    -> device photon split + the sky levels' Gamma draws
+    for every source:  Source.resample()               -> flux Gamma conditionals (sources.py:327-345) and the
+                                                          location by slice sampling (sources.py:308-319)
+Two ways to run it, both shown here:
+    model.resample_model(n_sweeps)     all sources in lock-step on the device (celeste_mcmc.ModelGibbs)
+    model.resample_sources()           one Source.resample() per object, as the reference loops
 
-    python examples/gibbs_sweep.py [--sources 200] [--size 512]
+    python examples/gibbs_sweep.py [--sources 200] [--size 512] [--sweeps 5]
 """
 import argparse
 import os
@@ -26,7 +26,7 @@ from desi_mcmc_amd import models, synth  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--sources", type=int, default=200)
 ap.add_argument("--size", type=int, default=512)
-ap.add_argument("--proposals", type=int, default=32)
+ap.add_argument("--sweeps", type=int, default=5)
 args = ap.parse_args()
 
 BANDS = ["u", "g", "r", "i", "z"]
@@ -53,31 +53,29 @@ for im, e in zip(imgs, eps_true):
 t0 = time.perf_counter()
 ll0 = model.log_likelihood()
 t1 = time.perf_counter()
-noise = model.field_list[0].resample_photons(model.srcs, seed=11, rng=np.random.RandomState(0))
-t2 = time.perf_counter()
-print("field log-likelihood %.6e   (%.1f ms incl. first upload)" % (ll0, (t1 - t0) * 1e3))
-print("photon split of %d sources x 5 bands x %dx%d: %.1f ms; sky photons per band %s"
-      % (args.sources, H, W, (t2 - t1) * 1e3, {k: int(v) for k, v in noise.items()}))
+print("field log-likelihood %.6e   (%.1f ms incl. the first upload)" % (ll0, (t1 - t0) * 1e3))
 
-rs = np.random.RandomState(2)
-n_eval, t_ll = 0, 0.0
-for src in model.srcs:
-    # flux step: conjugate Gamma given the attributed photons (sources.py:327-345)
-    counts = {b: 0.0 for b in BANDS}
-    for samp, im, _ in src.sample_image_list:
-        counts[im.band] += samp.data.sum()
-    src.params.fluxes = np.array([rs.gamma(1.0 + counts[b], 1.0 / (1e-3 + im.kappa / im.calib))
-                                  for b, im in zip(BANDS, imgs)])
-    # location step: score a cloud of proposals around the current position in ONE launch
-    us = src.params.u[None, :] + rs.normal(0.0, 2e-5, size=(args.proposals, 2))
-    us[0] = src.params.u
-    ta = time.perf_counter()
-    ll = src.log_likelihood_batch(us=us)
-    t_ll += time.perf_counter() - ta
-    n_eval += len(us)
-    p = np.exp(ll - ll.max())
-    src.params.u = us[rs.choice(len(us), p=p / p.sum())]
+# the reference's call passes step=0.001 degrees, which its slicesample ignores (sigma stays 1.0 degree):
+# give the intent explicitly
+slice_args = dict(step_out=False, sigma=0.001)
+model.resample_model(1, seed=3, slice_args=slice_args)            # builds the device sampler, one sweep
+t2 = time.perf_counter()
+model.resample_model(args.sweeps, slice_args=slice_args)
 t3 = time.perf_counter()
-print("per-source updates: %d conditional log-likelihood evaluations in %.1f ms of device calls "
-      "(%.1f us each); whole source loop %.1f ms" % (n_eval, t_ll * 1e3, t_ll / n_eval * 1e6, (t3 - t2) * 1e3))
-print("field log-likelihood after the sweep %.6e" % model.log_likelihood())
+g = model.gibbs()
+print("%d sweeps of %d sources x 5 bands x %dx%d: %.1f ms per sweep (photon split %.1f, fluxes %.1f, locations %.1f; "
+      "%.0f slice rounds, %.1f likelihood evaluations per source and sweep)"
+      % (args.sweeps, args.sources, H, W, (t3 - t2) / args.sweeps * 1e3, g.timing["split"] / g.sweeps * 1e3,
+         g.timing["flux"] / g.sweeps * 1e3, g.timing["location"] / g.sweeps * 1e3, g.timing["rounds"] / g.sweeps,
+         g.timing["evals"] / g.sweeps / max(args.sources, 1)))
+print("field log-likelihood after the sweeps %.6e" % model.log_likelihood())
+
+# the per-object form (Field.resample_photons hands every Source its sample patches, then one
+# Source.resample() per object): the same conditionals, a Python loop over the sources
+t4 = time.perf_counter()
+for field in model.field_list:
+    field.resample_photons(model.srcs, seed=11, rng=np.random.RandomState(0))
+model.resample_sources(rng=np.random.RandomState(1))
+t5 = time.perf_counter()
+print("one per-object sweep (Source.resample x %d): %.1f ms" % (args.sources, (t5 - t4) * 1e3))
+print("field log-likelihood %.6e" % model.log_likelihood())
