@@ -1140,7 +1140,10 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     const int B = im->B;
     const int64_t S = src->S;
     // one allocation, carved: 2 x u64, 10 x f64 (x and x0 are 2 per chain), 4 x i32 per chain + owner + ll (S*B) + chain ids + 2 ints
-    const size_t per_chain = 2 * 8 + 10 * 8 + 4 * 4 + 4 + (size_t)B * 8 + 4 + (size_t)B * 8;
+    // blocks per (chain, band) job in rounds with at most SLICE_SPLIT_JOBS jobs left (measured at config 3: 4 blocks
+    // below 2048 jobs 29.4 ms per location step, below 8192 jobs 29.0; 8 blocks 29.4; without 30.3)
+    const int SLICE_SPLIT = 4, SLICE_SPLIT_JOBS = 8192;
+    const size_t per_chain = 2 * 8 + 10 * 8 + 4 * 4 + 4 + (size_t)B * 8 * SLICE_SPLIT + 4 + (size_t)B * 12;
     const size_t need = per_chain * (size_t)S + 64;
     if (need > im->slice_cap) {
         HIP_TRY(hipStreamSynchronize(st));
@@ -1168,7 +1171,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     ss.llh_s = (double *)p; p += 8 * S;
     ss.new_z = (double *)p; p += 8 * S;
     ss.new_llh = (double *)p; p += 8 * S;
-    double *d_ll = (double *)p; p += 8 * S * B;
+    double *d_ll = (double *)p; p += 8 * S * B * SLICE_SPLIT;
     ss.phase = (int *)p; p += 4 * S;
     ss.kdir = (int *)p; p += 4 * S;
     ss.first = (int *)p; p += 4 * S;
@@ -1177,6 +1180,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     int *d_ids = (int *)p; p += 4 * S;
     int *d_work = (int *)p; p += 4 * S * B;
     int *d_jobs = (int *)p; p += 4 * S * B;
+    int *d_live = (int *)p; p += 4 * S * B;      // the running chains' jobs, compacted (late rounds)
     int *d_flags = (int *)p;            // [0] chains still running, [1] error bits, [2] likelihood evaluations so far, [3] rounds with work
     // the proposal set: this catalogue with the locations rewritten every round
     HIP_TRY(hipMemcpyAsync(prop->d_type, src->d_type, sizeof(int) * S, hipMemcpyDeviceToDevice, st));
@@ -1194,7 +1198,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     // the (chain, band) jobs of a round, heaviest first (the photon rectangles are fixed for the call)
     hipLaunchKernelGGL(k_job_work, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, src->d_type, im->d_snz, S, B, d_work);
     hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, d_work, (int)(S * B), d_jobs);
-    int64_t rounds = 0, evals = 0, queued = 0;
+    int64_t rounds = 0, evals = 0, queued = 0, live = S;
     int *h_flags = reinterpret_cast<int *>(c->pinned + MAX_BANDS + 2);
     int rc = CEL_OK;
     // The chains advance on the device alone (propose -> records -> likelihoods -> consume), so rounds
@@ -1204,6 +1208,15 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     const int SLICE_BATCH = 4;
     for (;;) {
         const int nb = (int)std::min<int64_t>(SLICE_BATCH, (int64_t)max_rounds - queued);
+        // few chains left (at most `live`, the count of the last readback): their one-wave jobs no longer fill
+        // the GPU and a round lasts as long as its longest job -- every job is dealt to SLICE_SPLIT blocks then
+        const int nsplit = (c->variant != 0 && live * B <= SLICE_SPLIT_JOBS) ? SLICE_SPLIT : 1;
+        if (nsplit > 1) {
+            // ... and only the running chains' jobs are launched: a list compacted once per batch (a chain that
+            // finishes inside the batch leaves jobs that retire at their first instruction)
+            HIP_TRY(hipMemsetAsync(d_flags + 4, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_slice_live_jobs, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, ss, S, B, d_live, d_flags + 4);
+        }
         for (int k = 0; k < nb; k++) {
             hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags, queued == 0 ? 1 : 0);
             prop->gen = ++g_source_gen;
@@ -1213,16 +1226,18 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
                 LAUNCH_EV(k_patch_ll, dim3((unsigned)(S * B)), dim3(256), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
                           d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, 0, d_ll);
             else
-                LAUNCH_EV(k_patch_ll_hw<0>, dim3((unsigned)(S * B)), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
+                LAUNCH_EV(k_patch_ll_hw<0>, dim3((unsigned)((nsplit > 1 ? live * B : S * B) * nsplit)), dim3(64), st, EV0(c, pi), EV1(c, pi),
+                          im->d_bands, B, S, im->d_recs,
                           d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll,
-                          (const int *)d_jobs);
-            hipLaunchKernelGGL(k_slice_consume, dim3(g256), dim3(256), 0, st, ss, S, B, d_ll, sigma, d_flags, d_flags + 1);
+                          (const int *)(nsplit > 1 ? d_live : d_jobs), nsplit, (const int *)(nsplit > 1 ? d_flags + 4 : nullptr));
+            hipLaunchKernelGGL(k_slice_consume, dim3(g256), dim3(256), 0, st, ss, S, c->variant == 0 ? B : B * nsplit, d_ll, sigma, d_flags, d_flags + 1);
             queued++;
         }
         HIP_TRY(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
         const int running = h_flags[0], err = h_flags[1];
+        live = running;
         if (err & 1) return fail(CEL_ERR_INVALID, "Slice sampler got a NaN");
         if (err & 2) return fail(CEL_ERR_INVALID, "Slice sampler shrank to zero!");
         evals = h_flags[2];

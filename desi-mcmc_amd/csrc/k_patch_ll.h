@@ -128,8 +128,13 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
               const int *__restrict__ owner, const int4 *__restrict__ pbox, const int64_t *__restrict__ offsets,
               const double *__restrict__ data, const double *__restrict__ nelec, int H, int W,
               const int4 *__restrict__ nzbox /* NB*B from k_patch_nzbox, or nullptr: evaluate the whole patch */,
-              double Tdrop, double *__restrict__ out /* P*B */,
-              const int *__restrict__ job_order = nullptr /* P*B: launch order of the (proposal, band) jobs, heaviest first */) {
+              double Tdrop, double *__restrict__ out /* P*B*nsplit */,
+              const int *__restrict__ job_order = nullptr /* P*B: launch order of the (proposal, band) jobs, heaviest first */,
+              int nsplit = 1 /* blocks per job: block (job, part) takes the job's chunks c with c % nsplit == part and writes
+                                out[job * nsplit + part]; part 0 carries the terms that are not sums over pixels.  A round of
+                                few, long one-wave jobs (the late rounds of the slice sampler) otherwise lasts as long as
+                                its longest job while most of the GPU idles */,
+              const int *__restrict__ job_count = nullptr /* with job_order: only its first *job_count entries are jobs */) {
     __shared__ double acc[HW_TH * HW_TW];
     __shared__ CompTab T;
     __shared__ double et[64];
@@ -138,12 +143,16 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     double *lt = reinterpret_cast<double *>(&T);
     const int lane = threadIdx.x;
     const int half = lane >> 5, col = lane & 31;
-    const int64_t job = job_order ? job_order[blockIdx.x] : blockIdx.x;
+    const int part = (nsplit > 1) ? (int)(blockIdx.x % (unsigned)nsplit) : 0;
+    const int64_t jslot = (nsplit > 1) ? (int64_t)(blockIdx.x / (unsigned)nsplit) : (int64_t)blockIdx.x;
+    if (job_count && jslot >= *job_count) return;      // wave-uniform: behind the end of a compacted job list
+    const int64_t job = job_order ? job_order[jslot] : jslot;
+    double *const outp = out + job * nsplit + part;
     const int b = (int)(job % B);
     const int64_t p = job / B;
     const BandDev *bd = bands + b;
     if (owner && owner[p] < 0) {        // a retired proposal slot (the device-resident slice sampler's finished chains)
-        if (lane == 0) out[job] = 0.0;
+        if (lane == 0) *outp = 0.0;
         return;
     }
     const int64_t ob = (int64_t)(owner ? owner[p] : 0) * B + b;
@@ -155,11 +164,11 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     const double counts = rec.scale;
     const double wsum = bd->w[0] + bd->w[1] + bd->w[2];
     if (nx <= 0 || ny <= 0 || (MODE == 3 && rec.type < 0)) {   // no sample image in this band / no stamp
-        if (lane == 0) out[job] = 0.0;
+        if (lane == 0) *outp = 0.0;
         return;
     }
     if (rec.type == -3 && MODE == 0) {  // psf_ns is None (sources.py:160-163)
-        if (lane == 0) out[job] = -counts * wsum;
+        if (lane == 0) *outp = (part == 0) ? -counts * wsum : 0.0;
         return;
     }
     if (rec.type < 0) rec.type = (rec.type == -2) ? 1 : 0;    // imposed limits: the kind still renders
@@ -184,7 +193,7 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
             alive = !(0.5 * qmin > 750.0);
         }
         if (__ballot(alive) == 0ull) {
-            if (lane == 0) out[job] = -counts * wsum;
+            if (lane == 0) *outp = (part == 0) ? -counts * wsum : 0.0;
             return;
         }
     }
@@ -198,9 +207,11 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     const double *z = (MODE == 3) ? nullptr : (data ? data + offsets[ob] : nelec + (int64_t)b * H * W + (int64_t)bx.z * W + bx.x);
     const int64_t zpitch = data ? nx : W;
     double a = 0.0, m = 0.0;
+    int chunk = 0;
     for (int Y0 = ev.z; Y0 < ev.w; Y0 += HW_TH) {
         const int rb = min(HW_TH, ev.w - Y0);
-        for (int X0 = ev.x; X0 < ev.y; X0 += HW_TW) {
+        for (int X0 = ev.x; X0 < ev.y; X0 += HW_TW, chunk++) {
+            if (nsplit > 1 && chunk % nsplit != part) continue;
             const int xi = X0 + col;
             const bool on = xi < ev.y;
 #pragma unroll
@@ -254,7 +265,7 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     }
     a = wave_sum(a);
     m = wave_sum(m);
-    if (lane == 0) out[job] = (MODE == 0) ? a - counts * wsum : (MODE == 3) ? m : a - m;
+    if (lane == 0) *outp = (MODE == 0) ? ((part == 0) ? a - counts * wsum : a) : (MODE == 3) ? m : a - m;
 }
 
 // work estimate of every (chain, band) job of the device slice sampler: components x pixels of the

@@ -106,8 +106,8 @@ k_slice_propose(SliceState st, int64_t S, double *__restrict__ prop_radec, int *
 
 // consume the round's log-likelihoods (per (chain, band), summed in band order as the host sums them)
 __global__ void __launch_bounds__(256)
-k_slice_consume(SliceState st, int64_t S, int B, const double *__restrict__ ll_pb, double sigma, int *__restrict__ n_active,
-                int *__restrict__ err) {
+k_slice_consume(SliceState st, int64_t S, int B /* entries per chain: bands x blocks per job, in that order */,
+                const double *__restrict__ ll_pb, double sigma, int *__restrict__ n_active, int *__restrict__ err) {
 #pragma clang fp contract(off)
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool active = false, scored = false;
@@ -155,4 +155,13 @@ k_slice_consume(SliceState st, int64_t S, int B, const double *__restrict__ ll_p
     const unsigned long long m = __ballot(active), me = __ballot(scored);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_active, __popcll(m));
     if ((threadIdx.x & 63) == 0 && me) atomicAdd(err + 1, __popcll(me));         // evaluations so far (int: < 2^31 per call)
+}
+
+// the (chain, band) jobs of the chains that are still running, in no particular order (they all start at once:
+// the list is only built when it is shorter than the GPU has wave slots)
+__global__ void __launch_bounds__(256)
+k_slice_live_jobs(SliceState st, int64_t S, int B, int *__restrict__ list, int *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * B) return;
+    if (st.phase[i / B] != SL_FINAL) list[atomicAdd(count, 1)] = (int)i;
 }
