@@ -1033,7 +1033,10 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
     int64_t *d_off = nullptr;
     int *d_owner = nullptr;
     double *d_data = nullptr, *d_out = nullptr;
-    std::vector<double> hout((size_t)(P * B));
+    // a call with few proposals is a handful of one-wave jobs as long as their longest: each is dealt to PLL_PARTS blocks
+    // (the values do not depend on it: the kernel sums its chunks in PLL_PARTS classes either way)
+    const int nparts = (c->variant != 0 && mode == 0 && P * B <= 8192) ? PLL_PARTS : 1;
+    std::vector<double> hout((size_t)(P * B * nparts));
     hipError_t e;
 #define PL_TRY(expr)                                                                     \
     do {                                                                                 \
@@ -1043,7 +1046,7 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
     int4 *d_nz = nullptr;
     if ((rc = scratch_get(c, 0, sizeof(int4) * (resident ? 0 : 2 * nb) + sizeof(int) * (owner ? P : 0), (void **)&d_box)) ||
         (rc = scratch_get(c, 1, sizeof(int64_t) * (nb + 1), (void **)&d_off)) ||
-        (rc = scratch_get(c, 2, sizeof(double) * P * B, (void **)&d_out)))
+        (rc = scratch_get(c, 2, sizeof(double) * P * B * nparts, (void **)&d_out)))
         return rc;
     if (owner) {
         d_owner = reinterpret_cast<int *>(d_box + (resident ? 0 : 2 * nb));
@@ -1075,8 +1078,9 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
         else if (mode == 0) {
             if (!resident)
                 hipLaunchKernelGGL(k_patch_nzbox, dim3((unsigned)nb), dim3(64), 0, c->stream, d_box, d_off, d_data, d_nz);
-            hipLaunchKernelGGL(k_patch_ll_hw<0>, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
-                               d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, d_nz, c->tail_T, d_out);
+            hipLaunchKernelGGL(k_patch_ll_hw<0>, dim3((unsigned)(P * B * nparts)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                               d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, d_nz, c->tail_T, d_out,
+                               (const int *)nullptr, nparts);
         } else if (mode == 2)
             hipLaunchKernelGGL(k_patch_ll_hw<2>, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
                                d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
@@ -1086,11 +1090,16 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
         prof_end(c, pi);
     }
     PL_TRY(hipGetLastError());
-    PL_TRY(hipMemcpyAsync(hout.data(), d_out, sizeof(double) * P * B, hipMemcpyDeviceToHost, c->stream));
+    PL_TRY(hipMemcpyAsync(hout.data(), d_out, sizeof(double) * P * B * nparts, hipMemcpyDeviceToHost, c->stream));
     PL_TRY(hipStreamSynchronize(c->stream));
     for (int64_t p = 0; p < P; p++) {
         double s = 0.0;
-        for (int b = 0; b < B; b++) s += hout[(size_t)(p * B + b)];   // band order, like the reference's image loop
+        for (int b = 0; b < B; b++) {                       // band order, like the reference's image loop
+            const double *q = hout.data() + (size_t)(p * B + b) * nparts;
+            double x = q[0];
+            for (int k = 1; k < nparts; k++) x += q[k];     // a job's parts first, in order (as k_slice_consume does)
+            s += x;
+        }
         ll_out[p] = s;
     }
 #undef PL_TRY
@@ -1142,7 +1151,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     // one allocation, carved: 2 x u64, 10 x f64 (x and x0 are 2 per chain), 4 x i32 per chain + owner + ll (S*B) + chain ids + 2 ints
     // blocks per (chain, band) job in rounds with at most SLICE_SPLIT_JOBS jobs left (measured at config 3: 4 blocks
     // below 2048 jobs 29.4 ms per location step, below 8192 jobs 29.0; 8 blocks 29.4; without 30.3)
-    const int SLICE_SPLIT = 4, SLICE_SPLIT_JOBS = 8192;
+    const int SLICE_SPLIT = PLL_PARTS, SLICE_SPLIT_JOBS = 8192;
     const size_t per_chain = 2 * 8 + 10 * 8 + 4 * 4 + 4 + (size_t)B * 8 * SLICE_SPLIT + 4 + (size_t)B * 12;
     const size_t need = per_chain * (size_t)S + 64;
     if (need > im->slice_cap) {
@@ -1230,7 +1239,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
                           im->d_bands, B, S, im->d_recs,
                           d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll,
                           (const int *)(nsplit > 1 ? d_live : d_jobs), nsplit, (const int *)(nsplit > 1 ? d_flags + 4 : nullptr));
-            hipLaunchKernelGGL(k_slice_consume, dim3(g256), dim3(256), 0, st, ss, S, c->variant == 0 ? B : B * nsplit, d_ll, sigma, d_flags, d_flags + 1);
+            hipLaunchKernelGGL(k_slice_consume, dim3(g256), dim3(256), 0, st, ss, S, B, nsplit, d_ll, sigma, d_flags, d_flags + 1);
             queued++;
         }
         HIP_TRY(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 4, hipMemcpyDeviceToHost, st));

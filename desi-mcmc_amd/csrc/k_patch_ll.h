@@ -122,6 +122,7 @@ k_patch_nzbox(const int4 *__restrict__ pbox, const int64_t *__restrict__ offsets
     if (lane == 0) nz[i] = (xhi >= 0) ? make_int4(bx.x + xlo, bx.x + xhi + 1, bx.z + ylo, bx.z + yhi + 1) : make_int4(0, 0, 0, 0);
 }
 
+#define PLL_PARTS 4
 template <int MODE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__restrict__ recs,
@@ -130,10 +131,12 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
               const int4 *__restrict__ nzbox /* NB*B from k_patch_nzbox, or nullptr: evaluate the whole patch */,
               double Tdrop, double *__restrict__ out /* P*B*nsplit */,
               const int *__restrict__ job_order = nullptr /* P*B: launch order of the (proposal, band) jobs, heaviest first */,
-              int nsplit = 1 /* blocks per job: block (job, part) takes the job's chunks c with c % nsplit == part and writes
-                                out[job * nsplit + part]; part 0 carries the terms that are not sums over pixels.  A round of
-                                few, long one-wave jobs (the late rounds of the slice sampler) otherwise lasts as long as
-                                its longest job while most of the GPU idles */,
+              int nsplit = 1 /* 1 or PLL_PARTS blocks per job: block (job, part) takes the job's chunks c with
+                                c % PLL_PARTS == part and writes out[job * PLL_PARTS + part]; part 0 carries the terms that
+                                are not sums over pixels.  A round of few, long one-wave jobs (the late rounds of the slice
+                                sampler, a caller with a handful of proposals) otherwise lasts as long as its longest job
+                                while most of the GPU idles.  MODE 0 sums its chunks in PLL_PARTS classes either way and
+                                whoever adds the parts adds them in order, so a value does not depend on nsplit */,
               const int *__restrict__ job_count = nullptr /* with job_order: only its first *job_count entries are jobs */) {
     __shared__ double acc[HW_TH * HW_TW];
     __shared__ CompTab T;
@@ -143,11 +146,11 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     double *lt = reinterpret_cast<double *>(&T);
     const int lane = threadIdx.x;
     const int half = lane >> 5, col = lane & 31;
-    const int part = (nsplit > 1) ? (int)(blockIdx.x % (unsigned)nsplit) : 0;
-    const int64_t jslot = (nsplit > 1) ? (int64_t)(blockIdx.x / (unsigned)nsplit) : (int64_t)blockIdx.x;
+    const int part = (nsplit > 1) ? (int)(blockIdx.x % (unsigned)PLL_PARTS) : 0;
+    const int64_t jslot = (nsplit > 1) ? (int64_t)(blockIdx.x / (unsigned)PLL_PARTS) : (int64_t)blockIdx.x;
     if (job_count && jslot >= *job_count) return;      // wave-uniform: behind the end of a compacted job list
     const int64_t job = job_order ? job_order[jslot] : jslot;
-    double *const outp = out + job * nsplit + part;
+    double *const outp = out + job * (nsplit > 1 ? PLL_PARTS : 1) + part;
     const int b = (int)(job % B);
     const int64_t p = job / B;
     const BandDev *bd = bands + b;
@@ -207,11 +210,12 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     const double *z = (MODE == 3) ? nullptr : (data ? data + offsets[ob] : nelec + (int64_t)b * H * W + (int64_t)bx.z * W + bx.x);
     const int64_t zpitch = data ? nx : W;
     double a = 0.0, m = 0.0;
+    double apart[PLL_PARTS] = {0.0, 0.0, 0.0, 0.0};     // MODE 0: the chunk classes' sums (statically indexed below)
     int chunk = 0;
     for (int Y0 = ev.z; Y0 < ev.w; Y0 += HW_TH) {
         const int rb = min(HW_TH, ev.w - Y0);
         for (int X0 = ev.x; X0 < ev.y; X0 += HW_TW, chunk++) {
-            if (nsplit > 1 && chunk % nsplit != part) continue;
+            if (nsplit > 1 && chunk % PLL_PARTS != part) continue;
             const int xi = X0 + col;
             const bool on = xi < ev.y;
 #pragma unroll
@@ -260,12 +264,32 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
                     }
                 }
             }
+            if (MODE == 0) {        // wave-uniform class: four predicated adds, no dynamically indexed registers
+#pragma unroll
+                for (int k = 0; k < PLL_PARTS; k++)
+                    if ((chunk % PLL_PARTS) == k) apart[k] += a;
+                a = 0.0;
+            }
             __syncthreads();
         }
     }
+    if (MODE == 0) {
+        // ((A0 - counts * wsum) + A1) + A2) + A3: one block forms it itself, PLL_PARTS blocks leave the additions to the reader
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < PLL_PARTS; k++) {
+            if (nsplit > 1 && k != part) continue;
+            if (k > 0 && k >= chunk) continue;      // a class without any chunk is 0.0: adding it changes nothing (`chunk` = the job's chunk count here)
+            double ak = wave_sum(apart[k]);
+            if (k == 0) ak -= counts * wsum;
+            tot = (nsplit > 1 || k == 0) ? ak : tot + ak;
+        }
+        if (lane == 0) *outp = tot;
+        return;
+    }
     a = wave_sum(a);
     m = wave_sum(m);
-    if (lane == 0) *outp = (MODE == 0) ? ((part == 0) ? a - counts * wsum : a) : (MODE == 3) ? m : a - m;
+    if (lane == 0) *outp = (MODE == 3) ? m : a - m;
 }
 
 // work estimate of every (chain, band) job of the device slice sampler: components x pixels of the

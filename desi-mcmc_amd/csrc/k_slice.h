@@ -106,7 +106,7 @@ k_slice_propose(SliceState st, int64_t S, double *__restrict__ prop_radec, int *
 
 // consume the round's log-likelihoods (per (chain, band), summed in band order as the host sums them)
 __global__ void __launch_bounds__(256)
-k_slice_consume(SliceState st, int64_t S, int B /* entries per chain: bands x blocks per job, in that order */,
+k_slice_consume(SliceState st, int64_t S, int B, int nparts /* blocks per (chain, band) job: their partial sums are added first, in order */,
                 const double *__restrict__ ll_pb, double sigma, int *__restrict__ n_active, int *__restrict__ err) {
 #pragma clang fp contract(off)
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -116,7 +116,12 @@ k_slice_consume(SliceState st, int64_t S, int B /* entries per chain: bands x bl
         if (ph != SL_FINAL) {
             scored = true;
             double v = 0.0;
-            for (int b = 0; b < B; b++) v += ll_pb[s * B + b];
+            for (int b = 0; b < B; b++) {
+                const double *q = ll_pb + (s * B + b) * nparts;
+                double x = q[0];
+                for (int k = 1; k < nparts; k++) x += q[k];
+                v += x;
+            }
             if (ph == SL_LEVEL) {
                 st.llh_s[s] = st.log_u[s] + v;                                   // slicesample.py:146
                 st.phase[s] = SL_SHRINK;
