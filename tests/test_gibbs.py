@@ -368,3 +368,21 @@ def test_slice_locations_error_paths(cel):
         f.images.slice_locations(f.sources, 1e-3, seed=1, max_rounds=1)
     radec, llh, st = f.images.slice_locations(f.sources, 1e-3, seed=1)
     assert st["rounds"] >= 4 and st["evals"] >= 4 * 20 and np.all(np.isfinite(llh))
+
+
+def test_conditional_loglik_does_not_depend_on_how_its_jobs_are_dealt(cel):
+    """a proposal's value is bit for bit the same in a small call (every (proposal, band) job dealt to four
+    blocks by chunk) and inside a call of 2 000 proposals (one block per job): the kernel sums a job's chunks in
+    four classes either way and the parts are added in one order.  The host and the device slice engines split
+    at different moments and must stay on the same trajectory."""
+    from desi_mcmc_amd import celeste_mcmc
+    imgs, params, pix, flux, nelec = small_scene(cel)
+    g = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params, seed=9)
+    g.resample_photons()
+    rs = np.random.RandomState(1)
+    idx = rs.randint(0, 4, size=2000)
+    U = g.u[idx] + rs.normal(0, 4e-5, size=(2000, 2))
+    big = g.location_loglik(idx, U)                     # 10 000 jobs: not split
+    for lo in (0, 7, 1500):
+        small = g.location_loglik(idx[lo:lo + 6], U[lo:lo + 6])     # 30 jobs: split
+        assert np.array_equal(small, big[lo:lo + 6])
