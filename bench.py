@@ -48,7 +48,7 @@ FLOP_PER_GAUSS = 35.0        # SURVEY 8d accounting: 10 arithmetic + exp counted
 #   traffic = 2 * FETCH_SIZE + WRITE_SIZE (gfx950 correction, re-calibrated with tools/calib_traffic.hip)
 #   valu    = SQ_INSTS_VALU (wave-instructions), busy = 2 * SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES
 PMC = {   # (workload, kernel, tail_log, layout) -> dict
-    ("mixed10k_2048", "recurrence", 32.0, 1): dict(traffic=387167872.0, valu_insts=6.0091e+08, valu_busy=0.83,
+    ("mixed10k_2048", "recurrence", 32.0, 1): dict(traffic=387331424.0, valu_insts=6.0091e+08, valu_busy=0.83,
                                                    source="profiles/r02_final_pmc.json"),
     ("stars10k_2048", "recurrence", 32.0, 1): dict(traffic=365595168.0, valu_insts=5.8377e+07, valu_busy=0.65,
                                                    source="profiles/r02_stars_pmc.json"),
