@@ -17,7 +17,8 @@ Algorithm per chain (slicesample.py:114-203, component-wise or random directions
             doubling, the interval passes `acceptable`, :119-131); else the interval shrinks to new_z
 Random numbers: one counter-based stream per chain (SplitMix64 of (seed, chain id, counter)), so
 a chain's trajectory does not depend on which other chains run beside it.  The reference draws
-from numpy's global MT19937; parity with it is in distribution.
+from numpy's global MT19937; handed the draws a reference run made (`rng=`), the engine returns
+that run's samples bit for bit (tests/test_slicesample.py against tests/golden/slicesample.npz).
 
 Reference behaviour kept on purpose: `upper_bound` / `lower_bound` are checked at the start
 (:206-211) and turned into per-direction bounds (:134-139) that are never used afterwards; the
@@ -66,7 +67,7 @@ _P_LEVEL, _P_OUT_DOUBLE, _P_OUT_LEFT, _P_OUT_RIGHT, _P_SHRINK, _P_ACCEPT, _P_DON
 
 def slicesample_lockstep(init_x, logprob_batch, sigma=1.0, step_out=True, max_steps_out=1000, compwise=True,
                          numdir=2, doubling_step=True, upper_bound=np.inf, lower_bound=-np.inf, seed=0,
-                         chain_ids=None, stats=None):
+                         chain_ids=None, stats=None, rng=None):
     """One slicesample() update of S chains at once.
 
     init_x          (S, D) current states
@@ -75,6 +76,8 @@ def slicesample_lockstep(init_x, logprob_batch, sigma=1.0, step_out=True, max_st
                     interval while stepping out).
     other arguments as slicesample (slicesample.py:110-118); seed / chain_ids name the random streams
     stats           optional dict: receives 'rounds', 'evals', 'max_steps_in'
+    rng             optional replacement of the per-chain streams (`uniform(idx)`, `normal(idx)`): how the
+                    tests hand the engine the very draws the reference made (tests/golden/slicesample.npz)
     -> (new_x (S, D), new_llh (S,))"""
     X = np.array(init_x, dtype=np.float64, copy=True)
     if X.ndim != 2:
@@ -84,7 +87,8 @@ def slicesample_lockstep(init_x, logprob_batch, sigma=1.0, step_out=True, max_st
     lb = np.broadcast_to(np.asarray(lower_bound, dtype=np.float64), (S, D)) if np.ndim(lower_bound) else np.full((S, D), float(lower_bound))
     assert np.all(X < ub), "init_x >= ub"                     # slicesample.py:206-209
     assert np.all(X > lb), "init_x <= lb"
-    rng = ChainStreams(seed, np.arange(S) if chain_ids is None else chain_ids)
+    if rng is None:
+        rng = ChainStreams(seed, np.arange(S) if chain_ids is None else chain_ids)
     every = np.arange(S)
     # directions of this update: a random order of the axes (:214-221) or numdir random unit vectors (:223-228)
     if compwise:

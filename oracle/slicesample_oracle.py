@@ -10,10 +10,85 @@ the only change is where the random numbers come from: every `npr.rand()` / `npr
 reference is a draw from ONE stream handed in by the caller (the product's per-chain stream), in the
 reference's order, so that a chain of the lock-step engine can be compared with it draw for draw.
 `npr.shuffle(ordering)` (:216) becomes a stable argsort of one uniform per axis, as the engine does.
-Parity status: pinned by construction to the reference's control flow; the reference's own
-`__main__` demo (:230-283) is not a test and pins nothing.
+Parity status: PINNED.  tests/golden/make_golden.py (`gen_slicesample`) runs the reference's own
+`slicesample` in the build container with its module-level `npr` replaced by a recorder and stores,
+per call, every draw the reference made (in call order) and the `(x, llh)` it returned
+(tests/golden/slicesample.npz).  tests/test_slicesample.py feeds those draws to `scalar_slicesample`
+through `ReplayStream` and requires the reference's `(x, llh)` bit for bit, for every option set.
+`TARGETS` are the closed-form log-densities both sides evaluate (the same code, so the same bits).
 """
 import numpy as np
+
+_CI2 = np.linalg.inv(np.array([[2.0, 0.8], [0.8, 1.0]]))
+_MU2 = np.array([0.3, -1.0])
+_A4 = np.array([[1.0, 0.3, 0.0, -0.2], [0.3, 0.5, 0.1, 0.0], [0.0, 0.1, 2.0, 0.4], [-0.2, 0.0, 0.4, 0.8]])
+_CI4 = np.linalg.inv(_A4)
+
+
+def _gauss(x):
+    d = np.asarray(x, dtype=np.float64) - _MU2
+    return float(-0.5 * (d @ _CI2 @ d))
+
+
+def _bimodal(x):
+    x = np.asarray(x, dtype=np.float64)
+    return float(np.logaddexp(-0.5 * np.sum((x - 2.0) ** 2) / 0.3, -0.5 * np.sum((x + 2.0) ** 2) / 0.5))
+
+
+def _gauss4(x):
+    d = np.asarray(x, dtype=np.float64)
+    return float(-0.5 * (d @ _CI4 @ d))
+
+
+def _halfgauss(x):
+    """the bounded demo target of slicesample.py:261-264"""
+    x = np.asarray(x, dtype=np.float64)
+    if np.any(x <= 0.0):
+        return -np.inf
+    return float(-0.5 * np.sum(x ** 2))
+
+
+TARGETS = {"gauss": _gauss, "bimodal": _bimodal, "gauss4": _gauss4, "halfgauss": _halfgauss}
+
+# kinds of a recorded draw (tests/golden/slicesample.npz): npr.rand(), one element of npr.randn(D), one
+# sort key of npr.shuffle(ordering) -- the shuffled order is stored as the D keys whose stable argsort
+# gives it, key[ordering[i]] = (i + 0.5) / D, which is the form the restatement consumes
+DRAW_RAND, DRAW_RANDN, DRAW_SHUFFLE_KEY = 0, 1, 2
+
+
+def shuffle_keys(ordering):
+    ordering = np.asarray(ordering, dtype=np.int64)
+    keys = np.empty(ordering.size)
+    keys[ordering] = (np.arange(ordering.size) + 0.5) / ordering.size
+    return keys
+
+
+class ReplayStream(object):
+    """Hands recorded draws back in order, through the interface of the product's ChainStreams
+    (`uniform(idx)`, `normal(idx)` for ONE chain); refuses a draw of the wrong kind or past the end."""
+
+    def __init__(self, kinds, vals):
+        self.kinds, self.vals, self.pos = np.asarray(kinds), np.asarray(vals, dtype=np.float64), 0
+
+    def _next(self, allowed, idx):
+        if np.size(idx) != 1:
+            raise AssertionError("a replay stream carries one chain")
+        if self.pos >= self.vals.size:
+            raise AssertionError("more draws requested than the reference made")
+        if int(self.kinds[self.pos]) not in allowed:
+            raise AssertionError("draw %d: reference made kind %d, restatement asks for %s" % (self.pos, self.kinds[self.pos], allowed))
+        v = self.vals[self.pos]
+        self.pos += 1
+        return np.array([v])
+
+    def uniform(self, idx):
+        return self._next((DRAW_RAND, DRAW_SHUFFLE_KEY), idx)
+
+    def normal(self, idx):
+        return self._next((DRAW_RANDN,), idx)
+
+    def exhausted(self):
+        return self.pos == self.vals.size
 
 
 def scalar_slicesample(init_x, logprob, stream, chain, sigma=1.0, step_out=True, max_steps_out=1000, compwise=True,

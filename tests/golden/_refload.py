@@ -45,6 +45,8 @@ def _patch_numpy():
             setattr(np, name, val)
     if not hasattr(np, "row_stack"):
         np.row_stack = np.vstack
+    if not hasattr(np, "Inf"):                     # util/infer/slicesample.py:4 (removed in numpy 2.0)
+        np.Inf = np.inf
 
 
 # --------------------------------------------------------------------------

@@ -23,6 +23,9 @@ star_stamps.npz    A8  gen_point_source_psf_image (patch + box, edge cases, Q1)
 galaxy_stamps.npz  A14/A15/A17 gen_galaxy_transformation, component tables, gen_galaxy_psf_image
 mini_field.npz     A9-A11 + Q3 extension: mixed star/galaxy field, 5 bands, 96x80
 config1.npz        config 1: real stamps, catalogue sources, gen_model_image + celeste_likelihood
+source_ll.npz      (f)1 Source.log_likelihood / log_likelihood_isolated (sources.py:134-237)
+estep.npz          (f)4 gen_src_prob_layers reductions (celeste_em.py:38-91)
+slicesample.npz    config 5: slicesample (util/infer/slicesample.py:89-227) with every draw it made recorded
 """
 import os
 import sys
@@ -475,7 +478,93 @@ def gen_estep():
     save("estep.npz", star_idx=idx, xtilde=X, mass=F, noise=Z)
 
 
+class _RecordingRandom(object):
+    """Stands in for the `npr` of util/infer/slicesample.py:2: the same numpy generator calls, with
+    every result noted in call order (kinds as oracle.slicesample_oracle.DRAW_*)."""
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+        self.kinds, self.vals, self.perms = [], [], []
+
+    def rand(self, *shape):
+        assert not shape
+        v = self.rs.rand()
+        self.kinds.append(0)
+        self.vals.append(v)
+        return v
+
+    def randn(self, n):
+        v = self.rs.randn(n)
+        self.kinds.extend([1] * n)
+        self.vals.extend(v.tolist())
+        return v
+
+    def shuffle(self, ordering):
+        from oracle.slicesample_oracle import shuffle_keys
+        self.rs.shuffle(ordering)
+        self.perms.append(list(ordering))
+        self.kinds.extend([2] * len(ordering))
+        self.vals.extend(shuffle_keys(ordering).tolist())
+
+
+def gen_slicesample():
+    """slicesample.npz: chains of the reference's slicesample (util/infer/slicesample.py:89-227) on
+    closed-form targets, every option set tests/test_slicesample.py runs + the call
+    Source.resample_location makes (sources.py:315-319) + the 4-D random-direction call of
+    celeste_mcmc.py:229-239 + the bounded demo of slicesample.py:261-276.  Per call: the draws the
+    reference made, in order, and what it returned."""
+    import io
+    import json
+    from contextlib import redirect_stdout
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle.slicesample_oracle import TARGETS
+    import CelestePy.util.infer.slicesample as ref_ss
+    cases = [
+        ("gauss", dict(sigma=1.0, step_out=True, doubling_step=True)),
+        ("bimodal", dict(sigma=1.0, step_out=True, doubling_step=True)),
+        ("gauss", dict(sigma=0.4, step_out=True, doubling_step=False)),
+        ("bimodal", dict(sigma=0.4, step_out=True, doubling_step=False)),
+        ("gauss", dict(sigma=25.0, step_out=False)),
+        ("bimodal", dict(sigma=25.0, step_out=False)),
+        ("gauss", dict(sigma=0.7, step_out=True, doubling_step=True, compwise=False, numdir=3)),
+        ("bimodal", dict(sigma=0.7, step_out=True, doubling_step=True, compwise=False, numdir=3)),
+        ("gauss", dict(sigma=0.3, step_out=True, doubling_step=True, max_steps_out=3)),
+        ("bimodal", dict(sigma=0.3, step_out=True, doubling_step=True, max_steps_out=3)),
+        ("gauss", dict(step_out=False)),                                            # sources.py:315-319 (sigma stays 1.0)
+        ("gauss4", dict(sigma=0.5, step_out=True, doubling_step=True, compwise=False, numdir=4)),   # celeste_mcmc.py:229-239
+        ("gauss4", dict(sigma=0.5, step_out=True, doubling_step=True)),
+        ("halfgauss", dict(sigma=0.1, step_out=True, doubling_step=True, compwise=False, numdir=4, lower_bound=0.0)),
+        ("halfgauss", dict(sigma=0.6, step_out=True, doubling_step=False, lower_bound=0.0, upper_bound=50.0)),
+    ]
+    ncalls = 12
+    out = dict(ncases=np.array(len(cases)), ncalls=np.array(ncalls))
+    for ci, (tname, kw) in enumerate(cases):
+        f = TARGETS[tname]
+        D = 4 if tname in ("gauss4", "halfgauss") else 2
+        x = np.abs(np.random.RandomState(100 + ci).randn(D)) + 0.05
+        rec = _RecordingRandom(7000 + ci)
+        ref_ss.npr = rec
+        xs, lls, offs = [], [], [0]
+        x0 = x.copy()
+        for it in range(ncalls):
+            with redirect_stdout(io.StringIO()):
+                x, llh = ref_ss.slicesample(x.copy(), f, **kw)
+            xs.append(np.array(x, dtype=np.float64))
+            lls.append(float(llh))
+            offs.append(len(rec.vals))
+        out.update({"c%d_target" % ci: np.array(tname), "c%d_kw" % ci: np.array(json.dumps(kw)), "c%d_x0" % ci: x0,
+                    "c%d_draw_kind" % ci: np.array(rec.kinds, dtype=np.int8), "c%d_draw_val" % ci: np.array(rec.vals),
+                    "c%d_draw_off" % ci: np.array(offs, dtype=np.int64), "c%d_perms" % ci: np.array(rec.perms, dtype=np.int64),
+                    "c%d_x" % ci: np.array(xs), "c%d_llh" % ci: np.array(lls)})
+    ref_ss.npr = np.random
+    save("slicesample.npz", **out)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["slicesample"]:
+        gen_slicesample()
+        sys.exit(0)
     imgs = gen_bands()
     gen_wcs(imgs)
     gen_evaluator()
@@ -486,3 +575,4 @@ if __name__ == "__main__":
     gen_config1(imgs)
     gen_source_ll()
     gen_estep()
+    gen_slicesample()

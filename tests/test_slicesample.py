@@ -2,12 +2,70 @@
 oracle's scalar restatement of the reference's algorithm (oracle/slicesample_oracle.py, following
 CelestePy/util/infer/slicesample.py:89-227) fed with the same per-chain random stream, and for the
 distribution it leaves invariant."""
+import json
+import os
+
 import numpy as np
 import pytest
 
 import desi_mcmc_amd  # noqa: F401
 from desi_mcmc_amd.util.infer.slicesample import ChainStreams, slicesample, slicesample_lockstep
-from oracle.slicesample_oracle import scalar_slicesample
+from oracle.slicesample_oracle import DRAW_SHUFFLE_KEY, TARGETS, ReplayStream, scalar_slicesample
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "slicesample.npz")
+
+
+def _golden_cases():
+    g = np.load(GOLD)
+    for ci in range(int(g["ncases"])):
+        yield ci, {k[len("c%d_" % ci):]: g[k] for k in g.files if k.startswith("c%d_" % ci)}
+
+
+def test_restatement_reproduces_the_reference_run_bit_for_bit():
+    """THE PIN of oracle/slicesample_oracle.py: fed the draws the reference's own slicesample made
+    (recorded by tests/golden/make_golden.py::gen_slicesample while running
+    CelestePy/util/infer/slicesample.py:89-227 in the build container), the scalar restatement
+    consumes exactly those draws, kind by kind, and returns the reference's (x, llh) bit for bit --
+    15 option sets x 12 successive calls, including the call of sources.py:315-319, the 4-D
+    random-direction call of celeste_mcmc.py:229-239 and the bounded demo of slicesample.py:261-276."""
+    ncase = 0
+    for ci, c in _golden_cases():
+        kw = json.loads(str(c["kw"]))
+        kw.pop("lower_bound", None)                     # computed and never applied by the reference (:134-139)
+        kw.pop("upper_bound", None)
+        f = TARGETS[str(c["target"])]
+        x = c["x0"].copy()
+        off = c["draw_off"]
+        for it in range(c["x"].shape[0]):
+            st = ReplayStream(c["draw_kind"][off[it]:off[it + 1]], c["draw_val"][off[it]:off[it + 1]])
+            x, llh = scalar_slicesample(x.copy(), f, st, 0, **kw)
+            assert st.exhausted(), (ci, it, st.pos, off[it + 1] - off[it])
+            assert np.array_equal(x, c["x"][it]), (ci, it, x, c["x"][it])
+            assert llh == c["llh"][it], (ci, it)
+        # the stored sort keys are the reference's shuffles (one per component-wise call)
+        keys = c["draw_val"][c["draw_kind"] == DRAW_SHUFFLE_KEY]
+        if keys.size:
+            D = c["x0"].size
+            assert np.array_equal(np.argsort(keys.reshape(-1, D), axis=1, kind="stable"), c["perms"])
+        ncase += 1
+    assert ncase == 15
+
+
+def test_lockstep_engine_reproduces_the_reference_run_bit_for_bit():
+    """The PRODUCT engine itself, handed the reference's recorded draws through its `rng=` seam,
+    returns the reference's (x, llh) bit for bit: same draws in the same order, same arithmetic."""
+    for ci, c in _golden_cases():
+        kw = json.loads(str(c["kw"]))
+        f = TARGETS[str(c["target"])]
+        x = c["x0"].copy()
+        off = c["draw_off"]
+        for it in range(c["x"].shape[0]):
+            st = ReplayStream(c["draw_kind"][off[it]:off[it + 1]], c["draw_val"][off[it]:off[it + 1]])
+            X, ll = slicesample_lockstep(x[None, :], lambda idx, P: np.array([f(p) for p in P]), rng=st, **kw)
+            x = X[0]
+            assert st.exhausted(), (ci, it)
+            assert np.array_equal(x, c["x"][it]), (ci, it, x, c["x"][it])
+            assert ll[0] == c["llh"][it], (ci, it)
 
 
 def _targets():
