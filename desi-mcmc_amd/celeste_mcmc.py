@@ -99,10 +99,12 @@ class ModelGibbs(object):
         self.seed = int(seed)
         self.rng = np.random.RandomState(self.seed & 0x7FFFFFFF)
         self.flux_a_0, self.flux_b_0 = flux_a_0, flux_b_0
-        # Source.resample_location's call (sources.py:312-317): no stepping out; `step=` is not a
-        # slicesample argument, so sigma keeps its default 1.0 unless the caller sets it
-        self.slice_args = dict(step_out=False)
-        self.slice_args.update(slice_args or {})
+        # Source.resample_location's call (sources.py:312-317): no stepping out, step = du / 5 = 0.001
+        # degrees.  The reference's slicesample does not read `step=`, so what it effectively runs is an
+        # interval of sigma = 1.0 degree, with which a faint source can leave the frame for good (DESIGN Q13,
+        # Q15).  The default here is the call's INTENT (sigma = 0.001 deg); slice_args="literal" asks for the
+        # call as the reference executes it.
+        self.slice_args = self.slice_preset(slice_args)
         # where the slice sampler's state machine runs: "device" (cel_slice_locations: nothing but a
         # counter crosses PCIe per round; one field, the reference call's options), "host" (the numpy
         # engine of util/infer/slicesample.py: every option, any number of fields), "auto" = device
@@ -117,6 +119,23 @@ class ModelGibbs(object):
         self.active = np.ones(self.S, dtype=bool)
 
     # -- helpers ---------------------------------------------------------------------------------
+    SLICE_INTENDED = dict(step_out=False, sigma=1e-3)
+    SLICE_LITERAL = dict(step_out=False)                       # sigma stays slicesample's default, 1.0 degree
+
+    @classmethod
+    def slice_preset(cls, slice_args):
+        """None -> the intended call; "literal" -> the reference's effective call; a dict is laid over the
+        intended call's step_out=False (its sigma is then the caller's, or slicesample's default 1.0)"""
+        if slice_args is None or slice_args == "intended":
+            return dict(cls.SLICE_INTENDED)
+        if isinstance(slice_args, str):
+            if slice_args != "literal":
+                raise ValueError("slice_args preset must be 'intended' or 'literal'")
+            return dict(cls.SLICE_LITERAL)
+        out = dict(step_out=False)
+        out.update(slice_args)
+        return out
+
     @classmethod
     def from_images(cls, img_dicts, params, **kw):
         """fields given as the reference holds them: a list of {band letter: FitsImage} dicts
@@ -198,7 +217,14 @@ class ModelGibbs(object):
             from concurrent.futures import ThreadPoolExecutor
             self._pool = ThreadPoolExecutor(max_workers=1)
         fut = self._pool.submit(rates)
-        g = self.rng.standard_gamma(a_n)            # Gamma(a_n, 1 / b_n) = standard_gamma(a_n) * (1 / b_n), the same draws
+        try:
+            g = self.rng.standard_gamma(a_n)        # Gamma(a_n, 1 / b_n) = standard_gamma(a_n) * (1 / b_n), the same draws
+        finally:
+            # a Context is not thread-safe (scratch slots, the profile ring, the records are shared): whatever
+            # the host draw does, nobody touches this one again before the worker's device call has returned
+            worker_error = fut.exception()          # blocks until the worker is done
+        if worker_error is not None:
+            raise worker_error
         new = g * (1. / fut.result())
         self.fluxes = np.where(self.active[:, None], new, self.fluxes)
         self.timing["flux"] += time.perf_counter() - t0

@@ -996,11 +996,14 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
                            double *ll_out) {
     if (!im || !src || !ll_out) return fail(CEL_ERR_INVALID, "cel_patch_loglik: null argument");
     if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
-    if (mode != 0 && mode != 1 && mode != 2) return fail(CEL_ERR_INVALID, "mode must be 0 (conditional), 1 (isolated) or 2 (patch Poisson)");
+    if (mode != 0 && mode != 1 && mode != 2 && mode != 4)
+        return fail(CEL_ERR_INVALID, "mode must be 0 (conditional), 1 (isolated), 2 (patch Poisson) or 4 (Poisson on a background plane)");
     // resident form: boxes == offsets == data == NULL -> the patches of the last resident photon
     // split (mode 0) or the observed image on those boxes (mode 1); NB must be that split's S
     const bool resident = (!boxes && !offsets && !data);
     if (!resident && (!boxes || !offsets)) return fail(CEL_ERR_INVALID, "cel_patch_loglik: null boxes / offsets");
+    if (resident && mode > 1) return fail(CEL_ERR_INVALID, "the resident form scores mode 0 or 1");
+    const int nplanes = (mode == 4) ? 2 : 1;               // mode 4: data plane, then background plane
     if (resident && (im->samp_S <= 0 || NB != im->samp_S))
         return fail(CEL_ERR_INVALID, "resident form needs a resident photon split of NB = %lld sources (have %lld)",
                     (long long)NB, (long long)im->samp_S);
@@ -1015,9 +1018,9 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
     for (int64_t i = 0; i < (resident ? 0 : nb); i++) {
         int y0 = boxes[4 * i], y1 = boxes[4 * i + 1], x0 = boxes[4 * i + 2], x1 = boxes[4 * i + 3];
         int64_t area = (y1 > y0 && x1 > x0) ? (int64_t)(y1 - y0) * (x1 - x0) : 0;
-        if (offsets[i + 1] - offsets[i] != area)
-            return fail(CEL_ERR_INVALID, "patch set %lld band %d: offsets give %lld patch values, the box has %lld pixels",
-                        (long long)(i / B), (int)(i % B), (long long)(offsets[i + 1] - offsets[i]), (long long)area);
+        if (offsets[i + 1] - offsets[i] != area * nplanes)
+            return fail(CEL_ERR_INVALID, "patch set %lld band %d: offsets give %lld patch values, the box has %lld pixels x %d plane(s)",
+                        (long long)(i / B), (int)(i % B), (long long)(offsets[i + 1] - offsets[i]), (long long)area, nplanes);
         if (area > 0 && (y0 < 0 || x0 < 0 || y1 > im->H || x1 > im->W))
             return fail(CEL_ERR_INVALID, "patch set %lld band %d: patch limits outside the image", (long long)(i / B), (int)(i % B));
         hbox[(size_t)i] = make_int4(x0, x1, y0, y1);
@@ -1047,7 +1050,7 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
     if ((rc = scratch_get(c, 0, sizeof(int4) * (resident ? 0 : 2 * nb) + sizeof(int) * (owner ? P : 0), (void **)&d_box)) ||
         (rc = scratch_get(c, 1, sizeof(int64_t) * (nb + 1), (void **)&d_off)) ||
         (rc = scratch_get(c, 2, sizeof(double) * P * B * nparts, (void **)&d_out)))
-        return rc;
+        goto done;
     if (owner) {
         d_owner = reinterpret_cast<int *>(d_box + (resident ? 0 : 2 * nb));
         PL_TRY(hipMemcpyAsync(d_owner, owner, sizeof(int) * P, hipMemcpyHostToDevice, c->stream));
@@ -1066,7 +1069,7 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
     } else if (mem == CEL_DEVICE) {
         d_data = const_cast<double *>(data);
     } else {
-        if ((rc = scratch_get(c, 3, sizeof(double) * (offsets[nb] > 0 ? offsets[nb] : 1), (void **)&d_data))) return rc;
+        if ((rc = scratch_get(c, 3, sizeof(double) * (offsets[nb] > 0 ? offsets[nb] : 1), (void **)&d_data))) goto done;   // copies are queued: leave through the sync
         if (offsets[nb] > 0)
             PL_TRY(hipMemcpyAsync(d_data, data, sizeof(double) * offsets[nb], hipMemcpyHostToDevice, c->stream));
     }
@@ -1083,6 +1086,9 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
                                (const int *)nullptr, nparts);
         } else if (mode == 2)
             hipLaunchKernelGGL(k_patch_ll_hw<2>, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                               d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
+        else if (mode == 4)
+            hipLaunchKernelGGL(k_patch_ll_hw<4>, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
                                d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
         else
             hipLaunchKernelGGL(k_patch_ll_hw<1>, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,

@@ -10,6 +10,9 @@
 //   mode 1:  sum log(m + eps) * z  -  sum (m + eps)
 //   mode 2:  sum_{m>0} log(m) * z  -  sum m        (galaxy_source_like, celeste_galaxy_conditionals.py:15-42,
 //            on given limits; a pixel the model does not reach contributes nothing)
+//   mode 4:  sum_{z>=0, m+bg>0} log(m + bg) * z - (m + bg)   on a given BACKGROUND: the patch data is two planes,
+//            z then bg (everything else in the field rendered on the box); z < 0 marks a masked pixel.  The
+//            image_like closure of the star <-> galaxy move (sources.py:277-291).
 // z = the patch data (photons attributed to the source, or nelec for the isolated form).
 //
 // Two kernels with the same contract:
@@ -72,6 +75,9 @@ k_patch_ll(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__
         const double zi = z[(int64_t)yy * zpitch + xx];
         if (mode == 0) {
             if (v > 0.0) a += log(v) * zi;
+        } else if (mode == 4) {
+            v += z[(int64_t)n + (int64_t)yy * zpitch + xx];         // the background plane follows the data plane
+            if (v > 0.0 && zi >= 0.0) { a += log(v) * zi; m += v; }
         } else if (mode == 2) {
             if (v > 0.0) { a += log(v) * zi; m += v; }
         } else {
@@ -204,7 +210,7 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     int dropmode = HW_DROP_NONE;
     double log_floor = 0.0;
     if (Tdrop > 0.0) {
-        if (MODE == 0 || MODE == 2 || MODE == 3) dropmode = HW_DROP_SELF;
+        if (MODE == 0 || MODE == 2 || MODE == 3 || MODE == 4) dropmode = HW_DROP_SELF;
         else if (eps > 0.0 && counts > 0.0) { dropmode = HW_DROP_SKY; log_floor = (double)__logf((float)(eps / counts)); }
     }
     const double *z = (MODE == 3) ? nullptr : (data ? data + offsets[ob] : nelec + (int64_t)b * H * W + (int64_t)bx.z * W + bx.x);
@@ -240,9 +246,13 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
             // the chunk instead of predicated), issued only once the walk's registers are free
             const double *zp = z + (int64_t)(Y0 - bx.z) * zpitch + (min(xi, ev.y - 1) - bx.x);
             for (int r0 = 0; r0 < HW_TH / 2 && 2 * r0 < rb; r0 += 8) {
-                double zz[8];
+                double zz[8], bg[8];
 #pragma unroll
                 for (int r = 0; r < 8; r++) zz[r] = zp[(int64_t)min(2 * (r0 + r) + half, rb - 1) * zpitch];
+                if (MODE == 4) {        // the background plane follows the data plane (nx * ny values further on)
+#pragma unroll
+                    for (int r = 0; r < 8; r++) bg[r] = zp[(int64_t)nx * ny + (int64_t)min(2 * (r0 + r) + half, rb - 1) * zpitch];
+                }
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                     if (on && 2 * (r0 + r) + half < rb) {
@@ -256,6 +266,9 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
 #endif
                         } else if (MODE == 2) {
                             if (v > 0.0) { a += log_tab(v, lt) * zz[r]; m += v; }
+                        } else if (MODE == 4) {
+                            v += bg[r];
+                            if (v > 0.0 && zz[r] >= 0.0) { a += log_tab(v, lt) * zz[r]; m += v; }
                         } else {
                             v += eps;
                             a += log_tab(v, lt) * zz[r];

@@ -360,6 +360,29 @@ class ImageSet(object):
                                          (1 if isolated else 0) if mode is None else int(mode), L.dptr(out)))
         return out
 
+    def patch_loglik_planes(self, sources, boxes, planes):
+        """mode 4 of cel_patch_loglik: sum over bands of sum_{z>=0, m+bg>0} log(m + bg) z - (m + bg) for each of the
+        P proposals in `sources`.  boxes (B,4) y0,y1,x0,x1 (empty: band not scored); planes[b] = (2, ny, nx): the
+        observed counts (negative = masked pixel) and the background everything else contributes.  -> ll[P]
+        (poisson_loglike of sources.py:6-12 as the star <-> galaxy move uses it, :277-291)"""
+        boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(self.B, 4)
+        offs = np.zeros(self.B + 1, dtype=np.int64)
+        flat = []
+        for b in range(self.B):
+            y0, y1, x0, x1 = boxes[b]
+            n = int(y1 - y0) * int(x1 - x0) if (y1 > y0 and x1 > x0) else 0
+            if n:
+                p = L.f64(planes[b])
+                if p.shape != (2, y1 - y0, x1 - x0):
+                    raise ValueError("band %d: planes of shape %s do not match the box" % (b, p.shape))
+                flat.append(p.ravel())
+            offs[b + 1] = offs[b] + 2 * n
+        data = np.concatenate(flat) if flat else np.zeros(1)
+        out = np.zeros(sources.S)
+        L.check(L.lib().cel_patch_loglik(self._h, sources._h, boxes.ctypes.data_as(L.c_int32_p),
+                                         offs.ctypes.data_as(L.c_int64_p), data.ctypes.data, L.CEL_HOST, 4, L.dptr(out)))
+        return out
+
     def patch_loglik_multi(self, sources, owner, boxes, patches, isolated=False):
         """patch_loglik for proposals of many sources at once.  owner[p]: which patch set proposal p
         is scored on; boxes (NB, B, 4); patches[set][band] arrays or None.  -> ll[P]"""

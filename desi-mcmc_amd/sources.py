@@ -4,8 +4,9 @@
 render path -- compute_scatter_on_pixels / compute_model_patch (sources.py:351-395),
 flux_in_image (:120-129), get_bounding_box (:83-96), log_likelihood / log_likelihood_isolated /
 location_likelihood (:134-237) -- and for the per-source Gibbs updates that drive it: resample /
-resample_fluxes / resample_location (:242-349), the star <-> galaxy move's image_like
-(:275-306), make_bbox_dict / get_active_sources / generate_background_patch (:434-483).  It adds
+resample_fluxes / resample_location (:242-349), the star <-> galaxy move (:247-306: resample_type,
+calculate_acceptance_logprob, image_like -- current and proposed source scored in one device call),
+make_bbox_dict / get_active_sources / generate_background_patch (:434-483, array forms).  It adds
 log_likelihood_batch, which scores many proposals in one launch (the reference's slice sampler
 calls log_likelihood 10-50 times per source per sweep, sources.py:308-319).
 
@@ -16,8 +17,8 @@ celeste_mcmc.ModelGibbs -- the same steps for every source at once, patches resi
 
 Reference slips on this stretch, handled as follows:
   * resample_location calls slicesample without importing it (NameError) and passes `step=`, which
-    slicesample does not read: sigma stays 1.0 (degrees) and the bounds are never applied.  The call
-    is reproduced as written (`sigma=` may be given to override);
+    slicesample does not read: sigma stays 1.0 (degrees) and the bounds are never applied.  The default
+    here is the interval the call intends (du / 5 = 0.001 deg); `sigma=1.0` runs it as executed;
   * resample_fluxes passes the cached pixel grid as `u` (sources.py:338); the intended call -- the
     unit stamp at the current location on the source's own box -- is what is summed here.
 """
@@ -32,10 +33,10 @@ BANDS = ['u', 'g', 'r', 'i', 'z']
 
 def poisson_loglike(data, model_img, mask):
     """sum log(m) d - sum m over m > 0 & mask  -- sources.py:6-12"""
-    assert model_img.shape == mask.shape
-    assert data.shape == model_img.shape
-    good_pix = (model_img > 0.) & (mask != 0)
-    return np.sum(np.log(model_img[good_pix]) * data[good_pix]) - np.sum(model_img[good_pix])
+    assert data.shape == model_img.shape == mask.shape
+    keep = np.logical_and(model_img > 0., mask != 0)
+    m = model_img[keep]
+    return np.sum(np.log(m) * data[keep]) - np.sum(m)
 
 
 class SamplePatch(object):
@@ -146,38 +147,31 @@ class Source(object):
     @staticmethod
     def get_bounding_box(params, img):
         """(xlim, ylim), float limits  -- sources.py:83-96"""
-        if params.is_star():
-            bound = img.R
-        elif params.is_galaxy():
-            bound = gal_funs.gen_galaxy_psf_image_bound(params, img)
-        else:
+        if not (params.is_star() or params.is_galaxy()):
             raise ValueError("source type unknown")
-        px, py = img.equa2pixel(params.u)
-        xlim = (np.max([0, np.floor(px - bound)]), np.min([img.nelec.shape[1], np.ceil(px + bound)]))
-        ylim = (np.max([0, np.floor(py - bound)]), np.min([img.nelec.shape[0], np.ceil(py + bound)]))
-        return xlim, ylim
+        reach = img.R if params.is_star() else gal_funs.gen_galaxy_psf_image_bound(params, img)
+        centre = np.asarray(img.equa2pixel(params.u), dtype=np.float64)          # x, y
+        lo = np.maximum(np.floor(centre - reach), 0.)
+        hi = np.minimum(np.ceil(centre + reach), np.array(img.nelec.shape[::-1], dtype=np.float64))
+        return (lo[0], hi[0]), (lo[1], hi[1])
 
     def flux_in_image(self, fits_image, fluxes=None):
         """nanomaggies -> photon counts in this image  -- sources.py:120-129"""
-        if fluxes is not None:
-            f = fluxes[BANDS.index(fits_image.band)]
-        else:
-            f = self.params.flux_dict[fits_image.band]
-        return (f / fits_image.calib) * fits_image.kappa
+        band = fits_image.band
+        nmgy = self.params.flux_dict[band] if fluxes is None else fluxes[BANDS.index(band)]
+        return (nmgy / fits_image.calib) * fits_image.kappa
 
     def compute_scatter_on_pixels(self, fits_image, u=None, shape=None, xlim=None, ylim=None,
                                   pixel_grid=None, force_type=None):
         """unit-flux photon scatter image of this source  -- sources.py:351-388"""
-        u = self.params.u if u is None else u
-        render_star = self.is_star() if force_type is None else (force_type == 'star')
-        render_gal = self.is_galaxy() if force_type is None else (force_type == 'galaxy')
-        if render_star:
-            return _celeste.gen_point_source_psf_image(u, fits_image, xlim=xlim, ylim=ylim, pixel_grid=pixel_grid)
-        elif render_gal:
-            if shape is None:
-                shape = self.params.shape
-            return gal_funs.gen_galaxy_psf_image(shape, u, fits_image, xlim=xlim, ylim=ylim,
-                                                 check_overlap=True, unconstrained=False, return_patch=True)
+        kind = force_type or self.object_type
+        where = self.params.u if u is None else u
+        if kind == 'star':
+            return _celeste.gen_point_source_psf_image(where, fits_image, xlim=xlim, ylim=ylim, pixel_grid=pixel_grid)
+        if kind == 'galaxy':
+            return gal_funs.gen_galaxy_psf_image(self.params.shape if shape is None else shape, where, fits_image,
+                                                 xlim=xlim, ylim=ylim, check_overlap=True, unconstrained=False,
+                                                 return_patch=True)
         raise NotImplementedError("only stars and galaxies have photon scattering images")
 
     def compute_model_patch(self, fits_image, u=None, xlim=None, ylim=None):
@@ -250,26 +244,26 @@ class Source(object):
 
     def resample_fluxes(self, rng=None):
         """fluxes u,g,r,i,z given everything else: Gamma(a_0 + photons, 1 / (b_0 + sum(unit stamp) *
-        kappa / calib)) per band  -- sources.py:321-349"""
+        kappa / calib)) per band  -- sources.py:321-349 (a_0 = 5, b_0 = .005)"""
         rng = np.random if rng is None else rng
-        a_0, b_0 = 5., .005
-        band_counts = {b: 0 for b in BANDS}
-        psf_sums = {b: 0 for b in BANDS}
-        for src_img, fits_img, pixel_grid in self.sample_image_list:
-            band_counts[fits_img.band] += np.sum(np.array(src_img.data))
-            psf_ns, ylim, xlim = self.compute_scatter_on_pixels(fits_img)     # see the module docstring
-            if psf_ns is not None:
-                psf_sums[fits_img.band] += np.sum(psf_ns) * fits_img.kappa / fits_img.calib
-        a_n = a_0 + np.array([band_counts[b] for b in BANDS])
-        b_n = b_0 + np.array([psf_sums[b] for b in BANDS])
-        self.params.fluxes = rng.gamma(a_n, 1. / b_n)
+        photons, rate = np.full(5, 5.), np.full(5, .005)
+        for samp, im, _ in self.sample_image_list:
+            k = BANDS.index(im.band)
+            photons[k] += np.sum(samp.data)
+            stamp = self.compute_scatter_on_pixels(im)[0]                     # see the module docstring (Q14)
+            if stamp is not None:
+                rate[k] += np.sum(stamp) * im.kappa / im.calib
+        self.params.fluxes = rng.gamma(photons, 1. / rate)
 
     def resample_location(self, u=None, rng=None, **slice_args):
         """conditionally resample the location by slice sampling  -- sources.py:308-319"""
         if u is None:
             u = np.array(self.params.u, dtype=np.float64, copy=True)
-        kw = dict(step_out=False, upper_bound=self.u_upper, lower_bound=self.u_lower)
-        kw.update(slice_args)                 # `step=self.du/5` of the reference is not a slicesample argument
+        # `step=self.du/5` (0.001 deg) of the reference's call is not an argument its slicesample reads, so what
+        # the reference runs is sigma = 1.0 deg (Q13).  As in ModelGibbs the default here is the call's intent;
+        # pass sigma=1.0 for the literal behaviour.
+        kw = dict(step_out=False, sigma=float(np.mean(self.du)) / 5, upper_bound=self.u_upper, lower_bound=self.u_lower)
+        kw.update(slice_args)
         if "seed" not in kw:
             kw["seed"] = int((np.random if rng is None else rng).randint(0, 2 ** 31 - 1))
         u, ll = slicesample(u, lambda uu: self.location_likelihood(uu), **kw)
@@ -281,73 +275,98 @@ class Source(object):
         return
 
     # ---- star <-> galaxy move (sources.py:247-306) ------------------------------------------------
+    # Re-designed for the device: the reference renders, per image, the current and the proposed source on
+    # the bounding box and sums a masked Poisson term in numpy (the closure of :277-291, twice per image).
+    # Here every candidate (current, proposed, or any number of proposals of either type) is scored on
+    # every image of a same-shape group by ONE call of cel_patch_loglik in mode 4: the observed box and
+    # the stored background cross the ABI as two planes per band, masked pixels marked by a negative count.
+    def image_like_batch(self, candidates, images):
+        """sum over `images` of poisson_loglike(observed box, background + candidate's model patch, invvar mask)
+        for each SrcParams of `candidates` (stars and galaxies may be mixed)  -> (P,)"""
+        images = list(images)
+        P = len(candidates)
+        total = np.zeros(P)
+        by_shape = {}
+        for im in images:
+            by_shape.setdefault(im.nelec.shape, []).append(im)
+        for group in by_shape.values():
+            for lo in range(0, len(group), 16):
+                part = tuple(group[lo:lo + 16])
+                iset, pos = _celeste._image_subset(part)
+                boxes = np.zeros((iset.B, 4), dtype=np.int32)
+                planes = [None] * iset.B
+                for k, im in zip(pos, part):
+                    (x0, x1), (y0, y1) = self.bounding_boxes[im]
+                    y0, y1, x0, x1 = int(y0), int(y1), int(x0), int(x1)
+                    boxes[k] = (y0, y1, x0, x1)
+                    obs = np.array(im.nelec[y0:y1, x0:x1], dtype=np.float64)
+                    invvar = getattr(im, "invvar", None)
+                    if invvar is not None:
+                        obs[invvar[y0:y1, x0:x1] == 0] = -1.0
+                    planes[k] = np.stack([obs, np.asarray(self.background_image_dict[im], dtype=np.float64)])
+                flux_counts = lambda q, im: (q.flux_dict[im.band] / im.calib) * im.kappa      # noqa: E731  (sources.py:393-394)
+                typ, radec, counts_part, shape = _celeste._source_arrays(list(candidates), part, counts_fn=flux_counts)
+                counts = np.zeros((P, iset.B))
+                counts[:, pos] = counts_part
+                total += iset.patch_loglik_planes(iset._sources(typ, radec, counts, shape), boxes, planes)
+        return total
+
     def image_like(self, src, img):
-        """Poisson log-likelihood of `img` on this source's bounding box with `src` rendered on the
-        stored background  -- the closure of calculate_acceptance_logprob, sources.py:277-291"""
-        xlim, ylim = self.bounding_boxes[img]
-        background_img = self.background_image_dict[img]
-        data_img = img.nelec[ylim[0]:ylim[1], xlim[0]:xlim[1]]
-        invvar = getattr(img, "invvar", None)
-        mask_img = np.ones(data_img.shape) if invvar is None else invvar[ylim[0]:ylim[1], xlim[0]:xlim[1]]
-        model_img, _, _ = src.compute_model_patch(img, xlim=xlim, ylim=ylim)
-        return poisson_loglike(data=data_img, model_img=background_img + model_img, mask=mask_img)
+        """the closure of calculate_acceptance_logprob (sources.py:277-291) for one source on one image"""
+        return float(self.image_like_batch([src.params], [img])[0])
 
     def calculate_acceptance_logprob(self, proposal, logprob_proposal, logprob_reverse, logdet, images):
-        """sources.py:275-306; the priors (model.logprior) are the caller's"""
-        curr_like = np.sum([self.image_like(self, img) for img in images])
-        curr_logprior = self.model.logprior(self.params)
-        proposal_source = self.model._source_type(proposal, self.model)
-        prop_like = np.sum([self.image_like(proposal_source, img) for img in images])
-        prop_logprior = self.model.logprior(proposal_source.params)
-        return (prop_like + prop_logprior) - (curr_like + curr_logprior) + \
-               (logprob_reverse - logprob_proposal) + logdet
-
-    def resample_type(self, proposal_fun=None, rng=None):
-        """star vs galaxy by a reversible jump  -- sources.py:247-261.  Needs model.prior_sample /
-        model.logprior (priors are outside this path) and bounding_boxes / background_image_dict."""
-        rng = np.random if rng is None else rng
-        proposal_fun = self.propose_other_type_prior if proposal_fun is None else proposal_fun
-        proposal, logpdf, logreverse, logdet = proposal_fun()
-        fimgs = [self.model.field_list[0].img_dict[b] for b in self.model.bands]
-        accept_logprob = self.calculate_acceptance_logprob(proposal, logpdf, logreverse, logdet, fimgs)
-        if np.log(rng.rand()) < accept_logprob:
-            self.params = proposal
+        """log acceptance ratio of the type move (sources.py:275-306): current and proposed source scored in
+        one device call; the prior terms are the model's (priors are outside this path)"""
+        like_cur, like_prop = self.image_like_batch([self.params, proposal], images)
+        prior_cur, prior_prop = self.model.logprior(self.params), self.model.logprior(proposal)
+        return (like_prop + prior_prop) - (like_cur + prior_cur) + (logprob_reverse - logprob_proposal) + logdet
 
     def propose_other_type_prior(self):
-        """prior-based proposal  -- sources.py:263-273"""
-        if self.is_star():
-            params, logprob = self.model.prior_sample('galaxy', u=self.params.u)
-        elif self.is_galaxy():
-            params, logprob = self.model.prior_sample('star', u=self.params.u)
-        logreverse = self.model.logprior(self.params)
-        return params, logprob, logreverse, 0.
+        """a draw from the prior of the OTHER type at the current location (sources.py:263-273)
+        -> (params, log q(proposal), log q(reverse), log |det|)"""
+        other = 'galaxy' if self.is_star() else 'star'
+        drawn, logq = self.model.prior_sample(other, u=self.params.u)
+        return drawn, logq, self.model.logprior(self.params), 0.
+
+    def resample_type(self, proposal_fun=None, rng=None):
+        """Metropolis-Hastings flip star <-> galaxy (sources.py:247-261).  Needs model.prior_sample /
+        model.logprior (or a proposal_fun), self.bounding_boxes and self.background_image_dict.
+        -> True when the proposal was accepted"""
+        draw = (proposal_fun or self.propose_other_type_prior)()
+        field_imgs = [self.model.field_list[0].img_dict[b] for b in self.model.bands]
+        log_alpha = self.calculate_acceptance_logprob(*draw, images=field_imgs)
+        accepted = bool(np.log((np.random if rng is None else rng).rand()) < log_alpha)
+        if accepted:
+            self.params = draw[0]
+        return accepted
 
 
 # ---- source utility functions (sources.py:430-483) --------------------------------------------------
 def make_bbox_dict(params, images, pixel_radius=None):
-    """{img: (xlim, ylim)}: the area a source's model affects  -- sources.py:434-456"""
+    """{img: (xlim, ylim)}: the square of half-width pixel_radius about the source, cut to each image
+    (sources.py:434-456; like the reference, a radius must be given)"""
     if pixel_radius is None:
         raise NotImplementedError
-
-    def image_bbox(params, img):
-        img_ymax, img_xmax = img.nelec.shape
-        px, py = img.equa2pixel(params.u)
-        xlim = (np.max([0, int(np.floor(px - pixel_radius))]), np.min([img_xmax, int(np.ceil(px + pixel_radius))]))
-        ylim = (np.max([0, int(np.floor(py - pixel_radius))]), np.min([img_ymax, int(np.ceil(py + pixel_radius))]))
-        return xlim, ylim
-    return {img: image_bbox(params, img) for img in images}
+    images = list(images)
+    centre = np.array([im.equa2pixel(params.u) for im in images], dtype=np.float64).reshape(len(images), 2)   # x, y
+    size = np.array([im.nelec.shape[::-1] for im in images], dtype=np.int64).reshape(len(images), 2)         # W, H
+    lo = np.maximum(np.floor(centre - pixel_radius).astype(np.int64), 0)
+    hi = np.minimum(np.ceil(centre + pixel_radius).astype(np.int64), size)
+    return {im: ((int(lo[i, 0]), int(hi[i, 0])), (int(lo[i, 1]), int(hi[i, 1]))) for i, im in enumerate(images)}
 
 
 def get_active_sources(source, source_list, image):
-    """sources whose bounding box intersects `source`'s in `image`  -- sources.py:458-474"""
-    def intersect(sa, sb, image):
-        xlima, ylima = sa.bounding_boxes[image]
-        xlimb, ylimb = sb.bounding_boxes[image]
-        widtha, heighta = xlima[1] - xlima[0], ylima[1] - ylima[0]
-        widthb, heightb = xlimb[1] - xlimb[0], ylimb[1] - ylimb[0]
-        return (np.abs(xlima[0] - xlimb[0]) * 2 < (widtha + widthb)) and \
-               (np.abs(ylima[0] - ylimb[0]) * 2 < (heighta + heightb))
-    return [s for s in source_list if intersect(s, source, image) and s is not source]
+    """the other sources whose bounding box meets `source`'s in `image` under the reference's test
+    (sources.py:458-474: twice the distance of the boxes' lower corners against the summed extents, per
+    axis) -- one array comparison over the whole list"""
+    others = [s for s in source_list if s is not source]
+    if not others:
+        return []
+    lim = np.array([s.bounding_boxes[image] for s in [source] + others], dtype=np.float64)      # (n, axis, lo/hi)
+    corner, extent = lim[:, :, 0], lim[:, :, 1] - lim[:, :, 0]
+    meets = np.all(2.0 * np.abs(corner[1:] - corner[0]) < extent[1:] + extent[0], axis=1)
+    return [s for s, m in zip(others, meets) if m]
 
 
 def generate_background_patch(source, source_list, image):

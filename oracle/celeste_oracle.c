@@ -459,7 +459,7 @@ void orc_gen_model_image_fullframe(const orc_band *band, int H, int W, int64_t S
 /* One image's term of Source.log_likelihood (sources.py:134-183, mode 0) or
  * Source.log_likelihood_isolated (:188-237, mode 1): the source's unit stamp on the FIXED patch
  * limits box = {y0,y1,x0,x1} (compute_scatter_on_pixels with xlim/ylim, :351-388), scaled by
- * counts = flux_in_image (:120-129), against the patch data. */
+ * counts = flux_in_image (:120-129), against the patch data.  mode 4: the type move's image_like. */
 double orc_patch_loglik(const orc_band *b, int H, int W, int type, const double u[2],
                         const double shape[4], double counts, const int box[4], const double *data,
                         int mode) {
@@ -485,6 +485,15 @@ double orc_patch_loglik(const orc_band *b, int H, int W, int type, const double 
         double m = counts * patch[i];
         if (mode == 0) {
             if (m > 0.) a += (long double)(log(m) * data[i]);        /* mask = model_patch > 0 (:172-174) */
+        } else if (mode == 4) {
+            /* image_like of calculate_acceptance_logprob (sources.py:277-291): poisson_loglike (:6-12) of the
+             * observed box against background_img + model_img; data = [observed (n), background (n)], an observed
+             * value < 0 stands for mask == 0 */
+            m += data[n + i];
+            if (m > 0. && data[i] >= 0.) {
+                a += (long double)(log(m) * data[i]);
+                msum += (long double)m;
+            }
         } else {
             m += b->eps;                                              /* :219 */
             a += (long double)(log(m) * data[i]);

@@ -181,8 +181,9 @@ def test_reference_effective_call_sigma_one_degree(cel):
     (the kernel's far-proposal shortcut); the chain must still end next to the photons"""
     from desi_mcmc_amd import celeste_mcmc
     imgs, params, pix, flux, nelec = small_scene(cel)
-    g = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params, seed=4)      # slice_args: reference default
+    g = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params, seed=4, slice_args="literal")
     assert g.slice_args == dict(step_out=False)
+    assert celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params).slice_args == dict(step_out=False, sigma=1e-3)
     for it in range(3):
         g.sweep()
     assert g.timing["rounds"] / 3 > 20                         # ~log2(1 deg / posterior width) shrinks per axis
@@ -214,7 +215,9 @@ def test_celeste_base_resample_model_and_per_object_resample(cel):
     m.srcs[0].resample_location(rng=rng, sigma=1e-3)
     after = np.array(m.srcs[0].params.u)
     assert np.all(after != before[0]) and np.all(np.abs(imgs[2].equa2pixel(after) - pix[0]) < 0.3)
-    m.resample_sources(rng=rng)                                             # every source, reference call (sigma = 1 deg)
+    m.srcs[1].resample_location(rng=rng, sigma=1.0)                         # the call as the reference executes it (sigma = 1 deg)
+    assert np.all(np.abs(imgs[2].equa2pixel(m.srcs[1].params.u) - pix[1]) < 1.0)
+    m.resample_sources(rng=rng)                                             # every source, the intended 0.001-degree interval
     assert np.all(np.abs(imgs[2].equa2pixel(m.srcs[0].params.u) - pix[0]) < 0.3)
     m.srcs[0].store_sample()
     m.srcs[0].store_loglike()
@@ -232,11 +235,31 @@ def test_background_patch_and_image_like(cel, orc):
     img = imgs[2]
     for s in m.srcs:
         s.bounding_boxes = sources.make_bbox_dict(s.params, imgs, pixel_radius=45)
+    # the boxes: floor / ceil of centre -+ radius, cut to the frame (sources.py:441-455), scalar restatement
+    for s in m.srcs:
+        for im in imgs:
+            px, py = im.equa2pixel(s.params.u)
+            want = ((max(0, int(np.floor(px - 45))), min(112, int(np.ceil(px + 45)))),
+                    (max(0, int(np.floor(py - 45))), min(96, int(np.ceil(py + 45)))))
+            assert s.bounding_boxes[im] == want
+    with pytest.raises(NotImplementedError):
+        sources.make_bbox_dict(params[0], imgs)
     src = m.srcs[2]
     act = sources.get_active_sources(src, m.srcs, img)
     assert src not in act and len(act) >= 1
+    # the reference's pairwise test (sources.py:459-471), written out per pair
+    for other in m.srcs:
+        if other is src:
+            continue
+        (ax, ay), (bx, by) = src.bounding_boxes[img], other.bounding_boxes[img]
+        hit = (abs(ax[0] - bx[0]) * 2 < (ax[1] - ax[0]) + (bx[1] - bx[0])) and (abs(ay[0] - by[0]) * 2 < (ay[1] - ay[0]) + (by[1] - by[0]))
+        assert hit == (other in act)
+    assert sources.get_active_sources(src, [src], img) == []
     bg = sources.generate_background_patch(src, m.srcs, img)
     xlim, ylim = src.bounding_boxes[img]
+    box = [ylim[0], ylim[1], xlim[0], xlim[1]]
+    band = orc.pack_bands(load_golden("bands_253.npz"))[2].copy()
+    band[24:26] = [112 / 2.0, 96 / 2.0]
     want = np.zeros((ylim[1] - ylim[0], xlim[1] - xlim[0])) + img.epsilon
     for a in act:
         p, _, _ = a.compute_model_patch(img, xlim=xlim, ylim=ylim)
@@ -244,8 +267,91 @@ def test_background_patch_and_image_like(cel, orc):
     np.testing.assert_allclose(bg, want, rtol=1e-12)
     src.background_image_dict = {img: bg}
     ll = src.image_like(src, img)
+    cts = src.flux_in_image(img)
+    obs = img.nelec[ylim[0]:ylim[1], xlim[0]:xlim[1]]
+    o_ll = orc.patch_loglik(band, 96, 112, 1, src.params.u, src.params.shape, cts, box, np.stack([obs, bg]).ravel(), mode=4)
+    np.testing.assert_allclose(ll, o_ll, rtol=1e-11)
     model, _, _ = src.compute_model_patch(img, xlim=xlim, ylim=ylim)
-    np.testing.assert_allclose(ll, orc.poisson_loglike(img.nelec[ylim[0]:ylim[1], xlim[0]:xlim[1]], bg + model), rtol=1e-12)
+    np.testing.assert_allclose(ll, orc.poisson_loglike(obs, bg + model), rtol=1e-11)
+    # masked pixels (invvar == 0) drop out of both sums
+    img.invvar = np.ones_like(img.nelec)
+    img.invvar[ylim[0] + 3:ylim[0] + 20, xlim[0] + 5:xlim[0] + 30] = 0.0
+    try:
+        mask = img.invvar[ylim[0]:ylim[1], xlim[0]:xlim[1]]
+        np.testing.assert_allclose(src.image_like(src, img), orc.poisson_loglike(obs, bg + model, mask), rtol=1e-11)
+    finally:
+        del img.invvar
+
+
+class _FlatPrior(object):
+    """stand-in for the model's priors (out of scope): what Source.resample_type needs of its model"""
+    bands = BANDS
+
+    def __init__(self, cel, imgs, gal_shape):
+        import types
+        self.cel = cel
+        self.field_list = [types.SimpleNamespace(img_dict=dict(zip(BANDS, imgs)))]
+        self.gal_shape = gal_shape
+        self.lp = {0: -3.0, 1: -4.5}
+
+    def logprior(self, params):
+        return self.lp[params.a]
+
+    def prior_sample(self, kind, u):
+        if kind == 'galaxy':
+            th, sg, ph, rh = self.gal_shape
+            return self.cel.SrcParams(u=u, a=1, fluxes=self.fluxes.copy(), theta=th, sigma=sg, phi=ph, rho=rh), -2.0
+        return self.cel.SrcParams(u=u, a=0, fluxes=self.fluxes.copy()), -1.0
+
+
+def test_type_move_scores_both_types_in_one_call(cel, orc):
+    """Source.resample_type / calculate_acceptance_logprob / propose_other_type_prior (sources.py:247-306): the
+    acceptance ratio's likelihood terms against the oracle (mode 4 of orc_patch_loglik: poisson_loglike of the
+    observed box on background + model, all five bands), its prior / proposal terms, and the move itself: a
+    galaxy mis-typed as a star is flipped, a true star is not turned into an extended galaxy."""
+    from desi_mcmc_amd import models, sources
+    imgs, params, pix, flux, nelec = small_scene(cel)
+    m = models.Celeste()
+    m.add_field(dict(zip(BANDS, imgs)))
+    m.initialize_sources(init_src_params=params)
+    for s in m.srcs:
+        s.bounding_boxes = sources.make_bbox_dict(s.params, imgs, pixel_radius=40)
+    bands = orc.pack_bands(load_golden("bands_253.npz"))
+    for who, truth_is_galaxy in ((2, True), (0, False)):
+        src = m.srcs[who]
+        true_params = src.params
+        src.background_image_dict = {im: sources.generate_background_patch(src, m.srcs, im) for im in imgs}
+        prior = _FlatPrior(cel, imgs, gal_shape=(0.4, 1.2, 35.0, 0.6))
+        prior.fluxes = np.array([true_params.flux_dict[b] for b in BANDS])
+        src.model = prior
+        if truth_is_galaxy:                       # start from the wrong type: a star with the galaxy's fluxes
+            src.params = cel.SrcParams(u=true_params.u, a=0, fluxes=prior.fluxes.copy())
+        proposal, logq, logrev, logdet = src.propose_other_type_prior()
+        assert proposal.a == (1 if src.is_star() else 0) and logdet == 0. and logrev == prior.logprior(src.params)
+        assert logq == (-2.0 if proposal.a == 1 else -1.0)
+        got = src.calculate_acceptance_logprob(proposal, logq, logrev, logdet, imgs)
+        like = {}
+        for name, q in (("cur", src.params), ("prop", proposal)):
+            tot = 0.0
+            for b, im in enumerate(imgs):
+                band = bands[b].copy()
+                band[24:26] = [112 / 2.0, 96 / 2.0]
+                xlim, ylim = src.bounding_boxes[im]
+                obs = im.nelec[ylim[0]:ylim[1], xlim[0]:xlim[1]]
+                data = np.stack([obs, src.background_image_dict[im]]).ravel()
+                shape = q.shape if q.a == 1 else np.zeros(4)
+                tot += orc.patch_loglik(band, 96, 112, q.a, q.u, shape, q.flux_dict[im.band] / im.calib * im.kappa,
+                                        [ylim[0], ylim[1], xlim[0], xlim[1]], data, mode=4)
+            like[name] = tot
+        want = (like["prop"] + prior.logprior(proposal)) - (like["cur"] + prior.logprior(src.params)) + (logrev - logq) + logdet
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-10 * abs(like["cur"]))      # a difference of two sums of ~|like| each
+        np.testing.assert_allclose(src.image_like_batch([src.params, proposal], imgs), [like["cur"], like["prop"]], rtol=1e-11)
+        accepted = src.resample_type(rng=np.random.RandomState(1))
+        if truth_is_galaxy:
+            assert got > 50.0 and accepted and src.is_galaxy()            # the galaxy's photons do not fit a point source
+        else:
+            assert got < -50.0 and not accepted and src.is_star()
+        src.params = true_params
 
 
 def test_device_slice_sampler_follows_the_host_engine_chain_by_chain(cel):
@@ -255,7 +361,7 @@ def test_device_slice_sampler_follows_the_host_engine_chain_by_chain(cel):
     from desi_mcmc_amd import celeste_mcmc
     imgs, params, pix, flux, nelec = small_scene(cel)
     eps0 = [im.epsilon for im in imgs]
-    for sa in (dict(sigma=1e-3), None):
+    for sa in (None, "literal"):
         gs = {}
         for eng in ("host", "device"):
             for im, e in zip(imgs, eps0):          # a sweep redraws the images' sky levels: both engines start from the same
@@ -386,3 +492,71 @@ def test_conditional_loglik_does_not_depend_on_how_its_jobs_are_dealt(cel):
     for lo in (0, 7, 1500):
         small = g.location_loglik(idx[lo:lo + 6], U[lo:lo + 6])     # 30 jobs: split
         assert np.array_equal(small, big[lo:lo + 6])
+
+
+def test_config5_full_size_sweeps(cel, orc):
+    """BASELINE configs[4] at its full size -- 10 000 mixed sources x 5 bands x 2048^2, the field of
+    `bench.py --workload gibbs10k` -- through ModelGibbs.sweep (CelesteBase.resample_model, models.py:75-83;
+    Source.resample*, sources.py:242-349; slicesample, util/infer/slicesample.py:89-227): two sweeps with the
+    0.001-degree interval the reference's call intends and one with the literal 1 degree it effectively runs.
+      * every photon of every band goes to exactly one source or to the sky, in every sweep;
+      * the device state machine (cel_slice_locations) and the numpy engine (pinned to the reference's own
+        run, tests/test_slicesample.py) leave all 10 000 chains at the same place and flux, bit for bit;
+      * with the 0.001-degree interval every sampled source moves, none by as much as the interval's width
+        and 99.9 % by less than 5e-4 degrees;
+      * cel_stamp_mass (the rate term of resample_fluxes) against the oracle on a 200-source sample."""
+    from desi_mcmc_amd import celeste_mcmc, synth
+    ctx = cel.default_context(0)
+    f = synth.SyntheticField.from_config(ctx, "mixed10k_2048")
+    S, B = f.S, f.B
+    nel = f.nelec.reshape(B, -1).sum(axis=1)
+    eps0 = f.bands[:, 0].copy()
+    out = {}
+    for eng in ("host", "device"):
+        for b in range(B):
+            f.images.set_epsilon(b, eps0[b])                 # a sweep redraws the sky levels: same start for both engines
+        gf = celeste_mcmc.GibbsField(f.images, list(range(B)), f.bands[:, 2], f.bands[:, 1], f.H * f.W)
+        g = celeste_mcmc.ModelGibbs([gf], f.src["type"], f.src["radec"], f.flux5(), f.src["shape"], seed=12,
+                                    slice_args=dict(step_out=False, sigma=1e-3), engine=eng)
+        trace = []
+        for sweep in range(3):
+            if sweep == 2:
+                g.slice_args = g.slice_preset("literal")     # the call as written: sigma stays 1.0 degree (Q13)
+            noise = g.resample_photons()[0]
+            assert np.array_equal(gf.sums.sum(axis=0) + noise, nel), (eng, sweep)
+            assert gf.sums.shape == (S, B) and np.all(gf.sums >= 0) and np.all(gf.sums == np.rint(gf.sums))
+            g.resample_fluxes()
+            before = g.u.copy()
+            g.resample_locations()
+            g.sweeps += 1
+            trace.append((g.u.copy(), g.fluxes.copy(), g.active.copy(), before))
+        out[eng] = (g, trace)
+    (gh, th), (gd, td) = out["host"], out["device"]
+    for sweep in range(3):
+        assert np.array_equal(th[sweep][0], td[sweep][0]), "positions differ after sweep %d" % sweep
+        assert np.array_equal(th[sweep][1], td[sweep][1]), "fluxes differ after sweep %d" % sweep
+        assert np.array_equal(th[sweep][2], td[sweep][2])
+    assert gh.timing["rounds"] == gd.timing["rounds"] and gh.timing["evals"] == gd.timing["evals"]
+    assert gd.timing["evals"] >= 3 * 4 * S
+    for sweep in range(2):
+        u, _, active, before = td[sweep]
+        step = np.abs(u - before).max(axis=1)
+        assert active.sum() >= 0.99 * S
+        assert np.all(step[active] > 0), "a sampled source did not move"
+        assert np.all(step[~active] == 0)
+        # without stepping out a coordinate moves by less than the interval's width (1e-3 deg) -- a hard bound;
+        # all but a few faint, flat-likelihood sources stay within half of it
+        assert step.max() < 1e-3
+        assert np.mean(step < 5e-4) > 0.999 and np.median(step[active]) < 2e-5
+    assert np.abs(td[1][0] - f.src["radec"]).max() < 2e-3
+    # the rate term of the flux conditional at the chain's current state, against the oracle
+    sset = gd._sources(gd.fields[0])
+    mass = f.images.stamp_mass(sset)
+    pick = np.random.RandomState(3).choice(S, 200, replace=False)
+    for b in range(B):
+        band = f.bands[b].copy()
+        band[36] = f.images.band(b)[36]                      # R as the library computed it (pinned by test_fitsimage_radius_matches_reference)
+        for s in pick:
+            p, _, _ = orc.source_patch(band, f.H, f.W, gd.typ[s], gd.u[s], gd.shape[s])
+            want = 0.0 if p is None else p.sum()
+            np.testing.assert_allclose(mass[s, b], want, rtol=1e-10, atol=1e-300)
