@@ -496,9 +496,17 @@ def run_gibbs(args, env):
     S, B, H, W, fg = synth.CONFIGS[base]
     gf = celeste_mcmc.GibbsField(field.images, list(range(B)), field.bands[:, 2], field.bands[:, 1], H * W)
     slice_args = dict(step_out=False, sigma=args.slice_sigma)
-    g = celeste_mcmc.ModelGibbs([gf], field.src["type"], field.src["radec"], field.flux5(), field.src["shape"],
-                                seed=1 + 1000 * rank, slice_args=slice_args)       # one independent chain per rank
-    reducer = dist.LoglikReducer(1, device=local, depth=2) if world > 1 else None
+    strong = args.scaling == "strong"
+    if strong:
+        # ONE chain on all the GPUs: same seed everywhere, the sources dealt to the ranks for the
+        # per-source updates, one all-gather of the new locations and fluxes per sweep
+        deal = dist.SourceDeal(S, world, rank, device=local)
+        g = celeste_mcmc.ModelGibbs([gf], field.src["type"], field.src["radec"], field.flux5(), field.src["shape"],
+                                    seed=1, slice_args=slice_args, deal=deal)
+    else:
+        g = celeste_mcmc.ModelGibbs([gf], field.src["type"], field.src["radec"], field.flux5(), field.src["shape"],
+                                    seed=1 + 1000 * rank, slice_args=slice_args)   # one independent chain per rank
+    reducer = dist.LoglikReducer(1, device=local, depth=2) if (world > 1 and not strong) else None
     trace = []
 
     def step():
@@ -525,7 +533,8 @@ def run_gibbs(args, env):
     t_ll, n_ll = ctx.profile_get("stamps")          # cel_patch_loglik_multi + split + mass launches
     t_render, n_render = ctx.profile_get("render")
     ctx.profile(False)
-    dt_max, (updates,) = reduce_over_ranks(torch, world, local, dt, [float(g.active.sum()) * args.steps])
+    mine = g.active if not strong else (g.active & g.deal.mask)
+    dt_max, (updates,) = reduce_over_ranks(torch, world, local, dt, [float(mine.sum()) * args.steps])
     if rank != 0:
         return
     areas = gf.iset.sample_box_areas()
@@ -539,7 +548,7 @@ def run_gibbs(args, env):
         "metric": "end-to-end samples/sec, slice-sampling Gibbs sweeps over the 10k-source x %d-band x %d^2 synthetic field" % (B, H),
         "value": updates / dt_max, "unit": "source updates (samples)/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "gibbs10k", "sources": S, "bands": B, "frame": [H, W], "galaxy_fraction": fg,
                    "sweep": "photon split of all bands + sky level (models.py:123-160), then per source: flux Gamma "
                             "conditionals (sources.py:321-349) and location by slice sampling (sources.py:308-319), "
@@ -548,8 +557,11 @@ def run_gibbs(args, env):
                                  note="sigma in degrees.  The reference's call passes step=du/5=0.001 deg, which its "
                                       "slicesample ignores (sigma stays 1.0 deg); 0.001 is the call's intent and this "
                                       "bench's default, --slice-sigma 1.0 runs the literal behaviour"),
-                   "parallelism": "%d independent chain(s), 1 per GPU, over the same field; 1 all-reduce of the chains' "
-                                  "log-likelihood per sweep" % world,
+                   "parallelism": ("ONE chain on %d GPU(s): the photon split replicated (counter-based draws, bitwise equal on every "
+                                   "rank), the sources dealt round-robin to the ranks for the flux and location updates, 1 all-gather "
+                                   "of 7 doubles per source per sweep; the chain is the 1-GPU chain bit for bit" % world) if strong else
+                                  ("%d independent chain(s), 1 per GPU, over the same field; 1 all-reduce of the chains' "
+                                   "log-likelihood per sweep" % world),
                    "ranks": world, "collective_backend": env["backend"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": "k_patch_ll_hw (one slice round: host + launch, wall clock)",
@@ -559,7 +571,8 @@ def run_gibbs(args, env):
                  "sources_updated_per_sweep": float(g.active.sum())},
         "sweep_ms": {"photon_split_and_sky": g.timing["split"] / args.steps * 1e3, "flux": g.timing["flux"] / args.steps * 1e3,
                      "location_slice": g.timing["location"] / args.steps * 1e3,
-                     "trace_render": dt / args.steps * 1e3 - (g.timing["split"] + g.timing["flux"] + g.timing["location"]) / args.steps * 1e3},
+                     "merge_all_gather": g.timing.get("merge", 0.0) / args.steps * 1e3,
+                     "trace_render": dt / args.steps * 1e3 - (g.timing["split"] + g.timing["flux"] + g.timing["location"] + g.timing.get("merge", 0.0)) / args.steps * 1e3},
         "device_ms_per_sweep": {"per_source_kernels (split, mass, conditional ll)": t_ll * n_ll / args.steps,
                                 "k_render (split totals + trace)": t_render * n_render / args.steps},
         "loglik_before": ll0, "loglik_trace_tail": trace[-3:], "cpu_baseline": None}))
@@ -579,8 +592,9 @@ def main():
                     help="render tile geometry: 0 = 64x32 (k_render), 1 = 32x64 half-wave (k_render_hw)")
     ap.add_argument("--cpu-sample", type=int, default=400, help="sources in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="render workloads.  weak (default, what the driver runs): one field per GPU.  strong: ONE "
-                         "field cut into row strips, one per GPU (cel_images_set_window), total work fixed")
+                    help="weak (default, what the driver runs): one field (gibbs10k: one chain) per GPU.  strong: ONE "
+                         "field cut into row strips, one per GPU (cel_images_set_window), total work fixed; gibbs10k: ONE "
+                         "chain, its sources dealt to the GPUs")
     ap.add_argument("--n-fields", type=int, default=8, help="fields8_2048: number of fields dealt to the ranks")
     ap.add_argument("--streams", type=int, default=1,
                     help="fields8_2048: contexts (HIP streams, a host thread each) per GPU the rank's fields run on; 2 is 3 %% faster, "

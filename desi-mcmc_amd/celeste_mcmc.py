@@ -65,6 +65,7 @@ class GibbsField(object):
         self.epsilon = np.array(iset.eps, copy=True)
         self.sset = None
         self.prop = None
+        self.sub = None             # this rank's sources of a dealt chain (resample_fluxes)
         self.has_patch = None
 
 
@@ -89,7 +90,8 @@ class ModelGibbs(object):
 
     BANDS = ['u', 'g', 'r', 'i', 'z']
 
-    def __init__(self, fields, typ, u, fluxes, shape, seed=0, flux_a_0=5., flux_b_0=.005, slice_args=None, engine="auto"):
+    def __init__(self, fields, typ, u, fluxes, shape, seed=0, flux_a_0=5., flux_b_0=.005, slice_args=None, engine="auto",
+                 deal=None):
         self.fields = list(fields)
         self.typ = np.ascontiguousarray(typ, dtype=np.int32)
         self.S = self.typ.shape[0]
@@ -114,6 +116,13 @@ class ModelGibbs(object):
         self.engine = engine
         self.sweeps = 0
         self.timing = dict(split=0.0, flux=0.0, location=0.0, rounds=0, evals=0)
+        # ONE chain over several GPUs: `deal` (dist.SourceDeal) names the sources this rank
+        # updates.  Every rank runs the same photon split (counter-based draws: the replicas are bitwise equal) and
+        # the same host draws (same seed), updates the fluxes and locations of ITS sources only, and the ranks
+        # exchange the new rows with one all-gather per sweep.  The chain is the single-rank chain, bit for bit.
+        self.deal = deal
+        if deal is not None and deal.S != self.S:
+            raise ValueError("the deal is over %d sources, the catalogue has %d" % (deal.S, self.S))
         self._pool = None               # one worker thread: device calls that run beside host-side draws
         self.noise_sums = None
         self.active = np.ones(self.S, dtype=bool)
@@ -205,10 +214,20 @@ class ModelGibbs(object):
                 band_counts[:, f.band_index[b]] += f.sums[:, b]
         a_n = self.flux_a_0 + band_counts
 
+        mine = None if self.deal is None or self.deal.world == 1 else self.deal.mine
+
         def rates():        # the device's part (a ctypes call: runs beside the host's draws below)
             psf_sums = np.zeros((self.S, 5))
             for f in self.fields:
-                mass = f.iset.stamp_mass(f.sset) * f.has_patch          # sum of the unit stamp on its own box
+                if mine is None:
+                    mass = f.iset.stamp_mass(f.sset) * f.has_patch      # sum of the unit stamp on its own box
+                else:                   # this rank's sources only; a (source, band) value does not depend on the batch
+                    from . import field as _field
+                    if getattr(f, "sub", None) is None or f.sub.capacity < mine.size:
+                        f.sub = _field.SourceSet(f.iset.ctx, max(mine.size, 1), f.iset.B)
+                    f.sub.set(self.typ[mine], self.u[mine], self.counts(f, idx=mine), self.shape[mine])
+                    mass = np.zeros((self.S, f.iset.B))
+                    mass[mine] = f.iset.stamp_mass(f.sub) * f.has_patch[mine]
                 for b in range(f.iset.B):
                     psf_sums[:, f.band_index[b]] += mass[:, b] * (f.kappa[b] / f.calib[b])
             return self.flux_b_0 + psf_sums
@@ -226,7 +245,7 @@ class ModelGibbs(object):
         if worker_error is not None:
             raise worker_error
         new = g * (1. / fut.result())
-        self.fluxes = np.where(self.active[:, None], new, self.fluxes)
+        self.fluxes = np.where(self.active[:, None], new, self.fluxes)       # rows of other ranks' sources: merged at the sweep's end
         self.timing["flux"] += time.perf_counter() - t0
         return self.fluxes
 
@@ -261,14 +280,17 @@ class ModelGibbs(object):
             if not self._device_engine_applies():
                 raise ValueError("the device slice sampler runs one field with step_out=False, compwise=True")
             f = self.fields[0]
-            sset = self._sources(f)                        # the catalogue with the fluxes just drawn
-            new_u, _, st = f.iset.slice_locations(sset, self.slice_args.get("sigma", 1.0), self.seed * 7919 + self.sweeps)
+            sset = self._sources(f)                        # the catalogue with the fluxes just drawn (other ranks' rows are
+            # stale until the merge: a chain reads only its own source's counts)
+            ids = None if self.deal is None or self.deal.world == 1 else self.deal.chain_ids()
+            new_u, _, st = f.iset.slice_locations(sset, self.slice_args.get("sigma", 1.0), self.seed * 7919 + self.sweeps,
+                                                  chain_ids=ids)
             self.u = new_u
             self.timing["rounds"] += st["rounds"]
             self.timing["evals"] += st["evals"]
             self.timing["location"] += time.perf_counter() - t0
             return self.u
-        act = np.nonzero(self.active)[0]
+        act = np.nonzero(self.active if self.deal is None else (self.active & self.deal.mask))[0]
         for f in self.fields:
             f._counts = self.counts(f)
         if act.size:
@@ -289,7 +311,18 @@ class ModelGibbs(object):
         self.resample_photons()
         self.resample_fluxes()
         self.resample_locations()
+        self.merge_ranks()
         self.sweeps += 1
+
+    def merge_ranks(self):
+        """one chain over several GPUs: every rank's new fluxes and locations to every rank (one all-gather)"""
+        if self.deal is None or self.deal.world == 1:
+            return
+        import time
+        t0 = time.perf_counter()
+        both = self.deal.merge(np.concatenate([self.u, self.fluxes], axis=1))
+        self.u, self.fluxes = np.ascontiguousarray(both[:, :2]), np.ascontiguousarray(both[:, 2:])
+        self.timing["merge"] = self.timing.get("merge", 0.0) + time.perf_counter() - t0
 
     def log_likelihood(self):
         """sum of img_log_likelihood over every image of every field at the current state (models.py:104-108)"""

@@ -1214,6 +1214,11 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     hipLaunchKernelGGL(k_job_work, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, src->d_type, im->d_snz, S, B, d_work);
     hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, d_work, (int)(S * B), d_jobs);
     int64_t rounds = 0, evals = 0, queued = 0, live = S;
+    if (chain_ids) {                    // chains with a negative id are another rank's: they never run here
+        live = 0;
+        for (int64_t s = 0; s < S; s++) live += chain_ids[s] >= 0;
+        if (live < 1) live = 1;         // a launch needs a block; k_slice_live_jobs finds nothing to run
+    }
     int *h_flags = reinterpret_cast<int *>(c->pinned + MAX_BANDS + 2);
     int rc = CEL_OK;
     // The chains advance on the device alone (propose -> records -> likelihoods -> consume), so rounds

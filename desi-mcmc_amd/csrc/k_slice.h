@@ -69,8 +69,9 @@ k_slice_init(SliceState st, int64_t S, const double *__restrict__ radec, const i
     const double u0 = sl_uniform(st, s), u1 = sl_uniform(st, s);
     st.first[s] = (u1 < u0) ? 1 : 0;
     st.kdir[s] = 0;
-    // a source without any sample patch is left alone (the reference asserts there, sources.py:243)
-    const bool has_patch = soff[(s + 1) * B] > soff[s * B];
+    // a source without any sample patch is left alone (the reference asserts there, sources.py:243); so is one
+    // whose chain id is negative: it is another rank's to update (one chain dealt over several GPUs)
+    const bool has_patch = soff[(s + 1) * B] > soff[s * B] && !(chain_ids && chain_ids[s] < 0);
     if (has_patch) sl_start_direction(st, s, sigma);
     else st.phase[s] = SL_FINAL;
     owner[s] = has_patch ? (int)s : -1;

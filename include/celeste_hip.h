@@ -237,7 +237,9 @@ int cel_stamp_mass(cel_images *img, cel_sources *src, double *mass);
  * unfinished chain's next point is scored by the conditional-likelihood kernel (mode 0 of
  * cel_patch_loglik_multi, resident form) and the chains advance; rounds are queued four at a time and
  * four counters (chains running, error bits, evaluations, rounds that had work) cross PCIe per batch.
- * A source without any sample patch is left where it is.  Random numbers: one SplitMix64 stream per
+ * A source without any sample patch is left where it is, and so is one with chain_ids[s] < 0 (when ONE
+ * chain is dealt over several GPUs each rank updates only its own sources and the ranks exchange the
+ * new locations afterwards).  Random numbers: one SplitMix64 stream per
  * chain keyed by (seed, chain_ids[s] or s), in the reference's draw order -- the same streams and
  * arithmetic as the host engine of the Python mirror (util/infer/slicesample.py), chain for chain.
  *   radec_out  S*2 (host, may be NULL): the new locations; they also REPLACE src's locations on the device

@@ -64,6 +64,68 @@ def _worker(rank, world, port, mode, out_dir):
     td.destroy_process_group()
 
 
+def _deal_target(idx, P):
+    """a per-chain log-density (chain c is a Gaussian about (c, -c) of width 1 + c / 10): the stand-in for the
+    conditional likelihood of source c given the photon split"""
+    c = np.asarray(idx, dtype=np.float64)
+    return -0.5 * np.sum((P - np.stack([c, -c], axis=1)) ** 2, axis=1) / (1.0 + c / 10.0) ** 2
+
+
+def _deal_worker(rank, world, port, out_dir):
+    """ONE chain's per-source updates dealt to the ranks (dist.SourceDeal): every rank updates its own
+    sources with the lock-step slice sampler and the rows are exchanged with one all-gather"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from desi_mcmc_amd import dist
+    from desi_mcmc_amd.util.infer.slicesample import slicesample_lockstep
+    dist.init_from_env(backend="gloo")
+    S = 37                                                        # not a multiple of the world: the last rows are padded
+    deal = dist.SourceDeal(S, world, rank)
+    assert deal.mine.tolist() == list(range(rank, S, world)) and deal.mask.sum() == deal.mine.size
+    ids = deal.chain_ids()
+    assert np.array_equal(ids[deal.mine], deal.mine) and np.all(ids[~deal.mask] == -1)
+    X = np.column_stack([np.arange(S, dtype=np.float64), -np.arange(S, dtype=np.float64)]) + 0.25
+    extra = np.arange(S * 5, dtype=np.float64).reshape(S, 5)
+    for sweep in range(3):
+        new, _ = slicesample_lockstep(X[deal.mine], lambda i, P: _deal_target(deal.mine[i], P), sigma=1.5,
+                                      seed=100 + sweep, chain_ids=deal.mine)
+        X[deal.mine] = new
+        extra[deal.mine] += 1000.0 * (sweep + 1)                  # the "fluxes": also only this rank's rows
+        both = deal.merge(np.concatenate([X, extra], axis=1))
+        X, extra = both[:, :2].copy(), both[:, 2:].copy()
+    with pytest.raises(ValueError):
+        deal.merge(np.zeros((S + 1, 2)))
+    np.savez(os.path.join(out_dir, "deal_%d.npz" % rank), X=X, extra=extra)
+    dist.barrier()
+    import torch.distributed as td
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_chain_dealt_to_the_ranks_equals_the_single_rank_chain(tmp_path, world):
+    """the partition of SURVEY 8e for config 5: sources dealt round-robin, one all-gather per sweep; every
+    rank ends with the same state, and it is the state a single rank computes -- bit for bit (a chain's
+    random stream does not depend on which chains run beside it)"""
+    import torch.multiprocessing as mp
+    from desi_mcmc_amd import dist
+    from desi_mcmc_amd.util.infer.slicesample import slicesample_lockstep
+    mp.spawn(_deal_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    S = 37
+    X = np.column_stack([np.arange(S, dtype=np.float64), -np.arange(S, dtype=np.float64)]) + 0.25
+    extra = np.arange(S * 5, dtype=np.float64).reshape(S, 5)
+    for sweep in range(3):
+        X, _ = slicesample_lockstep(X, _deal_target, sigma=1.5, seed=100 + sweep)
+        extra += 1000.0 * (sweep + 1)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "deal_%d.npz" % r))
+        assert np.array_equal(got["X"], X) and np.array_equal(got["extra"], extra)
+    one = dist.SourceDeal(S)                                      # a world of one: merge is a copy, every source is mine
+    assert one.mine.size == S and np.array_equal(one.merge(X), X)
+    with pytest.raises(ValueError):
+        dist.SourceDeal(S, 2, 2)
+
+
 @pytest.mark.parametrize("mode", ["strips", "fields"])
 def test_world2_gloo_loglik_allreduce(tmp_path, mode):
     import torch.multiprocessing as mp

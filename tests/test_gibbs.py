@@ -5,6 +5,8 @@ Source.resample / resample_fluxes / resample_location (sources.py:242-349).
 RNG parity with the reference (randomkit + numpy's global MT19937) is impossible; what is checked:
 exact photon conservation, the Gamma conditionals' parameters, agreement of the batched device
 likelihood with the per-object one, and the posterior a short chain reaches for a bright star."""
+import os
+
 import numpy as np
 import pytest
 
@@ -560,3 +562,40 @@ def test_config5_full_size_sweeps(cel, orc):
             p, _, _ = orc.source_patch(band, f.H, f.W, gd.typ[s], gd.u[s], gd.shape[s])
             want = 0.0 if p is None else p.sum()
             np.testing.assert_allclose(mass[s, b], want, rtol=1e-10, atol=1e-300)
+
+
+@pytest.mark.parametrize("engine", ["device", "host"])
+def test_one_chain_on_two_ranks_is_the_single_rank_chain(cel, tmp_path, engine):
+    """ONE Gibbs chain partitioned over the GPUs.  Two fresh child processes (sharing GPU 0,
+    gloo for the exchange -- the arithmetic of bench.py --workload gibbs10k --scaling strong, which runs the same
+    dist.SourceDeal over RCCL) each run the replicated photon split and update the fluxes and locations of THEIR
+    sources only; one all-gather per sweep.  After every one of 3 sweeps both ranks hold the state the single-rank
+    chain (run here, in this process) holds: locations, fluxes, sky levels and the field log-likelihood, bit for bit."""
+    import socket
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _dealt_chain_rank import run_chain
+    S, size, sweeps = 600, 512, 3
+    one = run_chain(S, size, sweeps, engine)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dealt_chain_rank.py"),
+                                       str(tmp_path / ("rank%d.npz" % r)), str(S), str(size), str(sweeps), engine],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    evals = 0
+    for r in range(2):
+        got = np.load(str(tmp_path / ("rank%d.npz" % r)))
+        for k in ("u", "fluxes", "eps", "ll", "active"):
+            assert np.array_equal(got[k], one[k]), (r, k)
+        evals += int(got["evals"])
+    assert evals == int(one["evals"])                      # the two ranks shared the single chain's evaluations ...
+    assert 0.3 < int(got["evals"]) / evals < 0.7           # ... about evenly
+    assert np.all(np.abs(one["u"][-1] - one["u"][0]).max(axis=1)[one["active"]] > 0)
