@@ -231,3 +231,17 @@ def galaxy_source_like_grad(th, Z_s, images, check_overlap=True, unconstrained=F
     lls = _source_like_batch(ths, Z_s, images, limits)
     grad_RU = (lls[0::2] - lls[1::2]) / (2. * 1e-5)                                      # :72-80
     return np.concatenate([[grad_theta_s], grad_RU, np.array([grad_bs[b] for b in BANDS])])
+
+
+def galaxy_shape_prior_constrained(theta, sig, phi, rho, phi_max=180.):
+    """log prior of a galaxy's shape, -inf outside theta in (0,1), sig > 0, phi in (0, phi_max), rho in (0,1);
+    inside, the unnormalised inverse-gamma(1, 1) log-density of sig^2 -- celeste_galaxy_conditionals.py:268-275
+    with util/like/like_list.py:18-27.  Arrays broadcast.  The reference bounds phi by pi (its samplers think in
+    radians) while its renderer reads phi in DEGREES (:97, Q7); the default here is the renderer's unit, 180;
+    phi_max=np.pi is the literal bound."""
+    theta, sig, phi, rho = np.broadcast_arrays(*[np.asarray(v, dtype=np.float64) for v in (theta, sig, phi, rho)])
+    inside = (theta > 0.) & (theta < 1.) & (sig > 0.) & (phi > 0.) & (phi < phi_max) & (rho > 0.) & (rho < 1.)
+    out = np.full(theta.shape, -np.inf)
+    s2 = np.where(inside, sig * sig, 1.0)
+    out[inside] = (-2. * np.log(s2) - 1. / s2)[inside]
+    return out if out.ndim else float(out)

@@ -91,7 +91,7 @@ class ModelGibbs(object):
     BANDS = ['u', 'g', 'r', 'i', 'z']
 
     def __init__(self, fields, typ, u, fluxes, shape, seed=0, flux_a_0=5., flux_b_0=.005, slice_args=None, engine="auto",
-                 deal=None):
+                 deal=None, shape_args=None, shape_logprior=None, phi_period=180.):
         self.fields = list(fields)
         self.typ = np.ascontiguousarray(typ, dtype=np.int32)
         self.S = self.typ.shape[0]
@@ -107,6 +107,18 @@ class ModelGibbs(object):
         # Q15).  The default here is the call's INTENT (sigma = 0.001 deg); slice_args="literal" asks for the
         # call as the reference executes it.
         self.slice_args = self.slice_preset(slice_args)
+        # the galaxies' shape step (celeste_mcmc.py:224-243, slice_sample_skew): slicesample over (theta, sigma, phi,
+        # rho) along random directions with stepping out by doubling; sigma stays slicesample's default 1.0 there.
+        # The log-prior added to the conditional likelihood is the caller's (priors are outside this path); the
+        # default is the reference's galaxy_shape_prior_constrained with phi in the renderer's unit (degrees, Q7),
+        # and phi is wrapped into [0, phi_period) after the move as :241 wraps it into [0, pi).
+        self.shape_args = dict(step_out=True, doubling_step=True, compwise=False, numdir=4)
+        self.shape_args.update(shape_args or {})
+        self.phi_period = float(phi_period)
+        if shape_logprior is None:
+            from .celeste_galaxy_conditionals import galaxy_shape_prior_constrained
+            shape_logprior = lambda TH: galaxy_shape_prior_constrained(TH[:, 0], TH[:, 1], TH[:, 2], TH[:, 3], self.phi_period)   # noqa: E731
+        self.shape_logprior = shape_logprior
         # where the slice sampler's state machine runs: "device" (cel_slice_locations: nothing but a
         # counter crosses PCIe per round; one field, the reference call's options), "host" (the numpy
         # engine of util/infer/slicesample.py: every option, any number of fields), "auto" = device
@@ -115,7 +127,7 @@ class ModelGibbs(object):
             raise ValueError("engine must be auto, device or host")
         self.engine = engine
         self.sweeps = 0
-        self.timing = dict(split=0.0, flux=0.0, location=0.0, rounds=0, evals=0)
+        self.timing = dict(split=0.0, flux=0.0, location=0.0, rounds=0, evals=0, shape=0.0, shape_rounds=0, shape_evals=0)
         # ONE chain over several GPUs: `deal` (dist.SourceDeal) names the sources this rank
         # updates.  Every rank runs the same photon split (counter-based draws: the replicas are bitwise equal) and
         # the same host draws (same seed), updates the fluxes and locations of ITS sources only, and the ranks
@@ -266,6 +278,55 @@ class ModelGibbs(object):
             ll += f.iset.patch_loglik_resident(f.prop, owner)
         return ll
 
+    # -- the galaxies' shapes: celeste_mcmc.py:209-243 (skew_likelihood, slice_sample_skew) ---------------------------
+    def shape_logprob(self, idx, TH):
+        """skew_likelihood (celeste_mcmc.py:209-222) of chain idx[i] at shape TH[i] = (theta, sigma, phi, rho): the
+        log-prior, and where that is finite the source's conditional likelihood given its photons
+        (Source.log_likelihood(shape=...), sources.py:134-183) -- one launch for all of them"""
+        from . import field as _field
+        idx = np.asarray(idx, dtype=np.int64)
+        TH = np.asarray(TH, dtype=np.float64).reshape(idx.shape[0], 4)
+        out = np.asarray(self.shape_logprior(TH), dtype=np.float64).copy()
+        ok = np.isfinite(out)                       # outside the prior's support nothing is rendered (:213-214)
+        if not ok.any():
+            return out
+        sel = idx[ok]
+        ll = np.zeros(sel.shape[0])
+        owner = sel.astype(np.int32)
+        for f in self.fields:
+            if f.prop is None or f.prop.capacity < sel.shape[0]:
+                f.prop = _field.SourceSet(f.iset.ctx, max(2 * self.S, sel.shape[0], 16), f.iset.B)
+            cts = getattr(f, "_counts", None)
+            f.prop.set(self.typ[sel], self.u[sel], self.counts(f, idx=sel) if cts is None else cts[sel], TH[ok])
+            ll += f.iset.patch_loglik_resident(f.prop, owner)
+        out[ok] += ll
+        return out
+
+    def resample_shapes(self):
+        """slice_sample_skew (celeste_mcmc.py:224-243) for every galaxy at once: one slicesample update of
+        (theta, sigma, phi, rho) per galaxy -- random directions, stepping out by doubling -- all galaxies in
+        lock-step against the resident photon patches; phi is wrapped afterwards (:241).  Stars are skipped
+        (Source.resample_shape, sources.py:321-325)."""
+        import time
+        from .util.infer.slicesample import slicesample_lockstep
+        t0 = time.perf_counter()
+        mine = self.active if self.deal is None else (self.active & self.deal.mask)
+        gal = np.nonzero(mine & (self.typ == 1))[0]
+        for f in self.fields:
+            f._counts = self.counts(f)
+        if gal.size:
+            st = {}
+            new, _ = slicesample_lockstep(self.shape[gal], lambda i, TH: self.shape_logprob(gal[i], TH),
+                                          seed=self.seed * 104729 + self.sweeps, chain_ids=gal, stats=st, **self.shape_args)
+            new[:, 2] = (new[:, 2] + self.phi_period) % self.phi_period
+            self.shape[gal] = new
+            self.timing["shape_rounds"] += st["rounds"]
+            self.timing["shape_evals"] += st["evals"]
+        for f in self.fields:
+            f._counts = None
+        self.timing["shape"] += time.perf_counter() - t0
+        return self.shape
+
     def _device_engine_applies(self):
         a = self.slice_args
         return (len(self.fields) == 1 and not a.get("step_out", True) and a.get("compwise", True)
@@ -306,11 +367,15 @@ class ModelGibbs(object):
         self.timing["location"] += time.perf_counter() - t0
         return self.u
 
-    def sweep(self):
-        """CelesteBase.resample_model: every field's photons, then every source (fluxes, location)"""
+    def sweep(self, shapes=False):
+        """CelesteBase.resample_model: every field's photons, then every source (fluxes, location) -- and, with
+        shapes=True, the galaxies' shapes as sample_galaxy_params does (celeste_mcmc.py:166-243;
+        Source.resample_shape is a stub in the reference, sources.py:321-325, so it is off by default)"""
         self.resample_photons()
         self.resample_fluxes()
         self.resample_locations()
+        if shapes:
+            self.resample_shapes()
         self.merge_ranks()
         self.sweeps += 1
 
@@ -320,8 +385,9 @@ class ModelGibbs(object):
             return
         import time
         t0 = time.perf_counter()
-        both = self.deal.merge(np.concatenate([self.u, self.fluxes], axis=1))
-        self.u, self.fluxes = np.ascontiguousarray(both[:, :2]), np.ascontiguousarray(both[:, 2:])
+        both = self.deal.merge(np.concatenate([self.u, self.fluxes, self.shape], axis=1))
+        self.u, self.fluxes, self.shape = (np.ascontiguousarray(both[:, :2]), np.ascontiguousarray(both[:, 2:7]),
+                                           np.ascontiguousarray(both[:, 7:]))
         self.timing["merge"] = self.timing.get("merge", 0.0) + time.perf_counter() - t0
 
     def log_likelihood(self):

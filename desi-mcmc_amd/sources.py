@@ -270,9 +270,27 @@ class Source(object):
         self.params.u = u
         return u
 
-    def resample_shape(self):
-        """shape/extent of a galaxy: not implemented in the reference either (sources.py:321-325)"""
-        return
+    def resample_shape(self, rng=None, logprior=None, phi_period=180., **slice_args):
+        """shape / extent of a galaxy.  A TODO in the reference's Source (sources.py:321-325); the step run here is
+        its older sampler's slice_sample_skew (celeste_mcmc.py:209-243): one slicesample update of (theta, sigma,
+        phi, rho) along random directions with stepping out by doubling, on log-prior + conditional likelihood,
+        then phi wrapped into [0, phi_period).  Stars return at once, as in the reference."""
+        if self.is_star():
+            return
+        if logprior is None:
+            logprior = lambda th: gal_funs.galaxy_shape_prior_constrained(th[0], th[1], th[2], th[3], phi_period)   # noqa: E731
+
+        def skew_likelihood(th):
+            lp = logprior(th)
+            return lp + self.log_likelihood(shape=th) if np.isfinite(lp) else -np.inf
+        kw = dict(step_out=True, doubling_step=True, compwise=False, numdir=4)
+        kw.update(slice_args)
+        if "seed" not in kw:
+            kw["seed"] = int((np.random if rng is None else rng).randint(0, 2 ** 31 - 1))
+        th, _ = slicesample(np.array(self.params.shape, dtype=np.float64), skew_likelihood, **kw)
+        th[2] = (th[2] + phi_period) % phi_period
+        self.params.shape = th
+        return th
 
     # ---- star <-> galaxy move (sources.py:247-306) ------------------------------------------------
     # Re-designed for the device: the reference renders, per image, the current and the proposed source on

@@ -1,5 +1,5 @@
 """One rank of a Gibbs chain dealt over several processes (helper of tests/test_gibbs.py; not collected).
-Run with RANK / WORLD_SIZE / MASTER_* set:  python tests/_dealt_chain_rank.py OUT.npz S SIZE SWEEPS ENGINE
+Run with RANK / WORLD_SIZE / MASTER_* set:  python tests/_dealt_chain_rank.py OUT.npz S SIZE SWEEPS ENGINE SHAPES
 Builds the synthetic field (every rank the same), runs ModelGibbs with a dist.SourceDeal over the gloo
 process group (the ranks may share one GPU) and writes the chain's state after every sweep."""
 import os
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run_chain(S, size, sweeps, engine, deal=None, seed=4):
+def run_chain(S, size, sweeps, engine, deal=None, seed=4, shapes=False):
     import desi_mcmc_amd as cel
     from desi_mcmc_amd import celeste_mcmc, synth
     ctx = cel.default_context(0)
@@ -19,22 +19,24 @@ def run_chain(S, size, sweeps, engine, deal=None, seed=4):
     gf = celeste_mcmc.GibbsField(f.images, list(range(5)), f.bands[:, 2], f.bands[:, 1], size * size)
     g = celeste_mcmc.ModelGibbs([gf], f.src["type"], f.src["radec"], f.flux5(), f.src["shape"], seed=seed,
                                 engine=engine, deal=deal)
-    us, fls, eps, lls = [], [], [], []
+    us, fls, eps, lls, shs = [], [], [], [], []
     for _ in range(sweeps):
-        g.sweep()
+        g.sweep(shapes=shapes)
+        shs.append(g.shape.copy())
         us.append(g.u.copy())
         fls.append(g.fluxes.copy())
         eps.append(gf.epsilon.copy())
         lls.append(g.log_likelihood())
-    return dict(u=np.array(us), fluxes=np.array(fls), eps=np.array(eps), ll=np.array(lls),
-                evals=np.array(g.timing["evals"]), active=g.active.copy())
+    return dict(u=np.array(us), fluxes=np.array(fls), eps=np.array(eps), ll=np.array(lls), shape=np.array(shs),
+                evals=np.array(g.timing["evals"]), shape_evals=np.array(g.timing["shape_evals"]), active=g.active.copy())
 
 
 if __name__ == "__main__":
     out, S, size, sweeps, engine = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    shapes = sys.argv[6] == "1"
     from desi_mcmc_amd import dist
     rank, world, _ = dist.init_from_env(backend="gloo")
-    res = run_chain(S, size, sweeps, engine, deal=dist.SourceDeal(S, world, rank))
+    res = run_chain(S, size, sweeps, engine, deal=dist.SourceDeal(S, world, rank), shapes=shapes)
     np.savez(out, **res)
     dist.barrier()
     import torch.distributed as td

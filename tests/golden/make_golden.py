@@ -558,6 +558,22 @@ def gen_slicesample():
                     "c%d_draw_off" % ci: np.array(offs, dtype=np.int64), "c%d_perms" % ci: np.array(rec.perms, dtype=np.int64),
                     "c%d_x" % ci: np.array(xs), "c%d_llh" % ci: np.array(lls)})
     ref_ss.npr = np.random
+    # the log-prior slice_sample_skew adds to the likelihood (celeste_mcmc.py:209-214): inside and outside its support
+    rs = np.random.RandomState(77)
+    th = np.column_stack([rs.uniform(-0.2, 1.2, 200), rs.uniform(-0.5, 6.0, 200), rs.uniform(-0.5, 3.6, 200), rs.uniform(-0.2, 1.2, 200)])
+    out["prior_th"] = th
+    # galaxy_shape_prior_constrained (celeste_galaxy_conditionals.py:268-275) returns -inf outside its support and
+    # otherwise calls fast_inv_gamma_lnpdf, a name its module never imports (NameError): the support test is
+    # recorded from the function itself, the density from the function it means (util/like/like_list.py:18-27)
+    import CelestePy.util.like.like_list as ref_ll
+    lp = np.zeros(len(th))
+    for i, t in enumerate(th):
+        try:
+            lp[i] = ref_gal.galaxy_shape_prior_constrained(*t)
+            assert lp[i] == -np.inf
+        except NameError:
+            lp[i] = ref_ll.fast_inv_gamma_lnpdf(t[1] * t[1], a0=1., b0=1.)
+    out["prior_lp"] = lp
     save("slicesample.npz", **out)
 
 

@@ -569,15 +569,17 @@ def test_one_chain_on_two_ranks_is_the_single_rank_chain(cel, tmp_path, engine):
     """ONE Gibbs chain partitioned over the GPUs.  Two fresh child processes (sharing GPU 0,
     gloo for the exchange -- the arithmetic of bench.py --workload gibbs10k --scaling strong, which runs the same
     dist.SourceDeal over RCCL) each run the replicated photon split and update the fluxes and locations of THEIR
-    sources only; one all-gather per sweep.  After every one of 3 sweeps both ranks hold the state the single-rank
-    chain (run here, in this process) holds: locations, fluxes, sky levels and the field log-likelihood, bit for bit."""
+    sources only (the host-engine variant: the galaxies' shapes too); one all-gather per sweep.  After every one of
+    3 sweeps both ranks hold the state the single-rank chain (run here, in this process) holds: locations, fluxes,
+    shapes, sky levels and the field log-likelihood, bit for bit."""
     import socket
     import subprocess
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from _dealt_chain_rank import run_chain
     S, size, sweeps = 600, 512, 3
-    one = run_chain(S, size, sweeps, engine)
+    shapes = engine == "host"                   # the host-engine variant also runs the galaxies' shape step
+    one = run_chain(S, size, sweeps, engine, shapes=shapes)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -586,16 +588,108 @@ def test_one_chain_on_two_ranks_is_the_single_rank_chain(cel, tmp_path, engine):
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dealt_chain_rank.py"),
-                                       str(tmp_path / ("rank%d.npz" % r)), str(S), str(size), str(sweeps), engine],
+                                       str(tmp_path / ("rank%d.npz" % r)), str(S), str(size), str(sweeps), engine, "1" if shapes else "0"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     evals = 0
     for r in range(2):
         got = np.load(str(tmp_path / ("rank%d.npz" % r)))
-        for k in ("u", "fluxes", "eps", "ll", "active"):
+        for k in ("u", "fluxes", "eps", "ll", "active", "shape"):
             assert np.array_equal(got[k], one[k]), (r, k)
         evals += int(got["evals"])
+        assert (int(got["shape_evals"]) > 0) == shapes
     assert evals == int(one["evals"])                      # the two ranks shared the single chain's evaluations ...
     assert 0.3 < int(got["evals"]) / evals < 0.7           # ... about evenly
     assert np.all(np.abs(one["u"][-1] - one["u"][0]).max(axis=1)[one["active"]] > 0)
+
+
+def test_shape_logprob_vs_oracle_and_prior(cel, orc):
+    """ModelGibbs.shape_logprob = skew_likelihood (celeste_mcmc.py:209-222): log-prior + the conditional likelihood
+    as a function of (theta, sigma, phi, rho), against the oracle on the split's photons fetched to the host;
+    a shape outside the prior's support scores -inf and is never rendered"""
+    from desi_mcmc_amd import celeste_mcmc
+    from desi_mcmc_amd.celeste_galaxy_conditionals import galaxy_shape_prior_constrained as prior
+    imgs, params, pix, flux, nelec = small_scene(cel)
+    g = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params, seed=5)
+    g.resample_photons()
+    f = g.fields[0]
+    boxes, offs, data = f.iset.fetch_samples()
+    rs = np.random.RandomState(2)
+    idx = np.array([2, 3, 2, 3, 2, 3, 2])
+    TH = g.shape[idx] * rs.uniform(0.7, 1.4, size=(7, 4))
+    TH[:, 0] = np.clip(TH[:, 0], 0.05, 0.95)
+    TH[:, 3] = np.clip(TH[:, 3], 0.1, 0.95)
+    TH[4] = [1.2, 1.0, 30.0, 0.5]                      # theta outside (0, 1)
+    TH[5] = [0.5, -0.3, 30.0, 0.5]                     # negative radius
+    TH[6] = [0.5, 1.0, 30.0, 1.0]                      # rho on the boundary
+    got = g.shape_logprob(idx, TH)
+    assert np.all(got[4:] == -np.inf) and np.all(np.isfinite(got[:4]))
+    bands = orc.pack_bands(load_golden("bands_253.npz"))
+    for i in range(4):
+        s = idx[i]
+        want = prior(*TH[i])
+        for b in range(5):
+            band = bands[b].copy()
+            band[24:26] = [112 / 2.0, 96 / 2.0]
+            k = s * 5 + b
+            want += orc.patch_loglik(band, 96, 112, 1, g.u[s], TH[i], g.counts(f)[s, b], boxes[s, b], data[offs[k]:offs[k + 1]], mode=0)
+        np.testing.assert_allclose(got[i], want, rtol=1e-11)
+
+
+def _shape_fisher(cel, imgs, params, s):
+    """Cramer-Rao matrix of galaxy s's (sigma, rho) over all images, everything else fixed"""
+    from desi_mcmc_amd import models
+    m = models.Celeste()
+    m.initialize_sources(init_src_params=params)
+    info = np.zeros((2, 2))
+    p = params[s]
+    base = (p.sigma, p.rho)
+    for im in imgs:
+        lam = m.render_model_image(im)
+        d = []
+        for name, h in (("sigma", 1e-4), ("rho", 1e-4)):
+            v0 = getattr(p, name)
+            setattr(p, name, v0 + h)
+            lp = m.render_model_image(im)
+            setattr(p, name, v0 - h)
+            lm = m.render_model_image(im)
+            setattr(p, name, v0)
+            d.append((lp - lm) / (2 * h))
+        info += np.array([[np.sum(d[i] * d[j] / lam) for j in range(2)] for i in range(2)])
+    p.sigma, p.rho = base
+    return info
+
+
+def test_short_chain_recovers_a_bright_galaxys_shape(cel):
+    """sweeps with the shape step (slice_sample_skew, celeste_mcmc.py:224-243) on a scene whose brightest galaxy is
+    made 10x brighter: its (sigma, rho) posterior sits within a few Cramer-Rao errors of the truth with a spread of
+    that order; theta and phi stay in their supports; the stars' shape rows are never touched"""
+    from desi_mcmc_amd import celeste_mcmc
+    imgs, params, pix, flux, nelec = small_scene(cel)
+    params[2].fluxes = np.asarray(params[2].fluxes) * 10.0
+    from desi_mcmc_amd import models
+    from test_hip_parity import frame_images
+    m = models.Celeste()
+    m.initialize_sources(init_src_params=params)
+    rec = load_golden("bands_253.npz")
+    imgs0 = frame_images(cel, rec, 96, 112)
+    lam = np.stack([m.render_model_image(im) for im in imgs0])
+    imgs = frame_images(cel, rec, 96, 112, nelec=np.random.RandomState(13).poisson(lam).astype(np.float64))
+    cov = np.linalg.inv(_shape_fisher(cel, imgs, params, 2))
+    err = np.sqrt(np.diag(cov))
+    g = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params, seed=6)
+    truth = g.shape[2].copy()
+    keep = []
+    for it in range(60):
+        g.sweep(shapes=True)
+        if it >= 15:
+            keep.append(g.shape[2].copy())
+    keep = np.array(keep)
+    assert g.timing["shape_evals"] > 60 * 2 * 4 and g.timing["shape_rounds"] > 0
+    assert np.all(g.shape[:2] == 0.0)                                   # stars
+    assert np.all((keep[:, 0] > 0) & (keep[:, 0] < 1) & (keep[:, 2] >= 0) & (keep[:, 2] < 180))
+    mean, sd = keep[:, [1, 3]].mean(axis=0), keep[:, [1, 3]].std(axis=0)
+    assert np.all(np.abs(mean - truth[[1, 3]]) < 5 * err + 0.02), (mean, truth, err)
+    assert np.all(sd < 6 * err + 0.02) and np.all(sd > 0.15 * err), (sd, err)
+    assert abs(((keep[:, 2].mean() - truth[2] + 90) % 180) - 90) < 15   # the position angle, degrees

@@ -151,3 +151,18 @@ def test_scalar_api_and_bounds_checks():
         slicesample(np.array([1.0, 1.0]), lambda p: 0.0, upper_bound=np.array([0.5, 2.0]))
     with pytest.raises(Exception, match="NaN"):
         slicesample(np.array([0.0]), lambda p: float("nan") if abs(p[0]) > 1e-9 else 0.0, step_out=False, seed=1)
+
+
+def test_shape_prior_matches_the_reference():
+    """galaxy_shape_prior_constrained (celeste_galaxy_conditionals.py:268-275), the log-prior slice_sample_skew adds to
+    the conditional likelihood: support and values as the reference's own functions gave them (200 points in and
+    out of the support; phi bounded by pi as the reference bounds it).  The default bound is the renderer's unit."""
+    from desi_mcmc_amd.celeste_galaxy_conditionals import galaxy_shape_prior_constrained as prior
+    g = np.load(GOLD)
+    th, want = g["prior_th"], g["prior_lp"]
+    got = prior(th[:, 0], th[:, 1], th[:, 2], th[:, 3], phi_max=np.pi)
+    assert np.array_equal(got, want) and 40 < np.isfinite(want).sum() < 160
+    for t, w in zip(th[:20], want[:20]):
+        assert prior(*t, phi_max=np.pi) == w                       # scalar form
+    assert np.isfinite(prior(0.5, 1.0, 90.0, 0.5)) and prior(0.5, 1.0, 90.0, 0.5, phi_max=np.pi) == -np.inf
+    assert prior(0.5, 1.0, 180.0, 0.5) == -np.inf and prior(1.0, 1.0, 90.0, 0.5) == -np.inf
