@@ -42,17 +42,47 @@ FP64_VALU_PEAK_TF = 78.6     # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 FP64_LANE_OPS_PEAK = 3.93e13 # the same in lane-instructions per second (an fma counts once)
 FLOP_PER_GAUSS = 35.0        # SURVEY 8d accounting: 10 arithmetic + exp counted as 25
 
-# Per-launch PMC figures of the dominant kernel.  Counters cannot be read from inside this process
-# (rocprofv3 runs in its own passes: tools/pmc_pass.sh), so these are the committed measurements of
-# exactly this command, reported only for the configuration they were taken on (null otherwise):
+# Per-launch PMC figures of the dominant kernel.  Counters cannot be read from inside this process (rocprofv3
+# runs in its own passes: tools/profile_r03.sh), so they are READ AT RUN TIME from the committed summaries of
+# exactly this command -- and only when the summary was taken with the library that is loaded now (its sha256 is
+# stored in the profile): after any kernel change without a re-profile the fields print null instead of going stale.
 #   traffic = 2 * FETCH_SIZE + WRITE_SIZE (gfx950 correction, re-calibrated with tools/calib_traffic.hip)
 #   valu    = SQ_INSTS_VALU (wave-instructions), busy = 2 * SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES
-PMC = {   # (workload, kernel, tail_log, layout) -> dict
-    ("mixed10k_2048", "recurrence", 32.0, 1): dict(traffic=387331424.0, valu_insts=6.0091e+08, valu_busy=0.83,
-                                                   source="profiles/r02_final_pmc.json"),
-    ("stars10k_2048", "recurrence", 32.0, 1): dict(traffic=365595168.0, valu_insts=5.8377e+07, valu_busy=0.65,
-                                                   source="profiles/r02_stars_pmc.json"),
+PMC_PROFILES = {   # (workload, kernel, tail_log, layout) -> committed summary
+    ("mixed10k_2048", "recurrence", 32.0, 1): "profiles/r03_final_pmc.json",
+    ("stars10k_2048", "recurrence", 32.0, 1): "profiles/r03_stars_pmc.json",
 }
+
+
+def library_sha256():
+    import hashlib
+    from desi_mcmc_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def load_pmc(key, kernel="k_render_hw"):
+    """-> dict(traffic, valu_insts, valu_busy, source) from the committed summary, or dict(stale=reason)"""
+    rel = PMC_PROFILES.get(key)
+    if rel is None:
+        return None
+    path = os.path.join(ROOT, rel)
+    if not os.path.exists(path):
+        return {"stale": "%s not present" % rel}
+    prof = json.load(open(path))
+    have, want = prof.get("library_sha256"), library_sha256()
+    if have != want:
+        return {"stale": "%s was taken with library sha256 %s..., loaded is %s...: re-run tools/profile_r03.sh"
+                         % (rel, str(have)[:12], want[:12])}
+    ks = [k for k in prof["kernels"] if k.startswith(kernel)]
+    if not ks:
+        return {"stale": "%s holds no %s launches" % (rel, kernel)}
+    c = prof["kernels"][sorted(ks, key=lambda k: -prof["kernels"][k].get("SQ_INSTS_VALU", {}).get("last", 0.0))[0]]
+    last = lambda name: c[name]["last"]      # noqa: E731  -- the last launch: a timed-region step
+    return {"traffic": 2.0 * last("FETCH_SIZE") * 1024.0 + last("WRITE_SIZE") * 1024.0, "valu_insts": last("SQ_INSTS_VALU"),
+            "valu_busy": 2.0 * last("SQ_ACTIVE_INST_VALU") / last("SQ_WAVE_CYCLES"), "source": rel}
+
+
 CPU_THREADS_MAX = 16         # the GPU box's CPU share for one GPU
 
 RENDER_WORKLOADS = ("mixed10k_2048", "stars1k_512", "stars10k_2048", "stars2k_4096", "stamp51")
@@ -271,7 +301,10 @@ def run_render(args, env):
     if strong:   # rank 0's launch covers its strip of the pixels (and still reads every record)
         alg_bytes = 16.0 * B * (y1 - y0) * W + 128.0 * S * B
     achieved = alg_bytes / (t_render * 1e-3) / 1e9 if t_render > 0 else 0.0
-    pmc = None if strong else PMC.get((args.workload, args.kernel, args.tail_log, args.layout))
+    pmc = None if strong else load_pmc((args.workload, args.kernel, args.tail_log, args.layout))
+    pmc_note = None
+    if pmc is not None and "stale" in pmc:
+        pmc_note, pmc = pmc["stale"], None
     out = {
         # BASELINE.json's metric; `value` is its first half, `ms_per_step` its second
         "metric": ("source-pixel evals/sec + full-field log-lik ms, %s sources x %d bands x %d^2"
@@ -300,7 +333,7 @@ def run_render(args, env):
                    "ranks": world, "collective_backend": env["backend"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic"] if pmc else None,
-                     "traffic_source": pmc["source"] if pmc else None,
+                     "traffic_source": pmc["source"] if pmc else pmc_note,
                      "kernel": "k_render", "kernel_ms": t_render, "launches": n_render,
                      "algorithmic_bytes_per_launch": alg_bytes},
         "work": {"n_srcpix_per_step": n_srcpix_all, "n_gauss_per_step": n_gauss_all,
@@ -324,6 +357,8 @@ def run_render(args, env):
     out["fp64_valu"] = fp
     if world == 1 and not strong and args.legs == "all":
         extra_render_legs(args, env, field, out)
+        if args.workload == "mixed10k_2048":
+            out["secondary"] = secondary_legs(args, env, field)
     if world == 1 and args.cpu_sample > 0:
         from oracle import oracle as orc      # cpu_baseline leg only
         out["cpu_baseline"] = cpu_baseline(field, min(args.cpu_sample, S), orc)
@@ -404,6 +439,65 @@ def extra_render_legs(args, env, field, out):
                               "(python_api_list_ms: the per-object attribute gather dominates)" % len(plist))
     out["python_api_loglik_rel_diff"] = float(abs(ll_api - out["loglik"]) / abs(out["loglik"])) if out["loglik"] else None
     assert abs(ll_list - ll_api) <= 1e-12 * abs(ll_api)
+
+
+def secondary_legs(args, env, field):
+    """After the timed region of the default run (N = 1): bounded measurements of the OTHER configurations, so that the
+    driver's one line carries them too -- BASELINE configs[4] (Gibbs sweeps over this same field: samples/s and the
+    sweep's phases), configs[1] (stars1k_512) and the star-only regime where the HBM roof binds (stars10k_2048).
+    Each is what `bench.py --workload NAME` reports, on fewer steps; none of them touches the headline fields."""
+    torch, cel, dist, synth, ctx = env["torch"], env["cel"], env["dist"], env["synth"], env["ctx"]
+    from desi_mcmc_amd import celeste_mcmc
+    sec = {}
+    for name, steps in (("stars10k_2048", 100), ("stars1k_512", 200)):
+        f = synth.SyntheticField.from_config(ctx, name, seed=42)
+        S, B, H, W, fg = synth.CONFIGS[name]
+        for _ in range(30):
+            f.images.render(f.sources, loglik=True)
+        ctx.profile(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            f.images.render(f.sources, loglik=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t_render, n_render = ctx.profile_get("render")
+        ctx.profile(False)
+        st = f.images.stats()
+        alg = 16.0 * B * H * W + 128.0 * S * B
+        sec[name] = {"value": st["n_srcpix"] * steps / dt, "unit": "source-pixel evals/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+                     "roofline": {"bound": "hbm", "achieved": alg / (t_render * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": alg / (t_render * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "k_render", "kernel_ms": t_render,
+                                  "launches": n_render, "algorithmic_bytes_per_launch": alg}}
+        del f
+    S, B, H, W = field.S, field.B, field.H, field.W
+    gf = celeste_mcmc.GibbsField(field.images, list(range(B)), field.bands[:, 2], field.bands[:, 1], H * W)
+    g = celeste_mcmc.ModelGibbs([gf], field.src["type"], field.src["radec"], field.flux5(), field.src["shape"], seed=1)
+    eps0 = field.bands[:, 0].copy()
+    sweeps = 20
+    try:
+        for _ in range(3):
+            g.sweep()
+            g.log_likelihood()
+        for k in g.timing:
+            g.timing[k] = 0
+        ctx.profile(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(sweeps):
+            g.sweep()
+            g.log_likelihood()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        g.sweeps_timed = sweeps
+        rep = gibbs_report(g, gf, ctx, sweeps, dt, S, B)
+        ctx.profile(False)
+        sec["gibbs10k"] = dict({"value": float(g.active.sum()) * sweeps / dt, "unit": "source updates (samples)/s", "steps": sweeps,
+                                "ms_per_step": dt / sweeps * 1e3, "slice_sigma_deg": g.slice_args.get("sigma", 1.0)}, **rep)
+    finally:
+        for b in range(B):                      # the sweeps redrew the sky levels: the headline field gets its own back
+            field.images.set_epsilon(b, eps0[b])
+    return sec
 
 
 # ---- configs[3] stand-in: K fields dealt to ranks ----------------------------------------------------
@@ -487,6 +581,75 @@ def run_fields(args, env):
 
 
 # ---- configs[4]: Gibbs sweeps ------------------------------------------------------------------------
+def gibbs_cpu_baseline(field, g, gf, orc, n_sources=48):
+    """The CPU oracle (kind "port") on the location step of a BOUNDED sample of the same sweep: for each of the
+    sampled sources, as many conditional-likelihood evaluations (orc_patch_loglik, mode 0: the restatement of
+    Source.log_likelihood, sources.py:134-183) as the sampler made per source, in all bands, on the split's own
+    photon patches fetched to the host -- one thread per source on the host's cores (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    S, B = field.S, field.B
+    bands = field.bands.copy()
+    for b in range(B):
+        bands[b, 36] = field.images.band(b)[36]
+    boxes, offs, data = gf.iset.fetch_samples()
+    evals_per_source = max(1, int(round(g.timing["evals"] / max(g.sweeps_timed, 1) / max(float(g.active.sum()), 1.0))))
+    rs = np.random.RandomState(5)
+    pick = rs.choice(np.nonzero(g.active)[0], size=min(n_sources, int(g.active.sum())), replace=False)
+    cts = g.counts(gf)
+    jitter = rs.normal(0.0, 2e-5, size=(pick.size, evals_per_source, 2))
+    nthr = max(1, min(host_threads(), pick.size))
+    orc.set_threads(1)
+
+    def one(i):
+        s = pick[i]
+        tot = 0.0
+        for e in range(evals_per_source):
+            for b in range(B):
+                k = s * B + b
+                tot += orc.patch_loglik(bands[b], field.H, field.W, g.typ[s], g.u[s] + jitter[i, e], g.shape[s], cts[s, b],
+                                        boxes[s, b], data[offs[k]:offs[k + 1]], mode=0)
+        return tot
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=nthr) as pool:
+        list(pool.map(one, range(pick.size)))
+    dt = time.perf_counter() - t0
+    orc.set_threads(nthr)
+    return {"value": pick.size / dt, "unit": "source location updates/s", "cores": nthr, "kind": "port",
+            "sample": "%d of %d sources x %d conditional-likelihood evaluations (the sampler's mean per source) x %d bands on "
+                      "the split's photon patches, %.1f s wall (orc_patch_loglik, oracle/celeste_oracle.c; the location step "
+                      "only: it is 2/3 of the sweep)" % (pick.size, S, evals_per_source, B, dt)}
+
+
+def gibbs_report(g, gf, ctx, steps, dt, S, B):
+    """per-sweep figures of a timed run of ModelGibbs: phases, the conditional-likelihood kernel's own time (HIP events
+    attached to its launches) and the algorithmic bytes it walked (counted on the device)"""
+    t_ll, n_ll = ctx.profile_get("patch_ll")
+    t_split, n_split = ctx.profile_get("split")
+    t_mass, n_mass = ctx.profile_get("mass")
+    t_render, n_render = ctx.profile_get("render")
+    launches = max(g.timing.get("loc_launches", 0), 1)
+    alg_bytes = g.timing.get("loc_bytes", 0) / launches
+    achieved = alg_bytes / (t_ll * 1e-3) / 1e9 if t_ll > 0 else 0.0
+    known = g.timing["split"] + g.timing["flux"] + g.timing["location"] + g.timing.get("shape", 0.0) + g.timing.get("merge", 0.0)
+    return {
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "k_patch_ll_hw<0> (one slice round of every running chain)",
+                     "kernel_ms": t_ll, "launches": n_ll, "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "kernel_ms: HIP events attached to the kernel's dispatches, averaged over the timed sweeps' launches; bytes: "
+                             "per evaluation and band 8 B per pixel of the photon rectangle walked + a 128-B record, counted on the "
+                             "device.  The kernel is fp64-issue-bound like k_render (DESIGN.md 5); the HBM fraction is what the contract asks for"},
+        "work": {"slice_rounds_per_sweep": g.timing["rounds"] / steps, "loglik_evals_per_sweep": g.timing["evals"] / steps,
+                 "sources_updated_per_sweep": float(g.active.sum())},
+        "sweep_ms": {"photon_split_and_sky": g.timing["split"] / steps * 1e3, "flux": g.timing["flux"] / steps * 1e3,
+                     "location_slice": g.timing["location"] / steps * 1e3,
+                     "shape_slice": g.timing.get("shape", 0.0) / steps * 1e3,
+                     "merge_all_gather": g.timing.get("merge", 0.0) / steps * 1e3,
+                     "trace_render": (dt - known) / steps * 1e3},
+        "device_ms_per_sweep": {"k_patch_ll_hw<0> (location)": t_ll * n_ll / steps, "k_photon_split_hw": t_split * n_split / steps,
+                                "k_patch_ll_hw<3> (stamp mass)": t_mass * n_mass / steps,
+                                "k_render (split totals + trace)": t_render * n_render / steps}}
+
+
 def run_gibbs(args, env):
     torch, cel, dist, synth = env["torch"], env["cel"], env["dist"], env["synth"]
     rank, world, local, ctx = env["rank"], env["world"], env["local"], env["ctx"]
@@ -510,7 +673,7 @@ def run_gibbs(args, env):
     trace = []
 
     def step():
-        g.sweep()
+        g.sweep(shapes=args.shapes)
         ll = np.array([g.log_likelihood()])          # the chain's trace (one render)
         if reducer is not None:
             reducer.submit(ll)
@@ -530,21 +693,14 @@ def run_gibbs(args, env):
             trace.append(float(reducer.drain()[-1][0]))
     ll0 = g.log_likelihood()
     dt = Timer(dist, torch).run(step, args.warmup, args.steps, after_warmup, finish, prime=3)
-    t_ll, n_ll = ctx.profile_get("stamps")          # cel_patch_loglik_multi + split + mass launches
-    t_render, n_render = ctx.profile_get("render")
+    g.sweeps_timed = args.steps
+    rep = gibbs_report(g, gf, ctx, args.steps, dt, S, B)
     ctx.profile(False)
     mine = g.active if not strong else (g.active & g.deal.mask)
     dt_max, (updates,) = reduce_over_ranks(torch, world, local, dt, [float(mine.sum()) * args.steps])
     if rank != 0:
         return
-    areas = gf.iset.sample_box_areas()
-    # algorithmic HBM bytes of one conditional-likelihood launch: the photon patches of the scored
-    # proposals (8 B per patch pixel) + one 128-B record per (proposal, band)
-    evals_per_launch = g.timing["evals"] / max(g.timing["rounds"], 1)
-    alg_bytes = evals_per_launch * (8.0 * float(areas.sum()) / S + 128.0 * B)
-    ms_launch = g.timing["location"] / max(g.timing["rounds"], 1) * 1e3
-    achieved = alg_bytes / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
-    print(json.dumps({
+    out = {
         "metric": "end-to-end samples/sec, slice-sampling Gibbs sweeps over the 10k-source x %d-band x %d^2 synthetic field" % (B, H),
         "value": updates / dt_max, "unit": "source updates (samples)/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
@@ -552,30 +708,26 @@ def run_gibbs(args, env):
         "config": {"workload": "gibbs10k", "sources": S, "bands": B, "frame": [H, W], "galaxy_fraction": fg,
                    "sweep": "photon split of all bands + sky level (models.py:123-160), then per source: flux Gamma "
                             "conditionals (sources.py:321-349) and location by slice sampling (sources.py:308-319), "
-                            "all sources in lock-step; + one field log-likelihood per sweep (the trace)",
+                            "all sources in lock-step%s; + one field log-likelihood per sweep (the trace)"
+                            % ("; then every galaxy's shape by slice sampling (celeste_mcmc.py:224-243)" if args.shapes else ""),
                    "slice": dict(slice_args, compwise=True,
                                  note="sigma in degrees.  The reference's call passes step=du/5=0.001 deg, which its "
-                                      "slicesample ignores (sigma stays 1.0 deg); 0.001 is the call's intent and this "
-                                      "bench's default, --slice-sigma 1.0 runs the literal behaviour"),
+                                      "slicesample ignores (sigma stays 1.0 deg); 0.001 is the call's intent, the library's and "
+                                      "this bench's default; --slice-sigma 1.0 runs the literal behaviour"),
                    "parallelism": ("ONE chain on %d GPU(s): the photon split replicated (counter-based draws, bitwise equal on every "
                                    "rank), the sources dealt round-robin to the ranks for the flux and location updates, 1 all-gather "
-                                   "of 7 doubles per source per sweep; the chain is the 1-GPU chain bit for bit" % world) if strong else
+                                   "of 11 doubles per source per sweep; the chain is the 1-GPU chain bit for bit" % world) if strong else
                                   ("%d independent chain(s), 1 per GPU, over the same field; 1 all-reduce of the chains' "
                                    "log-likelihood per sweep" % world),
                    "ranks": world, "collective_backend": env["backend"]},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "k_patch_ll_hw (one slice round: host + launch, wall clock)",
-                     "kernel_ms": ms_launch, "launches": g.timing["rounds"], "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "fp64-issue-bound like k_render (DESIGN.md 5); the HBM fraction is reported because the contract asks for it"},
-        "work": {"slice_rounds_per_sweep": g.timing["rounds"] / args.steps, "loglik_evals_per_sweep": g.timing["evals"] / args.steps,
-                 "sources_updated_per_sweep": float(g.active.sum())},
-        "sweep_ms": {"photon_split_and_sky": g.timing["split"] / args.steps * 1e3, "flux": g.timing["flux"] / args.steps * 1e3,
-                     "location_slice": g.timing["location"] / args.steps * 1e3,
-                     "merge_all_gather": g.timing.get("merge", 0.0) / args.steps * 1e3,
-                     "trace_render": dt / args.steps * 1e3 - (g.timing["split"] + g.timing["flux"] + g.timing["location"] + g.timing.get("merge", 0.0)) / args.steps * 1e3},
-        "device_ms_per_sweep": {"per_source_kernels (split, mass, conditional ll)": t_ll * n_ll / args.steps,
-                                "k_render (split totals + trace)": t_render * n_render / args.steps},
-        "loglik_before": ll0, "loglik_trace_tail": trace[-3:], "cpu_baseline": None}))
+        "loglik_before": ll0, "loglik_trace_tail": trace[-3:]}
+    out.update(rep)
+    if world == 1 and args.cpu_sample > 0:
+        from oracle import oracle as orc      # cpu_baseline leg only
+        out["cpu_baseline"] = gibbs_cpu_baseline(field, g, gf, orc)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
 
 
 def main():
@@ -600,6 +752,7 @@ def main():
                     help="fields8_2048: contexts (HIP streams, a host thread each) per GPU the rank's fields run on; 2 is 3 %% faster, "
                          "but the kernels' event times then include each other")
     ap.add_argument("--slice-sigma", type=float, default=0.001, help="gibbs10k: slice-sampler interval width in degrees")
+    ap.add_argument("--shapes", action="store_true", help="gibbs10k: every sweep also resamples the galaxies' shapes")
     ap.add_argument("--legs", default="all", choices=["all", "none"],
                     help="render workloads at N=1: 'all' (default) adds the untimed-by-the-contract extras after the timed region "
                          "(evaluated-Gaussian count, fast tail preset, source-upload step, Python-API call); 'none' runs the "

@@ -349,6 +349,8 @@ class ModelGibbs(object):
             self.u = new_u
             self.timing["rounds"] += st["rounds"]
             self.timing["evals"] += st["evals"]
+            self.timing["loc_bytes"] = self.timing.get("loc_bytes", 0) + st["algorithmic_bytes"]
+            self.timing["loc_launches"] = self.timing.get("loc_launches", 0) + st["launches"]
             self.timing["location"] += time.perf_counter() - t0
             return self.u
         act = np.nonzero(self.active if self.deal is None else (self.active & self.deal.mask))[0]

@@ -429,6 +429,12 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         return CEL_OK;
     case CEL_OPT_DEBUG:
         if (!(v >= 0.0) || v > 4095.0) return fail(CEL_ERR_INVALID, "CEL_OPT_DEBUG must be in [0, 4095]");
+#ifndef CEL_ABLATE
+        // the shipped library carries no ablation path: only the two result-preserving diagnostic bits exist
+        if (((int)v) & ~(64 | 128))
+            return fail(CEL_ERR_INVALID, "CEL_OPT_DEBUG: the timing-only ablation bits exist only in a -DCEL_ABLATE build "
+                                         "(make -C desi-mcmc_amd/csrc ablate); this library accepts 64 and 128");
+#endif
         c->debug = (int)v;
         return CEL_OK;
     }
@@ -797,8 +803,12 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         pi = prof_slot(c, CEL_K_RENDER);
         if (im->TW == QW_TW)
             LAUNCH_EV(k_render_qw, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
-        else if (im->TW == HW_TW)
-            LAUNCH_EV(k_render_hw, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
+        else if (im->TW == HW_TW) {
+            // the production instantiation has no diagnostic code in it; counters, time stamps and (CEL_ABLATE
+            // builds) ablations live in the second one
+            if (a.timing || (c->debug & ~64)) LAUNCH_EV(k_render_hw<true>, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
+            else LAUNCH_EV(k_render_hw<false>, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
+        }
         else if (im->TH == 64)
             LAUNCH_EV((k_render<64>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
         else
@@ -1074,7 +1084,7 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
             PL_TRY(hipMemcpyAsync(d_data, data, sizeof(double) * offsets[nb], hipMemcpyHostToDevice, c->stream));
     }
     {
-        int pi = prof_begin(c, CEL_K_STAMPS);
+        int pi = prof_begin(c, CEL_K_PATCH_LL);
         if (c->variant == 0)
             hipLaunchKernelGGL(k_patch_ll, dim3((unsigned)(P * B)), dim3(256), 0, c->stream, im->d_bands, B, P, im->d_recs,
                                d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, mode, d_out);
@@ -1131,7 +1141,7 @@ int cel_stamp_mass(cel_images *im, cel_sources *src, double *mass) {
     if (rc) return rc;
     double *d_out = nullptr;
     if ((rc = scratch_get(c, 2, sizeof(double) * S * B, (void **)&d_out))) return rc;
-    int pi = prof_begin(c, CEL_K_STAMPS);
+    int pi = prof_begin(c, CEL_K_MASS);
     hipLaunchKernelGGL(k_patch_ll_hw<3>, dim3((unsigned)(S * B)), dim3(64), 0, c->stream, im->d_bands, B, S, im->d_recs,
                        (const int *)nullptr, (const int4 *)nullptr, (const int64_t *)nullptr, (const double *)nullptr,
                        (const double *)nullptr, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
@@ -1241,7 +1251,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
             hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags, queued == 0 ? 1 : 0);
             prop->gen = ++g_source_gen;
             if ((rc = run_prep(im, prop, d_owner))) return rc;
-            int pi = prof_slot(c, CEL_K_STAMPS);
+            int pi = prof_slot(c, CEL_K_PATCH_LL);
             if (c->variant == 0)
                 LAUNCH_EV(k_patch_ll, dim3((unsigned)(S * B)), dim3(256), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
                           d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, 0, d_ll);
@@ -1270,8 +1280,20 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     src->gen = ++g_source_gen;
     if (radec_out) HIP_TRY(hipMemcpyAsync(radec_out, ss.x, sizeof(double) * 2 * S, hipMemcpyDeviceToHost, st));
     if (llh_out) HIP_TRY(hipMemcpyAsync(llh_out, ss.new_llh, sizeof(double) * S, hipMemcpyDeviceToHost, st));
+    unsigned long long *d_bytes = reinterpret_cast<unsigned long long *>(((uintptr_t)(d_flags + 6) + 7) & ~(uintptr_t)7);
+    if (stats) {
+        // algorithmic bytes of the call: a chain made 1 + steps[s] evaluations (the first direction's level, then one
+        // per shrink step), each walking its photon rectangles
+        HIP_TRY(hipMemsetAsync(d_bytes, 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_slice_bytes, dim3(g256), dim3(256), 0, st, ss, S, B, (const int4 *)im->d_snz, d_bytes);
+        HIP_TRY(hipMemcpyAsync(h_flags + 6, d_bytes, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
-    if (stats) { stats[0] = rounds; stats[1] = evals; }
+    if (stats) {
+        stats[0] = rounds; stats[1] = evals;
+        stats[2] = (int64_t)(*reinterpret_cast<unsigned long long *>(h_flags + 6));
+        stats[3] = queued;
+    }
     return CEL_OK;
 }
 
@@ -1381,7 +1403,7 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         a.sums = fused_nz ? im->d_ssum : nullptr;
         a.debug = c->debug;
         if (hw && (rc = scratch_get(c, 2, sizeof(double) * 2 * (size_t)T, (void **)&a.partials))) return rc;
-        int pi = prof_begin(c, CEL_K_STAMPS);
+        int pi = prof_begin(c, CEL_K_SPLIT);
         if (hw) hipLaunchKernelGGL(k_photon_split_hw, dim3(2 * T), dim3(64), 0, c->stream, a);
         else hipLaunchKernelGGL(k_photon_split, dim3(T), dim3(64), 0, c->stream, a);
         prof_end(c, pi);
@@ -1476,7 +1498,7 @@ int cel_estep_stats(cel_images *im, cel_sources *src, double *xtilde, double *ma
         if ((rc = scratch_get(c, 4, sizeof(double) * S * B, (void **)&d_x)) ||
             (rc = scratch_get(c, 5, sizeof(double) * S * B, (void **)&d_m))) goto done;
         if (tiles && (rc = scratch_get(c, 6, sizeof(double) * 2 * (size_t)im->lists_cap, (void **)&d_part))) goto done;
-        int pi = prof_begin(c, CEL_K_STAMPS);
+        int pi = prof_begin(c, CEL_K_ESTEP);
         if (c->variant == 0)
             hipLaunchKernelGGL(k_estep_src, dim3((unsigned)(S * B)), dim3(256), 0, c->stream, im->d_bands, B, im->H, im->W,
                                S, im->d_recs, im->d_nelec, im->d_lambda, d_x, d_m);

@@ -13,6 +13,14 @@
 #pragma once
 #include "k_render.h"
 
+// timing-only ablation bits of CEL_OPT_DEBUG ride in bits 8.. of the render flags; they exist only in a
+// -DCEL_ABLATE build (tools/ablate_render.py builds its own library), never in the shipped one
+#ifdef CEL_ABLATE
+#define CEL_ABLATE_BITS(flags) ((flags) >> 8)
+#else
+#define CEL_ABLATE_BITS(flags) 0
+#endif
+
 #define HW_TW 32
 #define HW_TH 64
 #define HW_PAD 12   // zero components behind the compacted table: a half's group may read past the end
@@ -150,7 +158,9 @@ struct StarBatch {         // lane j's star of a tile's first batch, already in 
     bool valid;
 };
 
-// the first nstar entries of the tile's list (its stars) into the accumulator tile
+// the first nstar entries of the tile's list (its stars) into the accumulator tile.  DIAG: the tile-timing
+// counters and (CEL_ABLATE builds) the timing-only ablation switches; the production instantiation has neither.
+template <bool DIAG>
 __device__ __forceinline__ void star_pass(const RenderArgs &a, StarTab &ST, const double *__restrict__ et, double *__restrict__ acc,
                                           const SrcRec *__restrict__ recs, int64_t off, int nstar, int lane, int xi, int Y0,
                                           int strict, unsigned &dbg_halfrows, unsigned &dbg_pairs, const StarBatch *first = nullptr) {
@@ -201,8 +211,8 @@ __device__ __forceinline__ void star_pass(const RenderArgs &a, StarTab &ST, cons
                 ST.box[rank] = bx4;
             }
             __syncthreads();
-            if (a.timing) { dbg_pairs += (unsigned)nb; }
-            const int dbg = a.flags >> 8;
+            if (DIAG && a.timing) { dbg_pairs += (unsigned)nb; }
+            const int dbg = DIAG ? CEL_ABLATE_BITS(a.flags) : 0;
             for (int it = 0; 2 * it < nb && !(dbg & 2); it++) {
                 const bool valid = (2 * it + half) < nb;
                 const int j = min(2 * it + half, nb - 1);
@@ -213,7 +223,7 @@ __device__ __forceinline__ void star_pass(const RenderArgs &a, StarTab &ST, cons
                 const int rb = (valid && !(dbg & 1)) ? min(bx.w, Y0 + HW_TH) - Y0 : ra;
                 const bool on = (xi >= bx0) && (xi < bx.y);
                 const double amp = on ? ST.scale[j] : 0.0;
-                if (a.timing) {      // kept component-rows of the step = both halves' rows x 3; counted as half-tile widths
+                if (DIAG && a.timing) {      // kept component-rows of the step = both halves' rows x 3; counted as half-tile widths
                     const int rows_lo = __builtin_amdgcn_readlane(max(rb - ra, 0), 0), rows_hi = __builtin_amdgcn_readlane(max(rb - ra, 0), 32);
                     dbg_halfrows += (unsigned)(rows_lo + rows_hi) * K_PSF;
                 }
@@ -267,7 +277,7 @@ __device__ __forceinline__ void star_pass(const RenderArgs &a, StarTab &ST, cons
 // star table's LDS, dead by now: it takes the log table (128 doubles).  All 32 nelec loads of a lane
 // are issued before the first use (16 KB in flight per wave); PRE (nelec already in registers) is
 // kept for experiments.
-template <bool PRE>
+template <bool PRE, bool DIAG = false>
 __device__ __forceinline__ void hw_epilogue(const RenderArgs &a, const double *__restrict__ acc, double *__restrict__ lt,
                                             const BandDev *__restrict__ bd, int tile, int b, int xi, int Y0, int lane,
                                             const double *ne_pre) {
@@ -281,7 +291,8 @@ __device__ __forceinline__ void hw_epilogue(const RenderArgs &a, const double *_
     const bool ll = (a.flags & CEL_RENDER_LOGLIK) != 0;
     double part = 0.0;
     const int64_t plane = (int64_t)b * a.H * a.W;
-    if (xi < a.W && !((a.flags >> 8) & 16)) {
+    const int dbg = DIAG ? CEL_ABLATE_BITS(a.flags) : 0;
+    if (xi < a.W && !(dbg & 16)) {
         const int64_t base = plane + (int64_t)(Y0 + half) * a.W + xi;
         double ne[HW_TH / 2];
 #pragma unroll
@@ -292,7 +303,7 @@ __device__ __forceinline__ void hw_epilogue(const RenderArgs &a, const double *_
             if (Y0 + 2 * r + half < a.H) {
                 double lam = eps + acc[r * 64 + lane];
                 if (store) a.lambda[base + (int64_t)(2 * r) * a.W] = lam;
-                if (ll) part += ((a.flags >> 8) & 4) ? ne[r] - lam : ne[r] * log_tab(lam, lt) - lam;
+                if (ll) part += (dbg & 4) ? ne[r] - lam : ne[r] * log_tab(lam, lt) - lam;
             }
         }
     }
@@ -303,6 +314,11 @@ __device__ __forceinline__ void hw_epilogue(const RenderArgs &a, const double *_
 }
 
 static_assert(sizeof(CompTab) >= 128 * sizeof(double), "log table must fit the component table");
+// DIAG = false is the production kernel.  DIAG = true adds the per-tile work counters / time stamps of
+// CEL_OPT_TILE_TIMING and, in a -DCEL_ABLATE build only, the timing-only ablation switches of CEL_OPT_DEBUG:
+// the host launches it only when one of them is asked for, so the hottest loop of the library carries no
+// diagnostic branch, scalar register or counter (round 2: 8 flag tests inside per-source / per-batch code).
+template <bool DIAG>
 __global__ void __launch_bounds__(64)
 k_render_hw(RenderArgs a) {
     __shared__ double acc[HW_TH * HW_TW];
@@ -310,7 +326,9 @@ k_render_hw(RenderArgs a) {
     __shared__ double et[64];
     const int lane = threadIdx.x;
     const int half = lane >> 5, col = lane & 31;
-    const unsigned long long t_start = (a.timing || a.cost) ? wall_clock64() : 0ull;
+    unsigned long long *const timing = DIAG ? a.timing : nullptr;
+    const int dbg = DIAG ? CEL_ABLATE_BITS(a.flags) : 0;
+    const unsigned long long t_start = (timing || a.cost) ? wall_clock64() : 0ull;
     const int tile = a.order ? a.order[blockIdx.x] : blockIdx.x;
     const int per_band = a.ntx * a.nty;
     const int b = tile / per_band;
@@ -322,8 +340,8 @@ k_render_hw(RenderArgs a) {
     const BandDev *bd = a.bands + b;
 
     const int cnt = a.tile_cnt[tile];
-    if ((a.flags >> 8) & 8) return;             // ablation: launch + header load only
-    if (cnt == 0 && !a.timing) {
+    if (dbg & 8) return;             // ablation: launch + header load only
+    if (cnt == 0 && !timing) {
         // empty sky: lambda = eps on the whole tile -- pure streaming (nelec in, eps out), one log
         // per wave instead of one per pixel, no LDS.  Same arithmetic per pixel as the general
         // epilogue (ne * log(lam) - lam, rows in the same order).
@@ -388,7 +406,7 @@ k_render_hw(RenderArgs a) {
     unsigned dbg_halfrows = 0;                                   // star path: component-rows (each walked on 32 lanes, like the general path's)
     const int nent_all = (int)min((int64_t)cnt, a.capacity > off ? a.capacity - off : (int64_t)0);
     int nstar = min(a.tile_nstar ? a.tile_nstar[tile] : 0, nent_all);
-    if ((a.flags >> 8) & 32) nstar = 0;         // ablation: no star pass at all (and no general pass: see below)
+    if (dbg & 32) nstar = 0;         // ablation: no star pass at all (and no general pass: see below)
     if (a.variant == 0) nstar = 0;             // the direct evaluator takes every source through the general path
     if (nstar > 0) {
         StarTab &ST = *reinterpret_cast<StarTab *>(&T);
@@ -400,13 +418,13 @@ k_render_hw(RenderArgs a) {
     // return in order -- and in a persistent, software-pipelined star kernel: slower in every form,
     // 0.179 / 0.180 / 0.205 against 0.171 ms on the dense star field -- DESIGN.md 5.)
     if (nstar > 0)
-        star_pass(a, *reinterpret_cast<StarTab *>(&T), et, acc, recs, off, nstar, lane, xi, Y0, strict, dbg_halfrows, dbg_pairs);
+        star_pass<DIAG>(a, *reinterpret_cast<StarTab *>(&T), et, acc, recs, off, nstar, lane, xi, Y0, strict, dbg_halfrows, dbg_pairs);
 
     const LaneConst lc = lane_consts(lane, bd);
     // the rest of the tile's list (everything when there was no star pass), 64 indices per coalesced
     // load; the next source's record is in flight while the current one is evaluated
     const int64_t off2 = off + nstar;
-    const int nent = ((a.flags >> 8) & 32) ? 0 : nent_all - nstar;
+    const int nent = (dbg & 32) ? 0 : nent_all - nstar;
     int idx64 = (lane < nent) ? a.lists[off2 + lane] : 0;
     int recw_next = (nent > 0) ? rec_fetch(recs, __builtin_amdgcn_readlane(idx64, 0), lane) : 0;
 
@@ -449,7 +467,7 @@ k_render_hw(RenderArgs a) {
         }
         const unsigned long long km = __ballot(keep);
         const int Kk = __popcll(km);
-        if (a.timing) {   // diagnostic: rows / column-clipped area the kept components need one by one
+        if (timing) {   // diagnostic: rows / column-clipped area the kept components need one by one
             int ir = keep ? rhi - rlo : 0;
             float cw = 0.f;
             if (keep) {
@@ -501,7 +519,7 @@ k_render_hw(RenderArgs a) {
             const int L = __builtin_amdgcn_readfirstlane(T.gL[gi]);
             const int ga = __builtin_amdgcn_readfirstlane(T.gr0[gi]);
             const int gb = __builtin_amdgcn_readfirstlane(T.gr1[gi]);
-            if (a.timing) { dbg_comprows += (unsigned)(gb - ga) * (unsigned)R; dbg_pairs += 1; }
+            if (timing) { dbg_comprows += (unsigned)(gb - ga) * (unsigned)R; dbg_pairs += 1; }
             const int k0 = half ? p0 + gA : p0;
             if (L < 4) {
                 // pathologically sharp component: evaluate this pair of groups directly
@@ -524,15 +542,15 @@ k_render_hw(RenderArgs a) {
         }
     }
 
-    hw_epilogue<false>(a, acc, reinterpret_cast<double *>(&T), bd, tile, b, xi, Y0, lane, nullptr);
+    hw_epilogue<false, DIAG>(a, acc, reinterpret_cast<double *>(&T), bd, tile, b, xi, Y0, lane, nullptr);
     if (a.cost && lane == 0) a.cost[tile] = (int)min(wall_clock64() - t_start, 0x3fffffffull) + 1;
-    if (a.timing && lane == 0) {
-        a.timing[3 * (size_t)blockIdx.x + 0] = t_start;
-        a.timing[3 * (size_t)blockIdx.x + 1] = wall_clock64();
+    if (timing && lane == 0) {
+        timing[3 * (size_t)blockIdx.x + 0] = t_start;
+        timing[3 * (size_t)blockIdx.x + 1] = wall_clock64();
         // work counters of this tile (diagnostic): sources | pairs of groups << 12 | kept component-rows << 32
-        a.timing[3 * (size_t)blockIdx.x + 2] = (unsigned long long)(unsigned)cnt | ((unsigned long long)dbg_pairs << 12) |
+        timing[3 * (size_t)blockIdx.x + 2] = (unsigned long long)(unsigned)cnt | ((unsigned long long)dbg_pairs << 12) |
                                                ((unsigned long long)(dbg_comprows + dbg_halfrows) << 32);
         if ((a.flags >> 8) & 128)   // diagnostic (tools/row_waste.py): what the kept components need one by one
-            a.timing[3 * (size_t)blockIdx.x + 2] = (unsigned long long)dbg_pairrows | ((unsigned long long)(unsigned)(dbg_area / 32.f) << 32);
+            timing[3 * (size_t)blockIdx.x + 2] = (unsigned long long)dbg_pairrows | ((unsigned long long)(unsigned)(dbg_area / 32.f) << 32);
     }
 }

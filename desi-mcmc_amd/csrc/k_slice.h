@@ -171,3 +171,23 @@ k_slice_live_jobs(SliceState st, int64_t S, int B, int *__restrict__ list, int *
     if (i >= S * B) return;
     if (st.phase[i / B] != SL_FINAL) list[atomicAdd(count, 1)] = (int)i;
 }
+
+// algorithmic HBM bytes of a finished call (what bench.py prices the location step's kernel against): a chain that
+// ran made 1 + steps[s] evaluations, each of which reads, per band, one 128-B record and the 8-B photon counts of
+// the rectangle that holds the source's photons (k_patch_nzbox)
+__global__ void __launch_bounds__(256)
+k_slice_bytes(SliceState st, int64_t S, int B, const int4 *__restrict__ nzbox, unsigned long long *__restrict__ bytes) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0ull;
+    if (s < S && st.new_llh[s] == st.new_llh[s]) {          // NaN: the chain never ran
+        unsigned long long per = 0ull;
+        for (int b = 0; b < B; b++) {
+            const int4 q = nzbox[s * B + b];
+            const long long area = (q.y > q.x && q.w > q.z) ? (long long)(q.y - q.x) * (q.w - q.z) : 0;
+            per += 8ull * (unsigned long long)area + 128ull;
+        }
+        v = per * (unsigned long long)(1 + st.steps[s]);
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(bytes, v);
+}

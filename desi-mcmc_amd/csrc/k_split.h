@@ -23,6 +23,13 @@
 // rate in LDS, pass B walks the sources again in order and draws.  Stamps use the direct
 // evaluator: exact, every component.
 #pragma once
+// timing-only ablations of the split (1 = no draws, 2 = every draw 1, 4 = no stamp walk) exist only in a
+// -DCEL_ABLATE build (tools/ablate_render.py); the shipped kernel has no such switch
+#ifdef CEL_ABLATE
+#define SPLIT_ABLATE(a) ((a).debug)
+#else
+#define SPLIT_ABLATE(a) 0
+#endif
 #include "hw_source.h"
 
 #ifndef PHILOX_ROUNDS
@@ -480,7 +487,7 @@ k_photon_split_hw(SplitArgs a) {
         const bool on = (xi >= xa) && (xi <= xb);
         bool direct;
         const int Kk = hw_build(T, lc, rec, lane, dropmode, a.tail_T, log_sky, Y0, xa, xb, ra, rb, direct, nullptr, et);
-        if (!(a.debug & 4)) hw_walk(T, et, Kk, x, Y0, ra, rb, on, direct, one, lane);
+        if (!(SPLIT_ABLATE(a) & 4)) hw_walk(T, et, Kk, x, Y0, ra, rb, on, direct, one, lane);
         __syncthreads();
         // Two passes over the source's pixels on this half-tile.  Most draws are decided by ONE
         // uniform (U <= 1 - n p gives 0: a pixel in the source's tail); the few that are not would
@@ -501,7 +508,7 @@ k_photon_split_hw(SplitArgs a) {
                 const int n = left[li];
                 const double tot = rate[li];
                 covered |= 1u << r;
-                if (n > 0 && !(a.debug & 1)) {
+                if (n > 0 && !(SPLIT_ABLATE(a) & 1)) {
                     const double pr = F * fast_rcp(tot);                  // curr_prob / sum_probs (:147)
                     if (pr > 0.0) {
                         slow = true;
@@ -531,7 +538,7 @@ k_photon_split_hw(SplitArgs a) {
                 const int n = left[li];
                 const double tot = rate[li];
                 Philox g = philox_init(a.seed, (unsigned long long)(key0 + (int64_t)(Y0 + row) * a.W + xq), (unsigned)s);
-                const long long z = (a.debug & 2) ? 1 : binomial_draw((long long)n, F * fast_rcp(tot), g, et, lt);
+                const long long z = (SPLIT_ABLATE(a) & 2) ? 1 : binomial_draw((long long)n, F * fast_rcp(tot), g, et, lt);
                 left[li] = n - (int)z;
                 rate[li] = tot - F;
                 patch0[(int64_t)row * nx + xq] = (double)z;

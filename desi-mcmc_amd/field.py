@@ -280,7 +280,7 @@ class ImageSet(object):
         The sources' locations are updated in place on the device.  -> (radec[S,2], llh[S], dict(rounds, evals))"""
         S = sources.S
         radec, llh = np.zeros((S, 2)), np.zeros(S)
-        stats = np.zeros(2, dtype=np.int64)
+        stats = np.zeros(4, dtype=np.int64)
         ids = None
         if chain_ids is not None:
             ids = np.ascontiguousarray(chain_ids, dtype=np.int32)
@@ -294,7 +294,7 @@ class ImageSet(object):
             if "Slice sampler" in str(e):
                 raise Exception(str(e))          # the sampler's own failures are plain Exceptions in the reference
             raise
-        return radec, llh, dict(rounds=int(stats[0]), evals=int(stats[1]))
+        return radec, llh, dict(rounds=int(stats[0]), evals=int(stats[1]), algorithmic_bytes=int(stats[2]), launches=int(stats[3]))
 
     def sample_sums(self):
         """photons attributed to every (source, band) by the resident split -> (S, B)"""

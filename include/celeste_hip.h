@@ -78,16 +78,25 @@ enum {
                                2 = 16 columns x 128 rows, four component groups per column (fewer
                                recurrence seeds, more per-tile set-up: measured 4 % slower than 1
                                on the benchmark field, kept for fields of tall narrow boxes)      */
-    CEL_OPT_DEBUG = 8       /* diagnostic, timing-only: ablation bits for the render kernel (1 = skip the star
-                               walk, 2 = the star seeds + walk, 4 = the epilogue's log, 8 = everything after the
-                               tile header, 16 = the epilogue's global loads / stores, 32 = every source).
-                               Results are WRONG when non-zero; never set outside tools/ablate_render.py */
+    CEL_OPT_DEBUG = 8       /* diagnostics.  The shipped library accepts two result-preserving bits: 64 = the E-step
+                               takes its per-source form, 128 = CEL_OPT_TILE_TIMING's third word carries the
+                               row-waste counters of tools/row_waste.py.  The timing-only ABLATION bits (render:
+                               1 = skip the star walk, 2 = the star seeds + walk, 4 = the epilogue's log, 8 =
+                               everything after the tile header, 16 = the epilogue's global loads / stores, 32 =
+                               every source; photon split: 1 = no draws, 2 = every draw 1, 4 = no stamp walk) exist
+                               only in a -DCEL_ABLATE build (`make -C desi-mcmc_amd/csrc ablate`, loaded by
+                               tools/ablate_render.py); the shipped library refuses them: CEL_ERR_INVALID */
 };
 
 /* kernels reported by cel_profile_get */
 enum {
     CEL_K_PREP = 0, CEL_K_BIN = 1, CEL_K_RENDER = 2, CEL_K_REDUCE = 3, CEL_K_STAMPS = 4,
-    CEL_K_GMM = 5, CEL_K_COUNT = 6
+    CEL_K_GMM = 5,
+    CEL_K_PATCH_LL = 6,     /* k_patch_ll[_hw]: cel_patch_loglik[_multi] and every round of cel_slice_locations */
+    CEL_K_SPLIT = 7,        /* k_photon_split[_hw] */
+    CEL_K_MASS = 8,         /* cel_stamp_mass */
+    CEL_K_ESTEP = 9,        /* cel_estep_stats */
+    CEL_K_COUNT = 10
 };
 
 typedef struct cel_ctx cel_ctx;
@@ -244,7 +253,9 @@ int cel_stamp_mass(cel_images *img, cel_sources *src, double *mass);
  * arithmetic as the host engine of the Python mirror (util/infer/slicesample.py), chain for chain.
  *   radec_out  S*2 (host, may be NULL): the new locations; they also REPLACE src's locations on the device
  *   llh_out    S (host, may be NULL): log-likelihood at the new location (NaN for a source left alone)
- *   stats      2 (host, may be NULL): rounds, likelihood evaluations */
+ *   stats      4 (host, may be NULL): rounds, likelihood evaluations, the ALGORITHMIC HBM bytes those evaluations
+ *              read (per evaluation and band: 8 B per pixel of the photon rectangle it walks + one 128-B
+ *              record), conditional-likelihood launches */
 int cel_slice_locations(cel_images *img, cel_sources *src, const int32_t *chain_ids, double sigma, uint64_t seed,
                         int max_rounds, double *radec_out, double *llh_out, int64_t *stats);
 

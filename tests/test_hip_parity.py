@@ -649,6 +649,11 @@ def test_abi_error_paths(cel, ctx):
         ctx.set_option(1, 7.0)
     with pytest.raises(ValueError):
         ctx.set_tail_log(-1.0)
+    from desi_mcmc_amd import _lib
+    for bits in (1, 2, 4, 8, 16, 32, 6):                         # timing-only ablations: not in the shipped library
+        with pytest.raises(ValueError, match="CEL_ABLATE"):
+            ctx.set_option(_lib.CEL_OPT_DEBUG, bits)
+    assert ctx.get_option(_lib.CEL_OPT_DEBUG) == 0
     with pytest.raises(ValueError):
         iset.patch_loglik(sset, np.array([[0, 10, 0, 10], [0, 0, 0, 0]]), [np.zeros((9, 10)), None])
     iset.set_nelec(np.ones((2, 64, 64)))

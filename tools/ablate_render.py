@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
 """Timing-only ablations of k_render_hw (CEL_OPT_DEBUG): where a star field's kernel time goes.
-    python tools/ablate_render.py [--workload stars10k_2048]"""
+    make -C desi-mcmc_amd/csrc ablate && python tools/ablate_render.py [--workload stars10k_2048]
+The switches exist only in the -DCEL_ABLATE build of the library (tools/bin/libceleste_hip_ablate.so, built
+here when missing); the shipped library refuses them."""
 import argparse
 import os
+import subprocess
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import desi_mcmc_amd as cel  # noqa: E402
 from desi_mcmc_amd import _lib, synth  # noqa: E402
+
+subprocess.check_call(["make", "-C", os.path.join(ROOT, "desi-mcmc_amd", "csrc"), "-s", "ablate"])
+_lib.LIB_PATH = os.path.join(ROOT, "tools", "bin", "libceleste_hip_ablate.so")      # before the first call loads it
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="stars10k_2048")

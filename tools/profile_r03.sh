@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-3 profiles: rocprofv3 kernel stats + PMC passes of the bench workloads, summarised into profiles/r03_*.
+#   tools/profile_r03.sh [final|stars|gibbs|all]     (on the GPU box; raw results under gpurun_out/r03_*)
+# Counters in their own passes with --kernel-trace only (gpurun rule); the program right after `--`.
+set -e
+what=${1:-all}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+stats() {   # tag, bench args
+  tag=$1; shift
+  rm -rf $root/gpurun_out/r03_${tag}_stats
+  (cd $root && rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/r03_${tag}_stats -- python3 bench.py "$@" > $root/gpurun_out/r03_${tag}_bench.json 2> $root/gpurun_out/r03_${tag}_stats.log)
+  f=$(find $root/gpurun_out/r03_${tag}_stats -name "*kernel_stats.csv" | head -1)
+  cp "$f" $root/profiles/r03_${tag}_kernel_stats.csv
+  cp $root/gpurun_out/r03_${tag}_bench.json $root/profiles/r03_${tag}_bench.json
+  echo "== $tag"; head -8 $root/profiles/r03_${tag}_kernel_stats.csv
+}
+pmc() {     # tag, PMC_PROG
+  tag=$1; prog=$2
+  (cd $root && PMC_PROG="$prog" tools/pmc_pass.sh r03_$tag "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE" > gpurun_out/r03_${tag}_pmc.txt 2>&1)
+  (cd $root && python3 tools/pmc_summarise.py r03_$tag "PMC_PROG=\"$prog\" tools/pmc_pass.sh r03_$tag ..." > profiles/r03_${tag}_pmc.json)
+}
+if [ $what = final ] || [ $what = all ]; then
+  stats final --steps 200 --warmup 30 --cpu-sample 0 --legs none
+  pmc final "bench.py --steps 3 --warmup 1 --cpu-sample 0 --legs none"
+fi
+if [ $what = stars ] || [ $what = all ]; then
+  stats stars --workload stars10k_2048 --steps 200 --warmup 30 --cpu-sample 0 --legs none
+  pmc stars "bench.py --workload stars10k_2048 --steps 3 --warmup 1 --cpu-sample 0 --legs none"
+fi
+if [ $what = gibbs ] || [ $what = all ]; then
+  stats gibbs --workload gibbs10k --steps 10 --warmup 2 --cpu-sample 0
+  pmc aux "bench.py --workload gibbs10k --steps 2 --warmup 1 --cpu-sample 0"
+fi

@@ -33,10 +33,10 @@ timed("stamps, band r, all sources", lambda: f.images.stamps(f.sources, 2, scale
 
 ctx.profile(True)
 f.images.photon_split(f.sources, seed=1)
-print("k_photon_split kernel alone: %.2f ms" % ctx.profile_get("stamps")[0])
+print("k_photon_split kernel alone: %.2f ms" % ctx.profile_get("split")[0])
 ctx.profile(True)
 f.images.estep_stats(f.sources)
-print("k_estep_src kernel alone: %.2f ms" % ctx.profile_get("stamps")[0])
+print("k_estep_src kernel alone: %.2f ms" % ctx.profile_get("estep")[0])
 
 # conditional log-likelihoods of 16 proposals per source against the resident split
 P = 16
@@ -49,9 +49,9 @@ f.images.photon_split_resident(f.sources, seed=1)
 timed("resident split (5 bands)", lambda: f.images.photon_split_resident(f.sources, seed=1), 3)
 ctx.profile(True)
 f.images.photon_split_resident(f.sources, seed=1)
-print("  split kernel alone: %.2f ms, render kernels: %.2f ms" % (ctx.profile_get("stamps")[0], ctx.profile_get("render")[0]))
+print("  split kernel alone: %.2f ms, render kernels: %.2f ms" % (ctx.profile_get("split")[0], ctx.profile_get("render")[0]))
 timed("conditional ll, %d proposals" % (f.S * P), lambda: f.images.patch_loglik_resident(prop, owner), 3)
 ctx.profile(True)
 f.images.patch_loglik_resident(prop, owner)
-print("  k_prep: %.2f ms, k_patch_ll: %.2f ms" % (ctx.profile_get("prep")[0], ctx.profile_get("stamps")[0]))
+print("  k_prep: %.2f ms, k_patch_ll: %.2f ms" % (ctx.profile_get("prep")[0], ctx.profile_get("patch_ll")[0]))
 ctx.profile(False)

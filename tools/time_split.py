@@ -10,5 +10,5 @@ f.images.photon_split_resident(f.sources, seed=1)
 ctx.profile(True)
 for i in range(3):
     f.images.photon_split_resident(f.sources, seed=2 + i)
-ms, n = ctx.profile_get("stamps")
+ms, n = ctx.profile_get("split")
 print("split kernel: %.3f ms (mean of %d launches)" % (ms, n))
