@@ -74,7 +74,7 @@ def load_pmc(key, kernel="k_render_hw"):
     if have != want:
         return {"stale": "%s was taken with library sha256 %s..., loaded is %s...: re-run tools/profile_r03.sh"
                          % (rel, str(have)[:12], want[:12])}
-    ks = [k for k in prof["kernels"] if k.startswith(kernel)]
+    ks = [k for k in prof["kernels"] if kernel in k]
     if not ks:
         return {"stale": "%s holds no %s launches" % (rel, kernel)}
     c = prof["kernels"][sorted(ks, key=lambda k: -prof["kernels"][k].get("SQ_INSTS_VALU", {}).get("last", 0.0))[0]]

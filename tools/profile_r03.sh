@@ -1,24 +1,31 @@
 #!/bin/bash
 # Round-3 profiles: rocprofv3 kernel stats + PMC passes of the bench workloads, summarised into profiles/r03_*.
-#   tools/profile_r03.sh [final|stars|gibbs|all]     (on the GPU box; raw results under gpurun_out/r03_*)
+#   gpurun -- tools/profile_r03.sh [final|stars|gibbs|all]     (on the GPU box; everything lands under gpurun_out/r03_*)
+#   tools/profile_r03.sh collect                                (here, afterwards: the summaries to judge -> profiles/)
 # Counters in their own passes with --kernel-trace only (gpurun rule); the program right after `--`.
 set -e
 what=${1:-all}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
+if [ $what = collect ]; then
+  for f in $root/gpurun_out/r03_*_kernel_stats.csv $root/gpurun_out/r03_*_bench.json $root/gpurun_out/r03_*_pmc.json; do
+    [ -f "$f" ] && cp "$f" $root/profiles/
+  done
+  ls $root/profiles/r03_*
+  exit 0
+fi
 cd /tmp && export TMPDIR=/tmp
 stats() {   # tag, bench args
   tag=$1; shift
   rm -rf $root/gpurun_out/r03_${tag}_stats
   (cd $root && rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/r03_${tag}_stats -- python3 bench.py "$@" > $root/gpurun_out/r03_${tag}_bench.json 2> $root/gpurun_out/r03_${tag}_stats.log)
   f=$(find $root/gpurun_out/r03_${tag}_stats -name "*kernel_stats.csv" | head -1)
-  cp "$f" $root/profiles/r03_${tag}_kernel_stats.csv
-  cp $root/gpurun_out/r03_${tag}_bench.json $root/profiles/r03_${tag}_bench.json
-  echo "== $tag"; head -8 $root/profiles/r03_${tag}_kernel_stats.csv
+  cp "$f" $root/gpurun_out/r03_${tag}_kernel_stats.csv
+  echo "== $tag"; head -8 $root/gpurun_out/r03_${tag}_kernel_stats.csv
 }
 pmc() {     # tag, PMC_PROG
   tag=$1; prog=$2
   (cd $root && PMC_PROG="$prog" tools/pmc_pass.sh r03_$tag "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE" > gpurun_out/r03_${tag}_pmc.txt 2>&1)
-  (cd $root && python3 tools/pmc_summarise.py r03_$tag "PMC_PROG=\"$prog\" tools/pmc_pass.sh r03_$tag ..." > profiles/r03_${tag}_pmc.json)
+  (cd $root && python3 tools/pmc_summarise.py r03_$tag "PMC_PROG=\"$prog\" tools/pmc_pass.sh r03_$tag ..." > gpurun_out/r03_${tag}_pmc.json)
 }
 if [ $what = final ] || [ $what = all ]; then
   stats final --steps 200 --warmup 30 --cpu-sample 0 --legs none
