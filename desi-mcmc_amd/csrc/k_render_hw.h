@@ -112,16 +112,17 @@ __device__ __forceinline__ int slot_by_rows(bool keep, int rlo, int rhi) {
 // normaliser, row-to-row ratio are BAND constants (computed once per tile by lanes 0..2); a star
 // brings only its position, counts and box.  So the stars of a tile (they come first in its list,
 // k_bin2.h) need no per-source component table, no division, no drop test and no barrier pair per
-// source: up to 64 of them are staged in LDS per batch (40 bytes each, one lane per star), and the
-// two halves of the wave then walk TWO stars at a time -- lanes 0..31 star 2i, lanes 32..63 star
-// 2i+1, each all three components in one group over the star's rows on this tile.  One segment per
-// star: legal when no component's exponent can exceed 600 anywhere on a star's box (checked per
-// tile from the band's bounding radius; otherwise the stars take the general path below).
+// source: up to 64 of them are staged in LDS per batch (40 bytes each, one lane per star) and walked as
+// (star, column) tasks, 64 per step (star_pass below), each all three components in one group over the
+// star's rows on this tile.  One segment per star: legal when no component's exponent can exceed 600
+// anywhere on a star's box (checked per tile from the band's bounding radius; otherwise the stars take the
+// general path below).
 // Nothing is dropped here, so a star's pixels carry all three components (the general path skips
 // components below eps * e^-T on the tile): both agree with the reference to the test tolerances.
 struct StarTab {           // lives in the component table's LDS while the stars are processed
     double px[64], py[64], scale[64];
     int4 box[64];          // x0, x1, y0, y1
+    int cum[64];           // first (star, column) task of the sorted batch's star j
     double qa[K_PSF], qb[K_PSF], qc[K_PSF], eq[K_PSF], A0[K_PSF], mux[K_PSF], muy[K_PSF];
 };
 static_assert(sizeof(StarTab) <= sizeof(CompTab), "the star table must fit the component table's storage");
@@ -151,121 +152,142 @@ __device__ __forceinline__ bool star_setup(StarTab &ST, const BandDev *__restric
     return ok;
 }
 
-struct StarBatch {         // lane j's star of a tile's first batch, already in registers (k_render_stars prefetches it)
-    double2 pp;
-    double sc;
-    int4 bx;
-    bool valid;
-};
-
 // the first nstar entries of the tile's list (its stars) into the accumulator tile.  DIAG: the tile-timing
 // counters and (CEL_ABLATE builds) the timing-only ablation switches; the production instantiation has neither.
+//
+// Column tasks (round 3).  A star's 43-pixel box covers 32, or only a few, of a 32-column tile's columns: with one
+// star per half-wave 59 % of the lanes carried a column of their star.  Here the unit of work is one COLUMN of one
+// star: the batch's stars are sorted by the number of rows they have on the tile (descending), their column counts
+// are prefix-summed, and each step hands 64 consecutive (star, column) tasks to the 64 lanes -- a lane finds its
+// star by bisection of the prefix sums (6 LDS reads), seeds the three components at ITS star's first row and walks
+// ITS star's rows, row i of the step being row ra_lane + i of the tile.  Neighbouring tasks belong to the same or the
+// next star of the sorted order, so the lanes of a step have nearly equal row counts, and every lane carries a
+// column (all but the batch's last step).  The order in which a pixel receives its terms depends on the data only.
 template <bool DIAG>
 __device__ __forceinline__ void star_pass(const RenderArgs &a, StarTab &ST, const double *__restrict__ et, double *__restrict__ acc,
-                                          const SrcRec *__restrict__ recs, int64_t off, int nstar, int lane, int xi, int Y0,
-                                          int strict, unsigned &dbg_halfrows, unsigned &dbg_pairs, const StarBatch *first = nullptr) {
-    const int half = lane >> 5, col = lane & 31;
-    const double x = (double)xi;
-    {
-        double cqa[K_PSF], cqb[K_PSF], cqc[K_PSF], ceq[K_PSF], cA0[K_PSF], cmx[K_PSF], cmy[K_PSF];
+                                          const SrcRec *__restrict__ recs, int64_t off, int nstar, int lane, int X0, int Y0,
+                                          int strict, unsigned &dbg_halfrows, unsigned &dbg_pairs) {
+    double cqa[K_PSF], cqb[K_PSF], cqc[K_PSF], ceq[K_PSF], cA0[K_PSF], cmx[K_PSF], cmy[K_PSF];
 #pragma unroll
-        for (int k = 0; k < K_PSF; k++) {
-            cqa[k] = ST.qa[k]; cqb[k] = ST.qb[k]; cqc[k] = ST.qc[k]; ceq[k] = ST.eq[k];
-            cA0[k] = ST.A0[k]; cmx[k] = ST.mux[k]; cmy[k] = ST.muy[k];
+    for (int k = 0; k < K_PSF; k++) {
+        cqa[k] = ST.qa[k]; cqb[k] = ST.qb[k]; cqc[k] = ST.qc[k]; ceq[k] = ST.eq[k];
+        cA0[k] = ST.A0[k]; cmx[k] = ST.mux[k]; cmy[k] = ST.muy[k];
+    }
+    const int dbg = DIAG ? CEL_ABLATE_BITS(a.flags) : 0;
+    for (int base = 0; base < nstar; base += 64) {
+        const int nb = min(64, nstar - base);
+        __syncthreads();                   // the previous batch has been read
+        // One lane per star loads it; the batch is then SORTED by the number of rows the star has on this tile
+        // (descending; ties by list position).  The rank of a star is a count over the batch (<= 64 LDS
+        // broadcasts) and depends only on the data.  A star without a row or a column here sorts last.
+        double2 pp = make_double2(0.0, 0.0);
+        double sc = 0.0;
+        int4 bx4 = make_int4(0, 0, 0, 0);
+        int nrows = -1, ncols = 0;
+        if (lane < nb) {
+            const SrcRec *rp = recs + a.lists[off + base + lane];
+            pp = *reinterpret_cast<const double2 *>(&rp->px);
+            sc = rp->scale;
+            bx4 = *reinterpret_cast<const int4 *>(&rp->x0);
+            nrows = max(min(bx4.w, Y0 + HW_TH) - max(bx4.z + strict, Y0), 0);
+            ncols = max(min(bx4.y, X0 + HW_TW) - max(bx4.x + strict, X0), 0);
+            if (ncols == 0 || nrows == 0) { nrows = 0; ncols = 0; }
         }
-        double *colp = acc + col;
-        for (int base = 0; base < nstar; base += 64) {
-            const int nb = min(64, nstar - base);
-            __syncthreads();                   // the previous batch has been read
-            // One lane per star loads it; the batch is then SORTED by the number of rows the star has
-            // on this tile (descending; ties by list position), so that the two stars a wave walks
-            // together are of nearly equal length -- unsorted, a step lasts as long as the longer
-            // of two unrelated row counts (+25 % on a dense star field).  The rank of a star is a
-            // count over the batch (<= 64 LDS broadcasts), and depends only on the data.
-            double2 pp = make_double2(0.0, 0.0);
-            double sc = 0.0;
-            int4 bx4 = make_int4(0, 0, 0, 0);
-            int nrows = -1;
-            if (lane < nb) {
-                if (first && base == 0) {
-                    pp = first->pp; sc = first->sc; bx4 = first->bx;
-                } else {
-                    const SrcRec *rp = recs + a.lists[off + base + lane];
-                    pp = *reinterpret_cast<const double2 *>(&rp->px);
-                    sc = rp->scale;
-                    bx4 = *reinterpret_cast<const int4 *>(&rp->x0);
-                }
-                nrows = max(min(bx4.w, Y0 + HW_TH) - max(bx4.z + strict, Y0), 0);
-            }
-            int *srows = reinterpret_cast<int *>(ST.scale);      // scratch until the sorted table is written
-            srows[lane] = nrows;
-            __syncthreads();
-            int rank = 0;
-            for (int j = 0; j < nb; j++) {
-                const int rj = srows[j];
-                rank += (rj > nrows || (rj == nrows && j < lane)) ? 1 : 0;
-            }
-            __syncthreads();
-            if (lane < nb) {
-                ST.px[rank] = pp.x; ST.py[rank] = pp.y; ST.scale[rank] = sc;
-                ST.box[rank] = bx4;
-            }
-            __syncthreads();
-            if (DIAG && a.timing) { dbg_pairs += (unsigned)nb; }
-            const int dbg = DIAG ? CEL_ABLATE_BITS(a.flags) : 0;
-            for (int it = 0; 2 * it < nb && !(dbg & 2); it++) {
-                const bool valid = (2 * it + half) < nb;
-                const int j = min(2 * it + half, nb - 1);
-                const double px = ST.px[j], py = ST.py[j];
-                const int4 bx = ST.box[j];
-                const int bx0 = bx.x + strict, by0 = bx.z + strict;
-                const int ra = max(by0, Y0) - Y0;
-                const int rb = (valid && !(dbg & 1)) ? min(bx.w, Y0 + HW_TH) - Y0 : ra;
-                const bool on = (xi >= bx0) && (xi < bx.y);
-                const double amp = on ? ST.scale[j] : 0.0;
-                if (DIAG && a.timing) {      // kept component-rows of the step = both halves' rows x 3; counted as half-tile widths
-                    const int rows_lo = __builtin_amdgcn_readlane(max(rb - ra, 0), 0), rows_hi = __builtin_amdgcn_readlane(max(rb - ra, 0), 32);
-                    dbg_halfrows += (unsigned)(rows_lo + rows_hi) * K_PSF;
-                }
-                double g[K_PSF], r[K_PSF];
-                const double y0 = (double)(Y0 + ra);
+        int *srows = reinterpret_cast<int *>(ST.scale);      // scratch until the sorted table is written
+        srows[lane] = nrows;
+        __syncthreads();
+        int rank = 0;
+        for (int j = 0; j < nb; j++) {
+            const int rj = srows[j];
+            rank += (rj > nrows || (rj == nrows && j < lane)) ? 1 : 0;
+        }
+        __syncthreads();
+        ST.cum[lane] = 0;
+        if (lane < nb) {
+            ST.px[rank] = pp.x; ST.py[rank] = pp.y; ST.scale[rank] = sc;
+            ST.box[rank] = bx4;
+        }
+        __syncthreads();
+        // exclusive prefix sum of the column counts in sorted order (lane j = sorted star j): cum[j] = first task of star j
+        int w = 0;
+        if (lane < nb) {
+            const int4 q = ST.box[lane];
+            const int nr = max(min(q.w, Y0 + HW_TH) - max(q.z + strict, Y0), 0);
+            w = (nr > 0) ? max(min(q.y, X0 + HW_TW) - max(q.x + strict, X0), 0) : 0;
+        }
+        int incl = w;
 #pragma unroll
-                for (int k = 0; k < K_PSF; k++) {
-                    const double dx = x - (px + cmx[k]), dy = y0 - (py + cmy[k]);
-                    const double hx = cqb[k] * dx + cqc[k] * dy;
-                    const double e = -0.5 * (cqa[k] * dx * dx + (cqb[k] * dx + hx) * dy);
-                    const double er = fmin(fmax(-(hx + 0.5 * cqc[k]), -REC_EMAX * EXP_SCALE), REC_EMAX * EXP_SCALE);
-                    g[k] = (cA0[k] * amp) * exp_tab64(e, et);
-                    r[k] = exp_tab64(er, et);
-                }
-                int row = ra;
-                double *rowp = colp + ra * HW_TW;
-                for (; row + 3 < rb; row += 4, rowp += 4 * HW_TW) {       // four rows per trip: one address update, one bound test
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        ST.cum[lane] = (lane < nb) ? incl - w : 0x3fffffff;
+        __syncthreads();
+        if (DIAG && a.timing) { dbg_pairs += (unsigned)nb; }
+        for (int t0 = 0; t0 < total && !(dbg & 2); t0 += 64) {
+            const int t = t0 + lane;
+            const bool valid = t < total;
+            // the star this task belongs to: the last j with cum[j] <= t (stars without a column share their
+            // successor's cum and are passed over; entries behind the batch hold a sentinel)
+            int j = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+                if (ST.cum[min(j + step, 63)] <= t && j + step < 64) j += step;
+            const double px = ST.px[j], py = ST.py[j];
+            const int4 bx = ST.box[j];
+            const int bx0 = max(bx.x + strict, X0), by0 = bx.z + strict;
+            const int xi = bx0 + (t - ST.cum[j]);
+            const int ra = max(by0, Y0) - Y0;
+            const int n = (valid && !(dbg & 1)) ? max(min(bx.w, Y0 + HW_TH) - Y0 - ra, 0) : 0;
+            const double amp = valid ? ST.scale[j] : 0.0;
+            const int nmax = __builtin_amdgcn_readlane(n, 0);          // sorted: the step's first task has the most rows
+            if (DIAG && a.timing) dbg_halfrows += 2u * (unsigned)nmax * K_PSF;   // in half-tile (32-lane) widths, as the general path counts
+            const double x = (double)xi;
+            double g[K_PSF], r[K_PSF];
+            const double y0 = (double)(Y0 + ra);
+#pragma unroll
+            for (int k = 0; k < K_PSF; k++) {
+                const double dx = x - (px + cmx[k]), dy = y0 - (py + cmy[k]);
+                const double hx = cqb[k] * dx + cqc[k] * dy;
+                const double e = -0.5 * (cqa[k] * dx * dx + (cqb[k] * dx + hx) * dy);
+                const double er = fmin(fmax(-(hx + 0.5 * cqc[k]), -REC_EMAX * EXP_SCALE), REC_EMAX * EXP_SCALE);
+                g[k] = (cA0[k] * amp) * exp_tab64(e, et);
+                r[k] = exp_tab64(er, et);
+            }
+            double *rowp = acc + ra * HW_TW + (valid ? xi - X0 : 0);
+            int i = 0;
+            for (; i + 3 < nmax; i += 4, rowp += 4 * HW_TW) {       // four rows per trip: one address update, one bound test
 #pragma clang fp contract(off)
-                    double g1[K_PSF], r1[K_PSF];
-                    const double s0 = (g[0] + g[1]) + g[2];
+                double g1[K_PSF], r1[K_PSF];
+                const double s0 = (g[0] + g[1]) + g[2];
 #pragma unroll
-                    for (int k = 0; k < K_PSF; k++) { g1[k] = g[k] * r[k]; r1[k] = r[k] * ceq[k]; }
-                    const double s1 = (g1[0] + g1[1]) + g1[2];
+                for (int k = 0; k < K_PSF; k++) { g1[k] = g[k] * r[k]; r1[k] = r[k] * ceq[k]; }
+                const double s1 = (g1[0] + g1[1]) + g1[2];
 #pragma unroll
-                    for (int k = 0; k < K_PSF; k++) { g[k] = g1[k] * r1[k]; r[k] = r1[k] * ceq[k]; }
-                    const double s2 = (g[0] + g[1]) + g[2];
+                for (int k = 0; k < K_PSF; k++) { g[k] = g1[k] * r1[k]; r[k] = r1[k] * ceq[k]; }
+                const double s2 = (g[0] + g[1]) + g[2];
 #pragma unroll
-                    for (int k = 0; k < K_PSF; k++) { g1[k] = g[k] * r[k]; r1[k] = r[k] * ceq[k]; }
-                    const double s3 = (g1[0] + g1[1]) + g1[2];
+                for (int k = 0; k < K_PSF; k++) { g1[k] = g[k] * r[k]; r1[k] = r[k] * ceq[k]; }
+                const double s3 = (g1[0] + g1[1]) + g1[2];
 #pragma unroll
-                    for (int k = 0; k < K_PSF; k++) { g[k] = g1[k] * r1[k]; r[k] = r1[k] * ceq[k]; }
+                for (int k = 0; k < K_PSF; k++) { g[k] = g1[k] * r1[k]; r[k] = r1[k] * ceq[k]; }
+                if (i + 3 < n) {            // the whole trip lies inside this lane's rows (most lanes, most trips)
                     lds_add(&rowp[0], s0);
                     lds_add(&rowp[HW_TW], s1);
                     lds_add(&rowp[2 * HW_TW], s2);
                     lds_add(&rowp[3 * HW_TW], s3);
+                } else {
+                    if (i < n) lds_add(&rowp[0], s0);
+                    if (i + 1 < n) lds_add(&rowp[HW_TW], s1);
+                    if (i + 2 < n) lds_add(&rowp[2 * HW_TW], s2);
                 }
-                for (; row < rb; row++, rowp += HW_TW) {
+            }
+            for (; i < nmax; i++, rowp += HW_TW) {
 #pragma clang fp contract(off)
-                    lds_add(&rowp[0], (g[0] + g[1]) + g[2]);
+                if (i < n) lds_add(&rowp[0], (g[0] + g[1]) + g[2]);
 #pragma unroll
-                    for (int k = 0; k < K_PSF; k++) { g[k] = g[k] * r[k]; r[k] = r[k] * ceq[k]; }
-                }
+                for (int k = 0; k < K_PSF; k++) { g[k] = g[k] * r[k]; r[k] = r[k] * ceq[k]; }
             }
         }
     }
@@ -418,7 +440,7 @@ k_render_hw(RenderArgs a) {
     // return in order -- and in a persistent, software-pipelined star kernel: slower in every form,
     // 0.179 / 0.180 / 0.205 against 0.171 ms on the dense star field -- DESIGN.md 5.)
     if (nstar > 0)
-        star_pass<DIAG>(a, *reinterpret_cast<StarTab *>(&T), et, acc, recs, off, nstar, lane, xi, Y0, strict, dbg_halfrows, dbg_pairs);
+        star_pass<DIAG>(a, *reinterpret_cast<StarTab *>(&T), et, acc, recs, off, nstar, lane, X0, Y0, strict, dbg_halfrows, dbg_pairs);
 
     const LaneConst lc = lane_consts(lane, bd);
     // the rest of the tile's list (everything when there was no star pass), 64 indices per coalesced
