@@ -434,9 +434,21 @@ def extra_render_legs(args, env, field, out):
     for _ in range(3):
         ll_list = celeste.celeste_likelihood_multi_image(plist, imgs)
     out["python_api_list_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+    views = cel.SrcCatalog.from_params(plist).views()         # a LIST of per-source objects backed by one catalogue
+    ll_views = celeste.celeste_likelihood_multi_image(views, imgs)
+    views[17].u = views[17].u + 1e-5                          # a write through a view is seen by the next call
+    moved = celeste.celeste_likelihood_multi_image(views, imgs)
+    views[17].u = views[17].u - 1e-5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ll_views = celeste.celeste_likelihood_multi_image(views, imgs)
+    out["python_api_views_ms"] = (time.perf_counter() - t0) / n * 1e3
+    assert moved != ll_views and abs(ll_views - ll_api) <= 1e-12 * abs(ll_api)
     out["python_api_note"] = ("celeste_likelihood_multi_image(srcs, imgs) end to end, images resident after the first call: "
                               "srcs = SrcCatalog (arrays; python_api_ms) / a plain list of %d SrcParams objects "
-                              "(python_api_list_ms: the per-object attribute gather dominates)" % len(plist))
+                              "(python_api_list_ms: the per-object attribute gather dominates) / the list SrcCatalog.views() "
+                              "hands out: per-source objects with SrcParams' attributes, backed by the catalogue's arrays "
+                              "(python_api_views_ms)" % len(plist))
     out["python_api_loglik_rel_diff"] = float(abs(ll_api - out["loglik"]) / abs(out["loglik"])) if out["loglik"] else None
     assert abs(ll_list - ll_api) <= 1e-12 * abs(ll_api)
 

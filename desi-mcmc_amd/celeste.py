@@ -11,6 +11,8 @@ Divergences from the reference, all documented in DESIGN.md "Quirks":
   planck  stars given by temperature (`src.t`) need a hook: set `photons_expected_brightness`.
 """
 import collections
+import itertools
+import operator
 import sys
 import weakref
 
@@ -148,58 +150,95 @@ def expected_photons(src, image):
     raise Exception("No way to compute expected photons without at least fluxes or brightness")
 
 
-def _gather_fluxes(srcs, images, bidx):
+def _gather_fluxes(srcs, images, bidx, fls=None):
     """(S, B) fluxes in the images' bands: one pass over the sources, not S x B calls"""
     S = len(srcs)
-    fls = [s.fluxes for s in srcs]
-    if all(isinstance(f, dict) for f in fls):
+    if fls is None:
+        fls = [s.fluxes for s in srcs]
+    kinds = set(map(type, fls))
+    if kinds == {dict}:
         names = [im.band for im in images]
         return np.array([[f[n] for n in names] for f in fls], dtype=np.float64).reshape(S, len(images))
-    if not any(isinstance(f, dict) for f in fls):
+    if dict not in kinds:
+        if kinds == {np.ndarray}:
+            return np.concatenate(fls).astype(np.float64, copy=False).reshape(S, -1)[:, bidx]
         return np.array(fls, dtype=np.float64).reshape(S, -1)[:, bidx]
     return np.array([[_flux(s, im.band) for im in images] for s in srcs], dtype=np.float64).reshape(S, len(images))
 
 
+def _catalogue_rows(srcs):
+    """-> (SrcCatalog, row indices or None = every row in order) when `srcs` is a list of views of ONE catalogue
+    (SrcCatalog.views() or any selection of it); None otherwise.  The full list is recognised by object identity
+    in one C-level pass; a selection costs one attribute read per source."""
+    from .celeste_src import _SrcView
+    if not isinstance(srcs, (list, tuple)) or not srcs or type(srcs[0]) is not _SrcView:
+        return None
+    cat = srcs[0]._c
+    whole = getattr(cat, "_views", None)
+    if whole is not None and len(srcs) == len(whole) and (srcs is whole or all(map(operator.is_, srcs, whole))):
+        return cat, None
+    if not all(type(s) is _SrcView and s._c is cat for s in srcs):
+        return None
+    return cat, np.fromiter(map(operator.attrgetter("_i"), srcs), dtype=np.int64, count=len(srcs))
+
+
 def _source_arrays(srcs, images, counts_fn=expected_photons):
     """(type[S], radec[S,2], counts[S,B], shape[S,4]) of a sequence of SrcParams for the device.
-    A SrcCatalog hands its arrays over without any per-source work; a plain list is gathered with
-    one pass per attribute (no S x B nest of Python calls) when every source takes the same flux
-    convention, and source by source otherwise."""
+    A SrcCatalog -- or a list of its views, SrcCatalog.views() -- hands its arrays over without any per-source
+    work; a plain list of SrcParams is gathered with one C-level pass per attribute (no S x B nest of Python
+    calls) when every source takes the same flux convention, and source by source otherwise."""
     from .celeste_src import SrcCatalog
     B = len(images)
     bidx = [list(BANDS).index(im.band) for im in images]
     calib = np.array([im.calib for im in images])
     kappa = np.array([im.kappa for im in images])
+    rows = None
+    if not isinstance(srcs, SrcCatalog):
+        hit = _catalogue_rows(srcs)
+        if hit is not None:
+            srcs, rows = hit
     if isinstance(srcs, SrcCatalog):
-        a, fl = srcs.a, srcs.fluxes[:, bidx]
+        a, u, fl5, sh = srcs.a, srcs.u, srcs.fluxes, srcs.shape
+        if rows is not None:
+            a, u, fl5, sh = a[rows], u[rows], fl5[rows], sh[rows]
+        fl = fl5[:, bidx]
         if counts_fn is expected_photons:
             # celeste.py:35-62: stars / galaxies flux / calib * kappa, untyped rows kappa * flux
             counts = np.where((a >= 0)[:, None], fl / calib[None, :] * kappa[None, :], kappa[None, :] * fl)
         else:
             counts = (fl / calib[None, :]) * kappa[None, :]          # flux_dict convention (celeste.py:80-81,94)
         typ = (a == 1).astype(np.int32)
-        return typ, srcs.u, counts, np.where((a == 1)[:, None], srcs.shape, 0.0)
+        return typ, u, counts, np.where((a == 1)[:, None], sh, 0.0)
     S = len(srcs)
-    typ = np.fromiter((1 if s.a == 1 else 0 for s in srcs), dtype=np.int32, count=S)
     radec = np.zeros((S, 2))
     shape = np.zeros((S, 4))
     counts = np.zeros((S, B))
-    simple = counts_fn is not expected_photons or not any(getattr(s, "t", None) for s in srcs)
+    # one pass for what decides the route: type, temperature, flux container
+    try:
+        head = list(map(operator.attrgetter("a", "fluxes", "t"), srcs))
+    except AttributeError:                      # records without a temperature attribute
+        head = [(s.a, s.fluxes, getattr(s, "t", None)) for s in srcs]
+    typ = np.fromiter((1 if h[0] == 1 else 0 for h in head), dtype=np.int32, count=S)
+    simple = counts_fn is not expected_photons or not any(h[2] for h in head)
     if S and simple:
-        radec[:] = np.array([s.u for s in srcs], dtype=np.float64).reshape(S, 2)
+        us = list(map(operator.attrgetter("u"), srcs))
+        if set(map(type, us)) == {np.ndarray} and us[0].shape == (2,):
+            radec[:] = np.concatenate(us).reshape(S, 2)         # a (3,) among them fails the reshape, as np.array would
+        else:
+            radec[:] = np.array(us, dtype=np.float64).reshape(S, 2)
         gal = np.nonzero(typ)[0]
         if gal.size:
-            shape[gal] = [[srcs[i].theta, srcs[i].sigma, srcs[i].phi, srcs[i].rho] for i in gal]
+            pick = srcs if gal.size == S else [srcs[i] for i in gal]
+            shape[gal] = np.fromiter(itertools.chain.from_iterable(map(operator.attrgetter("theta", "sigma", "phi", "rho"), pick)),
+                                     dtype=np.float64, count=4 * gal.size).reshape(gal.size, 4)
         if counts_fn is expected_photons:
-            for s in srcs:
-                if s.a is None and s.fluxes is None:
-                    raise Exception("No way to compute expected photons without at least fluxes or brightness")
-            fl = _gather_fluxes(srcs, images, bidx)
-            untyped = np.fromiter((s.a is None for s in srcs), dtype=bool, count=S)
+            if any(h[0] is None and h[1] is None for h in head):
+                raise Exception("No way to compute expected photons without at least fluxes or brightness")
+            fl = _gather_fluxes(srcs, images, bidx, [h[1] for h in head])
+            untyped = np.fromiter((h[0] is None for h in head), dtype=bool, count=S)
             counts = np.where(untyped[:, None], kappa[None, :] * fl, fl / calib[None, :] * kappa[None, :])
         else:
-            fd = [s.flux_dict for s in srcs]
-            fl = np.array([[d[im.band] for im in images] for d in fd], dtype=np.float64).reshape(S, B)
+            fl = _gather_fluxes(srcs, images, bidx, [h[1] for h in head])      # flux_dict = the same numbers by band letter
             counts = (fl / calib[None, :]) * kappa[None, :]
         return typ, radec, counts, shape
     for s, src in enumerate(srcs):

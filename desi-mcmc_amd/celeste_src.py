@@ -106,6 +106,16 @@ class SrcCatalog(object):
     def __len__(self):
         return self.a.shape[0]
 
+    def views(self):
+        """The catalogue as a plain LIST of per-source objects with the attribute names of SrcParams, each a
+        window on this catalogue's arrays: what a caller that wants `list[SrcParams]` semantics (celeste_em.py:25,159,
+        celeste_mcmc.py:130 pass such lists) should hold.  Writing `srcs[i].u = ...` writes the arrays, and the
+        render / likelihood functions recognise the list (or any sub-list of it) and take the arrays without
+        touching the objects one by one.  The same objects are returned on every call."""
+        if getattr(self, "_views", None) is None or len(self._views) != len(self):
+            self._views = [_SrcView(self, i) for i in range(len(self))]
+        return self._views
+
     def __getitem__(self, i):
         if isinstance(i, slice):
             return SrcCatalog(self.a[i], self.u[i], self.fluxes[i], self.shape[i])

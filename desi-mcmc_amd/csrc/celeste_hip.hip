@@ -63,12 +63,17 @@ static int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// A failing call leaves the function at once -- but asynchronous copies queued earlier in it may still be reading
+// a local (a std::vector of staged arguments) or a caller's buffer: the error path drains the device first, so that
+// nothing is in flight when those go out of scope.  (Error paths only; scratch_get fails through here as well.)
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess)                                                                 \
+        if (e_ != hipSuccess) {                                                               \
+            (void)hipDeviceSynchronize();                                                     \
             return fail(e_ == hipErrorOutOfMemory ? CEL_ERR_NOMEM : CEL_ERR_HIP, "%s: %s (%s:%d)", \
                         #expr, hipGetErrorString(e_), __FILE__, __LINE__);                    \
+        }                                                                                     \
     } while (0)
 
 #include "device_common.h"

@@ -81,10 +81,17 @@ class CelesteBase(object):
         self.star_flux_prior_distn = star_flux_prior_distn
         self.gal_flux_prior_distn = gal_flux_prior_distn
 
-    def initialize_sources(self, init_srcs=None, init_src_params=None, photoobj_df=None):
+    def initialize_sources(self, init_srcs=None, init_src_params=None, photoobj_df=None, catalogue=False):
+        """models.py:62-73.  catalogue=True (an addition): the parameters are packed into ONE SrcCatalog and every
+        Source gets a view of its row (same attribute names, reads and writes go to the arrays), so that
+        `[s.params for s in model.srcs]` reaches the device without a per-object gather -- for sources given by
+        fluxes (a view has no black-body t / b)."""
         if init_srcs is not None:
             self.srcs = init_srcs
         elif init_src_params is not None:
+            if catalogue:
+                from .celeste_src import SrcCatalog
+                init_src_params = SrcCatalog.from_params(init_src_params).views()
             self.srcs = [self._source_type(s, self) for s in init_src_params]
         else:
             raise NotImplementedError("photoObj tables need the reference's data-acquisition layer")

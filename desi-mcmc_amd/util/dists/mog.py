@@ -39,6 +39,26 @@ def mog_loglike(x, means, icovs, dets, pis, device=0):
     return out
 
 
+def discrete(p, shape, rng=None):
+    """component labels drawn with probabilities p  -- mog.py:34-37: label = K - #{cumulative weights above the
+    uniform} = #{cumulative weights at or below it}, found by bisection instead of an (N, K) comparison.  Weights
+    that sum to less than one (a PSF's, 0.998) would send the last sliver to label K: it is given to K - 1.
+    Host-side draws from `rng` (numpy's global generator by default, as the reference)."""
+    rng = np.random if rng is None else rng
+    cum = np.cumsum(np.asarray(p, dtype=np.float64))
+    k = np.searchsorted(cum, rng.rand(int(np.prod(shape))), side="right")
+    return np.minimum(k, cum.shape[0] - 1).reshape(shape)
+
+
+def mog_samples(N, means, chols, pis, rng=None):
+    """N draws from the mixture: a label per draw, then mean + chol . white noise  -- mog.py:25-32"""
+    rng = np.random if rng is None else rng
+    means, chols = np.asarray(means, dtype=np.float64), np.asarray(chols, dtype=np.float64)
+    labels = discrete(pis, (N,), rng=rng)
+    white = rng.randn(N, means.shape[1])
+    return np.matmul(chols[labels], white[:, :, None])[:, :, 0] + means[labels]
+
+
 class MixtureOfGaussians(object):
     """Evaluate the (log) density of a 2-D mixture of Gaussians  -- mog.py:38-112"""
 
@@ -63,6 +83,15 @@ class MixtureOfGaussians(object):
 
     def mean(self, x=None):
         return np.dot(self.pis, self.means)
+
+    def var(self, x=None):
+        """the weighted sum of the component covariances  -- mog.py:69-70 (which reads a global `pis`; the
+        mixture's own weights are what it means)"""
+        return np.sum(self.covs * self.pis[:, None, None], axis=0)
+
+    def rvs(self, size=1, rng=None):
+        """mog.py:72-73"""
+        return mog_samples(size, self.means, self.chols, self.pis, rng=rng)
 
     def convolve(self, mog):
         """all pairs, this mixture's component index major  -- mog.py:75-81"""

@@ -251,3 +251,63 @@ def test_source_arrays_list_and_catalog_agree_for_every_flux_convention(built):
     ps[0].t, ps[0].a = 5000.0, 0
     with pytest.raises(NotImplementedError):
         celeste._source_arrays(ps, ims)
+
+
+def test_catalogue_views_reach_the_device_arrays_without_a_gather(built):
+    """SrcCatalog.views(): a plain list of per-source objects (what celeste_em.py:25,159 and celeste_mcmc.py:130 pass)
+    whose attributes read and write the catalogue's arrays.  _source_arrays recognises the list, any selection of it,
+    and sees a mutated parameter; a foreign object in the list sends it down the per-object route with the same result."""
+    from desi_mcmc_amd import celeste
+    from desi_mcmc_amd.fits_image import FitsImage
+    rs = np.random.RandomState(3)
+    S = 40
+    ps = [built.SrcParams(u=rs.rand(2), a=int(i % 3 == 0), fluxes=rs.rand(5) + 1, theta=.4, sigma=1.5 + i, phi=30., rho=.6) for i in range(S)]
+    imgs = [FitsImage(b, np.zeros((8, 8)), epsilon=1., kappa=2. + k, calib=.01 * (k + 1), weights=np.ones(3) / 3, means=np.zeros((3, 2)),
+                      covars=np.tile(np.eye(2), (3, 1, 1)), rho_n=np.zeros(2), phi_n=np.zeros(2), Ups_n=np.eye(2)) for k, b in enumerate("gri")]
+    cat = built.SrcCatalog.from_params(ps)
+    views = cat.views()
+    assert views is cat.views() and len(views) == S and isinstance(views, list)
+    want = celeste._source_arrays(ps, imgs)
+    for got in (celeste._source_arrays(views, imgs), celeste._source_arrays(list(views), imgs), celeste._source_arrays(cat, imgs)):
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+    assert celeste._catalogue_rows(views) == (cat, None)
+    sel = [views[i] for i in (5, 3, 11, 3)]
+    c, rows = celeste._catalogue_rows(sel)
+    assert c is cat and rows.tolist() == [5, 3, 11, 3]
+    for g, w in zip(celeste._source_arrays(sel, imgs), celeste._source_arrays([ps[i] for i in (5, 3, 11, 3)], imgs)):
+        assert np.array_equal(g, w)
+    # a write through a view is a write to the arrays: the next call sees it
+    views[7].u = np.array([0.25, 0.75])
+    views[9].sigma = 9.5
+    views[4].fluxes = dict(zip("ugriz", [1., 2., 3., 4., 5.]))
+    ps[7].u, ps[9].sigma, ps[4].fluxes = np.array([0.25, 0.75]), 9.5, np.array([1., 2., 3., 4., 5.])
+    for g, w in zip(celeste._source_arrays(views, imgs), celeste._source_arrays(ps, imgs)):
+        assert np.array_equal(g, w)
+    mixed = list(views)
+    mixed[2] = ps[2]                                         # not a view: no shortcut, same numbers
+    assert celeste._catalogue_rows(mixed) is None
+    for g, w in zip(celeste._source_arrays(mixed, imgs), celeste._source_arrays(ps, imgs)):
+        assert np.array_equal(g, w)
+    other = built.SrcCatalog.from_params(ps[:3]).views()
+    assert celeste._catalogue_rows([views[0], other[1]]) is None
+
+
+def test_mog_sampling_api(built):
+    """mog_samples / discrete / MixtureOfGaussians.rvs / var (util/dists/mog.py:25-37,69-73): host-side draws"""
+    from desi_mcmc_amd.util.dists import mog
+    p = np.array([.2, .5, .3])
+    u = np.random.RandomState(0).rand(5000)
+    want = p.shape[0] - np.sum(u[:, None] < np.cumsum(p), axis=1)            # the reference's expression (mog.py:36)
+    assert np.array_equal(mog.discrete(p, (5000,), rng=np.random.RandomState(0)), want)
+    assert mog.discrete(p, (4, 5), rng=np.random.RandomState(1)).shape == (4, 5)
+    assert mog.discrete(np.array([.3, .3]), (2000,), rng=np.random.RandomState(2)).max() == 1     # weights summing below one
+    m = mog.MixtureOfGaussians(np.array([[0., 0.], [3., 1.]]), np.array([[[1., .3], [.3, .5]], [[.2, 0.], [0., 2.]]]), np.array([.3, .7]))
+    x = m.rvs(100000, rng=np.random.RandomState(1))
+    assert x.shape == (100000, 2)
+    np.testing.assert_allclose(x.mean(axis=0), m.mean(), atol=0.02)
+    between = sum(w * np.outer(mu - m.mean(), mu - m.mean()) for w, mu in zip(m.pis, m.means))
+    np.testing.assert_allclose(np.cov(x.T), m.var() + between, atol=0.03)
+    np.testing.assert_allclose(m.var(), .3 * m.covs[0] + .7 * m.covs[1])
+    np.random.seed(5)
+    assert mog.mog_samples(3, m.means, m.chols, m.pis).shape == (3, 2)      # the global generator, as the reference
