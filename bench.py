@@ -648,7 +648,7 @@ def gibbs_report(g, gf, ctx, steps, dt, S, B):
                      "traffic": None, "kernel": "k_patch_ll_hw<0> (one slice round of every running chain)",
                      "kernel_ms": t_ll, "launches": n_ll, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "kernel_ms: HIP events attached to the kernel's dispatches, averaged over the timed sweeps' launches; bytes: "
-                             "per evaluation and band 8 B per pixel of the photon rectangle walked + a 128-B record, counted on the "
+                             "per evaluation and band 4 B per pixel (int32 photon counts) of the photon rectangle walked + a 128-B record, counted on the "
                              "device.  The kernel is fp64-issue-bound like k_render (DESIGN.md 5); the HBM fraction is what the contract asks for"},
         "work": {"slice_rounds_per_sweep": g.timing["rounds"] / steps, "loglik_evals_per_sweep": g.timing["evals"] / steps,
                  "sources_updated_per_sweep": float(g.active.sum())},
@@ -764,6 +764,8 @@ def main():
                     help="fields8_2048: contexts (HIP streams, a host thread each) per GPU the rank's fields run on; 2 is 3 %% faster, "
                          "but the kernels' event times then include each other")
     ap.add_argument("--slice-sigma", type=float, default=0.001, help="gibbs10k: slice-sampler interval width in degrees")
+    ap.add_argument("--photon-lists", type=int, default=0, choices=[0, 1, 2],
+                    help="gibbs10k: CEL_OPT_PHOTON_LISTS (0 = per patch whichever is cheaper, 1 = always at the photons, 2 = always densely)")
     ap.add_argument("--shapes", action="store_true", help="gibbs10k: every sweep also resamples the galaxies' shapes")
     ap.add_argument("--legs", default="all", choices=["all", "none"],
                     help="render workloads at N=1: 'all' (default) adds the untimed-by-the-contract extras after the timed region "
@@ -809,6 +811,7 @@ def main():
     ctx.set_option(_lib.CEL_OPT_TILE_ROWS, args.tile_rows)
     ctx.set_option(_lib.CEL_OPT_TILE_LAYOUT, args.layout)
     ctx.set_option(_lib.CEL_OPT_TILE_ORDER, args.tile_order)
+    ctx.set_option(_lib.CEL_OPT_PHOTON_LISTS, args.photon_lists)
     backend = "none"
     if world > 1:
         import torch.distributed as td

@@ -112,6 +112,7 @@ struct cel_ctx {
     int tile_order = 1;       // 0 = launch k_render tiles in index order, 1 = heaviest first by the last render's measured tile durations (estimate when none), 2 = heaviest first by the estimate only
     int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created
     bool tile_timing = false; // diagnostic: k_render stamps each tile's start/end wall clock
+    int nz_force = 0;         // CEL_OPT_PHOTON_LISTS: 0 = per patch, whichever is estimated cheaper; 1 = every patch at its photons; 2 = never
     int debug = 0;            // CEL_OPT_DEBUG: timing-only ablation bits handed to the render kernel (results are wrong when set)
     int tile_layout = 1;      // 0: 64 x tile_rows tiles, one lane per column (k_render)
                               // 1: 32 x 64 tiles, two component groups per column (k_render_hw)
@@ -175,10 +176,16 @@ struct cel_images {
     int64_t clist_cap = 0;
     unsigned long long *d_timing = nullptr;   // CEL_OPT_TILE_TIMING diagnostic stamps, 3 per tile
     // device-resident sample patches of the last resident photon split (source-major, index s*B+b)
-    double *d_samp = nullptr;
+    int *d_samp = nullptr;      // the resident photon split's sample patches: int32 photon counts, source-major
     int4 *d_snz = nullptr;      // nonzero rectangles of the resident sample patches (k_patch_nzbox)
     double *d_ssum = nullptr;   // photons per (source, band) of the resident split, summed by the split kernel itself
     bool ssum_valid = false;
+    // photon lists of the resident split (k_nz_layout / k_nz_compact): per patch the pixels that hold a photon
+    int *d_nnz = nullptr, *d_nzmode = nullptr;
+    int64_t *d_nzoff = nullptr;
+    NzEntry *d_nzlist = nullptr;
+    int64_t nzlist_cap = 0;
+    bool nz_valid = false;
     double *d_rate = nullptr;   // per-pixel total rates of the photon split (strict boxes), B*H*W, on first use
     int64_t samp_cap = 0;
     int4 *d_sbox = nullptr;
@@ -432,6 +439,10 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         if (v != 0.0 && v != 1.0 && v != 2.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TILE_LAYOUT must be 0, 1 or 2");
         c->tile_layout = (int)v;
         return CEL_OK;
+    case CEL_OPT_PHOTON_LISTS:
+        if (v != 0.0 && v != 1.0 && v != 2.0) return fail(CEL_ERR_INVALID, "CEL_OPT_PHOTON_LISTS must be 0, 1 or 2");
+        c->nz_force = (int)v;
+        return CEL_OK;
     case CEL_OPT_DEBUG:
         if (!(v >= 0.0) || v > 4095.0) return fail(CEL_ERR_INVALID, "CEL_OPT_DEBUG must be in [0, 4095]");
 #ifndef CEL_ABLATE
@@ -456,6 +467,7 @@ int cel_ctx_get_option(cel_ctx *c, int key, double *v) {
     case CEL_OPT_TILE_ROWS: *v = c->tile_rows; return CEL_OK;
     case CEL_OPT_TILE_TIMING: *v = c->tile_timing ? 1.0 : 0.0; return CEL_OK;
     case CEL_OPT_TILE_LAYOUT: *v = c->tile_layout; return CEL_OK;
+    case CEL_OPT_PHOTON_LISTS: *v = c->nz_force; return CEL_OK;
     case CEL_OPT_DEBUG: *v = c->debug; return CEL_OK;
     }
     return fail(CEL_ERR_INVALID, "unknown option %d", key);
@@ -468,7 +480,8 @@ int cel_images_destroy(cel_images *im) {
     (void)hipStreamSynchronize(im->ctx->stream);
     void *ptrs[] = {im->d_bands, im->d_nelec, im->d_lambda, im->d_partials, im->d_llband, im->d_recs,
                     im->d_boxes, im->d_kind, im->d_status, im->d_tile_cnt, im->d_tile_nstar, im->d_tile_work, im->d_tile_cost, im->d_order, im->d_tile_off, im->d_lists, im->d_stats,
-                    im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff, im->d_rate, im->d_snz, im->d_ssum};
+                    im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff, im->d_rate, im->d_snz, im->d_ssum,
+                    im->d_nnz, im->d_nzmode, im->d_nzoff, im->d_nzlist};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (im->d_slice) (void)hipFree(im->d_slice);
@@ -1075,7 +1088,7 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
         d_nz = im->d_snz;
         d_box = im->d_sbox;
         d_off = im->d_soff;
-        d_data = (mode != 1) ? im->d_samp : nullptr;      // mode 1 reads nelec on the boxes
+        d_data = nullptr;                                 // mode 0: the int32 patches (below); mode 1 reads nelec on the boxes
     } else {
         PL_TRY(hipMemcpyAsync(d_box, hbox.data(), sizeof(int4) * nb, hipMemcpyHostToDevice, c->stream));
         PL_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice, c->stream));
@@ -1090,24 +1103,40 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
     }
     {
         int pi = prof_begin(c, CEL_K_PATCH_LL);
-        if (c->variant == 0)
-            hipLaunchKernelGGL(k_patch_ll, dim3((unsigned)(P * B)), dim3(256), 0, c->stream, im->d_bands, B, P, im->d_recs,
-                               d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, mode, d_out);
-        else if (mode == 0) {
+        // the resident split's patches are int32 photon counts (mode 0); everything a caller hands over, and the observed
+        // image the resident mode 1 reads, is double
+        const int *i_data = (resident && mode == 0) ? im->d_samp : nullptr;
+        if (c->variant == 0) {
+            if (i_data)
+                hipLaunchKernelGGL(k_patch_ll<int>, dim3((unsigned)(P * B)), dim3(256), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                                   d_owner, d_box, d_off, i_data, im->d_nelec, im->H, im->W, mode, d_out);
+            else
+                hipLaunchKernelGGL(k_patch_ll<double>, dim3((unsigned)(P * B)), dim3(256), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                                   d_owner, d_box, d_off, (const double *)d_data, im->d_nelec, im->H, im->W, mode, d_out);
+        } else if (mode == 0) {
             if (!resident)
-                hipLaunchKernelGGL(k_patch_nzbox, dim3((unsigned)nb), dim3(64), 0, c->stream, d_box, d_off, d_data, d_nz);
-            hipLaunchKernelGGL(k_patch_ll_hw<0>, dim3((unsigned)(P * B * nparts)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
-                               d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, d_nz, c->tail_T, d_out,
-                               (const int *)nullptr, nparts);
+                hipLaunchKernelGGL(k_patch_nzbox<double>, dim3((unsigned)nb), dim3(64), 0, c->stream, d_box, d_off, (const double *)d_data, d_nz);
+            if (i_data)
+                hipLaunchKernelGGL((k_patch_ll_hw<0, int>), dim3((unsigned)(P * B * nparts)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                                   d_owner, d_box, d_off, i_data, im->d_nelec, im->H, im->W, d_nz, c->tail_T, d_out,
+                                   (const int *)nullptr, nparts, (const int *)nullptr,
+                                   (const int *)(im->nz_valid ? im->d_nzmode : nullptr), (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist);
+            else
+                hipLaunchKernelGGL((k_patch_ll_hw<0, double>), dim3((unsigned)(P * B * nparts)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                                   d_owner, d_box, d_off, (const double *)d_data, im->d_nelec, im->H, im->W, d_nz, c->tail_T, d_out,
+                                   (const int *)nullptr, nparts, (const int *)nullptr);
         } else if (mode == 2)
-            hipLaunchKernelGGL(k_patch_ll_hw<2>, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
-                               d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
+            hipLaunchKernelGGL((k_patch_ll_hw<2, double>), dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                               d_owner, d_box, d_off, (const double *)d_data, im->d_nelec, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out,
+                               (const int *)nullptr, 1, (const int *)nullptr);
         else if (mode == 4)
-            hipLaunchKernelGGL(k_patch_ll_hw<4>, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
-                               d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
+            hipLaunchKernelGGL((k_patch_ll_hw<4, double>), dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                               d_owner, d_box, d_off, (const double *)d_data, im->d_nelec, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out,
+                               (const int *)nullptr, 1, (const int *)nullptr);
         else
-            hipLaunchKernelGGL(k_patch_ll_hw<1>, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
-                               d_owner, d_box, d_off, d_data, im->d_nelec, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
+            hipLaunchKernelGGL((k_patch_ll_hw<1, double>), dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                               d_owner, d_box, d_off, (const double *)d_data, im->d_nelec, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out,
+                               (const int *)nullptr, 1, (const int *)nullptr);
         prof_end(c, pi);
     }
     PL_TRY(hipGetLastError());
@@ -1147,7 +1176,7 @@ int cel_stamp_mass(cel_images *im, cel_sources *src, double *mass) {
     double *d_out = nullptr;
     if ((rc = scratch_get(c, 2, sizeof(double) * S * B, (void **)&d_out))) return rc;
     int pi = prof_begin(c, CEL_K_MASS);
-    hipLaunchKernelGGL(k_patch_ll_hw<3>, dim3((unsigned)(S * B)), dim3(64), 0, c->stream, im->d_bands, B, S, im->d_recs,
+    hipLaunchKernelGGL((k_patch_ll_hw<3, double>), dim3((unsigned)(S * B)), dim3(64), 0, c->stream, im->d_bands, B, S, im->d_recs,
                        (const int *)nullptr, (const int4 *)nullptr, (const int64_t *)nullptr, (const double *)nullptr,
                        (const double *)nullptr, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
     prof_end(c, pi);
@@ -1258,13 +1287,14 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
             if ((rc = run_prep(im, prop, d_owner))) return rc;
             int pi = prof_slot(c, CEL_K_PATCH_LL);
             if (c->variant == 0)
-                LAUNCH_EV(k_patch_ll, dim3((unsigned)(S * B)), dim3(256), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
-                          d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, 0, d_ll);
+                LAUNCH_EV(k_patch_ll<int>, dim3((unsigned)(S * B)), dim3(256), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
+                          d_owner, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_nelec, im->H, im->W, 0, d_ll);
             else
-                LAUNCH_EV(k_patch_ll_hw<0>, dim3((unsigned)((nsplit > 1 ? live * B : S * B) * nsplit)), dim3(64), st, EV0(c, pi), EV1(c, pi),
+                LAUNCH_EV((k_patch_ll_hw<0, int>), dim3((unsigned)((nsplit > 1 ? live * B : S * B) * nsplit)), dim3(64), st, EV0(c, pi), EV1(c, pi),
                           im->d_bands, B, S, im->d_recs,
-                          d_owner, im->d_sbox, im->d_soff, im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll,
-                          (const int *)(nsplit > 1 ? d_live : d_jobs), nsplit, (const int *)(nsplit > 1 ? d_flags + 4 : nullptr));
+                          d_owner, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll,
+                          (const int *)(nsplit > 1 ? d_live : d_jobs), nsplit, (const int *)(nsplit > 1 ? d_flags + 4 : nullptr),
+                          (const int *)(im->nz_valid ? im->d_nzmode : nullptr), (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist);
             hipLaunchKernelGGL(k_slice_consume, dim3(g256), dim3(256), 0, st, ss, S, B, nsplit, d_ll, sigma, d_flags, d_flags + 1);
             queued++;
         }
@@ -1348,7 +1378,7 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
     const int T = B * im->ntx * im->nty;
     int64_t total = 0;
     int64_t *d_off = nullptr;
-    double *d_samp = nullptr;
+    void *d_samp = nullptr;             // resident: int32 photon counts; a caller's buffer: doubles
     if (resident) {
         // patch boxes + offsets laid out on the device; only the total size comes back
         if (n + 1 > im->slay_cap) {
@@ -1357,12 +1387,19 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
             if (im->d_soff) (void)hipFree(im->d_soff);
             if (im->d_snz) (void)hipFree(im->d_snz);
             if (im->d_ssum) (void)hipFree(im->d_ssum);
+            if (im->d_nnz) (void)hipFree(im->d_nnz);
+            if (im->d_nzmode) (void)hipFree(im->d_nzmode);
+            if (im->d_nzoff) (void)hipFree(im->d_nzoff);
+            im->d_nnz = nullptr; im->d_nzmode = nullptr; im->d_nzoff = nullptr;
             im->d_sbox = nullptr; im->d_soff = nullptr; im->d_snz = nullptr; im->d_ssum = nullptr; im->slay_cap = 0;
             int64_t cap = n + n / 4 + 64;
             HIP_TRY(hipMalloc((void **)&im->d_sbox, sizeof(int4) * cap));
             HIP_TRY(hipMalloc((void **)&im->d_snz, sizeof(int4) * cap));
             HIP_TRY(hipMalloc((void **)&im->d_soff, sizeof(int64_t) * cap));
             HIP_TRY(hipMalloc((void **)&im->d_ssum, sizeof(double) * cap));
+            HIP_TRY(hipMalloc((void **)&im->d_nnz, sizeof(int) * cap));
+            HIP_TRY(hipMalloc((void **)&im->d_nzmode, sizeof(int) * cap));
+            HIP_TRY(hipMalloc((void **)&im->d_nzoff, sizeof(int64_t) * cap));
             im->slay_cap = cap;
         }
         hipLaunchKernelGGL(k_samp_layout, dim3(1), dim3(1024), 0, c->stream, im->d_recs, S, B, im->d_sbox, im->d_soff);
@@ -1373,7 +1410,7 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
             if (im->d_samp) (void)hipFree(im->d_samp);
             im->d_samp = nullptr; im->samp_cap = 0;
             int64_t cap = total + total / 8 + 1024;
-            HIP_TRY(hipMalloc((void **)&im->d_samp, sizeof(double) * cap));
+            HIP_TRY(hipMalloc((void **)&im->d_samp, sizeof(int) * cap));
             im->samp_cap = cap;
         }
         d_off = im->d_soff;
@@ -1385,17 +1422,21 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         if ((rc = scratch_get(c, 1, sizeof(int64_t) * (n + 1), (void **)&d_off))) return rc;
         HIP_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, c->stream));
         if (mem == CEL_DEVICE) d_samp = samp;
-        else if ((rc = scratch_get(c, 3, sizeof(double) * (total > 0 ? total : 1), (void **)&d_samp))) return rc;
+        else if ((rc = scratch_get(c, 3, sizeof(double) * (total > 0 ? total : 1), &d_samp))) return rc;
     }
     // resident + recurrence form: the kernel writes every interior pixel and reduces the photon
     // rectangles itself; otherwise zero the buffer and (resident) find the rectangles afterwards
     const bool fused_nz = resident && hw && n > 0;
     if (resident) im->ssum_valid = fused_nz;
+    // photon lists: pixel coordinates are packed into 16 bits each
+    const bool lists = fused_nz && im->W < 65536 && (im->win_y0 + im->H) < 65536 && c->nz_force != 2;
+    if (resident) im->nz_valid = false;
     if (fused_nz) HIP_TRY(hipMemsetAsync(im->d_ssum, 0, sizeof(double) * n, c->stream));
+    if (lists) HIP_TRY(hipMemsetAsync(im->d_nnz, 0, sizeof(int) * n, c->stream));
     if (fused_nz)
-        hipLaunchKernelGGL(k_samp_prepare, dim3((unsigned)n), dim3(64), 0, c->stream, im->d_sbox, im->d_soff, d_samp, im->d_snz);
+        hipLaunchKernelGGL(k_samp_prepare<int>, dim3((unsigned)n), dim3(64), 0, c->stream, im->d_sbox, im->d_soff, im->d_samp, im->d_snz);
     else if (total > 0)
-        HIP_TRY(hipMemsetAsync(d_samp, 0, sizeof(double) * total, c->stream));
+        HIP_TRY(hipMemsetAsync(d_samp, 0, (resident ? sizeof(int) : sizeof(double)) * total, c->stream));
     {
         SplitArgs a;
         a.bands = im->d_bands; a.recs = im->d_recs; a.lists = im->d_lists; a.tile_cnt = im->d_tile_cnt;
@@ -1406,22 +1447,45 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         a.rate_img = im->d_rate; a.tail_T = c->tail_T; a.nz = fused_nz ? im->d_snz : nullptr;
         a.order = (hw && c->tile_order) ? im->d_order : nullptr;
         a.sums = fused_nz ? im->d_ssum : nullptr;
+        a.nnz = lists ? im->d_nnz : nullptr;
         a.debug = c->debug;
         if (hw && (rc = scratch_get(c, 2, sizeof(double) * 2 * (size_t)T, (void **)&a.partials))) return rc;
         int pi = prof_begin(c, CEL_K_SPLIT);
-        if (hw) hipLaunchKernelGGL(k_photon_split_hw, dim3(2 * T), dim3(64), 0, c->stream, a);
-        else hipLaunchKernelGGL(k_photon_split, dim3(T), dim3(64), 0, c->stream, a);
+        if (hw && resident) hipLaunchKernelGGL(k_photon_split_hw<int>, dim3(2 * T), dim3(64), 0, c->stream, a);
+        else if (hw) hipLaunchKernelGGL(k_photon_split_hw<double>, dim3(2 * T), dim3(64), 0, c->stream, a);
+        else if (resident) hipLaunchKernelGGL(k_photon_split<int>, dim3(T), dim3(64), 0, c->stream, a);
+        else hipLaunchKernelGGL(k_photon_split<double>, dim3(T), dim3(64), 0, c->stream, a);
         prof_end(c, pi);
         hipLaunchKernelGGL(k_reduce, dim3(B), dim3(256), 0, c->stream, a.partials, (hw ? 2 : 1) * im->ntx * im->nty, im->d_llband);
         if (resident && n > 0 && !fused_nz)   // where each patch's photons are: the conditional likelihoods evaluate only there
-            hipLaunchKernelGGL(k_patch_nzbox, dim3((unsigned)n), dim3(64), 0, c->stream, im->d_sbox, im->d_soff, im->d_samp, im->d_snz);
+            hipLaunchKernelGGL(k_patch_nzbox<int>, dim3((unsigned)n), dim3(64), 0, c->stream, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_snz);
     }
+    if (lists)      // where each patch's photon list starts, and whether its likelihood is cheaper at the photons or densely
+        hipLaunchKernelGGL(k_nz_layout, dim3(1), dim3(1024), 0, c->stream, (const int *)im->d_nnz, (const int4 *)im->d_snz,
+                           (const int *)src->d_type, S, B, c->nz_force, im->d_nzoff, im->d_nzmode);
     HIP_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
+    if (lists) HIP_TRY(hipMemcpyAsync(c->pinned + MAX_BANDS + 2, im->d_nzoff + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     if (!resident && mem != CEL_DEVICE && total > 0)
         HIP_TRY(hipMemcpyAsync(samp, d_samp, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (noise) for (int b = 0; b < B; b++) noise[b] = c->pinned[b];
+    if (lists) {
+        int64_t nn = 0;
+        memcpy(&nn, c->pinned + MAX_BANDS + 2, sizeof(nn));
+        if (nn > im->nzlist_cap) {
+            if (im->d_nzlist) (void)hipFree(im->d_nzlist);
+            im->d_nzlist = nullptr; im->nzlist_cap = 0;
+            const int64_t cap = nn + nn / 4 + 1024;
+            HIP_TRY(hipMalloc((void **)&im->d_nzlist, sizeof(NzEntry) * cap));
+            im->nzlist_cap = cap;
+        }
+        // stream-ordered: whatever scores against these patches next runs behind it
+        hipLaunchKernelGGL(k_nz_compact, dim3((unsigned)n), dim3(64), 0, c->stream, (const int4 *)im->d_sbox, (const int64_t *)im->d_soff,
+                           (const int *)im->d_samp, (const int4 *)im->d_snz, (const int64_t *)im->d_nzoff, im->d_nzlist);
+        HIP_TRY(hipGetLastError());
+        im->nz_valid = true;
+    }
     return CEL_OK;
 }
 
@@ -1447,15 +1511,18 @@ int cel_samples_fetch(cel_images *im, int32_t *boxes, int64_t *offsets, double *
         }
     }
     if (offsets && (rc = copy_out(offsets, im->d_soff, sizeof(int64_t) * (n + 1), CEL_HOST, c->stream))) return rc;
-    if (data && im->samp_total > 0 &&
-        (rc = copy_out(data, im->d_samp, sizeof(double) * im->samp_total, CEL_HOST, c->stream))) return rc;
+    if (data && im->samp_total > 0) {           // int32 on the device, doubles across the ABI
+        std::vector<int> hs((size_t)im->samp_total);
+        if ((rc = copy_out(hs.data(), im->d_samp, sizeof(int) * im->samp_total, CEL_HOST, c->stream))) return rc;
+        for (int64_t i = 0; i < im->samp_total; i++) data[i] = (double)hs[(size_t)i];
+    }
     if (sums) {
         if (im->ssum_valid) {       // the split kernel summed them itself (exact: integer-valued)
             if ((rc = copy_out(sums, im->d_ssum, sizeof(double) * n, CEL_HOST, c->stream))) return rc;
         } else {
             double *d_sums = nullptr;
             if ((rc = scratch_get(c, 2, sizeof(double) * n, (void **)&d_sums))) return rc;
-            hipLaunchKernelGGL(k_patch_sums, dim3((unsigned)n), dim3(256), 0, c->stream, im->d_soff, im->d_samp, d_sums);
+            hipLaunchKernelGGL(k_patch_sums<int>, dim3((unsigned)n), dim3(256), 0, c->stream, im->d_soff, (const int *)im->d_samp, d_sums);
             if ((rc = copy_out(sums, d_sums, sizeof(double) * n, CEL_HOST, c->stream))) return rc;
         }
     }

@@ -49,5 +49,9 @@ static const double H_DEV_AMP[8] = {4.26347652e-02, 2.40127183e-01, 6.85907632e-
 static const double H_DEV_VAR[8] = {2.23759216e-04, 1.00220099e-03, 4.18731126e-03, 1.69432589e-02,
                                     6.84850479e-02, 2.87207080e-01, 1.33320254e+00, 8.40215071e+00};
 
+// one photon-holding pixel of a device-resident sample patch (k_nz_compact, k_split.h): x | y << 16 (absolute
+// pixel coordinates, both below 65 536) and the photons attributed to the source there
+struct NzEntry { int xy, z; };
+
 #define PI_D 3.14159265358979323846
 

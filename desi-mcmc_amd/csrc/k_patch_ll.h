@@ -25,11 +25,14 @@
 #pragma once
 #include "hw_source.h"
 
+// TZ: the patch data's element type -- double for patches a caller hands over, int for the device-resident photon
+// split (photon counts are integers: 4 bytes per pixel instead of 8, 1.6 GB instead of 3.2 GB at config 3)
+template <typename TZ>
 __global__ void __launch_bounds__(256)
 k_patch_ll(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__restrict__ recs,
            const int *__restrict__ owner /* P: which patch set a proposal is scored on, or nullptr = 0 */,
            const int4 *__restrict__ pbox /* NB*B: x0, x1, y0, y1 */, const int64_t *__restrict__ offsets /* NB*B+1 */,
-           const double *__restrict__ data, const double *__restrict__ nelec /* used when data == nullptr */,
+           const TZ *__restrict__ data, const double *__restrict__ nelec /* used when data == nullptr */,
            int H, int W, int mode, double *__restrict__ out /* P*B */) {
     __shared__ CompTab T;
     __shared__ double red[256], red2[256];
@@ -65,18 +68,19 @@ k_patch_ll(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__
     const double eps = bd->eps;
     // patch data: a packed buffer (photons attributed to the source), or -- when none is given --
     // the observed image itself on the box (the isolated form reads nelec, sources.py:204)
-    const double *z = data ? data + offsets[ob] : nelec + (int64_t)b * H * W + (int64_t)bx.z * W + bx.x;
+    const TZ *zd = data ? data + offsets[ob] : nullptr;
+    const double *zn = nelec + (int64_t)b * H * W + (int64_t)bx.z * W + bx.x;
     const int zpitch = data ? nx : W;
     double a = 0.0, m = 0.0;
     const int n = nx * ny;
     for (int i = tid; i < n; i += 256) {
         int yy = i / nx, xx = i - yy * nx;
         double v = counts * eval_direct(T, 0, K, (double)(bx.x + xx), (double)(bx.z + yy), 1.0);
-        const double zi = z[(int64_t)yy * zpitch + xx];
+        const double zi = zd ? (double)zd[(int64_t)yy * zpitch + xx] : zn[(int64_t)yy * zpitch + xx];
         if (mode == 0) {
             if (v > 0.0) a += log(v) * zi;
         } else if (mode == 4) {
-            v += z[(int64_t)n + (int64_t)yy * zpitch + xx];         // the background plane follows the data plane
+            v += (double)zd[(int64_t)n + (int64_t)yy * zpitch + xx];         // the background plane follows the data plane
             if (v > 0.0 && zi >= 0.0) { a += log(v) * zi; m += v; }
         } else if (mode == 2) {
             if (v > 0.0) { a += log(v) * zi; m += v; }
@@ -99,8 +103,9 @@ k_patch_ll(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__
 // (mode 0) sums log(m) * z, to which a pixel with z = 0 contributes exactly nothing, so the model
 // need only be evaluated inside this rectangle -- for a faint source a small fraction of its box
 // (the photons sit in the core, the box reaches out to the 1e-5 contour).  One wave per patch.
+template <typename TZ>
 __global__ void __launch_bounds__(64)
-k_patch_nzbox(const int4 *__restrict__ pbox, const int64_t *__restrict__ offsets, const double *__restrict__ data,
+k_patch_nzbox(const int4 *__restrict__ pbox, const int64_t *__restrict__ offsets, const TZ *__restrict__ data,
               int4 *__restrict__ nz /* x0, x1, y0, y1 (absolute), all 0 when the patch holds no photon */) {
     const int64_t i = blockIdx.x;
     const int4 bx = pbox[i];
@@ -108,12 +113,12 @@ k_patch_nzbox(const int4 *__restrict__ pbox, const int64_t *__restrict__ offsets
     const int lane = threadIdx.x;
     int xlo = INT_MAX, xhi = -1, ylo = INT_MAX, yhi = -1;
     if (nx > 0 && ny > 0) {
-        const double *z = data + offsets[i];
+        const TZ *z = data + offsets[i];
         const int64_t n = (int64_t)nx * ny;
         int yy = 0, xx = lane;
         while (xx >= nx) { xx -= nx; yy++; }
         for (int64_t k = lane; k < n; k += 64) {
-            if (z[k] != 0.0) {
+            if (z[k] != (TZ)0) {
                 xlo = min(xlo, xx); xhi = max(xhi, xx);
                 ylo = min(ylo, yy); yhi = max(yhi, yy);
             }
@@ -128,12 +133,52 @@ k_patch_nzbox(const int4 *__restrict__ pbox, const int64_t *__restrict__ offsets
     if (lane == 0) nz[i] = (xhi >= 0) ? make_int4(bx.x + xlo, bx.x + xhi + 1, bx.z + ylo, bx.z + yhi + 1) : make_int4(0, 0, 0, 0);
 }
 
+// One trip of the evaluation at the photons: lane l takes the list entries i0 + l, i0 + 64 + l, ... (P of them),
+// sums the K components at each (exponent = c0 + c1 X + c2 Y + c3 X^2 + c4 X Y + c5 Y^2, X, Y relative to the
+// source; cq holds c0..c5, the amplitude and a pad per component) and returns its share of sum z log(counts * stamp).
+template <int P>
+__device__ __forceinline__ double nz_trip(const NzEntry *__restrict__ L, int n, int i0, int lane, int K,
+                                          const double *__restrict__ cq, const double *__restrict__ ltq,
+                                          const double *__restrict__ et, double px, double py, double counts) {
+    double X[P], Y[P], XX[P], XY[P], YY[P], v[P], z[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int i = i0 + 64 * p + lane;
+        const NzEntry en = L[min(i, n - 1)];
+        X[p] = (double)(en.xy & 0xffff) - px;
+        Y[p] = (double)((unsigned)en.xy >> 16) - py;
+        XX[p] = X[p] * X[p]; XY[p] = X[p] * Y[p]; YY[p] = Y[p] * Y[p];
+        z[p] = (i < n) ? (double)en.z : 0.0;
+        v[p] = 0.0;
+    }
+    for (int k = 0; k < K; k++) {
+        const double *c = cq + 8 * k;
+        const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], A = c[6];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            double e = fma(c1, X[p], c0);
+            e = fma(c2, Y[p], e);
+            e = fma(c3, XX[p], e);
+            e = fma(c4, XY[p], e);
+            e = fma(c5, YY[p], e);
+            v[p] = fma(A, exp_tab64(fmax(e, -1.0e5), et), v[p]);
+        }
+    }
+    double a = 0.0;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const double m = counts * v[p];
+        if (z[p] != 0.0 && m > 0.0) a += log_tab(m, ltq) * z[p];
+    }
+    return a;
+}
+
 #define PLL_PARTS 4
-template <int MODE>
+template <int MODE, typename TZ = double>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__restrict__ recs,
               const int *__restrict__ owner, const int4 *__restrict__ pbox, const int64_t *__restrict__ offsets,
-              const double *__restrict__ data, const double *__restrict__ nelec, int H, int W,
+              const TZ *__restrict__ data, const double *__restrict__ nelec, int H, int W,
               const int4 *__restrict__ nzbox /* NB*B from k_patch_nzbox, or nullptr: evaluate the whole patch */,
               double Tdrop, double *__restrict__ out /* P*B*nsplit */,
               const int *__restrict__ job_order = nullptr /* P*B: launch order of the (proposal, band) jobs, heaviest first */,
@@ -143,7 +188,9 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
                                 sampler, a caller with a handful of proposals) otherwise lasts as long as its longest job
                                 while most of the GPU idles.  MODE 0 sums its chunks in PLL_PARTS classes either way and
                                 whoever adds the parts adds them in order, so a value does not depend on nsplit */,
-              const int *__restrict__ job_count = nullptr /* with job_order: only its first *job_count entries are jobs */) {
+              const int *__restrict__ job_count = nullptr /* with job_order: only its first *job_count entries are jobs */,
+              const int *__restrict__ nzmode = nullptr /* MODE 0, resident patches: per patch 1 = evaluate at its photons (k_nz_layout) */,
+              const int64_t *__restrict__ nzoff = nullptr, const NzEntry *__restrict__ nzlist = nullptr /* the photon lists */) {
     __shared__ double acc[HW_TH * HW_TW];
     __shared__ CompTab T;
     __shared__ double et[64];
@@ -206,6 +253,50 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
             return;
         }
     }
+    if (MODE == 0 && nzmode && nzmode[ob]) {
+        // ---- at the photons: sum over the patch's photon list of z log(counts * stamp(x, y)) ---------------------------
+        // Every lane takes a photon-holding pixel and sums all K components there by direct exponentials (table exp):
+        // e_k(x, y) = c0 + c1 X + c2 Y + c3 X^2 + c4 X Y + c5 Y^2 in coordinates X, Y relative to the SOURCE (so that no
+        // term is large where the value matters), 5 fma + the table exp + 1 fma per component.  Nothing is dropped.  A job
+        // is never dealt to several blocks here (it is short): part 0 does it, the other parts return 0.
+        if (part != 0) {
+            if (lane == 0) *outp = 0.0;
+            return;
+        }
+        double *ltq = acc;                       // the log table (128 doubles) and the components (8 doubles each) live in the tile's LDS
+        double *cq = acc + 128;
+        const int K = (rec.type == 0) ? K_PSF : K_GAL;
+        ltq[lane] = lt_ic;
+        ltq[64 + lane] = lt_lc;
+        if (lane < K) {
+            const Comp &c = cj;
+            const double ux = c.mx - rec.px, uy = c.my - rec.py;         // the component's centre seen from the source
+            const double qa = c.qa * EXP_SCALE, qb = c.qb * EXP_SCALE, qc = c.qc * EXP_SCALE;
+            // -1/2 (qa (X-ux)^2 + 2 qb (X-ux)(Y-uy) + qc (Y-uy)^2)
+            cq[8 * lane + 0] = -0.5 * (qa * ux * ux + 2.0 * qb * ux * uy + qc * uy * uy);
+            cq[8 * lane + 1] = qa * ux + qb * uy;
+            cq[8 * lane + 2] = qb * ux + qc * uy;
+            cq[8 * lane + 3] = -0.5 * qa;
+            cq[8 * lane + 4] = -qb;
+            cq[8 * lane + 5] = -0.5 * qc;
+            cq[8 * lane + 6] = c.A;
+            cq[8 * lane + 7] = 0.0;
+        }
+        __syncthreads();
+        const NzEntry *L = nzlist + nzoff[ob];
+        const int n = (int)(nzoff[ob + 1] - nzoff[ob]);
+        double a = 0.0;
+        // A component's eight constants come from LDS (the same address for every lane: the read still returns 512 B
+        // per wave-instruction), so a lane takes up to FOUR photons per trip and the constants are read once for all
+        // of them: with one photon per lane the kernel was bound by those reads, not by the arithmetic.
+        int i0 = 0;
+        for (; n - i0 > 128; i0 += 256) a += nz_trip<4>(L, n, i0, lane, K, cq, ltq, et, rec.px, rec.py, counts);
+        if (n - i0 > 64) { a += nz_trip<2>(L, n, i0, lane, K, cq, ltq, et, rec.px, rec.py, counts); i0 += 128; }
+        if (n - i0 > 0) a += nz_trip<1>(L, n, i0, lane, K, cq, ltq, et, rec.px, rec.py, counts);
+        a = wave_sum(a);
+        if (lane == 0) *outp = a - counts * wsum;
+        return;
+    }
     // mode 1 drops against the sky seen from the unit stamp: counts * g < eps e^-T
     int dropmode = HW_DROP_NONE;
     double log_floor = 0.0;
@@ -213,7 +304,9 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
         if (MODE == 0 || MODE == 2 || MODE == 3 || MODE == 4) dropmode = HW_DROP_SELF;
         else if (eps > 0.0 && counts > 0.0) { dropmode = HW_DROP_SKY; log_floor = (double)__logf((float)(eps / counts)); }
     }
-    const double *z = (MODE == 3) ? nullptr : (data ? data + offsets[ob] : nelec + (int64_t)b * H * W + (int64_t)bx.z * W + bx.x);
+    // the patch data: the caller's / the resident split's packed buffer (TZ), or -- none given -- the observed image on the box
+    const TZ *zd = (MODE == 3 || !data) ? nullptr : data + offsets[ob];
+    const double *zn = (MODE == 3 || data) ? nullptr : nelec + (int64_t)b * H * W + (int64_t)bx.z * W + bx.x;
     const int64_t zpitch = data ? nx : W;
     double a = 0.0, m = 0.0;
     double apart[PLL_PARTS] = {0.0, 0.0, 0.0, 0.0};     // MODE 0: the chunk classes' sums (statically indexed below)
@@ -244,14 +337,22 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
             }
             // the chunk's patch data, 16 rows of loads in flight at a time (addresses clamped into
             // the chunk instead of predicated), issued only once the walk's registers are free
-            const double *zp = z + (int64_t)(Y0 - bx.z) * zpitch + (min(xi, ev.y - 1) - bx.x);
+            const int64_t zo = (int64_t)(Y0 - bx.z) * zpitch + (min(xi, ev.y - 1) - bx.x);
             for (int r0 = 0; r0 < HW_TH / 2 && 2 * r0 < rb; r0 += 8) {
                 double zz[8], bg[8];
+                if (zd) {
+                    TZ raw[8];
 #pragma unroll
-                for (int r = 0; r < 8; r++) zz[r] = zp[(int64_t)min(2 * (r0 + r) + half, rb - 1) * zpitch];
+                    for (int r = 0; r < 8; r++) raw[r] = zd[zo + (int64_t)min(2 * (r0 + r) + half, rb - 1) * zpitch];
+#pragma unroll
+                    for (int r = 0; r < 8; r++) zz[r] = (double)raw[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; r++) zz[r] = zn[zo + (int64_t)min(2 * (r0 + r) + half, rb - 1) * zpitch];
+                }
                 if (MODE == 4) {        // the background plane follows the data plane (nx * ny values further on)
 #pragma unroll
-                    for (int r = 0; r < 8; r++) bg[r] = zp[(int64_t)nx * ny + (int64_t)min(2 * (r0 + r) + half, rb - 1) * zpitch];
+                    for (int r = 0; r < 8; r++) bg[r] = (double)zd[zo + (int64_t)nx * ny + (int64_t)min(2 * (r0 + r) + half, rb - 1) * zpitch];
                 }
 #pragma unroll
                 for (int r = 0; r < 8; r++) {

@@ -173,7 +173,7 @@ k_slice_live_jobs(SliceState st, int64_t S, int B, int *__restrict__ list, int *
 }
 
 // algorithmic HBM bytes of a finished call (what bench.py prices the location step's kernel against): a chain that
-// ran made 1 + steps[s] evaluations, each of which reads, per band, one 128-B record and the 8-B photon counts of
+// ran made 1 + steps[s] evaluations, each of which reads, per band, one 128-B record and the 4-B photon counts of
 // the rectangle that holds the source's photons (k_patch_nzbox)
 __global__ void __launch_bounds__(256)
 k_slice_bytes(SliceState st, int64_t S, int B, const int4 *__restrict__ nzbox, unsigned long long *__restrict__ bytes) {
@@ -184,7 +184,7 @@ k_slice_bytes(SliceState st, int64_t S, int B, const int4 *__restrict__ nzbox, u
         for (int b = 0; b < B; b++) {
             const int4 q = nzbox[s * B + b];
             const long long area = (q.y > q.x && q.w > q.z) ? (long long)(q.y - q.x) * (q.w - q.z) : 0;
-            per += 8ull * (unsigned long long)area + 128ull;
+            per += 4ull * (unsigned long long)area + 128ull;
         }
         v = per * (unsigned long long)(1 + st.steps[s]);
     }

@@ -235,13 +235,14 @@ k_samp_layout(const SrcRec *__restrict__ recs, int64_t S, int B, int4 *__restric
     if (tid == 0) soff[n] = carry;
 }
 
+template <typename TS>
 __global__ void __launch_bounds__(256)
-k_patch_sums(const int64_t *__restrict__ soff, const double *__restrict__ samp, double *__restrict__ sums) {
+k_patch_sums(const int64_t *__restrict__ soff, const TS *__restrict__ samp, double *__restrict__ sums) {
     __shared__ double red[256];
     const int64_t i = blockIdx.x;
     const int64_t lo = soff[i], hi = soff[i + 1];
     double a = 0.0;
-    for (int64_t k = lo + threadIdx.x; k < hi; k += 256) a += samp[k];
+    for (int64_t k = lo + threadIdx.x; k < hi; k += 256) a += (double)samp[k];
     red[threadIdx.x] = a;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -254,17 +255,92 @@ k_patch_sums(const int64_t *__restrict__ soff, const double *__restrict__ samp, 
 // Before a resident split on the recurrence kernel: that kernel writes every pixel strictly inside
 // a box exactly once, so only the first row and column of each patch need zeroing (not the whole
 // 3.2 GB buffer), and the photon rectangles it will reduce with atomics need their identity.
+template <typename TS>
 __global__ void __launch_bounds__(64)
-k_samp_prepare(const int4 *__restrict__ sbox, const int64_t *__restrict__ soff, double *__restrict__ samp,
+k_samp_prepare(const int4 *__restrict__ sbox, const int64_t *__restrict__ soff, TS *__restrict__ samp,
                int4 *__restrict__ nz) {
     const int64_t i = blockIdx.x;
     const int4 bx = sbox[i];
     const int nx = bx.y - bx.x, ny = bx.w - bx.z;
     if (threadIdx.x == 0) nz[i] = make_int4(INT_MAX, 0, INT_MAX, 0);      // x0, x1, y0, y1: empty
     if (nx <= 0 || ny <= 0) return;
-    double *p = samp + soff[i];
-    for (int x = threadIdx.x; x < nx; x += 64) p[x] = 0.0;
-    for (int y = threadIdx.x; y < ny; y += 64) p[(int64_t)y * nx] = 0.0;
+    TS *p = samp + soff[i];
+    for (int x = threadIdx.x; x < nx; x += 64) p[x] = (TS)0;
+    for (int y = threadIdx.x; y < ny; y += 64) p[(int64_t)y * nx] = (TS)0;
+}
+
+// ---- photon lists: the pixels of a sample patch that hold a photon ------------------------------------
+// The conditional likelihood of a source (k_patch_ll_hw, mode 0) is sum z log m over its patch: only pixels with
+// z > 0 contribute, and at config 3 they are a fifth of the rectangle that holds them (median fill: galaxies 0.21,
+// stars 0.29; tools/nz_fill.py).  So every patch also gets a compact list (x | y << 16, z) of its photons, in
+// row-major order (one wave per patch: the order, and with it every sum taken over the list, depends on the data
+// only), and the likelihood kernel evaluates a patch either at its photons (direct exponentials, every lane a
+// photon) or densely by the column recurrence, whichever the layout pass estimated cheaper:
+//     at the photons   ceil(nnz / 64) steps x K components x ~17 instructions
+//     densely          chunks of 32 x 64 pixels x (set-up + K x (seeds + rows)): ~1 900 (star) / ~6 800 (galaxy) each
+__global__ void __launch_bounds__(1024)
+k_nz_layout(const int *__restrict__ nnz, const int4 *__restrict__ nzbox, const int *__restrict__ type /* per source */,
+            int64_t S, int B, int force /* 0 = estimate, 1 = every patch at its photons, 2 = every patch densely */,
+            int64_t *__restrict__ loff /* S*B + 1: list offsets */, int *__restrict__ mode /* S*B: 1 = evaluate at the photons */) {
+    __shared__ long long part[1024];
+    __shared__ long long carry;
+    const int tid = threadIdx.x;
+    const int64_t n = S * B;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + tid;
+        long long cnt = 0;
+        if (i < n) {
+            cnt = nnz[i];
+            const int4 q = nzbox[i];
+            const int K = (type[i / B] == 0) ? K_PSF : K_GAL;
+            const long long chunks = (cnt > 0) ? (long long)((q.y - q.x + HW_TW - 1) / HW_TW) * ((q.w - q.z + HW_TH - 1) / HW_TH) : 0;
+            const long long sparse_cost = ((cnt + 63) / 64) * K * 17 + 150;
+            const long long dense_cost = chunks * ((K == K_PSF) ? 1900 : 6800);
+            mode[i] = (force == 1) ? 1 : (force == 2) ? 0 : (sparse_cost < dense_cost ? 1 : 0);
+        }
+        part[tid] = cnt;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            long long v = (tid >= o) ? part[tid - o] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        if (i < n) loff[i] = carry + part[tid] - cnt;
+        __syncthreads();
+        if (tid == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) loff[n] = carry;
+}
+
+__global__ void __launch_bounds__(64)
+k_nz_compact(const int4 *__restrict__ sbox, const int64_t *__restrict__ soff, const int *__restrict__ samp,
+             const int4 *__restrict__ nzbox, const int64_t *__restrict__ loff, NzEntry *__restrict__ list) {
+    const int64_t i = blockIdx.x;
+    const int4 bx = sbox[i], q = nzbox[i];
+    if (!(q.y > q.x && q.w > q.z)) return;
+    const int lane = threadIdx.x;
+    const int nx = bx.y - bx.x;
+    const int *p = samp + soff[i];
+    NzEntry *out = list + loff[i];
+    const int64_t cap = loff[i + 1] - loff[i];
+    int64_t pos = 0;
+    for (int y = q.z; y < q.w; y++) {
+        const int *row = p + (int64_t)(y - bx.z) * nx - bx.x;
+        for (int x0 = q.x; x0 < q.y; x0 += 64) {
+            const int x = x0 + lane;
+            const int z = (x < q.y) ? row[x] : 0;
+            const unsigned long long m = __ballot(z != 0);
+            if (z != 0) {
+                const int64_t k = pos + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                if (k < cap) out[k] = NzEntry{x | (y << 16), z};
+            }
+            pos += __popcll(m);
+        }
+    }
 }
 
 // diagnostic: N independent Binomial(n, p) draws (stream i), for the sampler's own tests
@@ -297,7 +373,8 @@ struct SplitArgs {
     const int64_t *tile_off;
     const double *nelec;
     const int64_t *offsets;     // [S*B + 1] packed position of the sample patch of (source s, band b) at s*B + b
-    double *samp;               // packed sample patches, zero-initialised by the caller
+    void *samp;                 // packed sample patches (the kernels' TS: double for a caller's buffer, int for the
+                                // device-resident split), zero-initialised by the caller
     double *partials;           // per-tile noise sums
     int64_t S, capacity;
     int B, H, W, ntx, nty, TW, TH;
@@ -310,10 +387,12 @@ struct SplitArgs {
     int4 *nz;                   // k_photon_split_hw: per patch, the rectangle holding its photons (min/max by atomics), or nullptr
     const int *order;           // k_photon_split_hw: tile launch order (heaviest first, from the totals render), or nullptr
     int debug;                  // CEL_OPT_DEBUG bits (timing-only ablations; results are wrong when set)
+    int *nnz;                   // k_photon_split_hw: pixels that received a photon, per (source, band), zeroed by the caller, or nullptr
     double *sums;               // k_photon_split_hw: photons per (source, band), index s*B + b, zeroed by the caller, or nullptr.
                                 // Integer-valued doubles: the atomic sums are exact, so their order does not matter
 };
 
+template <typename TS>
 __global__ void __launch_bounds__(64)
 k_photon_split(SplitArgs a) {
     __shared__ double rate[2048];     // remaining total rate of the pixel (sources not yet drawn + sky)
@@ -367,7 +446,7 @@ k_photon_split(SplitArgs a) {
             }
             __syncthreads();
             const int nx = bx1 - bx0;
-            double *patch = a.samp + a.offsets[(int64_t)s * a.B + b];    // source-major, like cel_patch_loglik_multi
+            TS *patch = static_cast<TS *>(a.samp) + a.offsets[(int64_t)s * a.B + b];    // source-major, like cel_patch_loglik_multi
             const bool colin = (xi > bx0) && (xi < bx1);                 // strict on the low side (:50)
             for (int i = 0; i < niter; i++) {
                 const int y = Y0 + i * rstep + rsub;
@@ -387,7 +466,7 @@ k_photon_split(SplitArgs a) {
                     }
                     left[li] = n - (int)z;
                     rate[li] = tot - F;                                   // sum_probs -= curr_prob (:152)
-                    patch[(int64_t)(y - by0) * nx + (xi - bx0)] = (double)z;
+                    patch[(int64_t)(y - by0) * nx + (xi - bx0)] = (TS)z;
                 }
             }
         }
@@ -417,6 +496,7 @@ k_photon_split(SplitArgs a) {
 // agree with the direct kernel's to ~1e-13, so the two kernels make the same draws except where a
 // uniform falls within that distance of a decision boundary.
 #define SP_TH 32
+template <typename TS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 k_photon_split_hw(SplitArgs a) {
     __shared__ double one[SP_TH * HW_TW];
@@ -496,8 +576,9 @@ k_photon_split_hw(SplitArgs a) {
         // 64 pixels per trip.  A pixel's draw takes the same numbers of its Philox stream either way.
         int zlo = INT_MAX, zhi = -1, xlo = INT_MAX, xhi = -1;   // where this lane's draws left photons
         double zsum = 0.0;
+        int zcnt = 0;
         const int nx = rec.x1 - rec.x0;
-        double *patch0 = a.samp + poff + (int64_t)(Y0 - rec.y0) * nx - rec.x0;   // + row * nx + x
+        TS *patch0 = static_cast<TS *>(a.samp) + poff + (int64_t)(Y0 - rec.y0) * nx - rec.x0;   // + row * nx + x
         int nq = 0;
         for (int r = ra >> 1; 2 * r < rb; r++) {
             const int row = 2 * r + half;
@@ -521,7 +602,7 @@ k_photon_split_hw(SplitArgs a) {
                 if (!slow) {
                     one[li] = 0.0;                    // the scratch tile is clean again for the next source
                     rate[li] = tot - F;               // sum_probs -= curr_prob (:152)
-                    patch0[(int64_t)row * nx + xi] = 0.0;
+                    patch0[(int64_t)row * nx + xi] = (TS)0;
                 }
             }
             const unsigned long long sm = __ballot(slow);
@@ -541,10 +622,11 @@ k_photon_split_hw(SplitArgs a) {
                 const long long z = (SPLIT_ABLATE(a) & 2) ? 1 : binomial_draw((long long)n, F * fast_rcp(tot), g, et, lt);
                 left[li] = n - (int)z;
                 rate[li] = tot - F;
-                patch0[(int64_t)row * nx + xq] = (double)z;
+                patch0[(int64_t)row * nx + xq] = (TS)z;
                 if (z > 0) {
                     zlo = min(zlo, row); zhi = max(zhi, row); xlo = min(xlo, xq); xhi = max(xhi, xq);
                     zsum += (double)z;
+                    zcnt += 1;
                 }
             }
         }
@@ -558,11 +640,13 @@ k_photon_split_hw(SplitArgs a) {
                 xlo = min(xlo, __shfl_xor(xlo, o)); xhi = max(xhi, __shfl_xor(xhi, o));
             }
             if (a.sums) zsum = wave_sum(zsum);
+            if (a.nnz) for (int o = 32; o > 0; o >>= 1) zcnt += __shfl_down(zcnt, o);
             if (lane == 0) {
                 int *q = reinterpret_cast<int *>(a.nz + ((int64_t)s * a.B + b));
                 atomicMin(q + 0, xlo); atomicMax(q + 1, xhi + 1);
                 atomicMin(q + 2, Y0 + zlo); atomicMax(q + 3, Y0 + zhi + 1);
                 if (a.sums) atomicAdd(a.sums + ((int64_t)s * a.B + b), zsum);
+                if (a.nnz) atomicAdd(a.nnz + ((int64_t)s * a.B + b), zcnt);
             }
         }
         __syncthreads();

@@ -78,6 +78,10 @@ enum {
                                2 = 16 columns x 128 rows, four component groups per column (fewer
                                recurrence seeds, more per-tile set-up: measured 4 % slower than 1
                                on the benchmark field, kept for fields of tall narrow boxes)      */
+    CEL_OPT_PHOTON_LISTS = 9, /* how the conditional likelihoods read a device-resident photon split: 0 (default) = per
+                               patch, at the pixels that hold a photon or densely, whichever the layout pass estimates
+                               cheaper; 1 = every patch at its photons; 2 = never (no lists are built).  The values
+                               agree to rounding; set it before cel_photon_split */
     CEL_OPT_DEBUG = 8       /* diagnostics.  The shipped library accepts two result-preserving bits: 64 = the E-step
                                takes its per-source form, 128 = CEL_OPT_TILE_TIMING's third word carries the
                                row-waste counters of tools/row_waste.py.  The timing-only ABLATION bits (render:
@@ -254,7 +258,7 @@ int cel_stamp_mass(cel_images *img, cel_sources *src, double *mass);
  *   radec_out  S*2 (host, may be NULL): the new locations; they also REPLACE src's locations on the device
  *   llh_out    S (host, may be NULL): log-likelihood at the new location (NaN for a source left alone)
  *   stats      4 (host, may be NULL): rounds, likelihood evaluations, the ALGORITHMIC HBM bytes those evaluations
- *              read (per evaluation and band: 8 B per pixel of the photon rectangle it walks + one 128-B
+ *              read (per evaluation and band: 4 B per pixel of the photon rectangle it walks + one 128-B
  *              record), conditional-likelihood launches */
 int cel_slice_locations(cel_images *img, cel_sources *src, const int32_t *chain_ids, double sigma, uint64_t seed,
                         int max_rounds, double *radec_out, double *llh_out, int64_t *stats);

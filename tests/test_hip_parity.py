@@ -814,7 +814,23 @@ def test_resident_split_and_loglik_equal_host_buffer_forms(cel, ctx):
             if host_patches[s][b] is None:
                 host_boxes[s, b] = 0
     ll_host = iset.patch_loglik_multi(prop, own, host_boxes, host_patches)
-    assert np.array_equal(ll_res, ll_host)
+    # the resident form reads each patch at its photons or densely, whichever is cheaper (CEL_OPT_PHOTON_LISTS): equal to
+    # the host-buffer form (always dense) to rounding, and bit for bit when the lists are switched off
+    np.testing.assert_allclose(ll_res, ll_host, rtol=1e-12)
+    from desi_mcmc_amd import _lib
+    for mode in (1, 2, 0):
+        ctx.set_option(_lib.CEL_OPT_PHOTON_LISTS, mode)
+        try:
+            iset.photon_split_resident(sset, seed=21)
+            ll_m = iset.patch_loglik_resident(prop, own)
+        finally:
+            ctx.set_option(_lib.CEL_OPT_PHOTON_LISTS, 0)
+        if mode == 2:
+            assert np.array_equal(ll_m, ll_host)
+        else:
+            np.testing.assert_allclose(ll_m, ll_host, rtol=1e-12)
+        if mode == 0:
+            assert np.array_equal(ll_m, ll_res)
     iso_res = iset.patch_loglik_resident(prop, own, isolated=True)
     iso_host = iset.patch_loglik_multi(prop, own, host_boxes,
                                        [[None if host_patches[s][b] is None else
