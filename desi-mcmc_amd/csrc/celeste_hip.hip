@@ -112,6 +112,7 @@ struct cel_ctx {
     int tile_order = 1;       // 0 = launch k_render tiles in index order, 1 = heaviest first by the last render's measured tile durations (estimate when none), 2 = heaviest first by the estimate only
     int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created
     bool tile_timing = false; // diagnostic: k_render stamps each tile's start/end wall clock
+    double nz_bias = getenv("CEL_NZ_BIAS") ? atof(getenv("CEL_NZ_BIAS")) : 4.0;   // see k_nz_layout (the env var: experiments only)
     int nz_force = 0;         // CEL_OPT_PHOTON_LISTS: 0 = per patch, whichever is estimated cheaper; 1 = every patch at its photons; 2 = never
     int debug = 0;            // CEL_OPT_DEBUG: timing-only ablation bits handed to the render kernel (results are wrong when set)
     int tile_layout = 1;      // 0: 64 x tile_rows tiles, one lane per column (k_render)
@@ -1066,7 +1067,10 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
     double *d_data = nullptr, *d_out = nullptr;
     // a call with few proposals is a handful of one-wave jobs as long as their longest: each is dealt to PLL_PARTS blocks
     // (the values do not depend on it: the kernel sums its chunks in PLL_PARTS classes either way)
-    const int nparts = (c->variant != 0 && mode == 0 && P * B <= 8192) ? PLL_PARTS : 1;
+    // (with photon lists a job always owns PLL_PARTS slots: the kernel that scores at the photons writes its four class sums)
+    const bool nzl = resident && mode == 0 && c->variant != 0 && im->nz_valid;
+    const int nsplit = (c->variant != 0 && mode == 0 && P * B <= 8192) ? PLL_PARTS : 1;
+    const int nparts = nzl ? PLL_PARTS : nsplit;
     std::vector<double> hout((size_t)(P * B * nparts));
     hipError_t e;
 #define PL_TRY(expr)                                                                     \
@@ -1116,12 +1120,16 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
         } else if (mode == 0) {
             if (!resident)
                 hipLaunchKernelGGL(k_patch_nzbox<double>, dim3((unsigned)nb), dim3(64), 0, c->stream, d_box, d_off, (const double *)d_data, d_nz);
-            if (i_data)
-                hipLaunchKernelGGL((k_patch_ll_hw<0, int>), dim3((unsigned)(P * B * nparts)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
+            if (i_data) {
+                hipLaunchKernelGGL((k_patch_ll_hw<0, int>), dim3((unsigned)(P * B * nsplit)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
                                    d_owner, d_box, d_off, i_data, im->d_nelec, im->H, im->W, d_nz, c->tail_T, d_out,
-                                   (const int *)nullptr, nparts, (const int *)nullptr,
-                                   (const int *)(im->nz_valid ? im->d_nzmode : nullptr), (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist);
-            else
+                                   (const int *)nullptr, nsplit, (const int *)nullptr, (const int *)(nzl ? im->d_nzmode : nullptr), 0, nparts);
+                if (nzl)                    // ... and the proposals whose patch is scored at its photons (the others return at once)
+                    hipLaunchKernelGGL(k_patch_ll_nz, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                                       (const int *)d_owner, (const int4 *)d_box, (const int4 *)d_nz, (const int *)im->d_nzmode,
+                                       (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_out, (const int *)nullptr,
+                                       (const int *)nullptr);
+            } else
                 hipLaunchKernelGGL((k_patch_ll_hw<0, double>), dim3((unsigned)(P * B * nparts)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
                                    d_owner, d_box, d_off, (const double *)d_data, im->d_nelec, im->H, im->W, d_nz, c->tail_T, d_out,
                                    (const int *)nullptr, nparts, (const int *)nullptr);
@@ -1202,8 +1210,8 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     // blocks per (chain, band) job in rounds with at most SLICE_SPLIT_JOBS jobs left (measured at config 3: 4 blocks
     // below 2048 jobs 29.4 ms per location step, below 8192 jobs 29.0; 8 blocks 29.4; without 30.3)
     const int SLICE_SPLIT = PLL_PARTS, SLICE_SPLIT_JOBS = 8192;
-    const size_t per_chain = 2 * 8 + 10 * 8 + 4 * 4 + 4 + (size_t)B * 8 * SLICE_SPLIT + 4 + (size_t)B * 12;
-    const size_t need = per_chain * (size_t)S + 64;
+    const size_t per_chain = 2 * 8 + 10 * 8 + 4 * 4 + 4 + (size_t)B * 8 * SLICE_SPLIT + 4 + (size_t)B * 4 * 6 * SLICE_SPLIT;
+    const size_t need = per_chain * (size_t)S + 128;
     if (need > im->slice_cap) {
         HIP_TRY(hipStreamSynchronize(st));
         if (im->d_slice) (void)hipFree(im->d_slice);
@@ -1237,10 +1245,16 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     ss.steps = (int *)p; p += 4 * S;
     int *d_owner = (int *)p; p += 4 * S;
     int *d_ids = (int *)p; p += 4 * S;
-    int *d_work = (int *)p; p += 4 * S * B;
-    int *d_jobs = (int *)p; p += 4 * S * B;
-    int *d_live = (int *)p; p += 4 * S * B;      // the running chains' jobs, compacted (late rounds)
-    int *d_flags = (int *)p;            // [0] chains still running, [1] error bits, [2] likelihood evaluations so far, [3] rounds with work
+    // per (job, part) block entries (k_job_work): work estimates, the heaviest-first block lists of a full round, and the
+    // running chains' blocks of the late rounds -- for the jobs scored densely and for those scored at their photons
+    int *d_work = (int *)p; p += 4 * S * B * SLICE_SPLIT;
+    int *d_jobs = (int *)p; p += 4 * S * B * SLICE_SPLIT;
+    int *d_live = (int *)p; p += 4 * S * B * SLICE_SPLIT;
+    int *d_work_nz = (int *)p; p += 4 * S * B * SLICE_SPLIT;
+    int *d_jobs_nz = (int *)p; p += 4 * S * B * SLICE_SPLIT;
+    int *d_live_nz = (int *)p; p += 4 * S * B * SLICE_SPLIT;
+    int *d_flags = (int *)p;            // [0] chains still running, [1] error bits, [2] likelihood evaluations so far, [3] rounds with work,
+                                        // [4] / [5] live dense / photon-list jobs of the batch, [6..7] byte counter, [8] / [9] dense / photon-list jobs
     // the proposal set: this catalogue with the locations rewritten every round
     HIP_TRY(hipMemcpyAsync(prop->d_type, src->d_type, sizeof(int) * S, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(prop->d_counts, src->d_counts, sizeof(double) * B * S, hipMemcpyDeviceToDevice, st));
@@ -1255,8 +1269,23 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     hipLaunchKernelGGL(k_slice_init, dim3(g256), dim3(256), 0, st, ss, S, src->d_radec, chain_ids ? d_ids : (const int *)nullptr,
                        im->d_soff, B, (unsigned long long)seed, sigma, d_owner);
     // the (chain, band) jobs of a round, heaviest first (the photon rectangles are fixed for the call)
-    hipLaunchKernelGGL(k_job_work, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, src->d_type, im->d_snz, S, B, d_work);
-    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, d_work, (int)(S * B), d_jobs);
+    // The blocks of a round.  With the recurrence kernels every (chain, band) job is one block, or PLL_PARTS blocks when it
+    // is long (k_job_work), listed heaviest first; with photon lists a patch is scored either densely (k_patch_ll_hw<0>) or
+    // at its photons (k_patch_ll_nz): two lists.  The photon rectangles, lists and routes are fixed for the call.
+    const bool use_nz = im->nz_valid && c->variant != 0;
+    int64_t n_dense = S * B, n_nz = 0;
+    if (c->variant != 0) {
+        const int nent = (int)(S * B * SLICE_SPLIT);
+        hipLaunchKernelGGL(k_job_work, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, st, src->d_type, im->d_snz, S, B, d_work,
+                           (const int *)(use_nz ? im->d_nzmode : nullptr), (const int *)im->d_nnz, use_nz ? d_work_nz : (int *)nullptr);
+        hipLaunchKernelGGL(k_order_members, dim3(1), dim3(1024), 0, st, d_work, nent, d_jobs, d_flags + 8);
+        if (use_nz) hipLaunchKernelGGL(k_order_members, dim3(1), dim3(1024), 0, st, d_work_nz, nent, d_jobs_nz, d_flags + 9);
+        int *h_cnt = reinterpret_cast<int *>(c->pinned + MAX_BANDS + 2);
+        h_cnt[1] = 0;
+        HIP_TRY(hipMemcpyAsync(h_cnt, d_flags + 8, sizeof(int) * (use_nz ? 2 : 1), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n_dense = h_cnt[0]; n_nz = use_nz ? h_cnt[1] : 0;
+    }
     int64_t rounds = 0, evals = 0, queued = 0, live = S;
     if (chain_ids) {                    // chains with a negative id are another rank's: they never run here
         live = 0;
@@ -1275,27 +1304,43 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         // few chains left (at most `live`, the count of the last readback): their one-wave jobs no longer fill
         // the GPU and a round lasts as long as its longest job -- every job is dealt to SLICE_SPLIT blocks then
         const int nsplit = (c->variant != 0 && live * B <= SLICE_SPLIT_JOBS) ? SLICE_SPLIT : 1;
+        const int ostr = (c->variant != 0) ? SLICE_SPLIT : 1;        // slots per job in d_ll: the recurrence kernels always fill all four
         if (nsplit > 1) {
             // ... and only the running chains' jobs are launched: a list compacted once per batch (a chain that
             // finishes inside the batch leaves jobs that retire at their first instruction)
-            HIP_TRY(hipMemsetAsync(d_flags + 4, 0, sizeof(int), st));
-            hipLaunchKernelGGL(k_slice_live_jobs, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, ss, S, B, d_live, d_flags + 4);
+            HIP_TRY(hipMemsetAsync(d_flags + 4, 0, sizeof(int) * 2, st));
+            hipLaunchKernelGGL(k_slice_live_jobs, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, ss, S, B, d_live, d_flags + 4,
+                               (const int *)(use_nz ? im->d_nzmode : nullptr), d_live_nz, d_flags + 5);
         }
         for (int k = 0; k < nb; k++) {
             hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags, queued == 0 ? 1 : 0);
             prop->gen = ++g_source_gen;
             if ((rc = run_prep(im, prop, d_owner))) return rc;
-            int pi = prof_slot(c, CEL_K_PATCH_LL);
-            if (c->variant == 0)
+            if (c->variant == 0) {
+                int pi = prof_slot(c, CEL_K_PATCH_LL);
                 LAUNCH_EV(k_patch_ll<int>, dim3((unsigned)(S * B)), dim3(256), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
                           d_owner, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_nelec, im->H, im->W, 0, d_ll);
-            else
-                LAUNCH_EV((k_patch_ll_hw<0, int>), dim3((unsigned)((nsplit > 1 ? live * B : S * B) * nsplit)), dim3(64), st, EV0(c, pi), EV1(c, pi),
-                          im->d_bands, B, S, im->d_recs,
-                          d_owner, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll,
-                          (const int *)(nsplit > 1 ? d_live : d_jobs), nsplit, (const int *)(nsplit > 1 ? d_flags + 4 : nullptr),
-                          (const int *)(im->nz_valid ? im->d_nzmode : nullptr), (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist);
-            hipLaunchKernelGGL(k_slice_consume, dim3(g256), dim3(256), 0, st, ss, S, B, nsplit, d_ll, sigma, d_flags, d_flags + 1);
+            } else {
+                // the blocks scored densely, then those scored at their photons; late rounds: only the running chains', all dealt
+                const int64_t gd = (nsplit > 1) ? std::min<int64_t>(live * B * SLICE_SPLIT, S * B * SLICE_SPLIT) : n_dense;
+                const int64_t gn = !use_nz ? 0 : (nsplit > 1) ? std::min<int64_t>(live * B * SLICE_SPLIT, S * B * SLICE_SPLIT) : n_nz;
+                if (gd > 0) {
+                    int pi = prof_slot(c, CEL_K_PATCH_LL);
+                    LAUNCH_EV((k_patch_ll_hw<0, int>), dim3((unsigned)gd), dim3(64), st, EV0(c, pi), EV1(c, pi),
+                              im->d_bands, B, S, im->d_recs,
+                              d_owner, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll,
+                              (const int *)(nsplit > 1 ? d_live : d_jobs), 1, (const int *)(nsplit > 1 ? d_flags + 4 : nullptr),
+                              (const int *)(use_nz ? im->d_nzmode : nullptr), 1, SLICE_SPLIT);
+                }
+                if (gn > 0) {
+                    int pi = prof_slot(c, CEL_K_PATCH_LL);
+                    LAUNCH_EV(k_patch_ll_nz, dim3((unsigned)gn), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
+                              (const int *)d_owner, (const int4 *)im->d_sbox, (const int4 *)im->d_snz, (const int *)im->d_nzmode,
+                              (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_ll,
+                              (const int *)(nsplit > 1 ? d_live_nz : d_jobs_nz), (const int *)(nsplit > 1 ? d_flags + 5 : nullptr));
+                }
+            }
+            hipLaunchKernelGGL(k_slice_consume, dim3(g256), dim3(256), 0, st, ss, S, B, ostr, d_ll, sigma, d_flags, d_flags + 1);
             queued++;
         }
         HIP_TRY(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
@@ -1320,7 +1365,8 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         // algorithmic bytes of the call: a chain made 1 + steps[s] evaluations (the first direction's level, then one
         // per shrink step), each walking its photon rectangles
         HIP_TRY(hipMemsetAsync(d_bytes, 0, sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_slice_bytes, dim3(g256), dim3(256), 0, st, ss, S, B, (const int4 *)im->d_snz, d_bytes);
+        hipLaunchKernelGGL(k_slice_bytes, dim3(g256), dim3(256), 0, st, ss, S, B, (const int4 *)im->d_snz, d_bytes,
+                           (const int *)(use_nz ? im->d_nzmode : nullptr), (const int64_t *)im->d_nzoff);
         HIP_TRY(hipMemcpyAsync(h_flags + 6, d_bytes, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
@@ -1462,7 +1508,7 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
     }
     if (lists)      // where each patch's photon list starts, and whether its likelihood is cheaper at the photons or densely
         hipLaunchKernelGGL(k_nz_layout, dim3(1), dim3(1024), 0, c->stream, (const int *)im->d_nnz, (const int4 *)im->d_snz,
-                           (const int *)src->d_type, S, B, c->nz_force, im->d_nzoff, im->d_nzmode);
+                           (const int *)src->d_type, S, B, c->nz_force, c->nz_bias, im->d_nzoff, im->d_nzmode);
     HIP_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
     if (lists) HIP_TRY(hipMemcpyAsync(c->pinned + MAX_BANDS + 2, im->d_nzoff + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     if (!resident && mem != CEL_DEVICE && total > 0)

@@ -189,8 +189,12 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
                                 while most of the GPU idles.  MODE 0 sums its chunks in PLL_PARTS classes either way and
                                 whoever adds the parts adds them in order, so a value does not depend on nsplit */,
               const int *__restrict__ job_count = nullptr /* with job_order: only its first *job_count entries are jobs */,
-              const int *__restrict__ nzmode = nullptr /* MODE 0, resident patches: per patch 1 = evaluate at its photons (k_nz_layout) */,
-              const int64_t *__restrict__ nzoff = nullptr, const NzEntry *__restrict__ nzlist = nullptr /* the photon lists */) {
+              const int *__restrict__ nzmode = nullptr /* MODE 0, resident patches: per patch 1 = scored at its photons by k_patch_ll_nz, not here */,
+              int encoded = 0 /* job_order holds (job << 3 | part << 1 | split) per BLOCK: a list may deal some jobs (the long ones) to
+                                 PLL_PARTS blocks and leave the others whole -- what the slice sampler launches in every round */,
+              int ostride = 0 /* doubles per job in `out` (0: PLL_PARTS when nsplit > 1, else 1).  A job that is not dealt writes its
+                                 value to slot 0 and zeros behind it, so that whoever adds a job's slots in order gets the same bits
+                                 whether the job was dealt or not */) {
     __shared__ double acc[HW_TH * HW_TW];
     __shared__ CompTab T;
     __shared__ double et[64];
@@ -199,19 +203,26 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     double *lt = reinterpret_cast<double *>(&T);
     const int lane = threadIdx.x;
     const int half = lane >> 5, col = lane & 31;
-    const int part = (nsplit > 1) ? (int)(blockIdx.x % (unsigned)PLL_PARTS) : 0;
-    const int64_t jslot = (nsplit > 1) ? (int64_t)(blockIdx.x / (unsigned)PLL_PARTS) : (int64_t)blockIdx.x;
+    int part = (nsplit > 1) ? (int)(blockIdx.x % (unsigned)PLL_PARTS) : 0;
+    const int64_t jslot = (nsplit > 1 && !encoded) ? (int64_t)(blockIdx.x / (unsigned)PLL_PARTS) : (int64_t)blockIdx.x;
     if (job_count && jslot >= *job_count) return;      // wave-uniform: behind the end of a compacted job list
-    const int64_t job = job_order ? job_order[jslot] : jslot;
-    double *const outp = out + job * (nsplit > 1 ? PLL_PARTS : 1) + part;
+    int64_t job = job_order ? job_order[jslot] : jslot;
+    bool split = nsplit > 1;
+    if (encoded) { split = (job & 1) != 0; part = (int)((job >> 1) & 3); job >>= 3; }
+    const int ostr = ostride ? ostride : (nsplit > 1 ? PLL_PARTS : 1);
+    double *const outp = out + job * ostr + (split ? part : 0);
+    // a job that is not dealt owns all of its ostr slots: value in the first, zeros behind
+    const int nfill = split ? 1 : ostr;
+#define PLL_PUT(v) do { if (lane < nfill) outp[lane] = (lane == 0) ? (v) : 0.0; } while (0)
     const int b = (int)(job % B);
     const int64_t p = job / B;
     const BandDev *bd = bands + b;
     if (owner && owner[p] < 0) {        // a retired proposal slot (the device-resident slice sampler's finished chains)
-        if (lane == 0) *outp = 0.0;
+        PLL_PUT(0.0);
         return;
     }
     const int64_t ob = (int64_t)(owner ? owner[p] : 0) * B + b;
+    if (MODE == 0 && nzmode && nzmode[ob]) return;      // this patch is scored at its photons, by k_patch_ll_nz
     RecU rec = rec_unpack(rec_fetch(recs + (int64_t)b * P, (int)p, lane));
     // MODE 3 (mass of the unit stamp on the source's OWN box, sources.py:338-339): the box is the record's
     const int4 bx = (MODE == 3) ? make_int4(rec.x0, rec.x1, rec.y0, rec.y1) : pbox[ob];
@@ -220,11 +231,11 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     const double counts = rec.scale;
     const double wsum = bd->w[0] + bd->w[1] + bd->w[2];
     if (nx <= 0 || ny <= 0 || (MODE == 3 && rec.type < 0)) {   // no sample image in this band / no stamp
-        if (lane == 0) *outp = 0.0;
+        PLL_PUT(0.0);
         return;
     }
     if (rec.type == -3 && MODE == 0) {  // psf_ns is None (sources.py:160-163)
-        if (lane == 0) *outp = (part == 0) ? -counts * wsum : 0.0;
+        PLL_PUT((part == 0 || !split) ? -counts * wsum : 0.0);
         return;
     }
     if (rec.type < 0) rec.type = (rec.type == -2) ? 1 : 0;    // imposed limits: the kind still renders
@@ -249,53 +260,9 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
             alive = !(0.5 * qmin > 750.0);
         }
         if (__ballot(alive) == 0ull) {
-            if (lane == 0) *outp = (part == 0) ? -counts * wsum : 0.0;
+            PLL_PUT((part == 0 || !split) ? -counts * wsum : 0.0);
             return;
         }
-    }
-    if (MODE == 0 && nzmode && nzmode[ob]) {
-        // ---- at the photons: sum over the patch's photon list of z log(counts * stamp(x, y)) ---------------------------
-        // Every lane takes a photon-holding pixel and sums all K components there by direct exponentials (table exp):
-        // e_k(x, y) = c0 + c1 X + c2 Y + c3 X^2 + c4 X Y + c5 Y^2 in coordinates X, Y relative to the SOURCE (so that no
-        // term is large where the value matters), 5 fma + the table exp + 1 fma per component.  Nothing is dropped.  A job
-        // is never dealt to several blocks here (it is short): part 0 does it, the other parts return 0.
-        if (part != 0) {
-            if (lane == 0) *outp = 0.0;
-            return;
-        }
-        double *ltq = acc;                       // the log table (128 doubles) and the components (8 doubles each) live in the tile's LDS
-        double *cq = acc + 128;
-        const int K = (rec.type == 0) ? K_PSF : K_GAL;
-        ltq[lane] = lt_ic;
-        ltq[64 + lane] = lt_lc;
-        if (lane < K) {
-            const Comp &c = cj;
-            const double ux = c.mx - rec.px, uy = c.my - rec.py;         // the component's centre seen from the source
-            const double qa = c.qa * EXP_SCALE, qb = c.qb * EXP_SCALE, qc = c.qc * EXP_SCALE;
-            // -1/2 (qa (X-ux)^2 + 2 qb (X-ux)(Y-uy) + qc (Y-uy)^2)
-            cq[8 * lane + 0] = -0.5 * (qa * ux * ux + 2.0 * qb * ux * uy + qc * uy * uy);
-            cq[8 * lane + 1] = qa * ux + qb * uy;
-            cq[8 * lane + 2] = qb * ux + qc * uy;
-            cq[8 * lane + 3] = -0.5 * qa;
-            cq[8 * lane + 4] = -qb;
-            cq[8 * lane + 5] = -0.5 * qc;
-            cq[8 * lane + 6] = c.A;
-            cq[8 * lane + 7] = 0.0;
-        }
-        __syncthreads();
-        const NzEntry *L = nzlist + nzoff[ob];
-        const int n = (int)(nzoff[ob + 1] - nzoff[ob]);
-        double a = 0.0;
-        // A component's eight constants come from LDS (the same address for every lane: the read still returns 512 B
-        // per wave-instruction), so a lane takes up to FOUR photons per trip and the constants are read once for all
-        // of them: with one photon per lane the kernel was bound by those reads, not by the arithmetic.
-        int i0 = 0;
-        for (; n - i0 > 128; i0 += 256) a += nz_trip<4>(L, n, i0, lane, K, cq, ltq, et, rec.px, rec.py, counts);
-        if (n - i0 > 64) { a += nz_trip<2>(L, n, i0, lane, K, cq, ltq, et, rec.px, rec.py, counts); i0 += 128; }
-        if (n - i0 > 0) a += nz_trip<1>(L, n, i0, lane, K, cq, ltq, et, rec.px, rec.py, counts);
-        a = wave_sum(a);
-        if (lane == 0) *outp = a - counts * wsum;
-        return;
     }
     // mode 1 drops against the sky seen from the unit stamp: counts * g < eps e^-T
     int dropmode = HW_DROP_NONE;
@@ -314,7 +281,7 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     for (int Y0 = ev.z; Y0 < ev.w; Y0 += HW_TH) {
         const int rb = min(HW_TH, ev.w - Y0);
         for (int X0 = ev.x; X0 < ev.y; X0 += HW_TW, chunk++) {
-            if (nsplit > 1 && chunk % PLL_PARTS != part) continue;
+            if (split && chunk % PLL_PARTS != part) continue;
             const int xi = X0 + col;
             const bool on = xi < ev.y;
 #pragma unroll
@@ -392,30 +359,202 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
         double tot = 0.0;
 #pragma unroll
         for (int k = 0; k < PLL_PARTS; k++) {
-            if (nsplit > 1 && k != part) continue;
+            if (split && k != part) continue;
             if (k > 0 && k >= chunk) continue;      // a class without any chunk is 0.0: adding it changes nothing (`chunk` = the job's chunk count here)
             double ak = wave_sum(apart[k]);
             if (k == 0) ak -= counts * wsum;
-            tot = (nsplit > 1 || k == 0) ? ak : tot + ak;
+            tot = (split || k == 0) ? ak : tot + ak;
         }
-        if (lane == 0) *outp = tot;
+        tot = __shfl(tot, 0);
+        PLL_PUT(tot);
         return;
     }
     a = wave_sum(a);
     m = wave_sum(m);
     if (lane == 0) *outp = (MODE == 3) ? m : a - m;
+#undef PLL_PUT
+}
+
+// ---- mode 0 at the photons ---------------------------------------------------------------------------------
+// sum over a patch's photon list (k_nz_compact) of z log(counts * stamp(x, y)) - counts * sum(psf weights): the same
+// value k_patch_ll_hw<0> forms over the photon rectangle, where only pixels with z > 0 contribute.  Every lane takes
+// photon-holding pixels and sums all K components there by direct exponentials (table exp), nothing is dropped:
+//     exponent = c0 + c1 X + c2 Y + c3 X^2 + c4 X Y + c5 Y^2,  X, Y relative to the SOURCE (no term is large where the
+//     value matters): 5 fma + the table exp + 1 fma per component and photon.
+// A kernel of its own because it needs a third of the dense kernel's registers and a fifth of its LDS: four waves per
+// SIMD instead of two hide the job's chain of dependent loads (job -> owner -> record -> list).
+#define NZ_TRIP 256          // photons per trip of the main loop (four per lane)
+#define NZ_SPLIT_PHOTONS 2048   // a list longer than this is worth dealing to PLL_PARTS blocks (k_job_work, k_slice_live_jobs)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__restrict__ recs,
+              const int *__restrict__ owner, const int4 *__restrict__ pbox, const int4 *__restrict__ nzbox,
+              const int *__restrict__ nzmode, const int64_t *__restrict__ nzoff, const NzEntry *__restrict__ nzlist,
+              double *__restrict__ out /* PLL_PARTS doubles per job */,
+              const int *__restrict__ job_order /* per BLOCK: job << 3 | part << 1 | split, or nullptr: block = job, whole */,
+              const int *__restrict__ job_count) {
+    __shared__ double et[64];
+    __shared__ double ltq[128];
+    __shared__ double cq[8 * K_GAL];
+    const int lane = threadIdx.x;
+    const int64_t jslot = blockIdx.x;
+    if (job_count && jslot >= *job_count) return;
+    int64_t job = job_order ? job_order[jslot] : jslot;
+    bool split = false;
+    int part = 0;
+    if (job_order) { split = (job & 1) != 0; part = (int)((job >> 1) & 3); job >>= 3; }
+    // The trips of a list fall into PLL_PARTS classes (trip t -> class t mod PLL_PARTS) that are ALWAYS summed apart: a
+    // whole job writes the four class sums to its four slots, a dealt job's block its class to its slot, and whoever
+    // adds the slots in order (k_slice_consume, the host loop of cel_patch_loglik_multi) gets the same bits either way.
+    double *const outp = out + job * PLL_PARTS;
+    const int b = (int)(job % B);
+    const int64_t p = job / B;
+    if (owner && owner[p] < 0) return;                  // a retired chain: nobody reads its slots
+    const int64_t ob = (int64_t)(owner ? owner[p] : 0) * B + b;
+    if (!nzmode[ob]) return;                            // scored densely, by k_patch_ll_hw<0>
+    const BandDev *bd = bands + b;
+    RecU rec = rec_unpack(rec_fetch(recs + (int64_t)b * P, (int)p, lane));
+    const int4 bx = pbox[ob], ev = nzbox[ob];
+    const double counts = rec.scale;
+    const double wsum = bd->w[0] + bd->w[1] + bd->w[2];
+    double mass_only = 0.0;                             // the value when no pixel contributes
+    bool done = false;
+    if (bx.y - bx.x <= 0 || bx.w - bx.z <= 0) done = true;                              // no sample image in this band
+    else if (rec.type == -3) { mass_only = -counts * wsum; done = true; }               // psf_ns is None (sources.py:160-163)
+    const int K = (rec.type == 0 || rec.type == -1) ? K_PSF : K_GAL;
+    if (!done) {
+        if (rec.type < 0) rec.type = (rec.type == -2) ? 1 : 0;
+        rec.scale = 1.0;
+        et[lane] = exp2((double)lane * (1.0 / 64.0));
+        ltq[lane] = c_log_ic[lane];
+        ltq[64 + lane] = c_log_lc[lane];
+        const LaneConst lc = lane_consts(lane, bd);
+        bool alive = false;
+        if (lane < K) {
+            const Comp c = make_comp_lc(lc, rec);
+            // exactly 0 on the whole photon rectangle (exp underflows below -745.2): only the mass term is left, as in the dense kernel
+            const double qmin = quad_min_rect(c.qa, c.qb, c.qc, (double)ev.x - c.mx, (double)(ev.y - 1) - c.mx,
+                                              (double)ev.z - c.my, (double)(ev.w - 1) - c.my);
+            alive = !(0.5 * qmin > 750.0);
+            const double ux = c.mx - rec.px, uy = c.my - rec.py;         // the component's centre seen from the source
+            const double qa = c.qa * EXP_SCALE, qb = c.qb * EXP_SCALE, qc = c.qc * EXP_SCALE;
+            cq[8 * lane + 0] = -0.5 * (qa * ux * ux + 2.0 * qb * ux * uy + qc * uy * uy);
+            cq[8 * lane + 1] = qa * ux + qb * uy;
+            cq[8 * lane + 2] = qb * ux + qc * uy;
+            cq[8 * lane + 3] = -0.5 * qa;
+            cq[8 * lane + 4] = -qb;
+            cq[8 * lane + 5] = -0.5 * qc;
+            cq[8 * lane + 6] = c.A;
+            cq[8 * lane + 7] = 0.0;
+        }
+        if (__ballot(alive) == 0ull) { mass_only = -counts * wsum; done = true; }
+    }
+    if (done) {
+        if (split) { if (lane == 0) outp[part] = (part == 0) ? mass_only : 0.0; }
+        else if (lane < PLL_PARTS) outp[lane] = (lane == 0) ? mass_only : 0.0;
+        return;
+    }
+    __syncthreads();
+    const NzEntry *L = nzlist + nzoff[ob];
+    const int n = (int)(nzoff[ob + 1] - nzoff[ob]);
+    double ac[PLL_PARTS] = {0.0, 0.0, 0.0, 0.0};
+    // A component's constants come from LDS (one address for every lane: the read still returns 512 B per
+    // wave-instruction), so a lane takes up to FOUR photons per trip and the constants are read once for all of
+    // them: with one photon per lane the reads, not the arithmetic, bound the kernel.
+    int t = 0;
+    for (int i0 = 0; i0 < n; i0 += NZ_TRIP, t++) {
+        const int cls = t & (PLL_PARTS - 1);
+        if (split && cls != part) continue;
+        const int left = n - i0;
+        double a;
+        if (left > 128) a = nz_trip<4>(L, n, i0, lane, K, cq, ltq, et, rec.px, rec.py, counts);
+        else if (left > 64) a = nz_trip<2>(L, n, i0, lane, K, cq, ltq, et, rec.px, rec.py, counts);
+        else a = nz_trip<1>(L, n, i0, lane, K, cq, ltq, et, rec.px, rec.py, counts);
+#pragma unroll
+        for (int k = 0; k < PLL_PARTS; k++)
+            if (cls == k) ac[k] += a;               // wave-uniform class: predicated adds, no dynamically indexed registers
+    }
+    double mine = 0.0;                                  // lane k < PLL_PARTS ends up with class k's sum
+#pragma unroll
+    for (int k = 0; k < PLL_PARTS; k++) {
+        if (split && k != part) continue;
+        double s = wave_sum(ac[k]);
+        if (k == 0) s -= counts * wsum;
+        s = __shfl(s, 0);
+        if (lane == k) mine = s;
+    }
+    if (split) { if (lane == part) outp[part] = mine; }
+    else if (lane < PLL_PARTS) outp[lane] = mine;
 }
 
 // work estimate of every (chain, band) job of the device slice sampler: components x pixels of the
 // photon rectangle its likelihood evaluates; k_order turns it into a heaviest-first launch order
 // (a round's 50 000 one-wave jobs differ by two orders of magnitude: in index order the launch
 // ends on a few late galaxies)
+// Entries are per (job, part): index i = job * PLL_PARTS + part.  A long job (more than PLL_SPLIT_CHUNKS chunks /
+// NZ_SPLIT_PHOTONS photons) is dealt to PLL_PARTS blocks -- all its parts are members, each with a quarter of the work
+// -- a short one stays whole (part 0 the member).  work = estimate << 1 | dealt; -1: not a block of this list.
+#define PLL_SPLIT_CHUNKS 6
 __global__ void __launch_bounds__(256)
-k_job_work(const int *__restrict__ type, const int4 *__restrict__ nzbox, int64_t S, int B, int *__restrict__ work) {
+k_job_work(const int *__restrict__ type, const int4 *__restrict__ nzbox, int64_t S, int B, int *__restrict__ work /* S*B*PLL_PARTS */,
+           const int *__restrict__ nzmode = nullptr, const int *__restrict__ nnz = nullptr,
+           int *__restrict__ work_nz = nullptr /* with nzmode: the blocks of the jobs scored at their photons */) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= S * B) return;
-    const int4 q = nzbox[i];
+    if (i >= S * B * PLL_PARTS) return;
+    const int64_t job = i / PLL_PARTS;
+    const int part = (int)(i % PLL_PARTS);
+    const int4 q = nzbox[job];
     const long long area = (q.y > q.x && q.w > q.z) ? (long long)(q.y - q.x) * (q.w - q.z) : 0;
-    const long long w = area * ((type[i / B] == 0) ? K_PSF : K_GAL) + 64;
-    work[i] = (int)min(w, (long long)0x3fffffff);
+    const int K = (type[job / B] == 0) ? K_PSF : K_GAL;
+    const bool sparse = nzmode && nzmode[job];
+    const long long chunks = area > 0 ? (long long)((q.y - q.x + HW_TW - 1) / HW_TW) * ((q.w - q.z + HW_TH - 1) / HW_TH) : 0;
+    const long long wd = area * K + 64;
+    const bool deal_d = chunks > PLL_SPLIT_CHUNKS;
+    int w = -1;
+    if (!sparse && (deal_d || part == 0)) w = (int)(min(deal_d ? wd / PLL_PARTS : wd, (long long)0x1fffffff) << 1) | (deal_d ? 1 : 0);
+    work[i] = w;
+    if (work_nz) {
+        int wn = -1;
+        if (sparse) {
+            const long long cnt = nnz[job];
+            const bool deal_n = cnt > NZ_SPLIT_PHOTONS;
+            const long long ws = cnt * K * 3 + 64;
+            if (deal_n || part == 0) wn = (int)(min(deal_n ? ws / PLL_PARTS : ws, (long long)0x1fffffff) << 1) | (deal_n ? 1 : 0);
+        }
+        work_nz[i] = wn;
+    }
+}
+
+// k_order (k_prep_bin.h) for the (job, part) entries of k_job_work: the members (work >= 0) come first, heaviest first,
+// each written as the kernels' block descriptor job << 3 | part << 1 | dealt (= 2 i + the work's low bit); *nmember
+// receives their number.  One block.
+__global__ void __launch_bounds__(1024)
+k_order_members(const int *__restrict__ work, int T, int *__restrict__ order, int *__restrict__ nmember) {
+    __shared__ int hist[257];
+    __shared__ int red[1024];
+    const int tid = threadIdx.x;
+    int mx = 0;
+    for (int i = tid; i < T; i += 1024) mx = max(mx, work[i] >> 1);
+    red[tid] = mx;
+    if (tid < 257) hist[tid] = 0;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = max(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    const long long wmax = red[0] > 0 ? red[0] : 1;
+    for (int i = tid; i < T; i += 1024) {
+        const int w = work[i];
+        atomicAdd(&hist[w < 0 ? 256 : 255 - (int)(((long long)(w >> 1) * 255) / wmax)], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {   // exclusive scan, bucket 0 = heaviest, bucket 256 = the non-members
+        int run = 0;
+        for (int k = 0; k < 257; k++) { int c = hist[k]; hist[k] = run; run += c; }
+        *nmember = hist[256];
+    }
+    __syncthreads();
+    for (int i = tid; i < T; i += 1024) {
+        const int w = work[i];
+        order[atomicAdd(&hist[w < 0 ? 256 : 255 - (int)(((long long)(w >> 1) * 255) / wmax)], 1)] = 2 * i + (w < 0 ? 0 : (w & 1));
+    }
 }

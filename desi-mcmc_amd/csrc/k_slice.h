@@ -164,19 +164,28 @@ k_slice_consume(SliceState st, int64_t S, int B, int nparts /* blocks per (chain
 }
 
 // the (chain, band) jobs of the chains that are still running, in no particular order (they all start at once:
-// the list is only built when it is shorter than the GPU has wave slots)
+// the list is only built when it is shorter than the GPU has wave slots).
+// Every live job is dealt to PLL_PARTS blocks here (few jobs are left: a round lasts as long as its longest block).
+// Entries are the likelihood kernels' block descriptors job << 3 | part << 1 | dealt.  With photon lists: two lists --
+// the jobs scored densely and the jobs scored at their photons, each for its kernel.
 __global__ void __launch_bounds__(256)
-k_slice_live_jobs(SliceState st, int64_t S, int B, int *__restrict__ list, int *__restrict__ count) {
+k_slice_live_jobs(SliceState st, int64_t S, int B, int *__restrict__ list, int *__restrict__ count,
+                  const int *__restrict__ nzmode = nullptr, int *__restrict__ list_nz = nullptr, int *__restrict__ count_nz = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S * B) return;
-    if (st.phase[i / B] != SL_FINAL) list[atomicAdd(count, 1)] = (int)i;
+    if (st.phase[i / B] == SL_FINAL) return;
+    const bool nz = nzmode && nzmode[i];
+    int *dst = nz ? list_nz : list;
+    const int at = atomicAdd(nz ? count_nz : count, 4);
+    for (int part = 0; part < 4; part++) dst[at + part] = (int)(i << 3) | (part << 1) | 1;
 }
 
 // algorithmic HBM bytes of a finished call (what bench.py prices the location step's kernel against): a chain that
 // ran made 1 + steps[s] evaluations, each of which reads, per band, one 128-B record and the 4-B photon counts of
 // the rectangle that holds the source's photons (k_patch_nzbox)
 __global__ void __launch_bounds__(256)
-k_slice_bytes(SliceState st, int64_t S, int B, const int4 *__restrict__ nzbox, unsigned long long *__restrict__ bytes) {
+k_slice_bytes(SliceState st, int64_t S, int B, const int4 *__restrict__ nzbox, unsigned long long *__restrict__ bytes,
+              const int *__restrict__ nzmode, const int64_t *__restrict__ nzoff) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long v = 0ull;
     if (s < S && st.new_llh[s] == st.new_llh[s]) {          // NaN: the chain never ran
@@ -184,7 +193,9 @@ k_slice_bytes(SliceState st, int64_t S, int B, const int4 *__restrict__ nzbox, u
         for (int b = 0; b < B; b++) {
             const int4 q = nzbox[s * B + b];
             const long long area = (q.y > q.x && q.w > q.z) ? (long long)(q.y - q.x) * (q.w - q.z) : 0;
-            per += 4ull * (unsigned long long)area + 128ull;
+            // a patch scored at its photons reads its list (8 B per photon-holding pixel) instead of the rectangle (4 B per pixel)
+            if (nzmode && nzmode[s * B + b]) per += 8ull * (unsigned long long)(nzoff[s * B + b + 1] - nzoff[s * B + b]) + 128ull;
+            else per += 4ull * (unsigned long long)area + 128ull;
         }
         v = per * (unsigned long long)(1 + st.steps[s]);
     }

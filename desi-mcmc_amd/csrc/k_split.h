@@ -281,6 +281,7 @@ k_samp_prepare(const int4 *__restrict__ sbox, const int64_t *__restrict__ soff, 
 __global__ void __launch_bounds__(1024)
 k_nz_layout(const int *__restrict__ nnz, const int4 *__restrict__ nzbox, const int *__restrict__ type /* per source */,
             int64_t S, int B, int force /* 0 = estimate, 1 = every patch at its photons, 2 = every patch densely */,
+            double bias /* force 0: at the photons unless that is estimated more than `bias` times the dense cost */,
             int64_t *__restrict__ loff /* S*B + 1: list offsets */, int *__restrict__ mode /* S*B: 1 = evaluate at the photons */) {
     __shared__ long long part[1024];
     __shared__ long long carry;
@@ -298,7 +299,7 @@ k_nz_layout(const int *__restrict__ nnz, const int4 *__restrict__ nzbox, const i
             const long long chunks = (cnt > 0) ? (long long)((q.y - q.x + HW_TW - 1) / HW_TW) * ((q.w - q.z + HW_TH - 1) / HW_TH) : 0;
             const long long sparse_cost = ((cnt + 63) / 64) * K * 17 + 150;
             const long long dense_cost = chunks * ((K == K_PSF) ? 1900 : 6800);
-            mode[i] = (force == 1) ? 1 : (force == 2) ? 0 : (sparse_cost < dense_cost ? 1 : 0);
+            mode[i] = (force == 1) ? 1 : (force == 2) ? 0 : ((double)sparse_cost < bias * (double)dense_cost ? 1 : 0);
         }
         part[tid] = cnt;
         __syncthreads();
