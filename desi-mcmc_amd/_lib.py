@@ -63,6 +63,8 @@ SYMBOLS = [
     ("cel_stamp_mass", C.c_int, [C.c_void_p, C.c_void_p, c_double_p]),
     ("cel_slice_locations", C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_double, C.c_uint64, C.c_int, c_double_p,
                                       c_double_p, c_int64_p]),
+    ("cel_slice_sample", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_int32_p, c_double_p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                   C.c_double, C.c_uint64, C.c_int, c_double_p, c_double_p, c_int64_p]),
     ("cel_source_boxes", C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, c_int32_p]),
     ("cel_photon_split", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, c_int64_p, C.c_void_p, C.c_int, c_double_p]),
     ("cel_samples_info", C.c_int, [C.c_void_p, c_int64_p, c_int64_p]),

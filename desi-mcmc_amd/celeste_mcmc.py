@@ -115,6 +115,7 @@ class ModelGibbs(object):
         self.shape_args = dict(step_out=True, doubling_step=True, compwise=False, numdir=4)
         self.shape_args.update(shape_args or {})
         self.phi_period = float(phi_period)
+        self._default_shape_prior = shape_logprior is None
         if shape_logprior is None:
             from .celeste_galaxy_conditionals import galaxy_shape_prior_constrained
             shape_logprior = lambda TH: galaxy_shape_prior_constrained(TH[:, 0], TH[:, 1], TH[:, 2], TH[:, 3], self.phi_period)   # noqa: E731
@@ -308,16 +309,33 @@ class ModelGibbs(object):
         lock-step against the resident photon patches; phi is wrapped afterwards (:241).  Stars are skipped
         (Source.resample_shape, sources.py:321-325)."""
         import time
-        from .util.infer.slicesample import slicesample_lockstep
+        from .util.infer.slicesample import ChainStreams, slicesample_lockstep
         t0 = time.perf_counter()
         mine = self.active if self.deal is None else (self.active & self.deal.mask)
         gal = np.nonzero(mine & (self.typ == 1))[0]
+        seed = self.seed * 104729 + self.sweeps
+        if self._shape_engine_on_device():
+            # the state machine on the device (cel_slice_sample): the directions are drawn here, from each chain's
+            # normal stream, exactly as the host engine draws them; nothing but counters crosses PCIe per round
+            f = self.fields[0]
+            sset = self._sources(f)
+            a = self.shape_args
+            dirs = None if a.get("compwise", True) else ChainStreams(seed, np.arange(self.S)).directions(int(a.get("numdir", 2)), 4)
+            ids = np.where(mine & (self.typ == 1), np.arange(self.S), -1).astype(np.int32)
+            new, _, st = f.iset.slice_sample(sset, 1, a.get("sigma", 1.0), seed, dirs=dirs, step_out=a.get("step_out", True),
+                                             max_steps_out=a.get("max_steps_out", 1000), phi_max=self.phi_period, chain_ids=ids)
+            new[:, 2] = np.where(ids >= 0, (new[:, 2] + self.phi_period) % self.phi_period, new[:, 2])
+            self.shape = new
+            self.timing["shape_rounds"] += st["rounds"]
+            self.timing["shape_evals"] += st["evals"]
+            self.timing["shape"] += time.perf_counter() - t0
+            return self.shape
         for f in self.fields:
             f._counts = self.counts(f)
         if gal.size:
             st = {}
             new, _ = slicesample_lockstep(self.shape[gal], lambda i, TH: self.shape_logprob(gal[i], TH),
-                                          seed=self.seed * 104729 + self.sweeps, chain_ids=gal, stats=st, **self.shape_args)
+                                          seed=seed, chain_ids=gal, stats=st, **self.shape_args)
             new[:, 2] = (new[:, 2] + self.phi_period) % self.phi_period
             self.shape[gal] = new
             self.timing["shape_rounds"] += st["rounds"]
@@ -326,6 +344,16 @@ class ModelGibbs(object):
             f._counts = None
         self.timing["shape"] += time.perf_counter() - t0
         return self.shape
+
+    def _shape_engine_on_device(self):
+        """the device runs the shape step when there is one field, the log-prior is the built-in one and the options are
+        those of slice_sample_skew's family: no stepping out or doubling, component-wise or random directions"""
+        a = self.shape_args
+        ok = (len(self.fields) == 1 and self._default_shape_prior and (not a.get("step_out", True) or a.get("doubling_step", True))
+              and set(a) <= {"step_out", "doubling_step", "compwise", "numdir", "sigma", "max_steps_out"})
+        if self.engine == "device" and not ok:
+            raise ValueError("the device shape sampler runs one field, the built-in log-prior, stepping out by doubling or none")
+        return ok and self.engine != "host"
 
     def _device_engine_applies(self):
         a = self.slice_args

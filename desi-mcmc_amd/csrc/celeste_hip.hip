@@ -84,6 +84,7 @@ static int fail(int code, const char *fmt, ...) {
 #include "k_render_qw.h"
 #include "k_misc.h"
 #include "k_patch_ll.h"
+#include "k_slice_gen.h"
 #include "k_estep.h"
 #include "k_split.h"
 #include "k_slice.h"
@@ -197,6 +198,9 @@ struct cel_images {
     void *d_slice = nullptr;
     size_t slice_cap = 0;
     cel_sources *slice_prop = nullptr;
+    void *d_sgen = nullptr;     // the general slice sampler's state (cel_slice_sample)
+    size_t sgen_cap = 0;
+    cel_sources *sgen_prop = nullptr;
     int64_t last_S = 0;
     double last_entries = 0;
 };
@@ -487,6 +491,8 @@ int cel_images_destroy(cel_images *im) {
         if (p) (void)hipFree(p);
     if (im->d_slice) (void)hipFree(im->d_slice);
     if (im->slice_prop) cel_sources_destroy(im->slice_prop);
+    if (im->sgen_prop) cel_sources_destroy(im->sgen_prop);
+    if (im->d_sgen) (void)hipFree(im->d_sgen);
     if (im->ev_step) (void)hipEventDestroy(im->ev_step);
     delete im;
     return CEL_OK;
@@ -1221,6 +1227,8 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     }
     if (!im->slice_prop || im->slice_prop->cap < S) {
         if (im->slice_prop) cel_sources_destroy(im->slice_prop);
+    if (im->sgen_prop) cel_sources_destroy(im->sgen_prop);
+    if (im->d_sgen) (void)hipFree(im->d_sgen);
         im->slice_prop = nullptr;
         int rc0 = cel_sources_create(c, S + S / 4 + 16, B, &im->slice_prop);
         if (rc0) return rc0;
@@ -1375,6 +1383,167 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         stats[2] = (int64_t)(*reinterpret_cast<unsigned long long *>(h_flags + 6));
         stats[3] = queued;
     }
+    return CEL_OK;
+}
+
+// The general slice sampler (k_slice_gen.h): random directions, stepping out by doubling, D = 2 or 4.
+int cel_slice_sample(cel_images *im, cel_sources *src, int param, const int32_t *chain_ids, const double *dirs, int numdir,
+                     int step_out, int max_steps_out, double sigma, double phi_max, uint64_t seed, int max_rounds,
+                     double *x_out, double *llh_out, int64_t *stats) {
+    if (!im || !src) return fail(CEL_ERR_INVALID, "cel_slice_sample: null argument");
+    if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
+    if (im->samp_S <= 0 || im->samp_S != src->S)
+        return fail(CEL_ERR_INVALID, "cel_slice_sample needs a resident photon split of these %lld sources (have %lld)",
+                    (long long)src->S, (long long)im->samp_S);
+    if (param != 0 && param != 1) return fail(CEL_ERR_INVALID, "cel_slice_sample: param must be 0 (location) or 1 (shape)");
+    if (!(sigma > 0.0) || max_rounds < 1 || max_steps_out < 0) return fail(CEL_ERR_INVALID, "cel_slice_sample: sigma and max_rounds must be positive");
+    const int D = param ? 4 : 2;
+    const int compwise = dirs ? 0 : 1;
+    const int ndir = compwise ? D : numdir;
+    if (ndir < 1 || ndir > 64) return fail(CEL_ERR_INVALID, "cel_slice_sample: numdir must be in [1, 64]");
+    cel_ctx *c = im->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int B = im->B;
+    const int64_t S = src->S;
+    const int ostr = (c->variant != 0) ? PLL_PARTS : 1;
+    // one allocation, carved: 2 x u64, (3 D + 13) x f64, (4 + D) x i32 per chain, the directions, 2 owners, 2 B ostr log-likelihood slots
+    const size_t per_chain = 2 * 8 + (size_t)(3 * D + 13) * 8 + (size_t)(4 + D) * 4 + (size_t)ndir * D * 8 + 2 * 4 + (size_t)2 * B * ostr * 8 + 4 +
+                             (size_t)2 * 2 * B * PLL_PARTS * 4;
+    const size_t need = per_chain * (size_t)S + 256;
+    if (need > im->sgen_cap) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (im->d_sgen) (void)hipFree(im->d_sgen);
+        im->d_sgen = nullptr; im->sgen_cap = 0;
+        HIP_TRY(hipMalloc(&im->d_sgen, need + need / 4));
+        im->sgen_cap = need + need / 4;
+    }
+    if (!im->sgen_prop || im->sgen_prop->cap < 2 * S) {
+        if (im->sgen_prop) cel_sources_destroy(im->sgen_prop);
+        im->sgen_prop = nullptr;
+        int rc0 = cel_sources_create(c, 2 * S + S / 2 + 16, B, &im->sgen_prop);
+        if (rc0) return rc0;
+    }
+    cel_sources *prop = im->sgen_prop;
+    char *p = (char *)im->d_sgen;
+    SliceGen g;
+    SliceState rs;
+    rs.key = (unsigned long long *)p; p += 8 * S;
+    rs.count = (unsigned long long *)p; p += 8 * S;
+    g.key = rs.key; g.count = rs.count;
+    g.x = (double *)p; p += 8 * S * D;
+    g.x0 = (double *)p; p += 8 * S * D;
+    g.dir = (double *)p; p += 8 * S * D;
+    g.lower = (double *)p; p += 8 * S;
+    g.upper = (double *)p; p += 8 * S;
+    g.log_u = (double *)p; p += 8 * S;
+    g.llh_s = (double *)p; p += 8 * S;
+    g.new_z = (double *)p; p += 8 * S;
+    g.new_llh = (double *)p; p += 8 * S;
+    g.start_lower = (double *)p; p += 8 * S;
+    g.start_upper = (double *)p; p += 8 * S;
+    g.acc_L = (double *)p; p += 8 * S;
+    g.acc_U = (double *)p; p += 8 * S;
+    g.pri = (double *)p; p += 16 * S;
+    double *d_dirs = (double *)p; p += 8 * S * ndir * D;
+    double *d_ll = (double *)p; p += 8 * 2 * S * B * ostr;
+    g.phase = (int *)p; p += 4 * S;
+    g.kdir = (int *)p; p += 4 * S;
+    g.l_out = (int *)p; p += 4 * S;
+    g.u_out = (int *)p; p += 4 * S;
+    g.order = (int *)p; p += 4 * S * D;
+    int *d_owner = (int *)p; p += 8 * S;
+    int *d_ids = (int *)p; p += 4 * S;
+    int *d_list = (int *)p; p += 4 * 2 * S * B * PLL_PARTS;          // the running chains' blocks (k_sg_live_jobs): dense, at the photons
+    int *d_list_nz = (int *)p; p += 4 * 2 * S * B * PLL_PARTS;
+    int *d_flags = (int *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    g.D = D; g.ndir = ndir; g.compwise = compwise; g.step_out = step_out ? 1 : 0; g.max_steps_out = max_steps_out; g.param = param;
+    g.sigma = sigma; g.phi_max = param ? phi_max : 0.0; g.dirs = compwise ? nullptr : d_dirs;
+    if (!compwise) HIP_TRY(hipMemcpyAsync(d_dirs, dirs, sizeof(double) * S * ndir * D, hipMemcpyHostToDevice, st));
+    if (chain_ids) HIP_TRY(hipMemcpyAsync(d_ids, chain_ids, sizeof(int) * S, hipMemcpyHostToDevice, st));
+    if (!compwise || chain_ids) HIP_TRY(hipStreamSynchronize(st));          // pageable sources must stay valid
+    HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(int) * 8, st));
+    const unsigned g256 = (unsigned)((S + 255) / 256);
+    // the proposal set: every chain's source twice, the sampled parameter rewritten every round
+    hipLaunchKernelGGL(k_sg_fill, dim3((unsigned)((2 * S + 255) / 256)), dim3(256), 0, st, S, B, (const int *)src->d_type,
+                       (const double *)src->d_radec, (const double *)src->d_counts, (const double *)src->d_shape,
+                       prop->d_type, prop->d_radec, prop->d_counts, prop->d_shape);
+    prop->S = 2 * S;
+    hipLaunchKernelGGL(k_sg_init, dim3(g256), dim3(256), 0, st, g, rs, S, (const double *)(param ? src->d_shape : src->d_radec),
+                       chain_ids ? (const int *)d_ids : (const int *)nullptr, (const int64_t *)im->d_soff, B, (const int *)src->d_type,
+                       (unsigned long long)seed);
+    const bool use_nz = im->nz_valid && c->variant != 0;
+    int64_t rounds = 0, evals = 0, queued = 0;
+    int *h_flags = reinterpret_cast<int *>(c->pinned + MAX_BANDS + 2);
+    int rc = CEL_OK;
+    const int64_t P = 2 * S;
+    const int BATCH = 4;
+    const int64_t DEAL_ALL_BELOW = 8192;          // (chain, slot, band) jobs: fewer than the GPU has wave slots for -- deal every job
+    int64_t live = S;                             // chains running at the last readback
+    // the first batch's block lists (every later one is built behind the batch before it); their counts come back now
+    int64_t n_dense = P * B, n_nz = 0;
+    if (c->variant != 0) {
+        hipLaunchKernelGGL(k_sg_live_jobs, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, g, S, B,
+                           (const int *)(use_nz ? im->d_nzmode : nullptr), (const int *)im->d_nnz, (const int4 *)im->d_snz, 0,
+                           d_list, d_flags + 4, d_list_nz, d_flags + 5);
+        HIP_TRY(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n_dense = h_flags[4]; n_nz = h_flags[5];
+    }
+    for (;;) {
+        const int nb = (int)std::min<int64_t>(BATCH, (int64_t)max_rounds - queued);
+        for (int k = 0; k < nb; k++) {
+            hipLaunchKernelGGL(k_sg_propose, dim3(g256), dim3(256), 0, st, g, rs, S, param ? prop->d_shape : prop->d_radec, d_owner, d_flags,
+                               queued == 0 ? 1 : 0);
+            prop->gen = ++g_source_gen;
+            if ((rc = run_prep(im, prop, d_owner))) return rc;
+            if (c->variant == 0) {
+                int pi = prof_slot(c, CEL_K_PATCH_LL);
+                LAUNCH_EV(k_patch_ll<int>, dim3((unsigned)(P * B)), dim3(256), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, P, im->d_recs,
+                          (const int *)d_owner, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_nelec, im->H, im->W, 0, d_ll);
+            } else {
+                if (n_dense > 0) {
+                    int pi = prof_slot(c, CEL_K_PATCH_LL);
+                    LAUNCH_EV((k_patch_ll_hw<0, int>), dim3((unsigned)n_dense), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, P, im->d_recs,
+                              (const int *)d_owner, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll,
+                              (const int *)d_list, 1, (const int *)nullptr, (const int *)(use_nz ? im->d_nzmode : nullptr), 1, PLL_PARTS);
+                }
+                if (n_nz > 0) {
+                    int pi = prof_slot(c, CEL_K_PATCH_LL);
+                    LAUNCH_EV(k_patch_ll_nz, dim3((unsigned)n_nz), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, P, im->d_recs,
+                              (const int *)d_owner, (const int4 *)im->d_sbox, (const int4 *)im->d_snz, (const int *)im->d_nzmode,
+                              (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_ll, (const int *)d_list_nz, (const int *)nullptr);
+                }
+            }
+            hipLaunchKernelGGL(k_sg_consume, dim3(g256), dim3(256), 0, st, g, rs, S, B, ostr, (const double *)d_ll, d_flags);
+            queued++;
+        }
+        if (c->variant != 0) {          // the next batch's blocks: the chains still running now
+            HIP_TRY(hipMemsetAsync(d_flags + 4, 0, sizeof(int) * 2, st));
+            hipLaunchKernelGGL(k_sg_live_jobs, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, g, S, B,
+                               (const int *)(use_nz ? im->d_nzmode : nullptr), (const int *)im->d_nnz, (const int4 *)im->d_snz,
+                               (live * 2 * B <= DEAL_ALL_BELOW) ? 1 : 0, d_list, d_flags + 4, d_list_nz, d_flags + 5);
+        }
+        HIP_TRY(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+        const int running = h_flags[0], err = h_flags[1];
+        if (c->variant != 0) { n_dense = h_flags[4]; n_nz = h_flags[5]; }
+        live = running;
+        if (err & 1) return fail(CEL_ERR_INVALID, "Slice sampler got a NaN");
+        if (err & 2) return fail(CEL_ERR_INVALID, "Slice sampler shrank to zero!");
+        evals = h_flags[2];
+        rounds = h_flags[3];
+        if (running == 0) break;
+        if (queued >= max_rounds) return fail(CEL_ERR_INVALID, "cel_slice_sample: %d rounds without every chain finishing", max_rounds);
+    }
+    // the new states replace the catalogue's
+    HIP_TRY(hipMemcpyAsync(param ? src->d_shape : src->d_radec, g.x, sizeof(double) * D * S, hipMemcpyDeviceToDevice, st));
+    src->gen = ++g_source_gen;
+    if (x_out) HIP_TRY(hipMemcpyAsync(x_out, g.x, sizeof(double) * D * S, hipMemcpyDeviceToHost, st));
+    if (llh_out) HIP_TRY(hipMemcpyAsync(llh_out, g.new_llh, sizeof(double) * S, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (stats) { stats[0] = rounds; stats[1] = evals; stats[2] = 0; stats[3] = queued; }
     return CEL_OK;
 }
 

@@ -1,0 +1,297 @@
+// k_slice_gen.h -- the general lock-step slice sampler on the device
+//
+// slicesample (CelestePy/util/infer/slicesample.py:89-227) over D = 2 (location) or D = 4 (galaxy shape:
+// theta, sigma, phi, rho) parameters of every source at once, with the options k_slice.h's fast path does not run:
+// random directions (compwise=False, numdir of them) and stepping out by doubling with the `acceptable` test
+// (:119-131, :150-157) -- the call of celeste_mcmc.py:229-239 (slice_sample_skew).  Same state machine as the host
+// engine (desi-mcmc_amd/util/infer/slicesample.py: phases LEVEL, OUT_DOUBLE, SHRINK, ACCEPT, DONE), same per-chain
+// SplitMix64 stream in the same draw order, same arithmetic (no FMA contraction), so a chain takes the same
+// trajectory on either engine.  The random directions come from the host (each chain's own normal stream, drawn in
+// numpy: log / cos / sqrt enter the POSITIONS and must be the host's to the bit); the device draws the uniforms.
+//
+// A chain needs up to TWO points per round (both ends of its interval while doubling or testing acceptability):
+// the proposal set has two slots per chain, 2 s and 2 s + 1; owner[slot] = s, or -1 for a slot that is not scored
+// (unused, or outside the prior's support: the likelihood is never evaluated there, celeste_mcmc.py:213-214).
+#pragma once
+#include "k_slice.h"
+
+#define SG_LEVEL 0
+#define SG_OUT_DOUBLE 1
+#define SG_SHRINK 4
+#define SG_ACCEPT 5
+#define SG_DONE 6
+#define SG_FINAL 7
+#define SG_MAXD 4
+
+struct SliceGen {              // SoA over chains
+    unsigned long long *key, *count;
+    double *x;                 // current state, D per chain
+    double *x0;                // the state the current direction started from, D per chain
+    double *dir;               // the current direction, D per chain
+    double *lower, *upper, *log_u, *llh_s, *new_z, *new_llh, *start_lower, *start_upper, *acc_L, *acc_U;
+    double *pri;               // log-prior of the points in the chain's two slots (2 per chain)
+    int *phase, *kdir, *l_out, *u_out, *order;      // order: compwise: the axes in the chain's random order (D per chain)
+    int D, ndir, compwise, step_out, max_steps_out, param;   // param: 0 = location (radec), 1 = shape
+    double sigma;
+    double phi_max;            // shape prior's bound on phi; <= 0: no prior (location)
+    const double *dirs;        // random directions from the host: [S][ndir][D], or nullptr (compwise)
+};
+
+// log-prior of a shape (celeste_galaxy_conditionals.py:268-275 with util/like/like_list.py:18-27, a0 = b0 = 1)
+__device__ inline double sg_shape_prior(const double *t, double phi_max) {
+#pragma clang fp contract(off)
+    const bool inside = t[0] > 0.0 && t[0] < 1.0 && t[1] > 0.0 && t[2] > 0.0 && t[2] < phi_max && t[3] > 0.0 && t[3] < 1.0;
+    if (!inside) return -INFINITY;
+    const double s2 = t[1] * t[1];
+    return -2.0 * log(s2) - 1.0 / s2;
+}
+
+// slicesample.py:142-146 + the direction (:213-228)
+__device__ inline void sg_start_direction(const SliceGen &g, const SliceState &rs, int64_t s) {
+#pragma clang fp contract(off)
+    const int D = g.D, k = g.kdir[s];
+    for (int d = 0; d < D; d++) {
+        g.x0[D * s + d] = g.x[D * s + d];
+        g.dir[D * s + d] = g.compwise ? ((g.order[D * s + k] == d) ? 1.0 : 0.0) : g.dirs[((int64_t)s * g.ndir + k) * D + d];
+    }
+    const double up = g.sigma * sl_uniform(rs, s);
+    g.upper[s] = up;
+    g.lower[s] = up - g.sigma;
+    g.log_u[s] = log(sl_uniform(rs, s));
+    g.phase[s] = SG_LEVEL;
+    g.l_out[s] = 0;
+    g.u_out[s] = 0;
+}
+
+__device__ inline void sg_enter_shrink(const SliceGen &g, int64_t s) {
+    g.start_lower[s] = g.lower[s];
+    g.start_upper[s] = g.upper[s];
+    g.phase[s] = SG_SHRINK;
+}
+
+__global__ void __launch_bounds__(256)
+k_sg_init(SliceGen g, SliceState rs, int64_t S, const double *__restrict__ init /* S*D */, const int *__restrict__ chain_ids,
+          const int64_t *__restrict__ soff, int B, const int *__restrict__ type, unsigned long long seed) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int D = g.D;
+    const unsigned long long id = (unsigned long long)(chain_ids ? chain_ids[s] : (int)s);
+    rs.key[s] = sl_mix(seed ^ (id * 0xD1342543DE82EF95ull));
+    rs.count[s] = 0ull;
+    for (int d = 0; d < D; d++) g.x[D * s + d] = init[D * s + d];
+    g.new_llh[s] = NAN;
+    g.kdir[s] = 0;
+    if (g.compwise) {
+        // a random order of the axes: the stable argsort of D uniforms (slicesample.py:214-221)
+        double u[SG_MAXD];
+        for (int d = 0; d < D; d++) u[d] = sl_uniform(rs, s);
+        for (int d = 0; d < D; d++) {
+            int rank = 0;
+            for (int e = 0; e < D; e++) rank += (u[e] < u[d] || (u[e] == u[d] && e < d)) ? 1 : 0;
+            g.order[D * s + rank] = d;
+        }
+    }
+    // left alone: a source without any sample patch (the reference asserts there, sources.py:243), one whose chain id is
+    // negative (another rank's), and -- shapes -- a star (sources.py:321-325)
+    const bool runs = soff[(s + 1) * B] > soff[s * B] && !(chain_ids && chain_ids[s] < 0) && (!g.param || type[s] == 1);
+    if (runs && g.ndir > 0) sg_start_direction(g, rs, s);
+    else g.phase[s] = SG_FINAL;
+}
+
+// the point(s) every unfinished chain needs next -> the proposal set's parameter rows 2 s and 2 s + 1
+__global__ void __launch_bounds__(256)
+k_sg_propose(SliceGen g, SliceState rs, int64_t S, double *__restrict__ prop /* 2S rows of D (radec) or 4 (shape) */,
+             int *__restrict__ owner /* 2S */, int *__restrict__ flags, int first) {
+#pragma clang fp contract(off)
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0) {
+        if (first || flags[0] > 0) flags[3] += 1;          // rounds that had a chain to score
+        flags[0] = 0;
+    }
+    if (s >= S) return;
+    const int ph = g.phase[s];
+    owner[2 * s] = -1;
+    owner[2 * s + 1] = -1;
+    if (ph == SG_FINAL) return;
+    const int D = g.D;
+    double z[2] = {0.0, 0.0};
+    int np = 1;
+    if (ph == SG_OUT_DOUBLE) { z[0] = g.lower[s]; z[1] = g.upper[s]; np = 2; }
+    else if (ph == SG_ACCEPT) { z[0] = g.acc_L[s]; z[1] = g.acc_U[s]; np = 2; }
+    else if (ph == SG_SHRINK) {
+        z[0] = (g.upper[s] - g.lower[s]) * sl_uniform(rs, s) + g.lower[s];          // slicesample.py:172
+        g.new_z[s] = z[0];
+    }
+    const int W = g.param ? 4 : 2;
+    for (int q = 0; q < np; q++) {
+        double t[SG_MAXD];
+        for (int d = 0; d < D; d++) t[d] = g.x0[D * s + d] + z[q] * g.dir[D * s + d];
+        double lp = 0.0;
+        if (g.param && g.phi_max > 0.0) lp = sg_shape_prior(t, g.phi_max);
+        g.pri[2 * s + q] = lp;
+        if (lp > -INFINITY) {                       // outside the prior's support nothing is rendered
+            for (int d = 0; d < D; d++) prop[(2 * s + q) * W + d] = t[d];
+            owner[2 * s + q] = (int)s;
+        }
+    }
+}
+
+// `acceptable` (slicesample.py:119-131), resumed with the values at the interval ends the previous halving asked for
+// (first = true: first entry).  Leaves the chain DONE (acceptable), SHRINK (not acceptable) or in ACCEPT with the next
+// pair of ends in acc_L / acc_U.
+__device__ inline void sg_accept_advance(const SliceGen &g, int64_t s, bool first, double vL, double vU) {
+#pragma clang fp contract(off)
+    if (!first && g.llh_s[s] >= vU && g.llh_s[s] >= vL) { g.phase[s] = SG_SHRINK; return; }
+    const double z = g.new_z[s];
+    for (;;) {
+        const double L = g.acc_L[s], U = g.acc_U[s];
+        if (!((U - L) > 1.1 * g.sigma)) { g.phase[s] = SG_DONE; return; }
+        const double middle = 0.5 * (L + U);
+        const bool splits = (middle > 0.0 && z >= middle) || (middle <= 0.0 && z < middle);
+        if (z < middle) g.acc_U[s] = middle;
+        else g.acc_L[s] = middle;
+        if (splits) { g.phase[s] = SG_ACCEPT; return; }       // both new ends have to be scored: next round
+    }
+}
+
+// consume the round's log-likelihoods: ll_pb holds PLL_PARTS slots per (proposal slot, band), added in order
+__global__ void __launch_bounds__(256)
+k_sg_consume(SliceGen g, SliceState rs, int64_t S, int B, int nparts, const double *__restrict__ ll_pb, int *__restrict__ flags) {
+#pragma clang fp contract(off)
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = false;
+    int scored = 0;
+    if (s < S) {
+        int ph = g.phase[s];
+        if (ph != SG_FINAL) {
+            double v[2];
+            const int np = (ph == SG_OUT_DOUBLE || ph == SG_ACCEPT) ? 2 : 1;
+            for (int q = 0; q < np; q++) {
+                const double lp = g.pri[2 * s + q];
+                if (lp > -INFINITY) {
+                    double acc = 0.0;
+                    for (int b = 0; b < B; b++) {
+                        const double *p = ll_pb + ((2 * s + q) * B + b) * nparts;
+                        double x = p[0];
+                        for (int k = 1; k < nparts; k++) x += p[k];
+                        acc += x;
+                    }
+                    v[q] = lp + acc;
+                } else {
+                    v[q] = -INFINITY;
+                }
+            }
+            scored = np;                            // points asked for, as the host engine counts them
+            if (ph == SG_LEVEL) {
+                g.llh_s[s] = g.log_u[s] + v[0];                                  // slicesample.py:146
+                if (g.step_out) g.phase[s] = SG_OUT_DOUBLE;
+                else sg_enter_shrink(g, s);
+            } else if (ph == SG_OUT_DOUBLE) {                                    // :151-157
+                const bool go = (v[0] > g.llh_s[s] || v[1] > g.llh_s[s]) && (g.l_out[s] + g.u_out[s]) < g.max_steps_out;
+                if (go) {
+                    const bool left = sl_uniform(rs, s) < 0.5;
+                    const double width = g.upper[s] - g.lower[s];
+                    if (left) { g.l_out[s] += 1; g.lower[s] -= width; }
+                    else { g.u_out[s] += 1; g.upper[s] += width; }
+                } else {
+                    sg_enter_shrink(g, s);
+                }
+            } else if (ph == SG_SHRINK) {                                        // :173-190
+                if (v[0] != v[0]) atomicOr(flags + 1, 1);                        // "Slice sampler got a NaN"
+                const double z = g.new_z[s];
+                if (v[0] > g.llh_s[s]) {
+                    g.new_llh[s] = v[0];
+                    if ((g.start_upper[s] - g.start_lower[s]) > 1.1 * g.sigma) {   // the doubled interval has to be tested (:177)
+                        g.acc_L[s] = g.start_lower[s];
+                        g.acc_U[s] = g.start_upper[s];
+                        sg_accept_advance(g, s, true, 0.0, 0.0);
+                    } else {
+                        g.phase[s] = SG_DONE;
+                    }
+                } else if (z < 0.0) {
+                    g.lower[s] = z;
+                } else if (z > 0.0) {
+                    g.upper[s] = z;
+                } else {
+                    atomicOr(flags + 1, 2);                                      // "Slice sampler shrank to zero!"
+                    g.phase[s] = SG_FINAL;
+                }
+            } else if (ph == SG_ACCEPT) {
+                sg_accept_advance(g, s, false, v[0], v[1]);
+                if (g.phase[s] == SG_SHRINK) {                                   // not acceptable: shrink as a rejection (:180-183)
+                    const double z = g.new_z[s];
+                    if (z < 0.0) g.lower[s] = z;
+                    else g.upper[s] = z;
+                }
+            }
+            if (g.phase[s] == SG_DONE) {                                         // move, then on to the next direction
+                const int D = g.D;
+                for (int d = 0; d < D; d++) g.x[D * s + d] = g.x0[D * s + d] + g.new_z[s] * g.dir[D * s + d];      // :203
+                const int k = g.kdir[s] + 1;
+                g.kdir[s] = k;
+                if (k >= g.ndir) g.phase[s] = SG_FINAL;
+                else {
+                    // the next direction starts where this one ended: its level needs the log-probability of a point that has
+                    // just been scored (the reference evaluates it again and gets the same number)
+                    sg_start_direction(g, rs, s);
+                    g.llh_s[s] = g.log_u[s] + g.new_llh[s];
+                    if (g.step_out) g.phase[s] = SG_OUT_DOUBLE;
+                    else sg_enter_shrink(g, s);
+                }
+            }
+            active = g.phase[s] != SG_FINAL;
+        }
+    }
+    const unsigned long long m = __ballot(active);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(flags, __popcll(m));
+    for (int o = 32; o > 0; o >>= 1) scored += __shfl_xor(scored, o);
+    if ((threadIdx.x & 63) == 0 && scored) atomicAdd(flags + 2, scored);          // evaluations so far
+}
+
+// the proposal set of a call: two slots per chain, everything but the sampled parameter copied from the catalogue
+__global__ void __launch_bounds__(256)
+k_sg_fill(int64_t S, int B, const int *__restrict__ type, const double *__restrict__ radec, const double *__restrict__ counts,
+          const double *__restrict__ shape, int *__restrict__ ptype, double *__restrict__ pradec, double *__restrict__ pcounts,
+          double *__restrict__ pshape) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * S) return;
+    const int64_t s = i >> 1;
+    ptype[i] = type[s];
+    pradec[2 * i] = radec[2 * s]; pradec[2 * i + 1] = radec[2 * s + 1];
+    for (int b = 0; b < B; b++) pcounts[i * B + b] = counts[s * B + b];
+    for (int d = 0; d < 4; d++) pshape[4 * i + d] = shape[4 * s + d];
+}
+
+
+// The blocks of the next rounds: for every running chain both of its slots x every band, as the likelihood kernels' block
+// descriptors job << 3 | part << 1 | dealt (job = slot * B + band) -- a long job (or, when few chains are left, every
+// job) dealt to PLL_PARTS blocks -- in two lists: the patches scored densely and those scored at their photons.  Built at
+// the end of a batch of rounds for the next one, so that its two counts ride back with the batch's flags and the next
+// launches are exactly as large as their lists.  A chain that finishes inside the batch leaves blocks that retire at
+// their first instructions (its slots' owner is -1), and so does the unused second slot of a chain that needs one point.
+__global__ void __launch_bounds__(256)
+k_sg_live_jobs(SliceGen g, int64_t S, int B, const int *__restrict__ nzmode, const int *__restrict__ nnz,
+               const int4 *__restrict__ nzbox, int deal_all, int *__restrict__ list, int *__restrict__ count,
+               int *__restrict__ list_nz, int *__restrict__ count_nz) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // (chain, band)
+    if (i >= S * B) return;
+    const int64_t s = i / B;
+    const int b = (int)(i % B);
+    if (g.phase[s] == SG_FINAL) return;
+    const bool nz = nzmode && nzmode[i];
+    bool deal = deal_all != 0;
+    if (!deal) {
+        if (nz) deal = nnz[i] > NZ_SPLIT_PHOTONS;
+        else {
+            const int4 q = nzbox[i];
+            deal = (q.y > q.x && q.w > q.z) && (long long)((q.y - q.x + HW_TW - 1) / HW_TW) * ((q.w - q.z + HW_TH - 1) / HW_TH) > PLL_SPLIT_CHUNKS;
+        }
+    }
+    const int per = deal ? PLL_PARTS : 1;
+    int *dst = nz ? list_nz : list;
+    const int at = atomicAdd(nz ? count_nz : count, 2 * per);
+    for (int q = 0; q < 2; q++) {
+        const int job = (int)((2 * s + q) * B + b);
+        for (int part = 0; part < per; part++) dst[at + q * per + part] = (job << 3) | (part << 1) | (deal ? 1 : 0);
+    }
+}

@@ -296,6 +296,38 @@ class ImageSet(object):
             raise
         return radec, llh, dict(rounds=int(stats[0]), evals=int(stats[1]), algorithmic_bytes=int(stats[2]), launches=int(stats[3]))
 
+    def slice_sample(self, sources, param, sigma, seed, dirs=None, step_out=True, max_steps_out=1000, phi_max=180.,
+                     chain_ids=None, max_rounds=20000):
+        """slicesample with random directions / stepping out by doubling for every source's location (param 0) or every
+        galaxy's shape (param 1) on the device (cel_slice_sample).  dirs (S, numdir, D) unit directions or None =
+        component-wise.  The sampled parameter is updated in place on the device.
+        -> (x[S,D], llh[S], dict(rounds, evals))"""
+        S = sources.S
+        D = 4 if param else 2
+        x, llh = np.zeros((S, D)), np.zeros(S)
+        stats = np.zeros(4, dtype=np.int64)
+        ids = None
+        if chain_ids is not None:
+            ids = np.ascontiguousarray(chain_ids, dtype=np.int32)
+            if ids.shape != (S,):
+                raise ValueError("chain_ids must have one entry per source")
+        numdir = 0
+        if dirs is not None:
+            dirs = L.f64(dirs)
+            if dirs.ndim != 3 or dirs.shape[0] != S or dirs.shape[2] != D:
+                raise ValueError("dirs must be (S, numdir, %d)" % D)
+            numdir = dirs.shape[1]
+        try:
+            L.check(L.lib().cel_slice_sample(self._h, sources._h, int(param), None if ids is None else ids.ctypes.data_as(L.c_int32_p),
+                                             None if dirs is None else L.dptr(dirs), int(numdir), 1 if step_out else 0,
+                                             int(max_steps_out), float(sigma), float(phi_max), C.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                             int(max_rounds), L.dptr(x), L.dptr(llh), stats.ctypes.data_as(L.c_int64_p)))
+        except ValueError as e:
+            if "Slice sampler" in str(e):
+                raise Exception(str(e))
+            raise
+        return x, llh, dict(rounds=int(stats[0]), evals=int(stats[1]), launches=int(stats[3]))
+
     def sample_sums(self):
         """photons attributed to every (source, band) by the resident split -> (S, B)"""
         S, tot = C.c_int64(0), C.c_int64(0)

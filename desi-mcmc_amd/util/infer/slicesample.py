@@ -41,13 +41,18 @@ def _splitmix(x):
 
 
 class ChainStreams(object):
-    """One uniform stream per chain: u(chain, k) = SplitMix64(SplitMix64(seed ^ chain * C) + k)."""
+    """Two streams per chain: the uniforms, u(chain, k) = SplitMix64(SplitMix64(seed ^ chain * C) + k), and -- keyed off
+    the same chain key -- the normals that make random directions.  The normals have a stream of their own so that a
+    chain's k-th direction does not depend on how many uniforms its earlier directions used: the device engine
+    (cel_slice_sample) is handed all directions up front, computed here (log, cos and sqrt enter the positions)."""
 
     def __init__(self, seed, chain_ids):
         ids = np.asarray(chain_ids, dtype=np.uint64)
         with np.errstate(over="ignore"):
             self.key = _splitmix((np.uint64(int(seed) & 0xFFFFFFFFFFFFFFFF) ^ (ids * np.uint64(0xD1342543DE82EF95))) & _M64)
+            self.nkey = _splitmix(self.key ^ np.uint64(0xA0761D6478BD642F))
         self.count = np.zeros(ids.shape[0], dtype=np.uint64)
+        self.ncount = np.zeros(ids.shape[0], dtype=np.uint64)
 
     def uniform(self, idx):
         """next uniform in (0, 1) of the chains idx (53 random bits, never 0)"""
@@ -56,9 +61,26 @@ class ChainStreams(object):
         self.count[idx] += np.uint64(1)
         return ((z >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
 
+    def _nuniform(self, idx):
+        with np.errstate(over="ignore"):
+            z = _splitmix((self.nkey[idx] + self.ncount[idx] * np.uint64(0x9E3779B97F4A7C15)) & _M64)
+        self.ncount[idx] += np.uint64(1)
+        return ((z >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
     def normal(self, idx):
-        u1, u2 = self.uniform(idx), self.uniform(idx)
+        """next standard normal of the chains idx (Box-Muller on two numbers of the chain's normal stream)"""
+        u1, u2 = self._nuniform(idx), self._nuniform(idx)
         return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+    def directions(self, numdir, D):
+        """(S, numdir, D): every chain's next `numdir` random unit directions, exactly as slicesample_lockstep draws them
+        one by one (slicesample.py:224-226)"""
+        every = np.arange(self.key.shape[0])
+        out = np.empty((every.size, numdir, D))
+        for k in range(numdir):
+            dr = np.stack([self.normal(every) for _ in range(D)], axis=1)
+            out[:, k] = dr / np.sqrt(np.sum(dr ** 2, axis=1, keepdims=True))
+        return out
 
 
 # phases of a chain inside one direction

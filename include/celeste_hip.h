@@ -263,6 +263,26 @@ int cel_stamp_mass(cel_images *img, cel_sources *src, double *mass);
 int cel_slice_locations(cel_images *img, cel_sources *src, const int32_t *chain_ids, double sigma, uint64_t seed,
                         int max_rounds, double *radec_out, double *llh_out, int64_t *stats);
 
+/* slicesample (CelestePy/util/infer/slicesample.py:89-227) with the options cel_slice_locations does not run -- random
+ * directions and stepping out by doubling with the `acceptable` test -- over every source's location (param 0: D = 2) or
+ * every GALAXY's shape (param 1: D = 4: theta, sigma, phi, rho; the call of CelestePy/celeste_mcmc.py:229-239,
+ * slice_sample_skew), as a lock-step state machine on the device against the resident photon split of exactly these
+ * sources.  Every round each unfinished chain's next one or two points are scored (mode 0 of cel_patch_loglik_multi,
+ * resident form) and the chains advance.  Same per-chain SplitMix64 streams, draw order and arithmetic as the host engine
+ * of the Python mirror (util/infer/slicesample.py), chain for chain.
+ *   dirs       S*numdir*D (host): the chains' random unit directions, drawn by the caller (the mirror draws them from each
+ *              chain's normal stream); NULL = component-wise, the axes in each chain's own random order (numdir ignored)
+ *   step_out   0 = none, 1 = doubling (at most max_steps_out doublings per direction)
+ *   phi_max    param 1: log-prior galaxy_shape_prior_constrained (celeste_galaxy_conditionals.py:268-275) with this bound on
+ *              phi is added to the conditional likelihood; a point outside its support scores -inf and is never rendered.
+ *              <= 0: no prior.  (Any other prior: the host engine.)
+ *   chain_ids  as cel_slice_locations; a star is left alone under param 1
+ *   x_out      S*D (host, may be NULL): the new states; they also REPLACE src's on the device.  llh_out, stats: as
+ *              cel_slice_locations (stats[2] = 0) */
+int cel_slice_sample(cel_images *img, cel_sources *src, int param, const int32_t *chain_ids, const double *dirs, int numdir,
+                     int step_out, int max_steps_out, double sigma, double phi_max, uint64_t seed, int max_rounds,
+                     double *x_out, double *llh_out, int64_t *stats);
+
 /* ---- photon split (Gibbs step) ------------------------------------------------------------ */
 /* boxes[(b*S+s)*4..] = y0,y1,x0,x1 and status[b*S+s] (as cel_stamp_boxes) for every band at once */
 int cel_source_boxes(cel_images *img, cel_sources *src, int32_t *boxes, int32_t *status);

@@ -693,3 +693,36 @@ def test_short_chain_recovers_a_bright_galaxys_shape(cel):
     assert np.all(np.abs(mean - truth[[1, 3]]) < 5 * err + 0.02), (mean, truth, err)
     assert np.all(sd < 6 * err + 0.02) and np.all(sd > 0.15 * err), (sd, err)
     assert abs(((keep[:, 2].mean() - truth[2] + 90) % 180) - 90) < 15   # the position angle, degrees
+
+
+@pytest.mark.parametrize("shape_args", [None, dict(compwise=True), dict(step_out=False, sigma=0.05, numdir=3, compwise=False)])
+def test_shape_step_device_engine_follows_the_host_engine(cel, shape_args):
+    """the general device slice sampler (cel_slice_sample: random directions from the chain's normal stream, stepping out by
+    doubling, the `acceptable` test, the built-in shape prior) and the numpy engine leave every galaxy with the same
+    (theta, sigma, phi, rho), bit for bit, after two sweeps with the shape step -- 300 mixed sources on 5 x 384^2 -- for
+    slice_sample_skew's own call (celeste_mcmc.py:229-239), its component-wise form and a no-step-out form; the stars'
+    rows are untouched; a custom log-prior sends the step to the host engine"""
+    from desi_mcmc_amd import celeste_mcmc, synth
+    ctx = cel.default_context(0)
+    out = {}
+    for eng in ("host", "device"):
+        f = synth.SyntheticField(ctx, 300, 5, 384, 384, frac_gal=0.5, seed=11)
+        gf = celeste_mcmc.GibbsField(f.images, list(range(5)), f.bands[:, 2], f.bands[:, 1], 384 * 384)
+        g = celeste_mcmc.ModelGibbs([gf], f.src["type"], f.src["radec"], f.flux5(), f.src["shape"], seed=8, engine=eng,
+                                    shape_args=shape_args)
+        assert g._shape_engine_on_device() == (eng == "device")
+        for _ in range(2):
+            g.sweep(shapes=True)
+        out[eng] = g
+    h, d = out["host"], out["device"]
+    assert np.array_equal(h.u, d.u) and np.array_equal(h.fluxes, d.fluxes)
+    assert np.array_equal(h.shape, d.shape), np.abs(h.shape - d.shape).max()
+    assert h.timing["shape_rounds"] == d.timing["shape_rounds"] and h.timing["shape_evals"] == d.timing["shape_evals"]
+    gal = (f.src["type"] == 1) & h.active
+    assert np.all(np.any(h.shape[gal] != f.src["shape"][gal], axis=1))               # every sampled galaxy moved
+    assert np.array_equal(h.shape[f.src["type"] == 0], f.src["shape"][f.src["type"] == 0])
+    assert np.all((h.shape[gal, 0] > 0) & (h.shape[gal, 0] < 1) & (h.shape[gal, 1] > 0) & (h.shape[gal, 3] > 0) & (h.shape[gal, 3] < 1))
+    assert np.all((h.shape[gal, 2] >= 0) & (h.shape[gal, 2] < 180))
+    custom = celeste_mcmc.ModelGibbs([gf], f.src["type"], f.src["radec"], f.flux5(), f.src["shape"], seed=8,
+                                     shape_logprior=lambda TH: np.where((TH[:, 0] > 0) & (TH[:, 0] < 1) & (TH[:, 1] > 0) & (TH[:, 3] > 0) & (TH[:, 3] < 1), 0.0, -np.inf))
+    assert not custom._shape_engine_on_device()
