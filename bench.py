@@ -589,7 +589,16 @@ def run_fields(args, env):
                      "traffic": None, "kernel": "k_render", "kernel_ms": t_render, "launches": n_render,
                      "algorithmic_bytes_per_launch": alg_bytes},
         "work": {"n_srcpix_per_step": srcpix_all, "n_gauss_per_step": gauss_all},
-        "loglik": float(np.sum(last["llb"])), "cpu_baseline": None}))
+        "loglik": float(np.sum(last["llb"])),
+        "cpu_baseline": _fields_cpu_baseline(args, fields[0], S) if (world == 1 and args.cpu_sample > 0) else None}))
+
+
+def _fields_cpu_baseline(args, field, S):
+    """the CPU oracle on a bounded sample of ONE of the set's fields (the fields are the configs[2] population)"""
+    from oracle import oracle as orc      # cpu_baseline leg only
+    out = cpu_baseline(field, min(args.cpu_sample, S), orc)
+    out["sample"] = "field 0 of the set: " + out["sample"]
+    return out
 
 
 # ---- configs[4]: Gibbs sweeps ------------------------------------------------------------------------
@@ -639,17 +648,24 @@ def gibbs_report(g, gf, ctx, steps, dt, S, B):
     t_split, n_split = ctx.profile_get("split")
     t_mass, n_mass = ctx.profile_get("mass")
     t_render, n_render = ctx.profile_get("render")
-    launches = max(g.timing.get("loc_launches", 0), 1)
-    alg_bytes = g.timing.get("loc_bytes", 0) / launches
-    achieved = alg_bytes / (t_ll * 1e-3) / 1e9 if t_ll > 0 else 0.0
+    # a round of the location step is one or two launches (the blocks scored densely, the blocks scored at their photons):
+    # the roofline is priced per ROUND -- the bytes its evaluations read over the kernel time of its launches
+    rounds = max(g.timing.get("loc_launches", 0), 1)
+    shapes_ran = g.timing.get("shape_evals", 0) > 0          # the shape step's launches are in the same event bucket: no price then
+    alg_bytes = g.timing.get("loc_bytes", 0) / rounds
+    round_ms = t_ll * n_ll / rounds
+    achieved = (alg_bytes / (round_ms * 1e-3) / 1e9) if (round_ms > 0 and not shapes_ran) else None
     known = g.timing["split"] + g.timing["flux"] + g.timing["location"] + g.timing.get("shape", 0.0) + g.timing.get("merge", 0.0)
     return {
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "k_patch_ll_hw<0> (one slice round of every running chain)",
-                     "kernel_ms": t_ll, "launches": n_ll, "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "kernel_ms: HIP events attached to the kernel's dispatches, averaged over the timed sweeps' launches; bytes: "
-                             "per evaluation and band 4 B per pixel (int32 photon counts) of the photon rectangle walked + a 128-B record, counted on the "
-                             "device.  The kernel is fp64-issue-bound like k_render (DESIGN.md 5); the HBM fraction is what the contract asks for"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "k_patch_ll_nz + k_patch_ll_hw<0> (one slice round of every running chain)",
+                     "kernel_ms": round_ms, "launches": rounds, "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "one launch = one round of the location step (its one or two dispatches); kernel_ms: HIP events attached to "
+                             "the dispatches, summed per round and averaged over the timed sweeps' rounds; bytes: per evaluation and band "
+                             "8 B per photon-holding pixel of a patch scored at its photons (4 B per pixel of the photon rectangle for one "
+                             "scored densely) + a 128-B record, counted on the device.  The kernels are fp64-issue-bound like k_render "
+                             "(DESIGN.md 5); the HBM fraction is what the contract asks for"},
         "work": {"slice_rounds_per_sweep": g.timing["rounds"] / steps, "loglik_evals_per_sweep": g.timing["evals"] / steps,
                  "sources_updated_per_sweep": float(g.active.sum())},
         "sweep_ms": {"photon_split_and_sky": g.timing["split"] / steps * 1e3, "flux": g.timing["flux"] / steps * 1e3,
@@ -657,7 +673,7 @@ def gibbs_report(g, gf, ctx, steps, dt, S, B):
                      "shape_slice": g.timing.get("shape", 0.0) / steps * 1e3,
                      "merge_all_gather": g.timing.get("merge", 0.0) / steps * 1e3,
                      "trace_render": (dt - known) / steps * 1e3},
-        "device_ms_per_sweep": {"k_patch_ll_hw<0> (location)": t_ll * n_ll / steps, "k_photon_split_hw": t_split * n_split / steps,
+        "device_ms_per_sweep": {"k_patch_ll_nz + k_patch_ll_hw<0> (location%s)" % (" + shapes" if shapes_ran else ""): t_ll * n_ll / steps, "k_photon_split_hw": t_split * n_split / steps,
                                 "k_patch_ll_hw<3> (stamp mass)": t_mass * n_mass / steps,
                                 "k_render (split totals + trace)": t_render * n_render / steps}}
 

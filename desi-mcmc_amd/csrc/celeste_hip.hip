@@ -1286,8 +1286,14 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         const int nent = (int)(S * B * SLICE_SPLIT);
         hipLaunchKernelGGL(k_job_work, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, st, src->d_type, im->d_snz, S, B, d_work,
                            (const int *)(use_nz ? im->d_nzmode : nullptr), (const int *)im->d_nnz, use_nz ? d_work_nz : (int *)nullptr);
-        hipLaunchKernelGGL(k_order_members, dim3(1), dim3(1024), 0, st, d_work, nent, d_jobs, d_flags + 8);
-        if (use_nz) hipLaunchKernelGGL(k_order_members, dim3(1), dim3(1024), 0, st, d_work_nz, nent, d_jobs_nz, d_flags + 9);
+        // members compacted by the whole GPU, then ordered heaviest first by one block (the live-list arrays are free now)
+        HIP_TRY(hipMemsetAsync(d_flags + 8, 0, sizeof(int) * 2, st));
+        hipLaunchKernelGGL(k_list_members, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, st, d_work, nent, d_live, d_live_nz, d_flags + 8);
+        hipLaunchKernelGGL(k_order_compact, dim3(1), dim3(1024), 0, st, (const int *)d_live, (const int *)d_live_nz, (const int *)(d_flags + 8), d_jobs);
+        if (use_nz) {
+            hipLaunchKernelGGL(k_list_members, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, st, d_work_nz, nent, d_live, d_live_nz, d_flags + 9);
+            hipLaunchKernelGGL(k_order_compact, dim3(1), dim3(1024), 0, st, (const int *)d_live, (const int *)d_live_nz, (const int *)(d_flags + 9), d_jobs_nz);
+        }
         int *h_cnt = reinterpret_cast<int *>(c->pinned + MAX_BANDS + 2);
         h_cnt[1] = 0;
         HIP_TRY(hipMemcpyAsync(h_cnt, d_flags + 8, sizeof(int) * (use_nz ? 2 : 1), hipMemcpyDeviceToHost, st));
@@ -1307,19 +1313,14 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     // while the host takes its turn.  A round queued after the last chain has finished scores nothing
     // (every job retires at its first instruction) and is not counted.
     const int SLICE_BATCH = 4;
+    const int ostr = (c->variant != 0) ? SLICE_SPLIT : 1;        // slots per job in d_ll: the recurrence kernels always fill all four
+    // the blocks of the coming batch: the full heaviest-first lists while (nearly) every chain runs, afterwards the running
+    // chains' blocks (k_slice_live_jobs, built behind the batch before: their counts came back with its flags)
+    int64_t live_dense = -1, live_nz = -1;                       // < 0: no live lists yet
     for (;;) {
         const int nb = (int)std::min<int64_t>(SLICE_BATCH, (int64_t)max_rounds - queued);
-        // few chains left (at most `live`, the count of the last readback): their one-wave jobs no longer fill
-        // the GPU and a round lasts as long as its longest job -- every job is dealt to SLICE_SPLIT blocks then
-        const int nsplit = (c->variant != 0 && live * B <= SLICE_SPLIT_JOBS) ? SLICE_SPLIT : 1;
-        const int ostr = (c->variant != 0) ? SLICE_SPLIT : 1;        // slots per job in d_ll: the recurrence kernels always fill all four
-        if (nsplit > 1) {
-            // ... and only the running chains' jobs are launched: a list compacted once per batch (a chain that
-            // finishes inside the batch leaves jobs that retire at their first instruction)
-            HIP_TRY(hipMemsetAsync(d_flags + 4, 0, sizeof(int) * 2, st));
-            hipLaunchKernelGGL(k_slice_live_jobs, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, ss, S, B, d_live, d_flags + 4,
-                               (const int *)(use_nz ? im->d_nzmode : nullptr), d_live_nz, d_flags + 5);
-        }
+        const bool use_live = live_dense >= 0 && (live_dense + live_nz) * 4 < (n_dense + n_nz) * 3;
+        const int64_t gd = use_live ? live_dense : n_dense, gn = !use_nz ? 0 : (use_live ? live_nz : n_nz);
         for (int k = 0; k < nb; k++) {
             hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags, queued == 0 ? 1 : 0);
             prop->gen = ++g_source_gen;
@@ -1329,15 +1330,12 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
                 LAUNCH_EV(k_patch_ll<int>, dim3((unsigned)(S * B)), dim3(256), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
                           d_owner, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_nelec, im->H, im->W, 0, d_ll);
             } else {
-                // the blocks scored densely, then those scored at their photons; late rounds: only the running chains', all dealt
-                const int64_t gd = (nsplit > 1) ? std::min<int64_t>(live * B * SLICE_SPLIT, S * B * SLICE_SPLIT) : n_dense;
-                const int64_t gn = !use_nz ? 0 : (nsplit > 1) ? std::min<int64_t>(live * B * SLICE_SPLIT, S * B * SLICE_SPLIT) : n_nz;
                 if (gd > 0) {
                     int pi = prof_slot(c, CEL_K_PATCH_LL);
                     LAUNCH_EV((k_patch_ll_hw<0, int>), dim3((unsigned)gd), dim3(64), st, EV0(c, pi), EV1(c, pi),
                               im->d_bands, B, S, im->d_recs,
                               d_owner, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll,
-                              (const int *)(nsplit > 1 ? d_live : d_jobs), 1, (const int *)(nsplit > 1 ? d_flags + 4 : nullptr),
+                              (const int *)(use_live ? d_live : d_jobs), 1, (const int *)nullptr,
                               (const int *)(use_nz ? im->d_nzmode : nullptr), 1, SLICE_SPLIT);
                 }
                 if (gn > 0) {
@@ -1345,17 +1343,24 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
                     LAUNCH_EV(k_patch_ll_nz, dim3((unsigned)gn), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
                               (const int *)d_owner, (const int4 *)im->d_sbox, (const int4 *)im->d_snz, (const int *)im->d_nzmode,
                               (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_ll,
-                              (const int *)(nsplit > 1 ? d_live_nz : d_jobs_nz), (const int *)(nsplit > 1 ? d_flags + 5 : nullptr));
+                              (const int *)(use_live ? d_live_nz : d_jobs_nz), (const int *)nullptr);
                 }
             }
             hipLaunchKernelGGL(k_slice_consume, dim3(g256), dim3(256), 0, st, ss, S, B, ostr, d_ll, sigma, d_flags, d_flags + 1);
             queued++;
         }
-        HIP_TRY(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+        if (c->variant != 0) {          // the running chains' blocks, for the next batch; few chains left: every job dealt
+            HIP_TRY(hipMemsetAsync(d_flags + 4, 0, sizeof(int) * 2, st));
+            hipLaunchKernelGGL(k_slice_live_jobs, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, ss, S, B, d_live, d_flags + 4,
+                               (const int *)(use_nz ? im->d_nzmode : nullptr), d_live_nz, d_flags + 5, (const int *)im->d_nnz,
+                               (const int4 *)im->d_snz, (live * B <= SLICE_SPLIT_JOBS) ? 1 : 0);
+        }
+        HIP_TRY(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
         const int running = h_flags[0], err = h_flags[1];
         live = running;
+        if (c->variant != 0) { live_dense = h_flags[4]; live_nz = h_flags[5]; }
         if (err & 1) return fail(CEL_ERR_INVALID, "Slice sampler got a NaN");
         if (err & 2) return fail(CEL_ERR_INVALID, "Slice sampler shrank to zero!");
         evals = h_flags[2];

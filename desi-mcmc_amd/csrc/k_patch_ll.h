@@ -558,3 +558,39 @@ k_order_members(const int *__restrict__ work, int T, int *__restrict__ order, in
         order[atomicAdd(&hist[w < 0 ? 256 : 255 - (int)(((long long)(w >> 1) * 255) / wmax)], 1)] = 2 * i + (w < 0 ? 0 : (w & 1));
     }
 }
+
+// The same in two steps, 4 x faster (three quarters of the (job, part) entries are not members): the members first
+// compacted by the whole GPU (one atomic per wave), then ordered by one block.
+__global__ void __launch_bounds__(256)
+k_list_members(const int *__restrict__ work, int T, int *__restrict__ work_c, int *__restrict__ desc_c, int *__restrict__ nmember) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = (i < T) ? work[i] : -1;
+    const int at = wave_reserve(nmember, w >= 0 ? 1 : 0);
+    if (w >= 0) { work_c[at] = w >> 1; desc_c[at] = 2 * i + (w & 1); }
+}
+
+__global__ void __launch_bounds__(1024)
+k_order_compact(const int *__restrict__ work_c, const int *__restrict__ desc_c, const int *__restrict__ n_ptr, int *__restrict__ order) {
+    __shared__ int hist[256];
+    __shared__ int red[1024];
+    const int tid = threadIdx.x;
+    const int T = *n_ptr;
+    int mx = 0;
+    for (int i = tid; i < T; i += 1024) mx = max(mx, work_c[i]);
+    red[tid] = mx;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = max(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    const long long wmax = red[0] > 0 ? red[0] : 1;
+    for (int i = tid; i < T; i += 1024) atomicAdd(&hist[255 - (int)(((long long)work_c[i] * 255) / wmax)], 1);
+    __syncthreads();
+    if (tid == 0) {   // exclusive scan, bucket 0 = heaviest
+        int run = 0;
+        for (int k = 0; k < 256; k++) { int c = hist[k]; hist[k] = run; run += c; }
+    }
+    __syncthreads();
+    for (int i = tid; i < T; i += 1024) order[atomicAdd(&hist[255 - (int)(((long long)work_c[i] * 255) / wmax)], 1)] = desc_c[i];
+}

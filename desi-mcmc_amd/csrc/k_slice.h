@@ -165,19 +165,35 @@ k_slice_consume(SliceState st, int64_t S, int B, int nparts /* blocks per (chain
 
 // the (chain, band) jobs of the chains that are still running, in no particular order (they all start at once:
 // the list is only built when it is shorter than the GPU has wave slots).
-// Every live job is dealt to PLL_PARTS blocks here (few jobs are left: a round lasts as long as its longest block).
-// Entries are the likelihood kernels' block descriptors job << 3 | part << 1 | dealt.  With photon lists: two lists --
-// the jobs scored densely and the jobs scored at their photons, each for its kernel.
+// Entries are the likelihood kernels' block descriptors job << 3 | part << 1 | dealt: a long job -- or, when few chains
+// are left and a round lasts as long as its longest block, every job (deal_all) -- is dealt to PLL_PARTS blocks.  With
+// photon lists: two lists, the jobs scored densely and the jobs scored at their photons, each for its kernel.  Built
+// behind a batch of rounds for the next one, so that the counts ride back with the batch's flags and the next launches
+// are exactly as large as their lists.
 __global__ void __launch_bounds__(256)
 k_slice_live_jobs(SliceState st, int64_t S, int B, int *__restrict__ list, int *__restrict__ count,
-                  const int *__restrict__ nzmode = nullptr, int *__restrict__ list_nz = nullptr, int *__restrict__ count_nz = nullptr) {
+                  const int *__restrict__ nzmode, int *__restrict__ list_nz, int *__restrict__ count_nz,
+                  const int *__restrict__ nnz, const int4 *__restrict__ nzbox, int deal_all) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= S * B) return;
-    if (st.phase[i / B] == SL_FINAL) return;
-    const bool nz = nzmode && nzmode[i];
+    const bool alive = i < S * B && st.phase[i / B] != SL_FINAL;
+    bool nz = false, deal = deal_all != 0;
+    if (alive) {
+        nz = nzmode && nzmode[i];
+        if (!deal) {
+            if (nz) deal = nnz[i] > 2048;               // NZ_SPLIT_PHOTONS (k_patch_ll.h)
+            else {
+                const int4 q = nzbox[i];
+                deal = (q.y > q.x && q.w > q.z) && (long long)((q.y - q.x + 31) / 32) * ((q.w - q.z + 63) / 64) > 6;     // PLL_SPLIT_CHUNKS
+            }
+        }
+    }
+    const int per = deal ? 4 : 1;
+    const int at_d = wave_reserve(count, (alive && !nz) ? per : 0);
+    const int at_n = nzmode ? wave_reserve(count_nz, (alive && nz) ? per : 0) : 0;
+    if (!alive) return;
     int *dst = nz ? list_nz : list;
-    const int at = atomicAdd(nz ? count_nz : count, 4);
-    for (int part = 0; part < 4; part++) dst[at + part] = (int)(i << 3) | (part << 1) | 1;
+    const int at = nz ? at_n : at_d;
+    for (int part = 0; part < per; part++) dst[at + part] = (int)(i << 3) | (part << 1) | (deal ? 1 : 0);
 }
 
 // algorithmic HBM bytes of a finished call (what bench.py prices the location step's kernel against): a chain that

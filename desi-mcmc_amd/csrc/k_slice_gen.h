@@ -274,22 +274,26 @@ k_sg_live_jobs(SliceGen g, int64_t S, int B, const int *__restrict__ nzmode, con
                const int4 *__restrict__ nzbox, int deal_all, int *__restrict__ list, int *__restrict__ count,
                int *__restrict__ list_nz, int *__restrict__ count_nz) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // (chain, band)
-    if (i >= S * B) return;
-    const int64_t s = i / B;
-    const int b = (int)(i % B);
-    if (g.phase[s] == SG_FINAL) return;
-    const bool nz = nzmode && nzmode[i];
-    bool deal = deal_all != 0;
-    if (!deal) {
-        if (nz) deal = nnz[i] > NZ_SPLIT_PHOTONS;
-        else {
-            const int4 q = nzbox[i];
-            deal = (q.y > q.x && q.w > q.z) && (long long)((q.y - q.x + HW_TW - 1) / HW_TW) * ((q.w - q.z + HW_TH - 1) / HW_TH) > PLL_SPLIT_CHUNKS;
+    const int64_t s = (i < S * B) ? i / B : 0;
+    const int b = (int)(i - s * B);
+    const bool alive = i < S * B && g.phase[s] != SG_FINAL;
+    bool nz = false, deal = deal_all != 0;
+    if (alive) {
+        nz = nzmode && nzmode[i];
+        if (!deal) {
+            if (nz) deal = nnz[i] > NZ_SPLIT_PHOTONS;
+            else {
+                const int4 q = nzbox[i];
+                deal = (q.y > q.x && q.w > q.z) && (long long)((q.y - q.x + HW_TW - 1) / HW_TW) * ((q.w - q.z + HW_TH - 1) / HW_TH) > PLL_SPLIT_CHUNKS;
+            }
         }
     }
     const int per = deal ? PLL_PARTS : 1;
+    const int at_d = wave_reserve(count, (alive && !nz) ? 2 * per : 0);       // one atomic per wave and list
+    const int at_n = nzmode ? wave_reserve(count_nz, (alive && nz) ? 2 * per : 0) : 0;
+    if (!alive) return;
     int *dst = nz ? list_nz : list;
-    const int at = atomicAdd(nz ? count_nz : count, 2 * per);
+    const int at = nz ? at_n : at_d;
     for (int q = 0; q < 2; q++) {
         const int job = (int)((2 * s + q) * B + b);
         for (int part = 0; part < per; part++) dst[at + q * per + part] = (job << 3) | (part << 1) | (deal ? 1 : 0);
