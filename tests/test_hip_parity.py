@@ -1087,6 +1087,25 @@ def test_integration_md_ctypes_binding(cel, orc):
     check(L.cel_patch_loglik_multi(img, prop, owner.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(S),
                                    None, None, None, 1, 0, llp.ctypes.data_as(dp)))
     assert np.all(np.isfinite(llp)) and np.array_equal(llp[0::2], llp[1::2])      # identical proposals, identical scores
+    # the device-resident per-source updates, as the document calls them
+    new_radec, llh, stats = np.zeros((S, 2)), np.zeros(S), np.zeros(4, dtype=np.int64)
+    check(L.cel_slice_locations(img, srch, None, C.c_double(1e-3), C.c_uint64(5), 4000, new_radec.ctypes.data_as(dp),
+                                llh.ctypes.data_as(dp), stats.ctypes.data_as(C.POINTER(C.c_int64))))
+    assert stats[0] >= 4 and stats[1] >= 4 * S and stats[2] > 0 and np.all(np.abs(new_radec - radec) < 1e-3)
+    mass = np.zeros((S, B))
+    check(L.cel_stamp_mass(img, srch, mass.ctypes.data_as(dp)))
+    assert np.all(mass > 0.5) and np.all(mass < 1.01)
+    rs = np.random.RandomState(4)
+    numdir = 4
+    dirs = rs.normal(size=(S, numdir, 4))
+    dirs = np.ascontiguousarray(dirs / np.sqrt(np.sum(dirs ** 2, axis=2, keepdims=True)))
+    th, llh2, stats2 = np.zeros((S, 4)), np.zeros(S), np.zeros(4, dtype=np.int64)
+    check(L.cel_slice_sample(img, srch, 1, None, dirs.ctypes.data_as(dp), numdir, 1, 1000, C.c_double(1.0), C.c_double(180.0),
+                             C.c_uint64(9), 20000, th.ctypes.data_as(dp), llh2.ctypes.data_as(dp),
+                             stats2.ctypes.data_as(C.POINTER(C.c_int64))))
+    gal = typ == 1
+    assert np.array_equal(th[~gal], shape[~gal]) and np.all(np.any(th[gal] != shape[gal], axis=1))     # stars are left alone
+    assert np.all((th[gal, 0] > 0) & (th[gal, 0] < 1) & (th[gal, 1] > 0) & (th[gal, 3] > 0) & (th[gal, 3] < 1)) and stats2[1] > 0
     for h in (prop, srch):
         check(L.cel_sources_destroy(h))
     check(L.cel_images_destroy(img))
