@@ -688,9 +688,18 @@ def run_gibbs(args, env):
     gf = celeste_mcmc.GibbsField(field.images, list(range(B)), field.bands[:, 2], field.bands[:, 1], H * W)
     slice_args = dict(step_out=False, sigma=args.slice_sigma)
     strong = args.scaling == "strong"
-    if strong:
-        # ONE chain on all the GPUs: same seed everywhere, the sources dealt to the ranks for the
-        # per-source updates, one all-gather of the new locations and fluxes per sweep
+    if strong and args.split == "strips":
+        # ONE chain on all the GPUs, partitioned as SURVEY 8e prescribes: row strips -- a rank splits the photons of its strip
+        # plus a halo, owns the sources of its strip; sky-photon sums, the trace and the new rows are exchanged
+        boxes, status = field.images.source_boxes(field.sources)
+        deal, gf = celeste_mcmc.strip_gibbs_field(ctx, field.bands, field.nelec, field.src["pix"][:, 1], boxes, status, world, rank,
+                                                  device=local)
+        field.images.close()                # the whole frame is not needed on this rank any more
+        g = celeste_mcmc.ModelGibbs([gf], field.src["type"], field.src["radec"], field.flux5(), field.src["shape"],
+                                    seed=1, slice_args=slice_args, deal=deal)
+    elif strong:
+        # ONE chain on all the GPUs: same seed everywhere, the photon split replicated, the sources dealt
+        # to the ranks for the per-source updates, one all-gather of the new locations and fluxes per sweep
         deal = dist.SourceDeal(S, world, rank, device=local)
         g = celeste_mcmc.ModelGibbs([gf], field.src["type"], field.src["radec"], field.flux5(), field.src["shape"],
                                     seed=1, slice_args=slice_args, deal=deal)
@@ -742,7 +751,11 @@ def run_gibbs(args, env):
                                  note="sigma in degrees.  The reference's call passes step=du/5=0.001 deg, which its "
                                       "slicesample ignores (sigma stays 1.0 deg); 0.001 is the call's intent, the library's and "
                                       "this bench's default; --slice-sigma 1.0 runs the literal behaviour"),
-                   "parallelism": ("ONE chain on %d GPU(s): the photon split replicated (counter-based draws, bitwise equal on every "
+                   "parallelism": ("ONE chain on %d GPU(s), partitioned by row strips: a rank holds its strip + a halo (window rows %s of "
+                                   "%d), splits those photons, owns the sources of its strip; per sweep 1 all-gather of 11 doubles per "
+                                   "source + 2 rank-ordered sums of 5 doubles (sky photons, trace)" % (world, list(g.deal.window), H))
+                                  if (strong and args.split == "strips") else
+                                  ("ONE chain on %d GPU(s): the photon split replicated (counter-based draws, bitwise equal on every "
                                    "rank), the sources dealt round-robin to the ranks for the flux and location updates, 1 all-gather "
                                    "of 11 doubles per source per sweep; the chain is the 1-GPU chain bit for bit" % world) if strong else
                                   ("%d independent chain(s), 1 per GPU, over the same field; 1 all-reduce of the chains' "
@@ -782,6 +795,9 @@ def main():
     ap.add_argument("--slice-sigma", type=float, default=0.001, help="gibbs10k: slice-sampler interval width in degrees")
     ap.add_argument("--photon-lists", type=int, default=0, choices=[0, 1, 2],
                     help="gibbs10k: CEL_OPT_PHOTON_LISTS (0 = per patch whichever is cheaper, 1 = always at the photons, 2 = always densely)")
+    ap.add_argument("--split", default="replicated", choices=["replicated", "strips"],
+                    help="gibbs10k --scaling strong: every rank runs the whole photon split (the chain is the 1-GPU chain bit for "
+                         "bit), or the split is partitioned by row strips like the sources (SURVEY 8e)")
     ap.add_argument("--shapes", action="store_true", help="gibbs10k: every sweep also resamples the galaxies' shapes")
     ap.add_argument("--legs", default="all", choices=["all", "none"],
                     help="render workloads at N=1: 'all' (default) adds the untimed-by-the-contract extras after the timed region "

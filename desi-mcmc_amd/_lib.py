@@ -46,6 +46,7 @@ SYMBOLS = [
     ("cel_images_set_nelec", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("cel_images_set_epsilon", C.c_int, [C.c_void_p, C.c_int, C.c_double]),
     ("cel_images_set_window", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    ("cel_images_set_noise_rows", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("cel_images_get_band", C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     ("cel_images_get_lambda", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("cel_images_device_ptrs", C.c_int, [C.c_void_p, c_void_pp, c_void_pp]),

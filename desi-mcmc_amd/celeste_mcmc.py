@@ -51,12 +51,45 @@ def sample_source_photons_single_image_cython(img, srcs, seed=None):
     return samp[0], noise[0]
 
 
+def gamma_by_stream(a, seed, ids):
+    """Standard Gamma(a) variates, one per element of `a`, each from ITS OWN counter-based stream (seed, ids[i]) -- so that a
+    source's flux draw does not depend on which other sources are drawn beside it, by which rank, or in what order (numpy's
+    generator hands a sequential stream to a rejection sampler: the numbers an element gets depend on every element before
+    it).  Marsaglia & Tsang (2000): x ~ N(0,1), v = (1 + c x)^3, accept when log u < x^2/2 + d - d v + d log v with
+    d = a - 1/3, c = 1 / sqrt(9 d); a < 1 through Gamma(a + 1) U^(1/a).  Host-side, vectorised: a round over the elements
+    still waiting for an acceptance (~5 % per round)."""
+    from .util.infer.slicesample import ChainStreams
+    a = np.asarray(a, dtype=np.float64)
+    st = ChainStreams(seed, np.asarray(ids))
+    n = a.shape[0]
+    boost = a < 1.0
+    aa = np.where(boost, a + 1.0, a)
+    d = aa - 1.0 / 3.0
+    c = 1.0 / np.sqrt(9.0 * d)
+    out = np.empty(n)
+    todo = np.arange(n)
+    while todo.size:
+        x, u = st.normal(todo), st.uniform(todo)
+        v = (1.0 + c[todo] * x) ** 3
+        ok = v > 0.0
+        ok[ok] = np.log(u[ok]) < 0.5 * x[ok] * x[ok] + d[todo[ok]] * (1.0 - v[ok] + np.log(v[ok]))
+        out[todo[ok]] = d[todo[ok]] * v[ok]
+        todo = todo[~ok]
+    if boost.any():
+        idx = np.nonzero(boost)[0]
+        out[idx] *= st.uniform(idx) ** (1.0 / a[idx])
+    return out
+
+
 # ---- the whole Gibbs sweep, catalogue-wide and device-resident -------------------------------------
 class GibbsField(object):
     """One field's images on the device plus what the sweep needs to know about them."""
 
-    def __init__(self, iset, band_index, calib, kappa, npix, a_0=5, b_0=.005):
+    def __init__(self, iset, band_index, calib, kappa, npix, a_0=5, b_0=.005, trace_iset=None):
         self.iset = iset
+        # a strip-partitioned chain (dist.StripDeal): `iset` holds this rank's window (strip + halo), `trace_iset` its strip
+        # alone -- what this rank adds to the field's log-likelihood; npix stays the whole frame's
+        self.trace_iset = trace_iset
         self.band_index = np.asarray(band_index, dtype=np.int64)      # which of u,g,r,i,z each image is
         self.calib = np.asarray(calib, dtype=np.float64)
         self.kappa = np.asarray(kappa, dtype=np.float64)
@@ -67,6 +100,34 @@ class GibbsField(object):
         self.prop = None
         self.sub = None             # this rank's sources of a dealt chain (resample_fluxes)
         self.has_patch = None
+
+
+def strip_gibbs_field(ctx, bands, nelec, rows, boxes, status, world, rank, band_index=None, slack=48, device=None):
+    """This rank's part of ONE chain partitioned by row strips (dist.StripDeal).
+        bands (B, 37) cel_band records, nelec (B, H, W) the whole frame's pixels (every rank can read them: only the window is
+        uploaded), rows (S,) the sources' pixel rows, boxes (B, S, 4) / status (B, S) their boxes on the whole frame
+        (ImageSet.source_boxes): the halo is as tall as this rank's sources' boxes reach beyond its strip, plus `slack` rows
+        for the few pixels they move per sweep.
+    -> (StripDeal, GibbsField over the window with the strip as its trace image set)"""
+    from . import dist as _dist
+    from . import field as _field
+    B, H, W = nelec.shape
+    probe = _dist.StripDeal(rows, H, world, rank)
+    mine = probe.mine
+    has = status[:, mine] > 0
+    reach = max(int(np.max(np.where(has, probe.strip[0] - boxes[:, mine, 0], 0), initial=0)),
+                int(np.max(np.where(has, boxes[:, mine, 1] - probe.strip[1], 0), initial=0)), 0)
+    deal = _dist.StripDeal(rows, H, world, rank, halo=reach + slack, device=device)
+    w0, w1 = deal.window
+    win = _field.ImageSet(ctx, bands, w1 - w0, W, nelec=np.ascontiguousarray(nelec[:, w0:w1]))
+    win.set_window(w0, H)
+    win.set_noise_rows(*deal.noise_rows())
+    y0, y1 = deal.strip
+    strip = _field.ImageSet(ctx, bands, max(y1 - y0, 1), W, nelec=np.ascontiguousarray(nelec[:, y0:max(y1, y0 + 1)]))
+    strip.set_window(y0, H)
+    bands = np.asarray(bands)
+    gf = GibbsField(win, list(range(B)) if band_index is None else band_index, bands[:, 2], bands[:, 1], H * W, trace_iset=strip)
+    return deal, gf
 
 
 class ModelGibbs(object):
@@ -85,8 +146,9 @@ class ModelGibbs(object):
     reference asserts there, sources.py:243).
 
     Random numbers: Philox on the device for the split (keyed by pixel and source), one SplitMix64
-    stream per source for the slice sampler, numpy's generator for the Gamma draws -- all derived
-    from `seed`; a chain is reproducible and does not depend on batching."""
+    stream per source for the slice sampler and per (source, band) for the flux Gamma draws, numpy's
+    generator for the sky levels' -- all derived from `seed`; a chain is reproducible and does not
+    depend on batching, nor on how it is dealt over ranks."""
 
     BANDS = ['u', 'g', 'r', 'i', 'z']
 
@@ -201,6 +263,11 @@ class ModelGibbs(object):
         for k, f in enumerate(self.fields):
             seed = (self.seed * 1000003 + self.sweeps * 8191 + k) & (2 ** 64 - 1)
             noise = f.iset.photon_split_resident(self._sources(f), seed)
+            if self.deal is not None and self.deal.kind == "strips":
+                # this rank split its window and counted its strip's sky photons: the frame's sum over the ranks; and its own
+                # sources' boxes have to lie inside the window (their patches must be complete)
+                noise = self.deal.rank_sum(noise)
+                self.deal.check_boxes(*f.iset.source_boxes(f.sset))
             f.sums = f.iset.sample_sums()                              # photons per (source, image)
             f.has_patch = f.iset.sample_box_areas() > 0
             any_patch |= f.has_patch.any(axis=1)
@@ -211,6 +278,8 @@ class ModelGibbs(object):
             f.epsilon = self.rng.gamma(a_n, 1. / b_n)
             for b in range(f.iset.B):
                 f.iset.set_epsilon(b, f.epsilon[b])
+                if f.trace_iset is not None:
+                    f.trace_iset.set_epsilon(b, f.epsilon[b])
                 if getattr(f, "images", None) is not None:
                     f.images[b].epsilon = float(f.epsilon[b])
         self.active = any_patch
@@ -250,7 +319,8 @@ class ModelGibbs(object):
             self._pool = ThreadPoolExecutor(max_workers=1)
         fut = self._pool.submit(rates)
         try:
-            g = self.rng.standard_gamma(a_n)        # Gamma(a_n, 1 / b_n) = standard_gamma(a_n) * (1 / b_n), the same draws
+            # Gamma(a_n, 1 / b_n) = standard Gamma(a_n) * (1 / b_n); every (source, band) draws from its own stream
+            g = gamma_by_stream(a_n.ravel(), self.seed * 15485863 + self.sweeps, np.arange(self.S * 5)).reshape(self.S, 5)
         finally:
             # a Context is not thread-safe (scratch slots, the profile ring, the records are shared): whatever
             # the host draw does, nobody touches this one again before the worker's device call has returned
@@ -423,7 +493,16 @@ class ModelGibbs(object):
     def log_likelihood(self):
         """sum of img_log_likelihood over every image of every field at the current state (models.py:104-108)"""
         tot = 0.0
+        strips = self.deal is not None and self.deal.kind == "strips"
         for f in self.fields:
-            ll, _ = f.iset.render(self._sources(f), loglik=True)
+            if strips:          # this rank's strip of every image; the strips' sums added over the ranks
+                from . import field as _field
+                if getattr(f, "trace_sset", None) is None or f.trace_sset.capacity < self.S:
+                    f.trace_sset = _field.SourceSet(f.trace_iset.ctx, max(self.S, 1), f.trace_iset.B)
+                ll, _ = f.trace_iset.render(f.trace_sset.set(self.typ, self.u, self.counts(f), self.shape), loglik=True)
+            else:
+                ll, _ = f.iset.render(self._sources(f), loglik=True)
             tot += ll
+        if strips:
+            tot = float(self.deal.rank_sum([tot])[0])
         return tot

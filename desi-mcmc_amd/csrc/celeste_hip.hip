@@ -144,6 +144,7 @@ struct cel_images {
     cel_ctx *ctx = nullptr;
     int B = 0, H = 0, W = 0;   // H = rows held on the device (the window height)
     int full_H = 0, win_y0 = 0;  // the window is rows [win_y0, win_y0 + H) of a full_H-row frame
+    int noise_y0 = 0, noise_y1 = 0x7fffffff;     // window rows whose sky photons cel_photon_split's noise sums count
     int TW = 64, TH = 32, ntx = 0, nty = 0;   // render tile geometry (fixed at creation)
     cel_band hb[MAX_BANDS];
     BandDev *d_bands = nullptr;
@@ -592,6 +593,14 @@ int cel_images_set_window(cel_images *im, int y0, int full_H) {
     im->win_y0 = y0;
     im->full_H = full_H;
     im->recs_gen = im->hbox_gen = 0;      // boxes are cut to the window
+    return CEL_OK;
+}
+
+int cel_images_set_noise_rows(cel_images *im, int y0, int y1) {
+    if (!im) return fail(CEL_ERR_INVALID, "null images");
+    if (y0 < 0 || y1 < y0) return fail(CEL_ERR_INVALID, "cel_images_set_noise_rows: rows [%d, %d)", y0, y1);
+    im->noise_y0 = y0;
+    im->noise_y1 = y1;
     return CEL_OK;
 }
 
@@ -1664,6 +1673,7 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         a.partials = im->d_partials; a.S = S; a.capacity = im->lists_cap; a.B = B; a.H = im->H; a.W = im->W;
         a.ntx = im->ntx; a.nty = im->nty; a.TW = im->TW; a.TH = im->TH; a.seed = seed;
         a.win_y0 = im->win_y0; a.full_H = im->full_H;
+        a.noise_y0 = im->noise_y0; a.noise_y1 = im->noise_y1;
         a.rate_img = im->d_rate; a.tail_T = c->tail_T; a.nz = fused_nz ? im->d_snz : nullptr;
         a.order = (hw && c->tile_order) ? im->d_order : nullptr;
         a.sums = fused_nz ? im->d_ssum : nullptr;

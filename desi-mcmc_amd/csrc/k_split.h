@@ -387,6 +387,8 @@ struct SplitArgs {
     double tail_T;              // k_photon_split_hw: drop threshold of the per-source tiles
     int4 *nz;                   // k_photon_split_hw: per patch, the rectangle holding its photons (min/max by atomics), or nullptr
     const int *order;           // k_photon_split_hw: tile launch order (heaviest first, from the totals render), or nullptr
+    int noise_y0, noise_y1;     // rows [noise_y0, noise_y1) of the window whose sky photons the noise sums count (a rank of a
+                                // strip-partitioned chain splits a halo beyond its strip and counts its strip only)
     int debug;                  // CEL_OPT_DEBUG bits (timing-only ablations; results are wrong when set)
     int *nnz;                   // k_photon_split_hw: pixels that received a photon, per (source, band), zeroed by the caller, or nullptr
     double *sums;               // k_photon_split_hw: photons per (source, band), index s*B + b, zeroed by the caller, or nullptr.
@@ -477,6 +479,7 @@ k_photon_split(SplitArgs a) {
     double noise = 0.0;
     for (int i = 0; i < niter; i++) {
         const int y = Y0 + i * rstep + rsub;
+        if (y < a.noise_y0 || y >= a.noise_y1) continue;
         if ((covered >> i) & 1u) noise += (double)left[i * 64 + lane];
         else if (xi < a.W && y < a.H) noise += a.nelec[plane + (int64_t)y * a.W + xi];
     }
@@ -658,6 +661,7 @@ k_photon_split_hw(SplitArgs a) {
 #pragma unroll
     for (int r = 0; r < SP_TH / 2; r++) {
         const int y = Y0 + 2 * r + half;
+        if (y < a.noise_y0 || y >= a.noise_y1) continue;
         if ((covered >> r) & 1u) noise += (double)left[r * 64 + lane];
         else if (xi < a.W && y < a.H) noise += a.nelec[plane + (int64_t)y * a.W + xi];
     }

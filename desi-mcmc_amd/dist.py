@@ -38,48 +38,110 @@ class SourceDeal(object):
     per-source updates (Source.resample_fluxes / resample_location, CelestePy/sources.py:308-349) are
     independent of each other, so rank r updates the sources s = r (mod world) -- a round-robin deal keeps
     stars, galaxies and bright sources evenly spread -- and the new rows are exchanged with ONE all-gather
-    per merge (10 000 x 7 doubles per sweep at config 5: 560 KB over xGMI).  The merged arrays are identical
+    per merge (10 000 x 11 doubles per sweep at config 5: 880 KB over xGMI).  The merged arrays are identical
     on every rank, to the bit, and identical to what a single rank computes (the per-chain random streams
-    do not depend on which other chains run beside them)."""
+    do not depend on which other chains run beside them).  Every rank runs the whole photon split here
+    (`kind` = "replicated"); StripDeal partitions that too."""
 
-    def __init__(self, S, world=1, rank=0, device=None):
+    kind = "replicated"
+
+    def __init__(self, S, world=1, rank=0, device=None, owner=None):
         self.S, self.world, self.rank = int(S), int(world), int(rank)
         if not 0 <= self.rank < self.world:
             raise ValueError("rank %d outside a world of %d" % (rank, world))
         self.device = device
-        self.mine = np.arange(self.rank, self.S, self.world)              # indices of this rank's sources
+        # owner[s] = the rank that updates source s
+        self.owner = (np.arange(self.S) % self.world) if owner is None else np.asarray(owner, dtype=np.int64)
+        if self.owner.shape != (self.S,) or (self.S and (self.owner.min() < 0 or self.owner.max() >= self.world)):
+            raise ValueError("owner must name a rank for every source")
+        self.rows_of = [np.nonzero(self.owner == r)[0] for r in range(self.world)]
+        self.mine = self.rows_of[self.rank]                               # indices of this rank's sources
         self.mask = np.zeros(self.S, dtype=bool)
         self.mask[self.mine] = True
-        self.per_rank = (self.S + self.world - 1) // self.world           # rows every rank contributes (padded)
+        self.per_rank = max([r.size for r in self.rows_of] + [1])         # rows every rank contributes (padded)
 
     def chain_ids(self):
         """cel_slice_locations' chain_ids: a source's own index where it is this rank's, -1 elsewhere"""
         return np.where(self.mask, np.arange(self.S), -1).astype(np.int32)
 
+    def _gather(self, send):
+        """(n, k) of this rank -> (world, n, k) of every rank (one all_gather_into_tensor)"""
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(np.ascontiguousarray(send, dtype=np.float64))
+        if dist.get_backend() == "nccl":
+            t = t.cuda(self.device if self.device is not None else torch.cuda.current_device())
+        recv = torch.empty((self.world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)      # rank-major concatenation
+        dist.all_gather_into_tensor(recv, t)
+        return recv.cpu().numpy().reshape(self.world, t.shape[0], t.shape[1])
+
     def merge(self, arr):
         """arr (S, k) with this rank's rows up to date -> (S, k) with every row taken from its owner"""
         arr = np.ascontiguousarray(arr, dtype=np.float64)
-        if self.world == 1:
-            return arr.copy()
-        import torch
-        import torch.distributed as dist
         if arr.ndim != 2 or arr.shape[0] != self.S:
             raise ValueError("merge takes an (S, k) array")
-        k = arr.shape[1]
-        send = np.zeros((self.per_rank, k))
+        if self.world == 1:
+            return arr.copy()
+        send = np.zeros((self.per_rank, arr.shape[1]))
         send[:self.mine.size] = arr[self.mine]
-        t = torch.from_numpy(send)
-        on_gpu = dist.get_backend() == "nccl"
-        if on_gpu:
-            t = t.cuda(self.device if self.device is not None else torch.cuda.current_device())
-        recv = torch.empty((self.world * self.per_rank, k), dtype=t.dtype, device=t.device)      # rank-major concatenation
-        dist.all_gather_into_tensor(recv, t)
-        got = recv.cpu().numpy().reshape(self.world, self.per_rank, k)
+        got = self._gather(send)
         out = np.empty_like(arr)
         for r in range(self.world):
-            rows = np.arange(r, self.S, self.world)
-            out[rows] = got[r, :rows.size]
+            out[self.rows_of[r]] = got[r, :self.rows_of[r].size]
         return out
+
+    def rank_sum(self, x):
+        """sum over ranks of a small vector, in rank order on every rank (identical bits everywhere)"""
+        x = np.atleast_1d(np.asarray(x, dtype=np.float64))
+        if self.world == 1:
+            return x.copy()
+        got = self._gather(x.reshape(1, -1))
+        out = np.zeros(x.shape[0])
+        for r in range(self.world):
+            out += got[r, 0]
+        return out
+
+
+class StripDeal(SourceDeal):
+    """ONE chain partitioned over the ranks as SURVEY 8e prescribes for config 5: "per-source conditional updates ... are
+    embarrassingly parallel over sources; the photon split is per-pixel and needs complete per-pixel source lists, so it
+    uses the same spatial partition."  The frame is cut into tile-aligned row strips (strip_rows); rank r owns the sources
+    whose (initial) pixel row lies in strip r, and holds the images on the WINDOW = its strip plus a halo as tall as its own
+    sources' boxes reach (cel_images_set_window), so that (a) every pixel of an own source's box sees its complete list of
+    sources -- every rank holds the whole catalogue, the binning cuts it to the window -- and the own sources' sample
+    patches are complete, and (b) the split costs each rank window / frame of the whole.  A pixel's draws are keyed by its
+    FULL-FRAME index and the source index, so whoever splits a pixel draws the same photons.  The sky photons of the strip
+    rows only are counted (cel_images_set_noise_rows) and the strips' sums added over the ranks for the sky level's Gamma
+    conditional (CelestePy/models.py:155-160); the trace's log-likelihood is the strips' sum likewise.
+    The window's row origin enters the pixel arithmetic (positions are window-relative), so this chain agrees with the
+    single-rank one to rounding (1e-12 on a sweep's fluxes), not bit for bit as the replicated deal does."""
+
+    kind = "strips"
+
+    def __init__(self, rows, H, world=1, rank=0, halo=0, device=None):
+        rows = np.asarray(rows, dtype=np.float64)
+        edges = np.array([strip_rows(H, world, r)[1] for r in range(world)])
+        owner = np.minimum(np.searchsorted(edges, np.clip(np.floor(rows), 0, H - 1), side="right"), world - 1)
+        SourceDeal.__init__(self, rows.shape[0], world, rank, device=device, owner=owner)
+        self.H = int(H)
+        self.strip = strip_rows(H, world, rank)
+        halo = int(-(-int(halo) // TILE_ROWS) * TILE_ROWS)               # whole tiles
+        self.window = (max(0, self.strip[0] - halo), min(self.H, self.strip[1] + halo))
+
+    def noise_rows(self):
+        """the strip's rows inside the window (window-relative): what the split's noise sums count"""
+        return self.strip[0] - self.window[0], self.strip[1] - self.window[0]
+
+    def check_boxes(self, boxes, status):
+        """boxes (B, S, 4) = y0, y1, x0, x1 relative to the window, status (B, S): an own source's box must not be cut by
+        the window (it may end at the frame's edge)"""
+        y0, y1 = boxes[:, self.mine, 0], boxes[:, self.mine, 1]
+        has = status[:, self.mine] > 0
+        top_cut = has & (y0 <= 0) & (self.window[0] > 0)
+        bot_cut = has & (y1 >= self.window[1] - self.window[0]) & (self.window[1] < self.H)
+        if top_cut.any() or bot_cut.any():
+            raise RuntimeError("StripDeal: %d of this rank's source boxes reach beyond the window rows %s: enlarge the halo"
+                               % (int(top_cut.sum() + bot_cut.sum()), self.window))
 
 
 def init_from_env(backend=None):

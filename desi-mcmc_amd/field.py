@@ -165,6 +165,10 @@ class ImageSet(object):
         """This set holds rows [y0, y0+H) of a full_H-row frame (row-strip partition, dist.py)."""
         L.check(L.lib().cel_images_set_window(self._h, int(y0), int(full_H)))
 
+    def set_noise_rows(self, y0, y1):
+        """rows [y0, y1) of this set (window-relative) that photon_split's noise sums count (a strip inside its halo)"""
+        L.check(L.lib().cel_images_set_noise_rows(self._h, int(y0), int(y1)))
+
     def set_epsilon(self, band, eps):
         L.check(L.lib().cel_images_set_epsilon(self._h, int(band), float(eps)))
         self.eps[int(band)] = float(eps)

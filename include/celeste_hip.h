@@ -150,6 +150,12 @@ int cel_images_set_epsilon(cel_images *img, int band, double eps);
  * the full frame (celeste.py:130-140) and then cut to the window, so the strips tile the frame's
  * model image exactly.  WCS (rho) stays that of the full frame. */
 int cel_images_set_window(cel_images *img, int y0, int full_H);
+/* Rows [y0, y1) of THIS image set (window-relative) whose left-over photons cel_photon_split's noise sums count; default:
+ * every row.  One Gibbs chain partitioned over GPUs by row strips ("the photon split ... uses the same spatial
+ * partition"): a rank's image set holds its strip plus a halo as tall as its own sources' boxes reach, so that their sample
+ * patches are complete; the sky photons of the halo rows belong to the neighbours' sums (Field.resample_photons,
+ * CelestePy/models.py:155-160, needs the frame's total: the ranks all-reduce their strips' sums). */
+int cel_images_set_noise_rows(cel_images *img, int y0, int y1);
 int cel_images_get_band(cel_images *img, int band, cel_band *out);
 /* copy the last rendered model images (B*H*W) out */
 int cel_images_get_lambda(cel_images *img, double *out, int mem);

@@ -133,14 +133,12 @@ def test_model_gibbs_conserves_photons_and_draws_the_gamma_conditionals(cel):
         # the sky level's Gamma conditional (models.py:155-160): mean (a_0 + noise) / (b_0 + npix)
         assert np.all(np.abs(f.epsilon / ((5 + noise) / (.005 + 96 * 112)) - 1.0) < 0.01)
         assert np.all([abs(im.epsilon - e) == 0 for im, e in zip(imgs, f.epsilon)])
-        # the flux Gamma conditional (sources.py:341-345), re-drawn here with the same generator state
-        state = g.rng.get_state()
+        # the flux Gamma conditional (sources.py:341-345): shape 5 + photons, rate .005 + mass kappa / calib, every
+        # (source, band) drawn from its own stream -- re-drawn here from the same streams
         mass = f.iset.stamp_mass(f.sset)
         fl = g.resample_fluxes().copy()
-        chk = np.random.RandomState(0)
-        chk.set_state(state)
-        want = chk.gamma(5. + f.sums, 1. / (.005 + mass * (f.kappa / f.calib)[None, :]))
-        np.testing.assert_allclose(fl, want, rtol=1e-12)
+        std = celeste_mcmc.gamma_by_stream((5. + f.sums).ravel(), g.seed * 15485863 + g.sweeps, np.arange(20)).reshape(4, 5)
+        np.testing.assert_allclose(fl, std / (.005 + mass * (f.kappa / f.calib)[None, :]), rtol=1e-12)
         g.resample_locations()
         g.sweeps += 1
     assert g.timing["rounds"] > 0 and g.timing["evals"] >= 4 * g.timing["rounds"] // 4
@@ -726,3 +724,47 @@ def test_shape_step_device_engine_follows_the_host_engine(cel, shape_args):
     custom = celeste_mcmc.ModelGibbs([gf], f.src["type"], f.src["radec"], f.flux5(), f.src["shape"], seed=8,
                                      shape_logprior=lambda TH: np.where((TH[:, 0] > 0) & (TH[:, 0] < 1) & (TH[:, 1] > 0) & (TH[:, 3] > 0) & (TH[:, 3] < 1), 0.0, -np.inf))
     assert not custom._shape_engine_on_device()
+
+
+def test_one_chain_partitioned_by_row_strips(cel, tmp_path):
+    """SURVEY 8e, config 5, the spatial partition: two child ranks (sharing GPU 0, gloo) each hold the images on their row
+    strip plus a halo, split only those rows' photons, own the sources whose row lies in their strip, count their strip's
+    sky photons (the sums are added over the ranks) and add their strip's log-likelihood to the trace (dist.StripDeal).
+      * every photon of the frame is accounted for once: the ranks' own sources' photons + the summed sky photons;
+      * after the first sweep the own sources' photon sums are the single-rank split's, photon for photon (a pixel's draws
+        are keyed by its full-frame index and the source: whoever splits it draws the same), and the locations, fluxes, sky
+        levels and the field log-likelihood agree with the single-rank chain to rounding (the window's row origin enters
+        the pixel arithmetic: 1e-9 here, not bit for bit);
+      * both ranks hold the same merged state after every sweep, bit for bit."""
+    import socket
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _dealt_chain_rank import run_chain
+    S, size, sweeps = 600, 512, 3
+    one = run_chain(S, size, sweeps, "device")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dealt_chain_rank.py"),
+                                       str(tmp_path / ("strip%d.npz" % r)), str(S), str(size), str(sweeps), "device", "0", "strips"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    got = [np.load(str(tmp_path / ("strip%d.npz" % r))) for r in range(2)]
+    for k in ("u", "fluxes", "eps", "ll", "noise"):
+        assert np.array_equal(got[0][k], got[1][k]), k                   # one chain, the same on both ranks
+    own_sums = got[0]["sums"] + got[1]["sums"]                            # each rank reports its own sources' rows
+    assert np.all((got[0]["sums"] == 0) | (got[1]["sums"] == 0))
+    assert np.array_equal(own_sums[-1].sum(axis=0) + got[0]["noise"], got[0]["nelec_sum"])     # conservation over the ranks
+    assert np.array_equal(own_sums[0], one["sums"][0])                    # the first split: photon for photon
+    np.testing.assert_allclose(got[0]["u"][0], one["u"][0], rtol=1e-9, atol=0)
+    np.testing.assert_allclose(got[0]["fluxes"][0], one["fluxes"][0], rtol=1e-9)
+    np.testing.assert_allclose(got[0]["eps"][0], one["eps"][0], rtol=1e-12)
+    np.testing.assert_allclose(got[0]["ll"][0], one["ll"][0], rtol=1e-10)
+    assert 0.25 < (got[0]["sums"][0].sum() / own_sums[0].sum()) < 0.75    # the ranks shared the sources about evenly
+
