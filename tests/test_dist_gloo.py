@@ -126,6 +126,55 @@ def test_one_chain_dealt_to_the_ranks_equals_the_single_rank_chain(tmp_path, wor
         dist.SourceDeal(S, 2, 2)
 
 
+def _strip_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from desi_mcmc_amd import dist
+    dist.init_from_env(backend="gloo")
+    H, S = 300, 41
+    rows = np.random.RandomState(5).uniform(-3.0, H + 3.0, S)           # a few sources just off the frame
+    deal = dist.StripDeal(rows, H, world, rank, halo=50)
+    y0, y1 = deal.strip
+    assert (y0, y1) == dist.strip_rows(H, world, rank)
+    inside = (np.clip(np.floor(rows), 0, H - 1) >= y0) & (np.clip(np.floor(rows), 0, H - 1) < y1)
+    assert np.array_equal(deal.mask, inside) and deal.mine.size == inside.sum()
+    assert deal.window == (max(0, y0 - 64), min(H, y1 + 64))              # the halo in whole 32-row tiles
+    assert deal.noise_rows() == (y0 - deal.window[0], y1 - deal.window[0])
+    state = np.zeros((S, 3))
+    for sweep in range(2):
+        state[deal.mine] += (rank + 1) * 10.0 ** sweep + deal.mine[:, None] * 0.001        # only this rank's rows
+        state = deal.merge(state)
+    tot = deal.rank_sum(np.array([float(deal.mine.size), 1.0]))
+    assert tot.tolist() == [float(S), float(world)]
+    Hw = deal.window[1] - deal.window[0]
+    boxes = np.zeros((2, S, 4), dtype=np.int32)
+    boxes[:, :, 0], boxes[:, :, 1] = 5, Hw - 5
+    deal.check_boxes(boxes, np.ones((2, S), dtype=np.int32))               # inside the window: fine
+    if deal.window[0] > 0 and deal.mine.size:
+        boxes[0, deal.mine[0], 0] = 0                                       # an own box cut by the window's first row
+        with pytest.raises(RuntimeError, match="halo"):
+            deal.check_boxes(boxes, np.ones((2, S), dtype=np.int32))
+    np.savez(os.path.join(out_dir, "strip_%d.npz" % rank), state=state, owner=deal.owner)
+    dist.barrier()
+    import torch.distributed as td
+    td.destroy_process_group()
+
+
+def test_strip_deal_world3_gloo(tmp_path):
+    """dist.StripDeal: ownership by row strip, windows with halos, the merge of unequal shares and the rank-ordered sums"""
+    import torch.multiprocessing as mp
+    world = 3
+    mp.spawn(_strip_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), "strip_%d.npz" % r)) for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(res[r]["state"], res[0]["state"]) and np.array_equal(res[r]["owner"], res[0]["owner"])
+    owner, state = res[0]["owner"], res[0]["state"]
+    assert set(owner.tolist()) == {0, 1, 2}
+    want = (owner[:, None] + 1) * 11.0 + 2 * np.arange(len(owner))[:, None] * 0.001
+    np.testing.assert_allclose(state, np.repeat(want, 3, axis=1).reshape(len(owner), 3), rtol=1e-15)
+
+
 @pytest.mark.parametrize("mode", ["strips", "fields"])
 def test_world2_gloo_loglik_allreduce(tmp_path, mode):
     import torch.multiprocessing as mp
