@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libceleste_hip.so")
+# CEL_HIP_LIBRARY: another build of the same sources (tools: the -DCEL_ABLATE library, occupancy experiments); never a fallback
+LIB_PATH = os.environ.get("CEL_HIP_LIBRARY") or os.path.join(_HERE, "libceleste_hip.so")
 
 CEL_OK, CEL_ERR_INVALID, CEL_ERR_HIP, CEL_ERR_NOMEM, CEL_ERR_NO_DEVICE = 0, 1, 2, 3, 4
 CEL_HOST, CEL_DEVICE = 0, 1

@@ -507,6 +507,10 @@ k_photon_split_hw(SplitArgs a) {
     __shared__ double rate[SP_TH * HW_TW];
     __shared__ int left[SP_TH * HW_TW];
     __shared__ CompTab T;
+#ifdef SPLIT_LDS_PAD        // occupancy experiments only
+    __shared__ double lds_pad[SPLIT_LDS_PAD / 8];
+    if (a.S < 0) lds_pad[threadIdx.x] = 1.0;
+#endif
     // pixels of the current source whose draw needs the sampler proper: queued in the component table's
     // LDS, which is dead between a source's walk and the next source's table (a barrier either side)
     static_assert(sizeof(CompTab) >= sizeof(unsigned short) * SP_TH * HW_TW, "the draw queue lives in the component table");

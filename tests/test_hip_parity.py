@@ -238,6 +238,11 @@ def test_config1_real_stamps(cel, stamp_images):
 # seeded synthetic fields against the CPU oracle
 # ------------------------------------------------------------------------------------------
 def oracle_bands(field):
+    """The field's band records for the oracle, with the star radius R the LIBRARY computed (cel_bounding_radius on the band's
+    PSF) copied in -- the synthetic records leave R = 0 = "compute it".  Handing the library's R to the checker is sound
+    because R itself is pinned separately: test_fitsimage_radius_matches_reference compares the same host function with the
+    reference's FitsImage.R on the real stamps (golden bands_253.npz), and tests/test_oracle.py pins the oracle's own
+    orc_bounding_radius to the reference's calc_bounding_radius (golden radius.npz)."""
     b = field.bands.copy()
     for i in range(b.shape[0]):
         b[i, 36] = field.images.band(i)[36]      # the radius the library computed
