@@ -768,3 +768,52 @@ def test_one_chain_partitioned_by_row_strips(cel, tmp_path):
     np.testing.assert_allclose(got[0]["ll"][0], one["ll"][0], rtol=1e-10)
     assert 0.25 < (got[0]["sums"][0].sum() / own_sums[0].sum()) < 0.75    # the ranks shared the sources about evenly
 
+
+
+def test_photon_lists_agree_with_the_dense_form_fuzz(cel):
+    """The conditional likelihood read at the photons (k_patch_ll_nz: direct exponentials at the pixels that hold a photon) against
+    the dense form (k_patch_ll_hw<0>: the column recurrence over the photon rectangle, CEL_OPT_PHOTON_LISTS = 2) on random
+    fields -- faint and very bright sources (lists from a handful to tens of thousands of photons: whole jobs and jobs dealt
+    to four blocks), tiny and large galaxies, sources on the frame's edge, proposals a fraction of a pixel to hundreds of
+    pixels away (the far shortcut) -- to 1e-12; and a value does not depend on the size of the call it is part of."""
+    from desi_mcmc_amd import _lib, synth
+    ctx = cel.default_context(0)
+    longest, shortest = 0, 1 << 30
+    for seed in range(6):
+        rs = np.random.RandomState(100 + seed)
+        S, H, W = 60, int(rs.choice([160, 256, 384])), int(rs.choice([192, 256, 320]))
+        f = synth.SyntheticField(ctx, S, 5, H, W, frac_gal=0.6, seed=200 + seed, with_nelec=False)
+        src = f.src
+        src["counts"] = src["counts"] * np.exp(rs.uniform(np.log(0.02), np.log(60.0), size=(S, 1)))     # 20 ... 5e6 photons
+        src["shape"][:, 1] = np.exp(rs.uniform(np.log(0.05), np.log(6.0), S))                            # r_e 0.05" ... 6"
+        edge = rs.rand(S) < 0.2
+        src["radec"][edge] = synth.pixel2equa(f.bands[0], np.column_stack([rs.choice([-3.0, 1.5, W - 2.0, W + 2.5], edge.sum()),
+                                                                           rs.uniform(0, H, edge.sum())]))
+        f.sources.set(src["type"], src["radec"], src["counts"], src["shape"])
+        f.images.render(f.sources)
+        f.images.set_nelec(rs.poisson(f.images.model_images()).astype(np.float64))
+        P = 5
+        own = np.repeat(np.arange(S, dtype=np.int32), P)
+        jit = rs.normal(0, 1.0, size=(S * P, 2)) * np.repeat(rs.choice([3e-6, 3e-5, 4e-4, 2e-2], S), P)[:, None]
+        prop = cel.SourceSet(ctx, S * P, 5).set(np.repeat(src["type"], P), np.repeat(src["radec"], P, axis=0) + jit,
+                                                np.repeat(src["counts"], P, axis=0), np.repeat(src["shape"], P, axis=0))
+        out = {}
+        for mode in (2, 1, 0):
+            ctx.set_option(_lib.CEL_OPT_PHOTON_LISTS, mode)
+            try:
+                f.images.photon_split_resident(f.sources, seed=seed)
+                out[mode] = f.images.patch_loglik_resident(prop, own)
+                if mode == 1:
+                    few = cel.SourceSet(ctx, 7, 5).set(np.repeat(src["type"], P)[11:18], (np.repeat(src["radec"], P, axis=0) + jit)[11:18],
+                                                       np.repeat(src["counts"], P, axis=0)[11:18], np.repeat(src["shape"], P, axis=0)[11:18])
+                    assert np.array_equal(f.images.patch_loglik_resident(few, own[11:18]), out[1][11:18])
+            finally:
+                ctx.set_option(_lib.CEL_OPT_PHOTON_LISTS, 0)
+        assert np.all(np.isfinite(out[2]))
+        np.testing.assert_allclose(out[1], out[2], rtol=1e-12)
+        np.testing.assert_allclose(out[0], out[2], rtol=1e-12)
+        boxes, offs, data = f.images.fetch_samples()
+        nnz = np.array([np.count_nonzero(data[offs[i]:offs[i + 1]]) for i in range(S * 5)])
+        longest = max(longest, int(nnz.max()))
+        shortest = min(shortest, int(nnz[nnz > 0].min()))
+    assert longest > 3 * 2048 and shortest < 64                   # lists dealt to four blocks, and lists shorter than one step
