@@ -718,7 +718,7 @@ static double rsq_galaxy() {
     return -2.0 * log1p(-q);         // scipy.stats.chi2.ppf(q, 2)
 }
 
-static int run_prep(cel_images *im, cel_sources *src, const int *d_live = nullptr) {
+static int run_prep(cel_images *im, cel_sources *src, const int *d_live = nullptr, int nobox = 0) {
     cel_ctx *c = im->ctx;
     int64_t n = src->S * im->B;
     int rc = ensure_recs(im, n > 0 ? n : 1);
@@ -727,9 +727,9 @@ static int run_prep(cel_images *im, cel_sources *src, const int *d_live = nullpt
     int pi = prof_slot(c, CEL_K_PREP);
     LAUNCH_EV(k_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), c->stream, EV0(c, pi), EV1(c, pi), im->d_bands, im->B,
               im->full_H, im->W, im->win_y0, im->H, src->S, src->d_type, src->d_radec, src->d_counts, src->d_shape,
-              rsq_galaxy(), im->d_recs, im->d_boxes, im->d_kind, im->d_status, im->d_cursor, d_live);
+              rsq_galaxy(), im->d_recs, im->d_boxes, im->d_kind, im->d_status, im->d_cursor, d_live, nobox);
     HIP_TRY(hipGetLastError());
-    im->recs_gen = d_live ? 0 : src->gen;      // a partial table is nobody else's
+    im->recs_gen = (d_live || nobox) ? 0 : src->gen;      // a partial table is nobody else's
     im->last_S = src->S;
     return CEL_OK;
 }
@@ -1333,7 +1333,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         for (int k = 0; k < nb; k++) {
             hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags, queued == 0 ? 1 : 0);
             prop->gen = ++g_source_gen;
-            if ((rc = run_prep(im, prop, d_owner))) return rc;
+            if ((rc = run_prep(im, prop, d_owner, 1))) return rc;      // the patch limits are fixed: no boxes
             if (c->variant == 0) {
                 int pi = prof_slot(c, CEL_K_PATCH_LL);
                 LAUNCH_EV(k_patch_ll<int>, dim3((unsigned)(S * B)), dim3(256), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
@@ -1510,7 +1510,7 @@ int cel_slice_sample(cel_images *im, cel_sources *src, int param, const int32_t 
             hipLaunchKernelGGL(k_sg_propose, dim3(g256), dim3(256), 0, st, g, rs, S, param ? prop->d_shape : prop->d_radec, d_owner, d_flags,
                                queued == 0 ? 1 : 0);
             prop->gen = ++g_source_gen;
-            if ((rc = run_prep(im, prop, d_owner))) return rc;
+            if ((rc = run_prep(im, prop, d_owner, 1))) return rc;      // the patch limits are fixed: no boxes
             if (c->variant == 0) {
                 int pi = prof_slot(c, CEL_K_PATCH_LL);
                 LAUNCH_EV(k_patch_ll<int>, dim3((unsigned)(P * B)), dim3(256), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, P, im->d_recs,

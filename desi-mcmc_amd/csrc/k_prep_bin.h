@@ -35,7 +35,10 @@ k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int w
        unsigned long long *__restrict__ cursor /* the binning pass's 4 cursors / flags, zeroed here (a memset of
                                                   its own cost 15 us of queue time per step), or nullptr */,
        const int *__restrict__ live /* [S] or nullptr: a source with live[s] < 0 is skipped (a retired slice chain:
-                                       nothing reads its records this round) */) {
+                                       nothing reads its records this round) */,
+       int nobox = 0 /* 1: the records feed conditional likelihoods on FIXED patch limits (the slice samplers' rounds): a
+                        galaxy's own box -- the bounding radius over its 42 convolved components, most of this kernel's
+                        arithmetic -- is not needed and is set to the whole window */) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 4 && cursor) cursor[i] = 0ull;
     if (i >= S * B) return;
@@ -94,7 +97,8 @@ k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int w
         // calc_bounding_radius over the 42 convolved components, error 1e-5, centre (px, py)
         double rsq_inv = 1.0 / rsq_gal;
         double bound = -INFINITY;
-        for (int k = 0; k < K_PSF; k++) {
+        if (nobox) bound = (w00 == w00 && w11 == w11) ? 4.0 * (double)(H + W) : NAN;
+        for (int k = 0; k < K_PSF && !nobox; k++) {
             double mx = (px + bd.mux[k]) - px, my = (py + bd.muy[k]) - py;
             double dist = sqrt(mx * mx + my * my);
             for (int j = 0; j < K_PROF; j++) {
