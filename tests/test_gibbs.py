@@ -817,3 +817,36 @@ def test_photon_lists_agree_with_the_dense_form_fuzz(cel):
         longest = max(longest, int(nnz.max()))
         shortest = min(shortest, int(nnz[nnz > 0].min()))
     assert longest > 3 * 2048 and shortest < 64                   # lists dealt to four blocks, and lists shorter than one step
+
+
+def test_slice_sample_and_planes_error_paths(cel):
+    """bad arguments of the round-3 entry points come back as ValueError (CEL_ERR_INVALID), never as a crash"""
+    from desi_mcmc_amd import synth
+    ctx = cel.default_context(0)
+    f = synth.SyntheticField(ctx, 20, 5, 128, 128, frac_gal=0.5, seed=2)
+    dirs = np.tile(np.eye(4)[None, :2, :], (20, 1, 1))
+    with pytest.raises(ValueError, match="resident photon split"):
+        f.images.slice_sample(f.sources, 1, 1.0, seed=1, dirs=dirs)                  # no split yet
+    f.images.photon_split_resident(f.sources, seed=3)
+    with pytest.raises(ValueError):
+        f.images.slice_sample(f.sources, 1, 0.0, seed=1, dirs=dirs)                  # sigma must be positive
+    with pytest.raises(ValueError, match="dirs"):
+        f.images.slice_sample(f.sources, 1, 1.0, seed=1, dirs=dirs[:, :, :2])        # shape directions are 4-vectors
+    with pytest.raises(ValueError, match="rounds"):
+        f.images.slice_sample(f.sources, 1, 1.0, seed=1, dirs=dirs, max_rounds=1)
+    other = cel.SourceSet(ctx, 7, 5).set(f.src["type"][:7], f.src["radec"][:7], f.src["counts"][:7], f.src["shape"][:7])
+    with pytest.raises(ValueError, match="resident photon split"):
+        f.images.slice_sample(other, 0, 1e-3, seed=1)                                # not the split's sources
+    x, llh, st = f.images.slice_sample(f.sources, 0, 1e-3, seed=1, step_out=False)   # component-wise locations through the general engine
+    assert x.shape == (20, 2) and st["evals"] >= 4 * 20 and np.all(np.abs(x - f.src["radec"]) < 1e-3)
+    th, llh, st = f.images.slice_sample(f.sources, 1, 1.0, seed=1, dirs=dirs)
+    gal = f.src["type"] == 1
+    assert np.array_equal(th[~gal], f.src["shape"][~gal]) and np.all(np.isfinite(llh[gal])) and np.all(np.isnan(llh[~gal]))
+    # mode 4: two planes per band
+    one = cel.SourceSet(ctx, 1, 5).set(f.src["type"][:1], f.src["radec"][:1], f.src["counts"][:1], f.src["shape"][:1])
+    boxes = np.zeros((5, 4), dtype=np.int32)
+    boxes[2] = [10, 30, 20, 50]
+    with pytest.raises(ValueError, match="planes"):
+        f.images.patch_loglik_planes(one, boxes, [None, None, np.zeros((20, 30)), None, None])
+    ll = f.images.patch_loglik_planes(one, boxes, [None, None, np.stack([np.full((20, 30), 3.0), np.full((20, 30), 400.0)]), None, None])
+    assert np.isfinite(ll[0])
