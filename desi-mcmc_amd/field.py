@@ -258,7 +258,7 @@ class ImageSet(object):
 
     # ---- device-resident Gibbs pieces: nothing but proposals and scalars crosses PCIe -------------
     def photon_split_resident(self, sources, seed):
-        """The photon split with the sample patches kept in device memory (3.2 GB at 10 000
+        """The photon split with the sample patches kept in device memory as int32 (1.6 GB at 10 000
         sources x 5 bands x 2048^2 never leave the GPU).  -> noise_sum[B]"""
         noise = np.zeros(self.B)
         L.check(L.lib().cel_photon_split(self._h, sources._h, C.c_uint64(int(seed) & (2 ** 64 - 1)), None, None,
