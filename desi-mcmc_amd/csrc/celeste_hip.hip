@@ -81,6 +81,7 @@ static int fail(int code, const char *fmt, ...) {
 #include "k_bin2.h"
 #include "k_render.h"
 #include "k_render_hw.h"
+#include "k_render_stars.h"
 #include "k_render_qw.h"
 #include "k_misc.h"
 #include "k_patch_ll.h"
@@ -166,6 +167,7 @@ struct cel_images {
     int *d_tile_cost = nullptr;   // measured duration of every tile in the last render (the next render's launch order)
     int64_t cost_S = -1;          // number of sources that render had (-1: nothing measured yet)
     bool bin_two_level = false;   // a super-tile once held more than BIN_CH candidates: coarse lists in global memory from then on
+    bool star_one_segment = false;   // every band passes star_setup's test: k_render_stars may take star tiles
     int64_t order_S = -1;         // d_order already holds the heaviest-first order of those costs (sorted behind that render's readback)
     hipEvent_t ev_step = nullptr; // marks a step's readback copy: the host waits for it, not for the sort queued behind it
     int64_t *d_tile_off = nullptr;
@@ -530,6 +532,16 @@ int cel_images_create(cel_ctx *c, int B, int H, int W, const cel_band *bands, ce
             im->hb[b].R = host_bounding_radius(bands[b].mu, bands[b].cov, K_PSF, 0.001, nullptr);
         band_to_dev(im->hb[b], hb[b]);
     }
+    im->star_one_segment = true;
+    for (int b = 0; b < B; b++)
+        for (int k = 0; k < K_PSF; k++) {      // star_setup's test (k_render_hw.h), on the host
+            const BandDev &d = hb[b];
+            const double inv = 1.0 / (d.cxx[k] * d.cyy[k] - d.cxy[k] * d.cxy[k]);
+            const double rb_ = d.R + 2.0;
+            const double emax = 0.5 * quad_max_rect_hw(d.cyy[k] * inv, -d.cxy[k] * inv, d.cxx[k] * inv, -rb_ - d.mux[k], rb_ - d.mux[k],
+                                                       -rb_ - d.muy[k], rb_ - d.muy[k]);
+            if (!(emax <= 0.999 * STAR_EMAX)) im->star_one_segment = false;
+        }
     size_t npix = (size_t)B * H * W;
     int T = B * im->ntx * im->nty;
     int rc = CEL_OK;
@@ -840,7 +852,17 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         else if (im->TW == HW_TW) {
             // the production instantiation has no diagnostic code in it; counters, time stamps and (CEL_ABLATE
             // builds) ablations live in the second one
+            static const int star_env = getenv("CEL_STAR_KERNEL") ? atoi(getenv("CEL_STAR_KERNEL")) : 0;
             if (a.timing || (c->debug & ~64)) LAUNCH_EV(k_render_hw<true>, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
+            else if (star_env && im->star_one_segment && c->variant != 0) {
+                switch (star_env) {
+                case 1: LAUNCH_EV((k_render_stars<1, false>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a); break;
+                case 4: LAUNCH_EV((k_render_stars<4, false>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a); break;
+                case 12: LAUNCH_EV((k_render_stars<2, true>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a); break;
+                case 14: LAUNCH_EV((k_render_stars<4, true>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a); break;
+                default: LAUNCH_EV((k_render_stars<2, false>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a); break;
+                }
+            }
             else LAUNCH_EV(k_render_hw<false>, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
         }
         else if (im->TH == 64)

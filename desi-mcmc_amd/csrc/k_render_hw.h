@@ -26,7 +26,7 @@
 #define HW_PAD 12   // zero components behind the compacted table: a half's group may read past the end
 
 // largest value of the convex form a x^2 + 2 b x y + c y^2 on a rectangle: at one of the corners
-__device__ inline double quad_max_rect_hw(double a, double b, double c, double x1, double x2, double y1, double y2) {
+__host__ __device__ inline double quad_max_rect_hw(double a, double b, double c, double x1, double x2, double y1, double y2) {
     double m = a * x1 * x1 + (2.0 * b * x1 + c * y1) * y1;
     m = fmax(m, a * x2 * x2 + (2.0 * b * x2 + c * y1) * y1);
     m = fmax(m, a * x1 * x1 + (2.0 * b * x1 + c * y2) * y2);
@@ -163,10 +163,47 @@ __device__ __forceinline__ bool star_setup(StarTab &ST, const BandDev *__restric
 // ITS star's rows, row i of the step being row ra_lane + i of the tile.  Neighbouring tasks belong to the same or the
 // next star of the sorted order, so the lanes of a step have nearly equal row counts, and every lane carries a
 // column (all but the batch's last step).  The order in which a pixel receives its terms depends on the data only.
-template <bool DIAG>
-__device__ __forceinline__ void star_pass(const RenderArgs &a, StarTab &ST, const double *__restrict__ et, double *__restrict__ acc,
-                                          const SrcRec *__restrict__ recs, int64_t off, int nstar, int lane, int X0, int Y0,
-                                          int strict, unsigned &dbg_halfrows, unsigned &dbg_pairs) {
+// star_stage puts one batch (<= 64 stars of the tile's list) into the table, sorted; star_walk adds the batch's
+// columns [Xa, Xa + CW) into an accumulator of CW doubles per row (the whole tile: Xa = X0, CW = HW_TW); a caller
+// that walks the same batch again (another part of the columns) puts a barrier between the walks.
+__device__ __forceinline__ void star_stage(const RenderArgs &a, StarTab &ST, const SrcRec *__restrict__ recs, int64_t off, int base, int nb,
+                                           int lane, int X0, int Y0, int strict) {
+    __syncthreads();                   // the previous batch has been read
+    // One lane per star loads it; the batch is then SORTED by the number of rows the star has on this tile
+    // (descending; ties by list position).  The rank of a star is a count over the batch (<= 64 LDS
+    // broadcasts) and depends only on the data.  A star without a row or a column here sorts last.
+    double2 pp = make_double2(0.0, 0.0);
+    double sc = 0.0;
+    int4 bx4 = make_int4(0, 0, 0, 0);
+    int nrows = -1;
+    if (lane < nb) {
+        const SrcRec *rp = recs + a.lists[off + base + lane];
+        pp = *reinterpret_cast<const double2 *>(&rp->px);
+        sc = rp->scale;
+        bx4 = *reinterpret_cast<const int4 *>(&rp->x0);
+        nrows = max(min(bx4.w, Y0 + HW_TH) - max(bx4.z + strict, Y0), 0);
+        const int ncols = max(min(bx4.y, X0 + HW_TW) - max(bx4.x + strict, X0), 0);
+        if (ncols == 0) nrows = 0;
+    }
+    int *srows = reinterpret_cast<int *>(ST.scale);      // scratch until the sorted table is written
+    srows[lane] = nrows;
+    __syncthreads();
+    int rank = 0;
+    for (int j = 0; j < nb; j++) {
+        const int rj = srows[j];
+        rank += (rj > nrows || (rj == nrows && j < lane)) ? 1 : 0;
+    }
+    __syncthreads();
+    if (lane < nb) {
+        ST.px[rank] = pp.x; ST.py[rank] = pp.y; ST.scale[rank] = sc;
+        ST.box[rank] = bx4;
+    }
+    __syncthreads();
+}
+
+template <bool DIAG, int CW>
+__device__ __forceinline__ void star_walk(const RenderArgs &a, StarTab &ST, const double *__restrict__ et, double *__restrict__ acc,
+                                          int nb, int lane, int Xa, int Y0, int strict, unsigned &dbg_halfrows) {
     double cqa[K_PSF], cqb[K_PSF], cqc[K_PSF], ceq[K_PSF], cA0[K_PSF], cmx[K_PSF], cmy[K_PSF];
 #pragma unroll
     for (int k = 0; k < K_PSF; k++) {
@@ -174,122 +211,100 @@ __device__ __forceinline__ void star_pass(const RenderArgs &a, StarTab &ST, cons
         cA0[k] = ST.A0[k]; cmx[k] = ST.mux[k]; cmy[k] = ST.muy[k];
     }
     const int dbg = DIAG ? CEL_ABLATE_BITS(a.flags) : 0;
+    // exclusive prefix sum of the column counts in sorted order (lane j = sorted star j): cum[j] = first task of star j
+    int w = 0;
+    if (lane < nb) {
+        const int4 q = ST.box[lane];
+        const int nr = max(min(q.w, Y0 + HW_TH) - max(q.z + strict, Y0), 0);
+        w = (nr > 0) ? max(min(q.y, Xa + CW) - max(q.x + strict, Xa), 0) : 0;
+    }
+    int incl = w;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    ST.cum[lane] = (lane < nb) ? incl - w : 0x3fffffff;
+    __syncthreads();
+    for (int t0 = 0; t0 < total && !(dbg & 2); t0 += 64) {
+        const int t = t0 + lane;
+        const bool valid = t < total;
+        // the star this task belongs to: the last j with cum[j] <= t (stars without a column share their
+        // successor's cum and are passed over; entries behind the batch hold a sentinel)
+        int j = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+            if (ST.cum[min(j + step, 63)] <= t && j + step < 64) j += step;
+        const double px = ST.px[j], py = ST.py[j];
+        const int4 bx = ST.box[j];
+        const int bx0 = max(bx.x + strict, Xa), by0 = bx.z + strict;
+        const int xi = bx0 + (t - ST.cum[j]);
+        const int ra = max(by0, Y0) - Y0;
+        const int n = (valid && !(dbg & 1)) ? max(min(bx.w, Y0 + HW_TH) - Y0 - ra, 0) : 0;
+        const double amp = valid ? ST.scale[j] : 0.0;
+        // sorted by rows: the step's first task has the most -- of the stars WITH a column here; one without
+        // passes its place to its successor, whose rows are no more
+        const int nmax = __builtin_amdgcn_readlane(n, 0);
+        if (DIAG && a.timing) dbg_halfrows += 2u * (unsigned)nmax * K_PSF;   // in half-tile (32-lane) widths, as the general path counts
+        const double x = (double)xi;
+        double g[K_PSF], r[K_PSF];
+        const double y0 = (double)(Y0 + ra);
+#pragma unroll
+        for (int k = 0; k < K_PSF; k++) {
+            const double dx = x - (px + cmx[k]), dy = y0 - (py + cmy[k]);
+            const double hx = cqb[k] * dx + cqc[k] * dy;
+            const double e = -0.5 * (cqa[k] * dx * dx + (cqb[k] * dx + hx) * dy);
+            const double er = fmin(fmax(-(hx + 0.5 * cqc[k]), -REC_EMAX * EXP_SCALE), REC_EMAX * EXP_SCALE);
+            g[k] = (cA0[k] * amp) * exp_tab64(e, et);
+            r[k] = exp_tab64(er, et);
+        }
+        double *rowp = acc + ra * CW + (valid ? xi - Xa : 0);
+        int i = 0;
+        for (; i + 3 < nmax; i += 4, rowp += 4 * CW) {       // four rows per trip: one address update, one bound test
+#pragma clang fp contract(off)
+            double g1[K_PSF], r1[K_PSF];
+            const double s0 = (g[0] + g[1]) + g[2];
+#pragma unroll
+            for (int k = 0; k < K_PSF; k++) { g1[k] = g[k] * r[k]; r1[k] = r[k] * ceq[k]; }
+            const double s1 = (g1[0] + g1[1]) + g1[2];
+#pragma unroll
+            for (int k = 0; k < K_PSF; k++) { g[k] = g1[k] * r1[k]; r[k] = r1[k] * ceq[k]; }
+            const double s2 = (g[0] + g[1]) + g[2];
+#pragma unroll
+            for (int k = 0; k < K_PSF; k++) { g1[k] = g[k] * r[k]; r1[k] = r[k] * ceq[k]; }
+            const double s3 = (g1[0] + g1[1]) + g1[2];
+#pragma unroll
+            for (int k = 0; k < K_PSF; k++) { g[k] = g1[k] * r1[k]; r[k] = r1[k] * ceq[k]; }
+            if (i + 3 < n) {            // the whole trip lies inside this lane's rows (most lanes, most trips)
+                lds_add(&rowp[0], s0);
+                lds_add(&rowp[CW], s1);
+                lds_add(&rowp[2 * CW], s2);
+                lds_add(&rowp[3 * CW], s3);
+            } else {
+                if (i < n) lds_add(&rowp[0], s0);
+                if (i + 1 < n) lds_add(&rowp[CW], s1);
+                if (i + 2 < n) lds_add(&rowp[2 * CW], s2);
+            }
+        }
+        for (; i < nmax; i++, rowp += CW) {
+#pragma clang fp contract(off)
+            if (i < n) lds_add(&rowp[0], (g[0] + g[1]) + g[2]);
+#pragma unroll
+            for (int k = 0; k < K_PSF; k++) { g[k] = g[k] * r[k]; r[k] = r[k] * ceq[k]; }
+        }
+    }
+}
+
+template <bool DIAG>
+__device__ __forceinline__ void star_pass(const RenderArgs &a, StarTab &ST, const double *__restrict__ et, double *__restrict__ acc,
+                                          const SrcRec *__restrict__ recs, int64_t off, int nstar, int lane, int X0, int Y0,
+                                          int strict, unsigned &dbg_halfrows, unsigned &dbg_pairs) {
     for (int base = 0; base < nstar; base += 64) {
         const int nb = min(64, nstar - base);
-        __syncthreads();                   // the previous batch has been read
-        // One lane per star loads it; the batch is then SORTED by the number of rows the star has on this tile
-        // (descending; ties by list position).  The rank of a star is a count over the batch (<= 64 LDS
-        // broadcasts) and depends only on the data.  A star without a row or a column here sorts last.
-        double2 pp = make_double2(0.0, 0.0);
-        double sc = 0.0;
-        int4 bx4 = make_int4(0, 0, 0, 0);
-        int nrows = -1, ncols = 0;
-        if (lane < nb) {
-            const SrcRec *rp = recs + a.lists[off + base + lane];
-            pp = *reinterpret_cast<const double2 *>(&rp->px);
-            sc = rp->scale;
-            bx4 = *reinterpret_cast<const int4 *>(&rp->x0);
-            nrows = max(min(bx4.w, Y0 + HW_TH) - max(bx4.z + strict, Y0), 0);
-            ncols = max(min(bx4.y, X0 + HW_TW) - max(bx4.x + strict, X0), 0);
-            if (ncols == 0 || nrows == 0) { nrows = 0; ncols = 0; }
-        }
-        int *srows = reinterpret_cast<int *>(ST.scale);      // scratch until the sorted table is written
-        srows[lane] = nrows;
-        __syncthreads();
-        int rank = 0;
-        for (int j = 0; j < nb; j++) {
-            const int rj = srows[j];
-            rank += (rj > nrows || (rj == nrows && j < lane)) ? 1 : 0;
-        }
-        __syncthreads();
-        ST.cum[lane] = 0;
-        if (lane < nb) {
-            ST.px[rank] = pp.x; ST.py[rank] = pp.y; ST.scale[rank] = sc;
-            ST.box[rank] = bx4;
-        }
-        __syncthreads();
-        // exclusive prefix sum of the column counts in sorted order (lane j = sorted star j): cum[j] = first task of star j
-        int w = 0;
-        if (lane < nb) {
-            const int4 q = ST.box[lane];
-            const int nr = max(min(q.w, Y0 + HW_TH) - max(q.z + strict, Y0), 0);
-            w = (nr > 0) ? max(min(q.y, X0 + HW_TW) - max(q.x + strict, X0), 0) : 0;
-        }
-        int incl = w;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o);
-            if (lane >= o) incl += up;
-        }
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        ST.cum[lane] = (lane < nb) ? incl - w : 0x3fffffff;
-        __syncthreads();
+        star_stage(a, ST, recs, off, base, nb, lane, X0, Y0, strict);
         if (DIAG && a.timing) { dbg_pairs += (unsigned)nb; }
-        for (int t0 = 0; t0 < total && !(dbg & 2); t0 += 64) {
-            const int t = t0 + lane;
-            const bool valid = t < total;
-            // the star this task belongs to: the last j with cum[j] <= t (stars without a column share their
-            // successor's cum and are passed over; entries behind the batch hold a sentinel)
-            int j = 0;
-#pragma unroll
-            for (int step = 32; step > 0; step >>= 1)
-                if (ST.cum[min(j + step, 63)] <= t && j + step < 64) j += step;
-            const double px = ST.px[j], py = ST.py[j];
-            const int4 bx = ST.box[j];
-            const int bx0 = max(bx.x + strict, X0), by0 = bx.z + strict;
-            const int xi = bx0 + (t - ST.cum[j]);
-            const int ra = max(by0, Y0) - Y0;
-            const int n = (valid && !(dbg & 1)) ? max(min(bx.w, Y0 + HW_TH) - Y0 - ra, 0) : 0;
-            const double amp = valid ? ST.scale[j] : 0.0;
-            const int nmax = __builtin_amdgcn_readlane(n, 0);          // sorted: the step's first task has the most rows
-            if (DIAG && a.timing) dbg_halfrows += 2u * (unsigned)nmax * K_PSF;   // in half-tile (32-lane) widths, as the general path counts
-            const double x = (double)xi;
-            double g[K_PSF], r[K_PSF];
-            const double y0 = (double)(Y0 + ra);
-#pragma unroll
-            for (int k = 0; k < K_PSF; k++) {
-                const double dx = x - (px + cmx[k]), dy = y0 - (py + cmy[k]);
-                const double hx = cqb[k] * dx + cqc[k] * dy;
-                const double e = -0.5 * (cqa[k] * dx * dx + (cqb[k] * dx + hx) * dy);
-                const double er = fmin(fmax(-(hx + 0.5 * cqc[k]), -REC_EMAX * EXP_SCALE), REC_EMAX * EXP_SCALE);
-                g[k] = (cA0[k] * amp) * exp_tab64(e, et);
-                r[k] = exp_tab64(er, et);
-            }
-            double *rowp = acc + ra * HW_TW + (valid ? xi - X0 : 0);
-            int i = 0;
-            for (; i + 3 < nmax; i += 4, rowp += 4 * HW_TW) {       // four rows per trip: one address update, one bound test
-#pragma clang fp contract(off)
-                double g1[K_PSF], r1[K_PSF];
-                const double s0 = (g[0] + g[1]) + g[2];
-#pragma unroll
-                for (int k = 0; k < K_PSF; k++) { g1[k] = g[k] * r[k]; r1[k] = r[k] * ceq[k]; }
-                const double s1 = (g1[0] + g1[1]) + g1[2];
-#pragma unroll
-                for (int k = 0; k < K_PSF; k++) { g[k] = g1[k] * r1[k]; r[k] = r1[k] * ceq[k]; }
-                const double s2 = (g[0] + g[1]) + g[2];
-#pragma unroll
-                for (int k = 0; k < K_PSF; k++) { g1[k] = g[k] * r[k]; r1[k] = r[k] * ceq[k]; }
-                const double s3 = (g1[0] + g1[1]) + g1[2];
-#pragma unroll
-                for (int k = 0; k < K_PSF; k++) { g[k] = g1[k] * r1[k]; r[k] = r1[k] * ceq[k]; }
-                if (i + 3 < n) {            // the whole trip lies inside this lane's rows (most lanes, most trips)
-                    lds_add(&rowp[0], s0);
-                    lds_add(&rowp[HW_TW], s1);
-                    lds_add(&rowp[2 * HW_TW], s2);
-                    lds_add(&rowp[3 * HW_TW], s3);
-                } else {
-                    if (i < n) lds_add(&rowp[0], s0);
-                    if (i + 1 < n) lds_add(&rowp[HW_TW], s1);
-                    if (i + 2 < n) lds_add(&rowp[2 * HW_TW], s2);
-                }
-            }
-            for (; i < nmax; i++, rowp += HW_TW) {
-#pragma clang fp contract(off)
-                if (i < n) lds_add(&rowp[0], (g[0] + g[1]) + g[2]);
-#pragma unroll
-                for (int k = 0; k < K_PSF; k++) { g[k] = g[k] * r[k]; r[k] = r[k] * ceq[k]; }
-            }
-        }
+        star_walk<DIAG, HW_TW>(a, ST, et, acc, nb, lane, X0, Y0, strict, dbg_halfrows);
     }
 }
 
@@ -335,6 +350,55 @@ __device__ __forceinline__ void hw_epilogue(const RenderArgs &a, const double *_
     }
 }
 
+// an empty tile: lambda = eps everywhere -- pure streaming (nelec in, eps out), one log per wave instead of
+// one per pixel, no LDS.  Same arithmetic per pixel as the general epilogue (ne * log(lam) - lam, rows in the
+// same order).  Shared by k_render_hw and k_render_stars.
+__device__ __forceinline__ void hw_empty_tile(const RenderArgs &a, const BandDev *__restrict__ bd, int tile, int b, int X0, int Y0,
+                                              int lane, unsigned long long t_start) {
+    const int half = lane >> 5, xi = X0 + (lane & 31);
+    const double eps = bd->eps;
+    const bool store = !(a.flags & CEL_RENDER_NO_STORE);
+    const bool ll = (a.flags & CEL_RENDER_LOGLIK) != 0;
+    const int64_t base = (int64_t)b * a.H * a.W + (int64_t)(Y0 + half) * a.W + xi;
+    double part = 0.0;
+    if ((a.W & 31) == 0 && Y0 + HW_TH <= a.H) {
+        // whole tile inside an aligned frame: 16 B per lane (4 rows of 16 lane-pairs per
+        // instruction), all 16 loads in flight before the first use
+        const int cp = lane & 15, rq = lane >> 4;
+        const int64_t b2 = (int64_t)b * a.H * a.W + (int64_t)(Y0 + rq) * a.W + X0 + 2 * cp;
+        const double leps = ll ? log(eps) : 0.0;
+        double2 ne2[HW_TH / 4];
+        if (ll) {
+#pragma unroll
+            for (int r = 0; r < HW_TH / 4; r++)
+                ne2[r] = *reinterpret_cast<const double2 *>(a.nelec + b2 + (int64_t)(4 * r) * a.W);
+        }
+#pragma unroll
+        for (int r = 0; r < HW_TH / 4; r++) {
+            if (store) *reinterpret_cast<double2 *>(a.lambda + b2 + (int64_t)(4 * r) * a.W) = make_double2(eps, eps);
+            if (ll) part += (ne2[r].x * leps - eps) + (ne2[r].y * leps - eps);
+        }
+    } else if (xi < a.W) {
+        double ne[HW_TH / 2];
+#pragma unroll
+        for (int r = 0; r < HW_TH / 2; r++)
+            ne[r] = (ll && Y0 + 2 * r + half < a.H) ? a.nelec[base + (int64_t)(2 * r) * a.W] : 0.0;
+        const double leps = ll ? log(eps) : 0.0;
+#pragma unroll
+        for (int r = 0; r < HW_TH / 2; r++) {
+            if (Y0 + 2 * r + half < a.H) {
+                if (store) a.lambda[base + (int64_t)(2 * r) * a.W] = eps;
+                if (ll) part += ne[r] * leps - eps;
+            }
+        }
+    }
+    if (ll) {
+        part = wave_sum(part);
+        if (lane == 0) a.partials[tile] = part;
+    }
+    if (a.cost && lane == 0) a.cost[tile] = (int)min(wall_clock64() - t_start, 0x3fffffffull) + 1;
+}
+
 static_assert(sizeof(CompTab) >= 128 * sizeof(double), "log table must fit the component table");
 // DIAG = false is the production kernel.  DIAG = true adds the per-tile work counters / time stamps of
 // CEL_OPT_TILE_TIMING and, in a -DCEL_ABLATE build only, the timing-only ablation switches of CEL_OPT_DEBUG:
@@ -363,53 +427,7 @@ k_render_hw(RenderArgs a) {
 
     const int cnt = a.tile_cnt[tile];
     if (dbg & 8) return;             // ablation: launch + header load only
-    if (cnt == 0 && !timing) {
-        // empty sky: lambda = eps on the whole tile -- pure streaming (nelec in, eps out), one log
-        // per wave instead of one per pixel, no LDS.  Same arithmetic per pixel as the general
-        // epilogue (ne * log(lam) - lam, rows in the same order).
-        const double eps = bd->eps;
-        const bool store = !(a.flags & CEL_RENDER_NO_STORE);
-        const bool ll = (a.flags & CEL_RENDER_LOGLIK) != 0;
-        const int64_t base = (int64_t)b * a.H * a.W + (int64_t)(Y0 + half) * a.W + xi;
-        double part = 0.0;
-        if ((a.W & 31) == 0 && Y0 + HW_TH <= a.H) {
-            // whole tile inside an aligned frame: 16 B per lane (4 rows of 16 lane-pairs per
-            // instruction), all 16 loads in flight before the first use
-            const int cp = lane & 15, rq = lane >> 4;
-            const int64_t b2 = (int64_t)b * a.H * a.W + (int64_t)(Y0 + rq) * a.W + X0 + 2 * cp;
-            const double leps = ll ? log(eps) : 0.0;
-            double2 ne2[HW_TH / 4];
-            if (ll) {
-#pragma unroll
-                for (int r = 0; r < HW_TH / 4; r++)
-                    ne2[r] = *reinterpret_cast<const double2 *>(a.nelec + b2 + (int64_t)(4 * r) * a.W);
-            }
-#pragma unroll
-            for (int r = 0; r < HW_TH / 4; r++) {
-                if (store) *reinterpret_cast<double2 *>(a.lambda + b2 + (int64_t)(4 * r) * a.W) = make_double2(eps, eps);
-                if (ll) part += (ne2[r].x * leps - eps) + (ne2[r].y * leps - eps);
-            }
-        } else if (xi < a.W) {
-            double ne[HW_TH / 2];
-#pragma unroll
-            for (int r = 0; r < HW_TH / 2; r++)
-                ne[r] = (ll && Y0 + 2 * r + half < a.H) ? a.nelec[base + (int64_t)(2 * r) * a.W] : 0.0;
-            const double leps = ll ? log(eps) : 0.0;
-#pragma unroll
-            for (int r = 0; r < HW_TH / 2; r++) {
-                if (Y0 + 2 * r + half < a.H) {
-                    if (store) a.lambda[base + (int64_t)(2 * r) * a.W] = eps;
-                    if (ll) part += ne[r] * leps - eps;
-                }
-            }
-        }
-        if (ll) {
-            part = wave_sum(part);
-            if (lane == 0) a.partials[tile] = part;
-        }
-        if (a.cost && lane == 0) a.cost[tile] = (int)min(wall_clock64() - t_start, 0x3fffffffull) + 1;
-        return;
-    }
+    if (cnt == 0 && !timing) { hw_empty_tile(a, bd, tile, b, X0, Y0, lane, t_start); return; }
 
     et[lane] = exp2((double)lane * (1.0 / 64.0));
 #pragma unroll
