@@ -47,7 +47,7 @@ FLOP_PER_GAUSS = 35.0        # SURVEY 8d accounting: 10 arithmetic + exp counted
 # exactly this command -- and only when the summary was taken with the library that is loaded now (its sha256 is
 # stored in the profile): after any kernel change without a re-profile the fields print null instead of going stale.
 #   traffic = 2 * FETCH_SIZE + WRITE_SIZE (gfx950 correction, re-calibrated with tools/calib_traffic.hip)
-#   valu    = SQ_INSTS_VALU (wave-instructions), busy = 2 * SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES
+#   valu    = SQ_INSTS_VALU (wave-instructions), busy = waves per SIMD * SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES
 PMC_PROFILES = {   # (workload, kernel, tail_log, layout) -> committed summary
     ("mixed10k_2048", "recurrence", 32.0, 1): "profiles/r03_final_pmc.json",
     ("stars10k_2048", "recurrence", 32.0, 1): "profiles/r03_stars_pmc.json",
@@ -61,7 +61,7 @@ def library_sha256():
         return hashlib.sha256(f.read()).hexdigest()
 
 
-def load_pmc(key, kernel="k_render_hw"):
+def load_pmc(key, kernel="k_render"):
     """-> dict(traffic, valu_insts, valu_busy, source) from the committed summary, or dict(stale=reason)"""
     rel = PMC_PROFILES.get(key)
     if rel is None:
@@ -77,10 +77,12 @@ def load_pmc(key, kernel="k_render_hw"):
     ks = [k for k in prof["kernels"] if kernel in k]
     if not ks:
         return {"stale": "%s holds no %s launches" % (rel, kernel)}
-    c = prof["kernels"][sorted(ks, key=lambda k: -prof["kernels"][k].get("SQ_INSTS_VALU", {}).get("last", 0.0))[0]]
+    name = sorted(ks, key=lambda k: -prof["kernels"][k].get("SQ_INSTS_VALU", {}).get("last", 0.0))[0]
+    c = prof["kernels"][name]
     last = lambda name: c[name]["last"]      # noqa: E731  -- the last launch: a timed-region step
+    waves_per_simd = 3.0 if "k_render_stars" in name else 2.0       # resident waves per SIMD (kernel-resource-usage)
     return {"traffic": 2.0 * last("FETCH_SIZE") * 1024.0 + last("WRITE_SIZE") * 1024.0, "valu_insts": last("SQ_INSTS_VALU"),
-            "valu_busy": 2.0 * last("SQ_ACTIVE_INST_VALU") / last("SQ_WAVE_CYCLES"), "source": rel}
+            "valu_busy": waves_per_simd * last("SQ_ACTIVE_INST_VALU") / last("SQ_WAVE_CYCLES"), "source": rel}
 
 
 CPU_THREADS_MAX = 16         # the GPU box's CPU share for one GPU
@@ -282,7 +284,7 @@ def run_render(args, env):
         if reducer is not None:
             last["llb"] = reducer.drain()[-1]
     dt = Timer(dist, torch).run(step, args.warmup, args.steps, after_warmup, finish, prime=100)
-    t_render, n_render = ctx.profile_get("render")
+    t_render, n_render, render_kernel = ctx.profile_render()
     t_bin, _ = ctx.profile_get("bin")
     t_prep, _ = ctx.profile_get("prep")
     t_red, _ = ctx.profile_get("reduce")
@@ -334,7 +336,7 @@ def run_render(args, env):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic"] if pmc else None,
                      "traffic_source": pmc["source"] if pmc else pmc_note,
-                     "kernel": "k_render", "kernel_ms": t_render, "launches": n_render,
+                     "kernel": render_kernel, "kernel_ms": t_render, "launches": n_render,
                      "algorithmic_bytes_per_launch": alg_bytes},
         "work": {"n_srcpix_per_step": n_srcpix_all, "n_gauss_per_step": n_gauss_all,
                  "gauss_evals_per_s": n_gauss_all * args.steps / dt_max,
@@ -400,7 +402,7 @@ def extra_render_legs(args, env, field, out):
                 llf, _ = field.images.render(field.sources, loglik=True)
             torch.cuda.synchronize()
             dtf = time.perf_counter() - t0
-            tk, _ = ctx.profile_get("render")
+            tk = ctx.profile_render()[0]
             ctx.profile(False)
             out["tail_log_fast_preset"] = {"tail_log": _lib.TAIL_LOG_FAST, "ms_per_step": dtf / n * 1e3, "k_render_ms": tk,
                                            "loglik_rel_diff_vs_default": float(abs(llf - out["loglik"]) / abs(out["loglik"])),
@@ -473,13 +475,13 @@ def secondary_legs(args, env, field):
             f.images.render(f.sources, loglik=True)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        t_render, n_render = ctx.profile_get("render")
+        t_render, n_render, render_kernel = ctx.profile_render()
         ctx.profile(False)
         st = f.images.stats()
         alg = 16.0 * B * H * W + 128.0 * S * B
         sec[name] = {"value": st["n_srcpix"] * steps / dt, "unit": "source-pixel evals/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
                      "roofline": {"bound": "hbm", "achieved": alg / (t_render * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": alg / (t_render * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "k_render", "kernel_ms": t_render,
+                                  "frac": alg / (t_render * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": render_kernel, "kernel_ms": t_render,
                                   "launches": n_render, "algorithmic_bytes_per_launch": alg}}
         del f
     S, B, H, W = field.S, field.B, field.H, field.W
@@ -556,7 +558,7 @@ def run_fields(args, env):
         if reducer is not None:
             last["llb"] = reducer.drain()[-1]
     dt = Timer(dist, torch).run(step, args.warmup, args.steps, after_warmup, finish, prime=max(2, 100 // max(K // world, 1)))
-    tn = [cx.profile_get("render") for cx in ctxs]
+    tn = [cx.profile_render()[:2] for cx in ctxs]
     n_render = sum(n for _, n in tn)
     t_render = sum(t * n for t, n in tn) / max(n_render, 1)
     for cx in ctxs:
@@ -647,7 +649,7 @@ def gibbs_report(g, gf, ctx, steps, dt, S, B):
     t_ll, n_ll = ctx.profile_get("patch_ll")
     t_split, n_split = ctx.profile_get("split")
     t_mass, n_mass = ctx.profile_get("mass")
-    t_render, n_render = ctx.profile_get("render")
+    t_render, n_render = ctx.profile_render()[:2]
     # a round of the location step is one or two launches (the blocks scored densely, the blocks scored at their photons):
     # the roofline is priced per ROUND -- the bytes its evaluations read over the kernel time of its launches
     rounds = max(g.timing.get("loc_launches", 0), 1)

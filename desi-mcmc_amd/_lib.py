@@ -16,13 +16,13 @@ CEL_OK, CEL_ERR_INVALID, CEL_ERR_HIP, CEL_ERR_NOMEM, CEL_ERR_NO_DEVICE = 0, 1, 2
 CEL_HOST, CEL_DEVICE = 0, 1
 CEL_RENDER_LOGLIK, CEL_RENDER_NO_STORE = 1, 2
 CEL_OPT_KERNEL, CEL_OPT_TAIL_LOG, CEL_OPT_PROFILE, CEL_OPT_TILE_ORDER, CEL_OPT_TILE_ROWS = 1, 2, 3, 4, 5
-CEL_OPT_TILE_TIMING, CEL_OPT_TILE_LAYOUT, CEL_OPT_DEBUG, CEL_OPT_PHOTON_LISTS = 6, 7, 8, 9
+CEL_OPT_TILE_TIMING, CEL_OPT_TILE_LAYOUT, CEL_OPT_DEBUG, CEL_OPT_PHOTON_LISTS, CEL_OPT_STAR_TILES = 6, 7, 8, 9, 10
 #: CEL_OPT_TAIL_LOG presets.  32 (the default): a skipped component is below eps * e^-32 on its tile, model pixels
 #: agree with the reference to ~1e-13, which is what the parity tests assert (1e-10).  20: the documented fast
 #: preset for callers that need only north_star's 1e-6 -- a skipped component is below eps * 2e-9, the sum of
 #: all skips on a pixel stays below ~1e-7 of lambda (tests/test_hip_parity.py::test_tail_log_fast_preset...).
 TAIL_LOG_DEFAULT, TAIL_LOG_FAST = 32.0, 20.0
-KERNELS = {"prep": 0, "bin": 1, "render": 2, "reduce": 3, "stamps": 4, "gmm": 5, "patch_ll": 6, "split": 7, "mass": 8, "estep": 9}
+KERNELS = {"prep": 0, "bin": 1, "render": 2, "reduce": 3, "stamps": 4, "gmm": 5, "patch_ll": 6, "split": 7, "mass": 8, "estep": 9, "render_stars": 10}
 BAND_DOUBLES = 37
 MAX_BANDS = 16
 

@@ -111,6 +111,7 @@ struct cel_ctx {
     int variant = 1;
     double tail_T = 32.0;
     bool profile = false;
+    int star_tiles = 1;       // CEL_OPT_STAR_TILES
     int tile_order = 1;       // 0 = launch k_render tiles in index order, 1 = heaviest first by the last render's measured tile durations (estimate when none), 2 = heaviest first by the estimate only
     int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created
     bool tile_timing = false; // diagnostic: k_render stamps each tile's start/end wall clock
@@ -215,6 +216,7 @@ struct cel_sources {
     int64_t cap = 0, S = 0;
     int B = 0;
     uint64_t gen = 0;              // changes with every cel_sources_set (process-wide counter)
+    int64_t n_gal = -1;            // entries that are not stars (type != 0); -1 = unknown (types set from device memory)
     int *d_type = nullptr;
     double *d_radec = nullptr, *d_counts = nullptr, *d_shape = nullptr;
 };
@@ -451,6 +453,10 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         if (v != 0.0 && v != 1.0 && v != 2.0) return fail(CEL_ERR_INVALID, "CEL_OPT_PHOTON_LISTS must be 0, 1 or 2");
         c->nz_force = (int)v;
         return CEL_OK;
+    case CEL_OPT_STAR_TILES:
+        if (v != 0.0 && v != 1.0 && v != 2.0) return fail(CEL_ERR_INVALID, "CEL_OPT_STAR_TILES must be 0, 1 or 2");
+        c->star_tiles = (int)v;
+        return CEL_OK;
     case CEL_OPT_DEBUG:
         if (!(v >= 0.0) || v > 4095.0) return fail(CEL_ERR_INVALID, "CEL_OPT_DEBUG must be in [0, 4095]");
 #ifndef CEL_ABLATE
@@ -476,6 +482,7 @@ int cel_ctx_get_option(cel_ctx *c, int key, double *v) {
     case CEL_OPT_TILE_TIMING: *v = c->tile_timing ? 1.0 : 0.0; return CEL_OK;
     case CEL_OPT_TILE_LAYOUT: *v = c->tile_layout; return CEL_OK;
     case CEL_OPT_PHOTON_LISTS: *v = c->nz_force; return CEL_OK;
+    case CEL_OPT_STAR_TILES: *v = c->star_tiles; return CEL_OK;
     case CEL_OPT_DEBUG: *v = c->debug; return CEL_OK;
     }
     return fail(CEL_ERR_INVALID, "unknown option %d", key);
@@ -683,6 +690,11 @@ int cel_sources_set(cel_sources *s, int64_t S, const int32_t *type, const double
     }
     s->S = S;
     s->gen = ++g_source_gen;
+    s->n_gal = -1;
+    if (mem != CEL_DEVICE) {
+        s->n_gal = 0;
+        for (int64_t i = 0; i < S; i++) s->n_gal += (type[i] != 0);
+    }
     return CEL_OK;
 }
 
@@ -846,23 +858,19 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
             if (!im->d_timing) HIP_TRY(hipMalloc((void **)&im->d_timing, sizeof(unsigned long long) * 3 * T));
             a.timing = im->d_timing;
         }
-        pi = prof_slot(c, CEL_K_RENDER);
+        // a catalogue without galaxies: the star-tile kernel (k_render_stars.h), when the frame fills its waves; the
+        // instantiation with counters / time stamps / ablations exists for the general kernel only
+        const bool diag = a.timing || (c->debug & ~64);
+        const bool stars_only = im->TW == HW_TW && !diag && c->star_tiles && src->n_gal == 0 && im->star_one_segment &&
+                                c->variant != 0 && (c->star_tiles == 2 || T >= 4096);
+        pi = prof_slot(c, stars_only ? CEL_K_RENDER_STARS : CEL_K_RENDER);
         if (im->TW == QW_TW)
             LAUNCH_EV(k_render_qw, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
         else if (im->TW == HW_TW) {
             // the production instantiation has no diagnostic code in it; counters, time stamps and (CEL_ABLATE
             // builds) ablations live in the second one
-            static const int star_env = getenv("CEL_STAR_KERNEL") ? atoi(getenv("CEL_STAR_KERNEL")) : 0;
-            if (a.timing || (c->debug & ~64)) LAUNCH_EV(k_render_hw<true>, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
-            else if (star_env && im->star_one_segment && c->variant != 0) {
-                switch (star_env) {
-                case 1: LAUNCH_EV((k_render_stars<1, false>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a); break;
-                case 4: LAUNCH_EV((k_render_stars<4, false>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a); break;
-                case 12: LAUNCH_EV((k_render_stars<2, true>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a); break;
-                case 14: LAUNCH_EV((k_render_stars<4, true>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a); break;
-                default: LAUNCH_EV((k_render_stars<2, false>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a); break;
-                }
-            }
+            if (diag) LAUNCH_EV(k_render_hw<true>, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
+            else if (stars_only) LAUNCH_EV((k_render_stars<2, false>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
             else LAUNCH_EV(k_render_hw<false>, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
         }
         else if (im->TH == 64)
@@ -1299,6 +1307,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     HIP_TRY(hipMemcpyAsync(prop->d_counts, src->d_counts, sizeof(double) * B * S, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(prop->d_shape, src->d_shape, sizeof(double) * 4 * S, hipMemcpyDeviceToDevice, st));
     prop->S = S;
+    prop->n_gal = -1;
     if (chain_ids) {
         HIP_TRY(hipMemcpyAsync(d_ids, chain_ids, sizeof(int) * S, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -1505,6 +1514,7 @@ int cel_slice_sample(cel_images *im, cel_sources *src, int param, const int32_t 
                        (const double *)src->d_radec, (const double *)src->d_counts, (const double *)src->d_shape,
                        prop->d_type, prop->d_radec, prop->d_counts, prop->d_shape);
     prop->S = 2 * S;
+    prop->n_gal = -1;
     hipLaunchKernelGGL(k_sg_init, dim3(g256), dim3(256), 0, st, g, rs, S, (const double *)(param ? src->d_shape : src->d_radec),
                        chain_ids ? (const int *)d_ids : (const int *)nullptr, (const int64_t *)im->d_soff, B, (const int *)src->d_type,
                        (unsigned long long)seed);

@@ -161,7 +161,7 @@ __device__ __forceinline__ double nz_trip(const NzEntry *__restrict__ L, int n, 
             e = fma(c3, XX[p], e);
             e = fma(c4, XY[p], e);
             e = fma(c5, YY[p], e);
-            v[p] = fma(A, exp_tab64(fmax(e, -1.0e5), et), v[p]);
+            v[p] = fma(A, exp_tab64_p4(e, et), v[p]);      // e is finite; far tails flush to 0 inside
         }
     }
     double a = 0.0;

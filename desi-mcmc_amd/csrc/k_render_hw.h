@@ -329,7 +329,31 @@ __device__ __forceinline__ void hw_epilogue(const RenderArgs &a, const double *_
     double part = 0.0;
     const int64_t plane = (int64_t)b * a.H * a.W;
     const int dbg = DIAG ? CEL_ABLATE_BITS(a.flags) : 0;
-    if (xi < a.W && !(dbg & 16)) {
+    // A tile wholly inside the frame takes a form without per-row bounds: with loads and stores under conditions the
+    // compiler cannot count what is outstanding where their paths meet and waits for EVERYTHING (s_waitcnt vmcnt(0))
+    // at every use of a loaded value and before every store -- once per row for the previous row's store to be
+    // acknowledged.  Here it counts (vmcnt(31) ... vmcnt(0)): the stores leave without anyone waiting for them.
+    const bool inside = (xi - (lane & 31) + HW_TW <= a.W) && (Y0 + HW_TH <= a.H);
+    if (inside && ll && !PRE && !dbg) {
+        const int64_t base = plane + (int64_t)(Y0 + half) * a.W + xi;
+        double ne[HW_TH / 2];
+#pragma unroll
+        for (int r = 0; r < HW_TH / 2; r++) ne[r] = a.nelec[base + (int64_t)(2 * r) * a.W];
+        if (store) {
+#pragma unroll
+            for (int r = 0; r < HW_TH / 2; r++) {
+                const double lam = eps + acc[r * 64 + lane];
+                a.lambda[base + (int64_t)(2 * r) * a.W] = lam;
+                part += ne[r] * log_tab(lam, lt) - lam;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < HW_TH / 2; r++) {
+                const double lam = eps + acc[r * 64 + lane];
+                part += ne[r] * log_tab(lam, lt) - lam;
+            }
+        }
+    } else if (xi < a.W && !(dbg & 16)) {
         const int64_t base = plane + (int64_t)(Y0 + half) * a.W + xi;
         double ne[HW_TH / 2];
 #pragma unroll

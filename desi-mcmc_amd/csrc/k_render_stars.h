@@ -18,8 +18,10 @@
 #include "k_render_hw.h"
 
 
-// a part's observed pixels into registers: 64 rows x CW columns at column Xa, 64 / CW rows per wave-instruction
-template <int CW>
+// a part's observed pixels into registers: 64 rows x CW columns at column Xa, 64 / CW rows per wave-instruction.
+// INSIDE: the tile lies wholly inside the frame and the log-likelihood is wanted -- no condition on any load or
+// store, so the compiler can count what is outstanding (see hw_epilogue).
+template <int CW, bool INSIDE>
 __device__ __forceinline__ void stars_nelec(const RenderArgs &a, int b, int Xa, int Y0, int lane, double (&ne)[HW_TH * CW / 64]) {
     constexpr int RPI = 64 / CW;
     const int c = lane % CW, rq = lane / CW;
@@ -27,34 +29,37 @@ __device__ __forceinline__ void stars_nelec(const RenderArgs &a, int b, int Xa, 
     const bool ll = (a.flags & CEL_RENDER_LOGLIK) != 0;
     const int64_t base = (int64_t)b * a.H * a.W + (int64_t)(Y0 + rq) * a.W + xi;
 #pragma unroll
-    for (int r = 0; r < HW_TH / RPI; r++)
-        ne[r] = (ll && xi < a.W && Y0 + RPI * r + rq < a.H) ? a.nelec[base + (int64_t)(RPI * r) * a.W] : 0.0;
+    for (int r = 0; r < HW_TH / RPI; r++) {
+        if (INSIDE) ne[r] = a.nelec[base + (int64_t)(RPI * r) * a.W];
+        else ne[r] = (ll && xi < a.W && Y0 + RPI * r + rq < a.H) ? a.nelec[base + (int64_t)(RPI * r) * a.W] : 0.0;
+    }
 }
 
 // epilogue of one part: lambda = eps + acc written once, the Poisson terms summed per lane
-template <int CW>
+template <int CW, bool INSIDE, bool STORE>
 __device__ __forceinline__ double stars_epilogue(const RenderArgs &a, const double *__restrict__ acc, const double *__restrict__ lt,
-                                                 double eps, int b, int Xa, int Y0, int lane, double (&ne)[HW_TH * CW / 64]) {
+                                                 double eps, int b, int Xa, int Y0, int lane, const double (&ne)[HW_TH * CW / 64]) {
     constexpr int RPI = 64 / CW;
     const int c = lane % CW, rq = lane / CW;
     const int xi = Xa + c;
-    const bool store = !(a.flags & CEL_RENDER_NO_STORE);
-    const bool ll = (a.flags & CEL_RENDER_LOGLIK) != 0;
+    const int64_t base = (int64_t)b * a.H * a.W + (int64_t)(Y0 + rq) * a.W + xi;
     double part = 0.0;
-    if (xi < a.W) {
-        const int64_t base = (int64_t)b * a.H * a.W + (int64_t)(Y0 + rq) * a.W + xi;
+    if (INSIDE) {
+#pragma unroll
+        for (int r = 0; r < HW_TH / RPI; r++) {
+            const double lam = eps + acc[r * 64 + lane];
+            if (STORE) a.lambda[base + (int64_t)(RPI * r) * a.W] = lam;
+            part += ne[r] * log_tab(lam, lt) - lam;
+        }
+    } else if (xi < a.W) {
+        const bool ll = (a.flags & CEL_RENDER_LOGLIK) != 0;
 #pragma unroll
         for (int r = 0; r < HW_TH / RPI; r++) {
             if (Y0 + RPI * r + rq < a.H) {
                 const double lam = eps + acc[r * 64 + lane];
+                if (STORE) a.lambda[base + (int64_t)(RPI * r) * a.W] = lam;
                 if (ll) part += ne[r] * log_tab(lam, lt) - lam;
-                ne[r] = lam;
             }
-        }
-        if (store) {     // behind the terms (see hw_epilogue)
-#pragma unroll
-            for (int r = 0; r < HW_TH / RPI; r++)
-                if (Y0 + RPI * r + rq < a.H) a.lambda[base + (int64_t)(RPI * r) * a.W] = ne[r];
         }
     }
     return part;
@@ -98,6 +103,8 @@ k_render_stars(RenderArgs a) {
     const double eps = bd->eps;
     unsigned d0 = 0;
     double part = 0.0;
+    const bool inside = (X0 + HW_TW <= a.W) && (Y0 + HW_TH <= a.H) && (a.flags & CEL_RENDER_LOGLIK);
+    const bool store = !(a.flags & CEL_RENDER_NO_STORE);
     if (nstar <= 64) star_stage(a, ST, recs, off, 0, nstar, lane, X0, Y0, strict);   // one batch: staged once for all parts
     for (int p = 0; p < ST_NP; p++) {
         const int Xa = X0 + p * ST_CW;
@@ -105,7 +112,7 @@ k_render_stars(RenderArgs a) {
 #pragma unroll
         for (int r = 0; r < HW_TH * ST_CW / 64; r++) acc[r * 64 + lane] = 0.0;
         double ne[HW_TH * ST_CW / 64];
-        if (PRE) stars_nelec<ST_CW>(a, b, Xa, Y0, lane, ne);
+        if (PRE && inside) stars_nelec<ST_CW, true>(a, b, Xa, Y0, lane, ne);
         if (nstar <= 64) {
             star_walk<false, ST_CW>(a, ST, et, acc, nstar, lane, Xa, Y0, strict, d0);
         } else {
@@ -116,8 +123,15 @@ k_render_stars(RenderArgs a) {
             }
         }
         __syncthreads();
-        if (!PRE) stars_nelec<ST_CW>(a, b, Xa, Y0, lane, ne);
-        part += stars_epilogue<ST_CW>(a, acc, lt, eps, b, Xa, Y0, lane, ne);
+        if (inside) {
+            if (!PRE) stars_nelec<ST_CW, true>(a, b, Xa, Y0, lane, ne);
+            part += store ? stars_epilogue<ST_CW, true, true>(a, acc, lt, eps, b, Xa, Y0, lane, ne)
+                          : stars_epilogue<ST_CW, true, false>(a, acc, lt, eps, b, Xa, Y0, lane, ne);
+        } else {
+            stars_nelec<ST_CW, false>(a, b, Xa, Y0, lane, ne);
+            part += store ? stars_epilogue<ST_CW, false, true>(a, acc, lt, eps, b, Xa, Y0, lane, ne)
+                          : stars_epilogue<ST_CW, false, false>(a, acc, lt, eps, b, Xa, Y0, lane, ne);
+        }
     }
     if (a.flags & CEL_RENDER_LOGLIK) {
         part = wave_sum(part);

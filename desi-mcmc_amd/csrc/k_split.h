@@ -535,14 +535,27 @@ k_photon_split_hw(SplitArgs a) {
     et[lane] = exp2((double)lane * (1.0 / 64.0));
     lt[lane] = c_log_ic[lane];
     lt[64 + lane] = c_log_lc[lane];
+    // Every load unconditional (a pixel outside the frame reads the band's first pixel and drops the value): with a
+    // load under a condition the compiler waits for each one before it issues the next (s_waitcnt vmcnt(0) where the
+    // paths meet) -- 16 memory round trips one behind the other at the start of every block.
+    {
+        double rt[SP_TH / 2], ne[SP_TH / 2];
 #pragma unroll
-    for (int r = 0; r < SP_TH / 2; r++) {
-        const int y = Y0 + 2 * r + half;
-        const bool in = (xi < a.W) && (y < a.H);
-        const int64_t idx = plane + (int64_t)y * a.W + xi;
-        one[r * 64 + lane] = 0.0;
-        rate[r * 64 + lane] = in ? a.rate_img[idx] : eps;
-        left[r * 64 + lane] = in ? photons_int(a.nelec[idx]) : 0;
+        for (int r = 0; r < SP_TH / 2; r++) {
+            const int y = Y0 + 2 * r + half;
+            const bool in = (xi < a.W) && (y < a.H);
+            const int64_t idx = in ? plane + (int64_t)y * a.W + xi : plane;
+            rt[r] = a.rate_img[idx];
+            ne[r] = a.nelec[idx];
+        }
+#pragma unroll
+        for (int r = 0; r < SP_TH / 2; r++) {
+            const int y = Y0 + 2 * r + half;
+            const bool in = (xi < a.W) && (y < a.H);
+            one[r * 64 + lane] = 0.0;
+            rate[r * 64 + lane] = in ? rt[r] : eps;
+            left[r * 64 + lane] = in ? photons_int(ne[r]) : 0;
+        }
     }
     const int cnt = a.tile_cnt[tile];
     const int64_t off = a.tile_off[tile];
@@ -662,12 +675,20 @@ k_photon_split_hw(SplitArgs a) {
     // what is left belongs to the sky (:153); a pixel nobody covers adds its nelec as it is, not
     // truncated to an integer (:91-93)
     double noise = 0.0;
+    double raw[SP_TH / 2];            // unconditional loads again (the tile is in L2): all 16 in flight at once
 #pragma unroll
     for (int r = 0; r < SP_TH / 2; r++) {
         const int y = Y0 + 2 * r + half;
-        if (y < a.noise_y0 || y >= a.noise_y1) continue;
-        if ((covered >> r) & 1u) noise += (double)left[r * 64 + lane];
-        else if (xi < a.W && y < a.H) noise += a.nelec[plane + (int64_t)y * a.W + xi];
+        const bool in = (xi < a.W) && (y < a.H);
+        raw[r] = a.nelec[in ? plane + (int64_t)y * a.W + xi : plane];
+    }
+#pragma unroll
+    for (int r = 0; r < SP_TH / 2; r++) {
+        const int y = Y0 + 2 * r + half;
+        const bool counted = (y >= a.noise_y0) && (y < a.noise_y1);
+        const bool in = (xi < a.W) && (y < a.H);
+        const double v = ((covered >> r) & 1u) ? (double)left[r * 64 + lane] : (in ? raw[r] : 0.0);
+        noise += counted ? v : 0.0;
     }
     noise = wave_sum(noise);
     if (lane == 0) a.partials[2 * tile + sub] = noise;

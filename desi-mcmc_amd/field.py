@@ -76,6 +76,15 @@ class Context(object):
         L.check(L.lib().cel_profile_get(self._h, L.KERNELS[kernel], C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_render(self):
+        """(mean ms, launches, kernel name) of the field render since the last reset: k_render_stars when the star-tile
+        kernel took the launches (CEL_OPT_STAR_TILES; a catalogue without galaxies), the general kernel otherwise"""
+        ms_s, n_s = self.profile_get("render_stars")
+        ms_g, n_g = self.profile_get("render")
+        if n_s > n_g:
+            return ms_s, n_s, "k_render_stars"
+        return ms_g, n_g, "k_render_hw"
+
     def gmm_like_2d(self, x, ws, mus, sigs, probs=None):
         """probs[n] = sum_k ws[k] N(x[n]; mus[k], sigs[k])  (gmm_like_fast.pyx:130-176)."""
         x, ws, mus, sigs = L.f64(x), L.f64(ws), L.f64(mus), L.f64(sigs)

@@ -82,6 +82,13 @@ enum {
                                patch, at the pixels that hold a photon or densely, whichever the layout pass estimates
                                cheaper; 1 = every patch at its photons; 2 = never (no lists are built).  The values
                                agree to rounding; set it before cel_photon_split */
+    CEL_OPT_STAR_TILES = 10,/* which kernel renders the field of a catalogue WITHOUT galaxies (known when the types
+                               came from host memory): 0 = the general one (k_render_hw); 1 (default) = k_render_stars
+                               -- the same 32 x 64 tiles taken in two column halves, 8 KB of accumulator instead of 16,
+                               three waves per SIMD instead of two -- when the frame has at least 4096 tiles (fewer
+                               would not fill the extra waves); 2 = k_render_stars at any size.  Tile layout 1 and the
+                               row-recurrence only.  The two kernels add a pixel's stars in different orders: values
+                               agree to rounding (1e-15), and which one runs depends on the call's inputs only */
     CEL_OPT_DEBUG = 8       /* diagnostics.  The shipped library accepts two result-preserving bits: 64 = the E-step
                                takes its per-source form, 128 = CEL_OPT_TILE_TIMING's third word carries the
                                row-waste counters of tools/row_waste.py.  The timing-only ABLATION bits (render:
@@ -100,7 +107,8 @@ enum {
     CEL_K_SPLIT = 7,        /* k_photon_split[_hw] */
     CEL_K_MASS = 8,         /* cel_stamp_mass */
     CEL_K_ESTEP = 9,        /* cel_estep_stats */
-    CEL_K_COUNT = 10
+    CEL_K_RENDER_STARS = 10,/* k_render_stars: the field render of a catalogue without galaxies (CEL_OPT_STAR_TILES) */
+    CEL_K_COUNT = 11
 };
 
 typedef struct cel_ctx cel_ctx;

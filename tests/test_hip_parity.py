@@ -425,6 +425,38 @@ def test_full_size_spot_check_vs_oracle(cel, ctx, orc, big_field):
         np.testing.assert_allclose(lam[b, y0:y0 + h, x0:x0 + w], o_lam[0, y0:y0 + h, x0:x0 + w], rtol=RT_LAM)
 
 
+def test_star_field_full_size_star_tile_kernel(cel, ctx, orc):
+    """10 000 stars x 5 bands x 2048^2 (bench workload stars10k_2048): a catalogue without galaxies on a frame of
+    10 240 tiles takes k_render_stars by default.  Every model pixel against the oracle (1e-10), the per-band
+    log-likelihoods (1e-11), the general kernel on the same input (rounding), run-to-run bit identity."""
+    from desi_mcmc_amd import synth
+    L = cel._lib
+    f = synth.SyntheticField.from_config(ctx, "stars10k_2048")
+    try:
+        ctx.profile(True)
+        ll1, llb1 = f.images.render(f.sources, loglik=True)
+        assert ctx.profile_render()[1:] == (1, "k_render_stars")
+        ctx.profile(False)
+        lam1 = f.images.model_images()
+        ll2, llb2 = f.images.render(f.sources, loglik=True)
+        assert ll1 == ll2 and np.array_equal(llb1, llb2) and np.array_equal(lam1, f.images.model_images())
+        ctx.set_option(L.CEL_OPT_STAR_TILES, 0)
+        ctx.profile(True)
+        ll0, llb0 = f.images.render(f.sources, loglik=True)
+        assert ctx.profile_render()[1:] == (1, "k_render_hw")
+        ctx.profile(False)
+        np.testing.assert_allclose(f.images.model_images(), lam1, rtol=1e-13)
+        np.testing.assert_allclose(llb0, llb1, rtol=1e-13)
+        o_lam, o_ll, o_st = orc.render_field(oracle_bands(f), f.H, f.W, f.src["type"], f.src["radec"],
+                                             f.src["counts"], f.src["shape"], f.nelec)
+        np.testing.assert_allclose(lam1, o_lam, rtol=RT_LAM)
+        np.testing.assert_allclose(llb1, o_ll, rtol=RT_LL)
+        assert f.images.stats()["n_srcpix"] == o_st["n_srcpix"]
+    finally:
+        ctx.set_option(L.CEL_OPT_STAR_TILES, 1)
+        ctx.profile(False)
+
+
 def test_config3_full_vs_oracle(cel, ctx, orc, big_field):
     """BASELINE configs[2] at full size against the CPU oracle over the WHOLE field: all 10 000
     sources, all 5 bands, every one of the 2.1e7 model pixels at 1e-10, per-band log-likelihoods at
@@ -1263,6 +1295,103 @@ def test_fuzz_star_fields_vs_oracle(cel, ctx, orc, seed):
     # the split conserves every photon on the same (stars-first) lists
     noise = iset.photon_split_resident(ss, seed=seed)
     np.testing.assert_array_equal(iset.sample_sums().sum(axis=0) + noise, nelec.reshape(5, -1).sum(axis=1))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_star_tile_kernel_vs_oracle_and_general_kernel(cel, ctx, orc, seed):
+    """k_render_stars (CEL_OPT_STAR_TILES; a catalogue without galaxies): the same random star fields as above --
+    frames that are no multiple of a tile (edge tiles take the bounded epilogue), tiles with several 64-star
+    batches, stars off every edge, a huge caller radius -- against the oracle (1e-10 / 1e-11) and against the
+    general kernel (rounding); with and without stored model images; which kernel ran is read off the profile
+    slots.  A sharp PSF or a huge radius (seeds 3, 4: no one-segment walk), one galaxy in the catalogue, or types that came from device memory keep the
+    general kernel."""
+    import ctypes as C
+    from desi_mcmc_amd import synth
+    L = cel._lib
+    rs = np.random.RandomState(100 + seed)
+    H, W = int(rs.randint(40, 300)), int(rs.randint(40, 300))
+    S = int(rs.choice([1, 7, 150, 900]))
+    f_bands = synth.make_bands(H, W, 5)
+    if seed == 3:
+        f_bands[:, 12:16] = np.array([0.02, 0.0, 0.0, 0.025])[None, :]
+    if seed == 4:
+        f_bands[:, 36] = 60.0
+    pix = np.column_stack([rs.uniform(-30, W + 30, S), rs.uniform(-30, H + 30, S)])
+    if seed == 5:
+        pix = np.column_stack([rs.uniform(10, 30, S), rs.uniform(5, 60, S)])
+    typ = np.zeros(S, dtype=np.int32)
+    counts = np.exp(rs.uniform(np.log(50.0), np.log(5e4), size=(S, 5)))
+    radec = synth.pixel2equa(f_bands[0], pix)
+    iset = cel.ImageSet(ctx, f_bands, H, W)
+    ss = cel.SourceSet(ctx, S, 5).set(typ, radec, counts)
+
+    def run(mode, sources=ss, store=True):
+        ctx.set_option(L.CEL_OPT_STAR_TILES, mode)
+        ctx.profile(True)
+        ll, llb = iset.render(sources, loglik=True, store=store)
+        n_star, n_gen = ctx.profile_get("render_stars")[1], ctx.profile_get("render")[1]
+        ctx.profile(False)
+        return ll, llb, n_star, n_gen
+
+    try:
+        assert ctx.get_option(L.CEL_OPT_STAR_TILES) == 1.0
+        with pytest.raises(ValueError):
+            ctx.set_option(L.CEL_OPT_STAR_TILES, 3)
+        ctx.set_option(L.CEL_OPT_STAR_TILES, 0)
+        iset.render(ss)
+        ob = f_bands.copy()
+        for b in range(5):
+            ob[b, 36] = iset.band(b)[36]
+        nelec = rs.poisson(iset.model_images()).astype(np.float64)
+        iset.set_nelec(nelec)
+        ll0, llb0, ns0, ng0 = run(0)
+        lam0 = iset.model_images()
+        assert (ns0, ng0) == (0, 1)
+        ll1, llb1, ns1, ng1 = run(1)                 # default: a frame of this size keeps the general kernel
+        assert (ns1, ng1) == (0, 1) and ll1 == ll0
+        ll2, llb2, ns2, ng2 = run(2)
+        lam2 = iset.model_images()
+        assert (ns2, ng2) == ((0, 1) if seed in (3, 4) else (1, 0))      # 3, 4: exponents beyond the one-segment bound
+        o_lam, o_ll, _ = orc.render_field(ob, H, W, typ, radec, counts, np.zeros((S, 4)), nelec)
+        np.testing.assert_allclose(lam2, o_lam, rtol=RT_LAM)
+        np.testing.assert_allclose(llb2, o_ll, rtol=RT_LL)
+        np.testing.assert_allclose(lam2, lam0, rtol=1e-13)
+        np.testing.assert_allclose(llb2, llb0, rtol=1e-13)
+        # log-likelihood only: nothing is stored (the images keep what the last storing render left)
+        iset.render(cel.SourceSet(ctx, 1, 5).set(typ[:1], radec[:1], counts[:1]))
+        keep = iset.model_images()
+        ll3, llb3, ns3, _ = run(2, store=False)
+        assert ns3 == (0 if seed in (3, 4) else 1)
+        np.testing.assert_array_equal(llb3, llb2)
+        np.testing.assert_array_equal(iset.model_images(), keep)
+        # a galaxy in the catalogue: the general kernel
+        typ_g = typ.copy(); typ_g[0] = 1
+        shape_g = np.zeros((S, 4)); shape_g[0] = [0.5, 2.0, 30.0, 0.7]
+        sg = cel.SourceSet(ctx, S, 5).set(typ_g, radec, counts, shape_g)
+        assert run(2, sources=sg)[2:] == (0, 1)
+        # types uploaded from device memory: the composition is unknown, the general kernel
+        hip = C.CDLL(L.LIB_PATH)                  # dlsym through the library finds the HIP runtime IT is linked to
+        hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipFree.argtypes = [C.c_void_p]
+        host = [typ, np.ascontiguousarray(radec), np.ascontiguousarray(counts), np.zeros((S, 4))]
+        dptr = []
+        for h in host:
+            d = C.c_void_p()
+            assert hip.hipMalloc(C.byref(d), max(h.nbytes, 8)) == 0
+            assert hip.hipMemcpy(d, h.ctypes.data, h.nbytes, 1) == 0
+            dptr.append(d)
+        sd = cel.SourceSet(ctx, S, 5)
+        sd.set_device(S, *[d.value for d in dptr])
+        sd.S = S
+        ll4, llb4, ns4, ng4 = run(2, sources=sd)
+        assert (ns4, ng4) == (0, 1)
+        np.testing.assert_array_equal(llb4, llb0)
+        for d in dptr:
+            hip.hipFree(d)
+    finally:
+        ctx.set_option(L.CEL_OPT_STAR_TILES, 1)
+        ctx.profile(False)
 
 
 def test_bench_line_contract_on_the_small_star_workload():
