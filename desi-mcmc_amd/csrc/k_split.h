@@ -199,38 +199,58 @@ __device__ inline long long binomial_draw(long long n, double p, Philox &g, cons
 // the (band, source) records into source-major patch boxes and offsets (an exclusive scan of the
 // box areas) in ONE block; k_patch_sums reduces every patch to its photon count (what the flux
 // Gibbs step conditions on, sources.py:327-345).
+// inclusive prefix sum over the 1024 threads of a block (+ the block's total, to every thread): a shuffle scan inside
+// every wave, the 16 wave totals through LDS -- two barriers; the Hillis-Steele scan over LDS it replaces took twenty
+__device__ __forceinline__ long long block_scan_1024(long long v, long long *__restrict__ wtot /* 16 */, long long &total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long up = __shfl_up(v, o);
+        if (lane >= o) v += up;
+    }
+    if (lane == 63) wtot[w] = v;
+    __syncthreads();
+    long long before = 0, all = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const long long t = wtot[j];
+        before += (j < w) ? t : 0;
+        all += t;
+    }
+    __syncthreads();                  // wtot is rewritten by the next call
+    total = all;
+    return v + before;
+}
+
 __global__ void __launch_bounds__(1024)
 k_samp_layout(const SrcRec *__restrict__ recs, int64_t S, int B, int4 *__restrict__ sbox /* S*B: x0,x1,y0,y1 */,
               int64_t *__restrict__ soff /* S*B + 1 */) {
-    __shared__ long long part[1024];
-    __shared__ long long carry;
+    __shared__ long long wtot[16];
     const int tid = threadIdx.x;
     const int64_t n = S * B;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n; base += 1024) {
-        const int64_t i = base + tid;          // i = s*B + b
-        long long area = 0;
+    // one block walks the table in chunks of 1024; a chunk's records are requested while the previous chunk is scanned
+    auto fetch = [&](int64_t i, int4 &bx, long long &area) {       // i = s*B + b
+        bx = make_int4(0, 0, 0, 0); area = 0;
         if (i < n) {
             const int64_t s = i / B;
             const int b = (int)(i - s * B);
             const SrcRec &r = recs[(int64_t)b * S + s];
-            const bool ok = r.type >= 0;
-            sbox[i] = ok ? make_int4(r.x0, r.x1, r.y0, r.y1) : make_int4(0, 0, 0, 0);
-            area = ok ? (long long)(r.x1 - r.x0) * (r.y1 - r.y0) : 0;
+            if (r.type >= 0) { bx = make_int4(r.x0, r.x1, r.y0, r.y1); area = (long long)(r.x1 - r.x0) * (r.y1 - r.y0); }
         }
-        part[tid] = area;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {            // inclusive Hillis-Steele scan
-            long long v = (tid >= o) ? part[tid - o] : 0;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
-        }
-        if (i < n) soff[i] = carry + part[tid] - area;   // exclusive
-        __syncthreads();
-        if (tid == 1023) carry += part[1023];
-        __syncthreads();
+    };
+    long long carry = 0;               // the same in every thread
+    int4 bx_next;
+    long long area_next;
+    fetch(tid, bx_next, area_next);
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + tid;
+        const int4 bx = bx_next;
+        const long long area = area_next;
+        fetch(i + 1024, bx_next, area_next);
+        long long total;
+        const long long incl = block_scan_1024(area, wtot, total);
+        if (i < n) { sbox[i] = bx; soff[i] = carry + incl - area; }      // exclusive
+        carry += total;
     }
     if (tid == 0) soff[n] = carry;
 }
@@ -283,15 +303,11 @@ k_nz_layout(const int *__restrict__ nnz, const int4 *__restrict__ nzbox, const i
             int64_t S, int B, int force /* 0 = estimate, 1 = every patch at its photons, 2 = every patch densely */,
             double bias /* force 0: at the photons unless that is estimated more than `bias` times the dense cost */,
             int64_t *__restrict__ loff /* S*B + 1: list offsets */, int *__restrict__ mode /* S*B: 1 = evaluate at the photons */) {
-    __shared__ long long part[1024];
-    __shared__ long long carry;
+    __shared__ long long wtot[16];
     const int tid = threadIdx.x;
     const int64_t n = S * B;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n; base += 1024) {
-        const int64_t i = base + tid;
-        long long cnt = 0;
+    auto fetch = [&](int64_t i, long long &cnt, int &md) {
+        cnt = 0; md = 0;
         if (i < n) {
             cnt = nnz[i];
             const int4 q = nzbox[i];
@@ -299,20 +315,21 @@ k_nz_layout(const int *__restrict__ nnz, const int4 *__restrict__ nzbox, const i
             const long long chunks = (cnt > 0) ? (long long)((q.y - q.x + HW_TW - 1) / HW_TW) * ((q.w - q.z + HW_TH - 1) / HW_TH) : 0;
             const long long sparse_cost = ((cnt + 63) / 64) * K * 17 + 150;
             const long long dense_cost = chunks * ((K == K_PSF) ? 1900 : 6800);
-            mode[i] = (force == 1) ? 1 : (force == 2) ? 0 : ((double)sparse_cost < bias * (double)dense_cost ? 1 : 0);
+            md = (force == 1) ? 1 : (force == 2) ? 0 : ((double)sparse_cost < bias * (double)dense_cost ? 1 : 0);
         }
-        part[tid] = cnt;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            long long v = (tid >= o) ? part[tid - o] : 0;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
-        }
-        if (i < n) loff[i] = carry + part[tid] - cnt;
-        __syncthreads();
-        if (tid == 1023) carry += part[1023];
-        __syncthreads();
+    };
+    long long carry = 0, cnt_next;
+    int md_next;
+    fetch(tid, cnt_next, md_next);
+    for (int64_t base = 0; base < n; base += 1024) {      // a chunk's inputs are requested while the previous chunk is scanned
+        const int64_t i = base + tid;
+        const long long cnt = cnt_next;
+        const int md = md_next;
+        fetch(i + 1024, cnt_next, md_next);
+        long long total;
+        const long long incl = block_scan_1024(cnt, wtot, total);
+        if (i < n) { mode[i] = md; loff[i] = carry + incl - cnt; }
+        carry += total;
     }
     if (tid == 0) loff[n] = carry;
 }
@@ -329,15 +346,27 @@ k_nz_compact(const int4 *__restrict__ sbox, const int64_t *__restrict__ soff, co
     NzEntry *out = list + loff[i];
     const int64_t cap = loff[i + 1] - loff[i];
     int64_t pos = 0;
-    for (int y = q.z; y < q.w; y++) {
-        const int *row = p + (int64_t)(y - bx.z) * nx - bx.x;
-        for (int x0 = q.x; x0 < q.y; x0 += 64) {
-            const int x = x0 + lane;
-            const int z = (x < q.y) ? row[x] : 0;
-            const unsigned long long m = __ballot(z != 0);
-            if (z != 0) {
+    // (row, 64-column chunk) steps in row-major order, four at a time: their loads are issued together (unconditional,
+    // clamped addresses) instead of one memory round trip per row, and taken in order afterwards
+    const int nch = (q.y - q.x + 63) >> 6;
+    const int nsteps = (q.w - q.z) * nch;
+    for (int u0 = 0; u0 < nsteps; u0 += 4) {
+        int z[4], xs[4], ys[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int u = min(u0 + j, nsteps - 1);
+            const int r = u / nch, ch = u - r * nch;
+            ys[j] = q.z + r;
+            xs[j] = q.x + 64 * ch + lane;
+            z[j] = p[(int64_t)(ys[j] - bx.z) * nx - bx.x + min(xs[j], q.y - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int zz = (u0 + j < nsteps && xs[j] < q.y) ? z[j] : 0;
+            const unsigned long long m = __ballot(zz != 0);
+            if (zz != 0) {
                 const int64_t k = pos + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                if (k < cap) out[k] = NzEntry{x | (y << 16), z};
+                if (k < cap) out[k] = NzEntry{xs[j] | (ys[j] << 16), zz};
             }
             pos += __popcll(m);
         }
