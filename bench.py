@@ -458,12 +458,13 @@ def extra_render_legs(args, env, field, out):
 def secondary_legs(args, env, field):
     """After the timed region of the default run (N = 1): bounded measurements of the OTHER configurations, so that the
     driver's one line carries them too -- BASELINE configs[4] (Gibbs sweeps over this same field: samples/s and the
-    sweep's phases), configs[1] (stars1k_512) and the star-only regime where the HBM roof binds (stars10k_2048).
+    sweep's phases), configs[1] (stars1k_512) and the star-only regimes where the HBM roof binds (stars10k_2048: a star on
+    every tile; stars2k_4096: a sparse 4096^2 frame, 1.34 GB of image traffic per launch -- `north_star`'s 60 %-of-HBM regime).
     Each is what `bench.py --workload NAME` reports, on fewer steps; none of them touches the headline fields."""
     torch, cel, dist, synth, ctx = env["torch"], env["cel"], env["dist"], env["synth"], env["ctx"]
     from desi_mcmc_amd import celeste_mcmc
     sec = {}
-    for name, steps in (("stars10k_2048", 100), ("stars1k_512", 200)):
+    for name, steps in (("stars10k_2048", 100), ("stars2k_4096", 100), ("stars1k_512", 200)):
         f = synth.SyntheticField.from_config(ctx, name, seed=42)
         S, B, H, W, fg = synth.CONFIGS[name]
         for _ in range(30):
@@ -795,6 +796,9 @@ def main():
                     help="fields8_2048: contexts (HIP streams, a host thread each) per GPU the rank's fields run on; 2 is 3 %% faster, "
                          "but the kernels' event times then include each other")
     ap.add_argument("--slice-sigma", type=float, default=0.001, help="gibbs10k: slice-sampler interval width in degrees")
+    ap.add_argument("--star-tiles", type=int, default=1, choices=[0, 1, 2],
+                    help="CEL_OPT_STAR_TILES: 0 = the general render kernel always, 1 (default) = k_render_stars for a catalogue "
+                         "without galaxies on a frame of at least 4096 tiles, 2 = at any size")
     ap.add_argument("--photon-lists", type=int, default=0, choices=[0, 1, 2],
                     help="gibbs10k: CEL_OPT_PHOTON_LISTS (0 = per patch whichever is cheaper, 1 = always at the photons, 2 = always densely)")
     ap.add_argument("--split", default="replicated", choices=["replicated", "strips"],
@@ -846,6 +850,7 @@ def main():
     ctx.set_option(_lib.CEL_OPT_TILE_LAYOUT, args.layout)
     ctx.set_option(_lib.CEL_OPT_TILE_ORDER, args.tile_order)
     ctx.set_option(_lib.CEL_OPT_PHOTON_LISTS, args.photon_lists)
+    ctx.set_option(_lib.CEL_OPT_STAR_TILES, args.star_tiles)
     backend = "none"
     if world > 1:
         import torch.distributed as td

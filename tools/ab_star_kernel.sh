@@ -1,15 +1,15 @@
 #!/bin/bash
-# A/B of the star-tile kernel (CEL_STAR_KERNEL = number of column parts, 0 = k_render_hw) on the star fields
+# A/B of the star-tile kernel (CEL_OPT_STAR_TILES through bench.py --star-tiles) on the star fields
 set -e
 mkdir -p gpurun_out
-for v in ${VARIANTS:-0 1 2 4}; do
-  CEL_STAR_KERNEL=$v python bench.py --workload stars10k_2048 --steps 200 --warmup 20 --legs none > gpurun_out/star_kernel_$v.json 2> gpurun_out/star_kernel_$v.err
-  CEL_STAR_KERNEL=$v python bench.py --workload stars1k_512 --steps 200 --warmup 20 --legs none > gpurun_out/star_kernel_1k_$v.json 2>> gpurun_out/star_kernel_$v.err
-done
-python - <<'PY'
-import json, os
-for v in os.environ.get("VARIANTS", "0 1 2 4").split():
-    for n in (f"star_kernel_{v}", f"star_kernel_1k_{v}"):
-        d=json.loads(open(f"gpurun_out/{n}.json").read().strip().splitlines()[-1])
-        print(n, round(d["ms_per_step"],4), d["roofline"].get("kernel_ms"), round(d["roofline"]["achieved"],1))
+for w in ${WORKLOADS:-stars10k_2048 stars2k_4096 stars1k_512}; do
+  for v in ${VARIANTS:-0 1}; do
+    python bench.py --workload $w --steps 200 --warmup 20 --legs none --cpu-sample 0 --star-tiles $v > gpurun_out/star_${w}_$v.json 2> gpurun_out/star_${w}_$v.err
+    python - $w $v <<'PY'
+import json, sys
+w, v = sys.argv[1:3]
+d = json.loads(open(f"gpurun_out/star_{w}_{v}.json").read().strip().splitlines()[-1])
+print(w, "star_tiles", v, "step %.4f ms" % d["ms_per_step"], d["roofline"]["kernel"], "%.4f ms" % d["roofline"]["kernel_ms"], "%.0f GB/s" % d["roofline"]["achieved"], "frac %.3f" % d["roofline"]["frac"])
 PY
+  done
+done

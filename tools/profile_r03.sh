@@ -26,14 +26,16 @@ pmc() {     # tag, PMC_PROG
   tag=$1; prog=$2
   (cd $root && PMC_PROG="$prog" tools/pmc_pass.sh r03_$tag "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE" > gpurun_out/r03_${tag}_pmc.txt 2>&1)
   (cd $root && python3 tools/pmc_summarise.py r03_$tag "PMC_PROG=\"$prog\" tools/pmc_pass.sh r03_$tag ..." > gpurun_out/r03_${tag}_pmc.json)
+  # the bench run that follows reads its PMC figures from profiles/ (and only when the library hash matches): hand it this pass
+  cp $root/gpurun_out/r03_${tag}_pmc.json $root/profiles/r03_${tag}_pmc.json
 }
 if [ $what = final ] || [ $what = all ]; then
-  stats final --steps 200 --warmup 30 --cpu-sample 0 --legs none
   pmc final "bench.py --steps 3 --warmup 1 --cpu-sample 0 --legs none"
+  stats final --steps 200 --warmup 30 --cpu-sample 0 --legs none
 fi
 if [ $what = stars ] || [ $what = all ]; then
-  stats stars --workload stars10k_2048 --steps 200 --warmup 30 --cpu-sample 0 --legs none
   pmc stars "bench.py --workload stars10k_2048 --steps 3 --warmup 1 --cpu-sample 0 --legs none"
+  stats stars --workload stars10k_2048 --steps 200 --warmup 30 --cpu-sample 0 --legs none
 fi
 if [ $what = gibbs ] || [ $what = all ]; then
   stats gibbs --workload gibbs10k --steps 10 --warmup 2 --cpu-sample 0
