@@ -111,7 +111,8 @@ struct cel_ctx {
     int variant = 1;
     double tail_T = 32.0;
     bool profile = false;
-    int star_tiles = 1;       // CEL_OPT_STAR_TILES
+    int star_tiles = (getenv("CEL_STAR_TILES") && atoi(getenv("CEL_STAR_TILES")) >= 0 && atoi(getenv("CEL_STAR_TILES")) <= 2)
+                         ? atoi(getenv("CEL_STAR_TILES")) : 1;       // CEL_OPT_STAR_TILES (the env var: the initial value, for test runs)
     int tile_order = 1;       // 0 = launch k_render tiles in index order, 1 = heaviest first by the last render's measured tile durations (estimate when none), 2 = heaviest first by the estimate only
     int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created
     bool tile_timing = false; // diagnostic: k_render stamps each tile's start/end wall clock
