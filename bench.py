@@ -798,7 +798,7 @@ def main():
     ap.add_argument("--slice-sigma", type=float, default=0.001, help="gibbs10k: slice-sampler interval width in degrees")
     ap.add_argument("--star-tiles", type=int, default=1, choices=[0, 1, 2],
                     help="CEL_OPT_STAR_TILES: 0 = the general render kernel always, 1 (default) = k_render_stars for a catalogue "
-                         "without galaxies on a frame of at least 4096 tiles, 2 = at any size")
+                         "without galaxies on a frame of more than 2048 tiles, 2 = at any size")
     ap.add_argument("--photon-lists", type=int, default=0, choices=[0, 1, 2],
                     help="gibbs10k: CEL_OPT_PHOTON_LISTS (0 = per patch whichever is cheaper, 1 = always at the photons, 2 = always densely)")
     ap.add_argument("--split", default="replicated", choices=["replicated", "strips"],

@@ -859,11 +859,12 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
             if (!im->d_timing) HIP_TRY(hipMalloc((void **)&im->d_timing, sizeof(unsigned long long) * 3 * T));
             a.timing = im->d_timing;
         }
-        // a catalogue without galaxies: the star-tile kernel (k_render_stars.h), when the frame fills its waves; the
+        // a catalogue without galaxies: the star-tile kernel (k_render_stars.h), when the frame has more tiles than the
+        // general kernel has wave slots (STAR_TILES_MIN; measured break-even, tools/star_tiles_threshold.py); the
         // instantiation with counters / time stamps / ablations exists for the general kernel only
         const bool diag = a.timing || (c->debug & ~64);
         const bool stars_only = im->TW == HW_TW && !diag && c->star_tiles && src->n_gal == 0 && im->star_one_segment &&
-                                c->variant != 0 && (c->star_tiles == 2 || T >= 4096);
+                                c->variant != 0 && (c->star_tiles == 2 || T > STAR_TILES_MIN);
         pi = prof_slot(c, stars_only ? CEL_K_RENDER_STARS : CEL_K_RENDER);
         if (im->TW == QW_TW)
             LAUNCH_EV(k_render_qw, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);

@@ -65,6 +65,11 @@ __device__ __forceinline__ double stars_epilogue(const RenderArgs &a, const doub
     return part;
 }
 
+// the host's rule (CEL_OPT_STAR_TILES = 1): frames with more tiles than k_render_hw has wave slots on the chip (256 CUs x 8).
+// Measured (tools/star_tiles_threshold.py, star-only fields): 640 tiles 0.039 / 0.042 ms (general / this kernel), 1 440
+// 0.034 / 0.036, 2 560 0.048 / 0.040, 5 760 0.080 / 0.070, 10 240 0.137 / 0.117.
+#define STAR_TILES_MIN 2048
+
 // flags bit (internal): this launch runs beside k_render_hw, which takes the tiles that hold a galaxy
 #define CEL_RENDER_SPLIT_STARS 8
 
