@@ -1357,6 +1357,11 @@ def test_star_tile_kernel_vs_oracle_and_general_kernel(cel, ctx, orc, seed):
         np.testing.assert_allclose(llb2, o_ll, rtol=RT_LL)
         np.testing.assert_allclose(lam2, lam0, rtol=1e-13)
         np.testing.assert_allclose(llb2, llb0, rtol=1e-13)
+        # model images only (no log-likelihood asked for: the bounded epilogue without its loads)
+        ctx.set_option(L.CEL_OPT_STAR_TILES, 2)
+        iset.render(cel.SourceSet(ctx, 1, 5).set(typ[:1], radec[:1], counts[:1]))
+        iset.render(ss)
+        np.testing.assert_array_equal(iset.model_images(), lam2)
         # log-likelihood only: nothing is stored (the images keep what the last storing render left)
         iset.render(cel.SourceSet(ctx, 1, 5).set(typ[:1], radec[:1], counts[:1]))
         keep = iset.model_images()
