@@ -353,6 +353,12 @@ __device__ __forceinline__ void hw_epilogue(const RenderArgs &a, const double *_
                 part += ne[r] * log_tab(lam, lt) - lam;
             }
         }
+    } else if (inside && !ll && !dbg) {      // model images only (gen_model_image): stores, none of them under a condition
+        if (store) {
+            const int64_t base = plane + (int64_t)(Y0 + half) * a.W + xi;
+#pragma unroll
+            for (int r = 0; r < HW_TH / 2; r++) a.lambda[base + (int64_t)(2 * r) * a.W] = eps + acc[r * 64 + lane];
+        }
     } else if (xi < a.W && !(dbg & 16)) {
         const int64_t base = plane + (int64_t)(Y0 + half) * a.W + xi;
         double ne[HW_TH / 2];

@@ -108,7 +108,8 @@ k_render_stars(RenderArgs a) {
     const double eps = bd->eps;
     unsigned d0 = 0;
     double part = 0.0;
-    const bool inside = (X0 + HW_TW <= a.W) && (Y0 + HW_TH <= a.H) && (a.flags & CEL_RENDER_LOGLIK);
+    const bool in_frame = (X0 + HW_TW <= a.W) && (Y0 + HW_TH <= a.H);
+    const bool inside = in_frame && (a.flags & CEL_RENDER_LOGLIK);
     const bool store = !(a.flags & CEL_RENDER_NO_STORE);
     if (nstar <= 64) star_stage(a, ST, recs, off, 0, nstar, lane, X0, Y0, strict);   // one batch: staged once for all parts
     for (int p = 0; p < ST_NP; p++) {
@@ -132,6 +133,13 @@ k_render_stars(RenderArgs a) {
             if (!PRE) stars_nelec<ST_CW, true>(a, b, Xa, Y0, lane, ne);
             part += store ? stars_epilogue<ST_CW, true, true>(a, acc, lt, eps, b, Xa, Y0, lane, ne)
                           : stars_epilogue<ST_CW, true, false>(a, acc, lt, eps, b, Xa, Y0, lane, ne);
+        } else if (in_frame) {                  // model images only: stores, none of them under a condition
+            if (store) {
+                constexpr int RPI = 64 / ST_CW;
+                const int64_t base = (int64_t)b * a.H * a.W + (int64_t)(Y0 + lane / ST_CW) * a.W + Xa + lane % ST_CW;
+#pragma unroll
+                for (int r = 0; r < HW_TH / RPI; r++) a.lambda[base + (int64_t)(RPI * r) * a.W] = eps + acc[r * 64 + lane];
+            }
         } else {
             stars_nelec<ST_CW, false>(a, b, Xa, Y0, lane, ne);
             part += store ? stars_epilogue<ST_CW, false, true>(a, acc, lt, eps, b, Xa, Y0, lane, ne)
