@@ -169,6 +169,7 @@ struct cel_images {
     int *d_tile_cost = nullptr;   // measured duration of every tile in the last render (the next render's launch order)
     int64_t cost_S = -1;          // number of sources that render had (-1: nothing measured yet)
     bool bin_two_level = false;   // a super-tile once held more than BIN_CH candidates: coarse lists in global memory from then on
+    bool nelec_u16 = false;          // every observed pixel in 0 ... 65 535: the split's 16-bit photons-left plane
     bool star_one_segment = false;   // every band passes star_setup's test: k_render_stars may take star tiles
     int64_t order_S = -1;         // d_order already holds the heaviest-first order of those costs (sorted behind that render's readback)
     hipEvent_t ev_step = nullptr; // marks a step's readback copy: the host waits for it, not for the sort queued behind it
@@ -592,8 +593,26 @@ int cel_images_set_nelec(cel_images *im, const double *nelec, int mem) {
     if (!im || !nelec) return fail(CEL_ERR_INVALID, "cel_images_set_nelec: null argument");
     HIP_TRY(hipSetDevice(im->ctx->device));
     int rc = copy_in(im->d_nelec, nelec, sizeof(double) * (size_t)im->B * im->H * im->W, mem, im->ctx->stream);
-    if (rc == CEL_OK) im->have_nelec = true;
-    return rc;
+    if (rc != CEL_OK) return rc;
+    im->have_nelec = true;
+    // the image's range: 0 ... 65 535 everywhere lets the photon split keep its photons-left plane in 16 bits (k_split.h)
+    im->nelec_u16 = false;
+    {
+        const int NB = 512;
+        double *d_rng = nullptr;
+        HIP_TRY(hipMalloc((void **)&d_rng, sizeof(double) * 3 * NB));
+        hipLaunchKernelGGL(k_nelec_range, dim3(NB), dim3(256), 0, im->ctx->stream, (const double *)im->d_nelec,
+                           (int64_t)im->B * im->H * im->W, d_rng);
+        std::vector<double> h((size_t)3 * NB);
+        hipError_t e = hipMemcpyAsync(h.data(), d_rng, sizeof(double) * 3 * NB, hipMemcpyDeviceToHost, im->ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(im->ctx->stream);
+        (void)hipFree(d_rng);
+        HIP_TRY(e);
+        double lo = INFINITY, hi = -INFINITY, bad = 0.0;
+        for (int k = 0; k < NB; k++) { lo = fmin(lo, h[3 * k]); hi = fmax(hi, h[3 * k + 1]); bad += h[3 * k + 2]; }
+        im->nelec_u16 = (bad == 0.0) && (lo >= 0.0) && (hi <= 65535.0);
+    }
+    return CEL_OK;
 }
 
 int cel_images_set_epsilon(cel_images *im, int band, double eps) {
@@ -638,7 +657,7 @@ int cel_images_get_lambda(cel_images *im, double *out, int mem) {
 
 int cel_images_device_ptrs(cel_images *im, void **nelec, void **lambda) {
     if (!im) return fail(CEL_ERR_INVALID, "null images");
-    if (nelec) *nelec = im->d_nelec;
+    if (nelec) { *nelec = im->d_nelec; im->nelec_u16 = false; }     // the caller may write it: no assumption about its range any more
     if (lambda) *lambda = im->d_lambda;
     return CEL_OK;
 }
@@ -1715,8 +1734,13 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         a.debug = c->debug;
         if (hw && (rc = scratch_get(c, 2, sizeof(double) * 2 * (size_t)T, (void **)&a.partials))) return rc;
         int pi = prof_begin(c, CEL_K_SPLIT);
-        if (hw && resident) hipLaunchKernelGGL(k_photon_split_hw<int>, dim3(2 * T), dim3(64), 0, c->stream, a);
-        else if (hw) hipLaunchKernelGGL(k_photon_split_hw<double>, dim3(2 * T), dim3(64), 0, c->stream, a);
+        if (hw && resident) {
+            if (im->nelec_u16) hipLaunchKernelGGL((k_photon_split_hw<int, unsigned short>), dim3(2 * T), dim3(64), 0, c->stream, a);
+            else hipLaunchKernelGGL((k_photon_split_hw<int, int>), dim3(2 * T), dim3(64), 0, c->stream, a);
+        } else if (hw) {
+            if (im->nelec_u16) hipLaunchKernelGGL((k_photon_split_hw<double, unsigned short>), dim3(2 * T), dim3(64), 0, c->stream, a);
+            else hipLaunchKernelGGL((k_photon_split_hw<double, int>), dim3(2 * T), dim3(64), 0, c->stream, a);
+        }
         else if (resident) hipLaunchKernelGGL(k_photon_split<int>, dim3(T), dim3(64), 0, c->stream, a);
         else hipLaunchKernelGGL(k_photon_split<double>, dim3(T), dim3(64), 0, c->stream, a);
         prof_end(c, pi);

@@ -389,6 +389,29 @@ k_binomial_draws(long long n, double p, unsigned long long seed, int64_t N, long
     out[i] = binomial_draw(n, p, g, et, lt);
 }
 
+// smallest / largest value of the observed image (and whether it holds a NaN), per block: the host finishes the
+// reduction.  Decides the photon split's instantiation (TL above).
+__global__ void __launch_bounds__(256)
+k_nelec_range(const double *__restrict__ x, int64_t n, double *__restrict__ out /* 3 per block: min, max, nan count */) {
+    __shared__ double slo[256], shi[256], snan[256];
+    double lo = INFINITY, hi = -INFINITY, bad = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = x[i];
+        if (v == v) { lo = fmin(lo, v); hi = fmax(hi, v); } else bad += 1.0;
+    }
+    slo[threadIdx.x] = lo; shi[threadIdx.x] = hi; snan[threadIdx.x] = bad;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            slo[threadIdx.x] = fmin(slo[threadIdx.x], slo[threadIdx.x + o]);
+            shi[threadIdx.x] = fmax(shi[threadIdx.x], shi[threadIdx.x + o]);
+            snan[threadIdx.x] += snan[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[3 * blockIdx.x] = slo[0]; out[3 * blockIdx.x + 1] = shi[0]; out[3 * blockIdx.x + 2] = snan[0]; }
+}
+
 // int(num_photons_xy) of the reference (celeste_sample_sources.pyx:105), without the undefined
 // behaviour of an out-of-range cast
 __device__ inline int photons_int(double nelec) {
@@ -529,12 +552,14 @@ k_photon_split(SplitArgs a) {
 // agree with the direct kernel's to ~1e-13, so the two kernels make the same draws except where a
 // uniform falls within that distance of a decision boundary.
 #define SP_TH 32
-template <typename TS>
+// TL: the type of the photons-left plane.  unsigned short (valid while every pixel of the image holds 0 ... 65 535 photons: the
+// host knows the image's range, k_nelec_range) takes the block from 25 312 to 23 264 B of LDS, 7 waves per CU instead of 6.
+template <typename TS, typename TL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 k_photon_split_hw(SplitArgs a) {
     __shared__ double one[SP_TH * HW_TW];
     __shared__ double rate[SP_TH * HW_TW];
-    __shared__ int left[SP_TH * HW_TW];
+    __shared__ TL left[SP_TH * HW_TW];
     __shared__ CompTab T;
 #ifdef SPLIT_LDS_PAD        // occupancy experiments only
     __shared__ double lds_pad[SPLIT_LDS_PAD / 8];
@@ -542,9 +567,13 @@ k_photon_split_hw(SplitArgs a) {
 #endif
     // pixels of the current source whose draw needs the sampler proper: queued in the component table's
     // LDS, which is dead between a source's walk and the next source's table (a barrier either side)
-    static_assert(sizeof(CompTab) >= sizeof(unsigned short) * SP_TH * HW_TW, "the draw queue lives in the component table");
+    // ... and behind the queue the sampler's log table (written per source once its table is dead: a block of its own
+    // kilobyte would cost the seventh wave -- LDS is handed out in 512-B granules)
+    static_assert(sizeof(CompTab) >= sizeof(unsigned short) * SP_TH * HW_TW + 128 * sizeof(double),
+                  "the draw queue and the log table live in the component table");
     unsigned short *queue = reinterpret_cast<unsigned short *>(&T);
-    __shared__ double et[64], lt[128];
+    double *lt = reinterpret_cast<double *>(reinterpret_cast<char *>(&T) + sizeof(unsigned short) * SP_TH * HW_TW);
+    __shared__ double et[64];
     const int lane = threadIdx.x;
     const int half = lane >> 5, col = lane & 31;
     const int sub = blockIdx.x & 1;
@@ -562,8 +591,6 @@ k_photon_split_hw(SplitArgs a) {
     const int64_t key0 = (int64_t)b * a.full_H * a.W + (int64_t)a.win_y0 * a.W;   // full-frame pixel index of (x=0, y=0)
     unsigned covered = 0u;            // bit r: this lane's pixel of row pair r lies strictly inside some source's box
     et[lane] = exp2((double)lane * (1.0 / 64.0));
-    lt[lane] = c_log_ic[lane];
-    lt[64 + lane] = c_log_lc[lane];
     // Every load unconditional (a pixel outside the frame reads the band's first pixel and drops the value): with a
     // load under a condition the compiler waits for each one before it issues the next (s_waitcnt vmcnt(0) where the
     // paths meet) -- 16 memory round trips one behind the other at the start of every block.
@@ -583,7 +610,7 @@ k_photon_split_hw(SplitArgs a) {
             const bool in = (xi < a.W) && (y < a.H);
             one[r * 64 + lane] = 0.0;
             rate[r * 64 + lane] = in ? rt[r] : eps;
-            left[r * 64 + lane] = in ? photons_int(ne[r]) : 0;
+            left[r * 64 + lane] = (TL)(in ? photons_int(ne[r]) : 0);
         }
     }
     const int cnt = a.tile_cnt[tile];
@@ -619,6 +646,8 @@ k_photon_split_hw(SplitArgs a) {
         const int Kk = hw_build(T, lc, rec, lane, dropmode, a.tail_T, log_sky, Y0, xa, xb, ra, rb, direct, nullptr, et);
         if (!(SPLIT_ABLATE(a) & 4)) hw_walk(T, et, Kk, x, Y0, ra, rb, on, direct, one, lane);
         __syncthreads();
+        lt[lane] = c_log_ic[lane];          // the component table is dead until the next source: queue + log table
+        lt[64 + lane] = c_log_lc[lane];
         // Two passes over the source's pixels on this half-tile.  Most draws are decided by ONE
         // uniform (U <= 1 - n p gives 0: a pixel in the source's tail); the few that are not would
         // each hold their whole wave in the sampler's loops.  Pass 1 settles the easy pixels and
@@ -636,7 +665,7 @@ k_photon_split_hw(SplitArgs a) {
             bool slow = false;
             if (on && row >= ra && row < rb) {
                 const double F = one[li];
-                const int n = left[li];
+                const int n = (int)left[li];
                 const double tot = rate[li];
                 covered |= 1u << r;
                 if (n > 0 && !(SPLIT_ABLATE(a) & 1)) {
@@ -666,11 +695,11 @@ k_photon_split_hw(SplitArgs a) {
                 const int row = 2 * (li >> 6) + ((li >> 5) & 1), xq = X0 + (li & 31);
                 const double F = one[li];
                 one[li] = 0.0;
-                const int n = left[li];
+                const int n = (int)left[li];
                 const double tot = rate[li];
                 Philox g = philox_init(a.seed, (unsigned long long)(key0 + (int64_t)(Y0 + row) * a.W + xq), (unsigned)s);
                 const long long z = (SPLIT_ABLATE(a) & 2) ? 1 : binomial_draw((long long)n, F * fast_rcp(tot), g, et, lt);
-                left[li] = n - (int)z;
+                left[li] = (TL)(n - (int)z);
                 rate[li] = tot - F;
                 patch0[(int64_t)row * nx + xq] = (TS)z;
                 if (z > 0) {

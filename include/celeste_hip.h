@@ -167,7 +167,9 @@ int cel_images_set_noise_rows(cel_images *img, int y0, int y1);
 int cel_images_get_band(cel_images *img, int band, cel_band *out);
 /* copy the last rendered model images (B*H*W) out */
 int cel_images_get_lambda(cel_images *img, double *out, int mem);
-/* raw device pointers of the library-owned B*H*W buffers (for zero-copy consumers) */
+/* raw device pointers of the library-owned B*H*W buffers (for zero-copy consumers).  Asking for `nelec` tells the library that
+ * the caller may write the observed image in place: it stops assuming the range cel_images_set_nelec found (the photon split's
+ * 16-bit photons-left plane) until the next cel_images_set_nelec */
 int cel_images_device_ptrs(cel_images *img, void **nelec, void **lambda);
 
 /* ---- sources ------------------------------------------------------------------------ */
