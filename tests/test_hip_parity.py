@@ -812,6 +812,63 @@ def test_photon_split_conservation_moments_quirks(cel, ctx, orc):
         assert tot == g["nelec"][b].sum()                                         # every photon lands exactly once
 
 
+def test_photon_split_image_range_instantiations(cel, ctx):
+    """The split keeps its photons-left plane in 16 bits while every observed pixel holds 0 ... 65 535 photons
+    (cel_images_set_nelec finds the range) and in 32 bits otherwise: the two instantiations make the same draws (a draw is
+    keyed by seed, pixel and source), a 70 000-photon pixel or a negative one is conserved exactly, and handing out the
+    image's device pointer (the caller may write it) switches the assumption off."""
+    from desi_mcmc_amd import field
+    g = load_golden("mini_field.npz")
+    H, W, S = int(g["H"]), int(g["W"]), 12
+    bands = field.pack_bands(g)
+    counts = g["flux"] / g["calib"][None, :] * g["kappa"][None, :] * 20.0
+    nelec = np.floor(g["nelec"]).astype(np.float64)
+    assert nelec.min() >= 0 and nelec.max() <= 65535
+    iset = cel.ImageSet(ctx, bands, H, W, nelec=nelec)
+    sset = cel.SourceSet(ctx, S, 5).set(g["is_gal"], g["radec"], counts, g["shape"])
+    p16, boxes, n16 = iset.photon_split(sset, seed=7)                 # 16-bit plane
+
+    def same(pa, pb, skip=None):
+        for b in range(5):
+            for s in range(S):
+                a_, b_ = pa[b][s], pb[b][s]
+                if a_ is None:
+                    assert b_ is None
+                    continue
+                if skip is not None and skip[0] == b:
+                    y0, y1, x0, x1 = boxes[b, s]
+                    yy, xx = skip[1] - y0, skip[2] - x0
+                    if 0 <= yy < a_.shape[0] and 0 <= xx < a_.shape[1]:
+                        a_, b_ = a_.copy(), b_.copy()
+                        a_[yy, xx] = b_[yy, xx] = 0
+                assert np.array_equal(a_, b_)
+
+    iset.device_ptrs()                                                # the caller may write nelec now: 32-bit plane
+    p32, _, n32 = iset.photon_split(sset, seed=7)
+    same(p16, p32)
+    assert np.array_equal(n16, n32)
+    # one pixel far beyond 16 bits, inside source 0's box of band 2; another one negative (sky-subtracted data), uncovered or not
+    y0, y1, x0, x1 = boxes[2, 0]
+    py, px = (y0 + y1) // 2, (x0 + x1) // 2
+    wide = nelec.copy()
+    wide[2, py, px] = 70000.0
+    wide[4, 3, 5] = -4.0
+    iset.set_nelec(wide)
+    pw, bw, nw = iset.photon_split(sset, seed=7)
+    assert np.array_equal(bw, boxes)
+    for b in range(5):
+        tot = sum(pw[b][s].sum() for s in range(S) if pw[b][s] is not None) + nw[b]
+        assert tot == wide[b].sum()
+    same(p16, pw, skip=(2, py, px))       # every other pixel draws what it drew before (the negative one has no photons to split)
+    got = sum(pw[2][s][py - boxes[2, s, 0], px - boxes[2, s, 2]] for s in range(S)
+              if pw[2][s] is not None and boxes[2, s, 0] < py < boxes[2, s, 1] and boxes[2, s, 2] < px < boxes[2, s, 3])
+    assert 0 < got <= 70000
+    iset.set_nelec(nelec)                                             # back inside the range: the 16-bit plane again
+    p16b, _, n16b = iset.photon_split(sset, seed=7)
+    same(p16, p16b)
+    assert np.array_equal(n16, n16b)
+
+
 def test_resident_split_and_loglik_equal_host_buffer_forms(cel, ctx):
     """device-resident sample patches (cel_photon_split with offsets = NULL, resident
     cel_patch_loglik_multi) give exactly what the host-buffer forms give for the same seed"""
