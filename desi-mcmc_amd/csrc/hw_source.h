@@ -119,15 +119,19 @@ __device__ __forceinline__ int hw_build(CompTab &T, const LaneConst &lc, const R
 // components; rows [ra, rb) bound the direct path, the recurrence walks each group's own rows.
 // (forced inline: as a called function it cost a scratch frame per chunk -- 12 GB of scratch writes
 // per 160 000-proposal launch of k_patch_ll_hw)
+// SUM: no tile -- every lane adds what it evaluates to `msum` (the sum over the 64 lanes is the source's total on the
+// rectangle's `on` columns and rows [ra, rb)); acc is not touched.
+template <bool SUM = false>
 __device__ __forceinline__ void hw_walk(const CompTab &T, const double *__restrict__ et, int Kk, double x, int Y0,
-                               int ra, int rb, bool on, bool direct, double *__restrict__ acc, int lane) {
+                               int ra, int rb, bool on, bool direct, double *__restrict__ acc, int lane,
+                               double *__restrict__ msum = nullptr) {
     const int half = lane >> 5, col = lane & 31;
     if (direct) {
         const int kh = (Kk + 1) / 2;
         const int k0 = half ? kh : 0, k1 = half ? Kk : kh;
         for (int row = ra; row < rb; row++) {
             double v = eval_direct(T, k0, k1, x, (double)(Y0 + row), 1.0 / EXP_SCALE);
-            if (on) lds_add(&acc[row * HW_TW + col], v);
+            if (on) { if (SUM) *msum += v; else lds_add(&acc[row * HW_TW + col], v); }
         }
         return;
     }
@@ -143,18 +147,18 @@ __device__ __forceinline__ void hw_walk(const CompTab &T, const double *__restri
             const int k1 = half ? p0 + R : p0 + gA;
             for (int row = ga; row < gb; row++) {
                 double v = eval_direct(T, k0, k1, x, (double)(Y0 + row), 1.0 / EXP_SCALE);
-                if (on) lds_add(&acc[row * HW_TW + col], v);
+                if (on) { if (SUM) *msum += v; else lds_add(&acc[row * HW_TW + col], v); }
             }
             continue;
         }
-        double *colp = acc + col;
+        double *colp = SUM ? nullptr : acc + col;
         switch (gA) {
-        case 6: rec_group_hw<6>(T, et, k0, x, Y0, ga, gb, L, on, colp); break;
-        case 5: rec_group_hw<5>(T, et, k0, x, Y0, ga, gb, L, on, colp); break;
-        case 4: rec_group_hw<4>(T, et, k0, x, Y0, ga, gb, L, on, colp); break;
-        case 3: rec_group_hw<3>(T, et, k0, x, Y0, ga, gb, L, on, colp); break;
-        case 2: rec_group_hw<2>(T, et, k0, x, Y0, ga, gb, L, on, colp); break;
-        default: rec_group_hw<1>(T, et, k0, x, Y0, ga, gb, L, on, colp); break;
+        case 6: rec_group_hw<6, HW_TW, SUM>(T, et, k0, x, Y0, ga, gb, L, on, colp, msum); break;
+        case 5: rec_group_hw<5, HW_TW, SUM>(T, et, k0, x, Y0, ga, gb, L, on, colp, msum); break;
+        case 4: rec_group_hw<4, HW_TW, SUM>(T, et, k0, x, Y0, ga, gb, L, on, colp, msum); break;
+        case 3: rec_group_hw<3, HW_TW, SUM>(T, et, k0, x, Y0, ga, gb, L, on, colp, msum); break;
+        case 2: rec_group_hw<2, HW_TW, SUM>(T, et, k0, x, Y0, ga, gb, L, on, colp, msum); break;
+        default: rec_group_hw<1, HW_TW, SUM>(T, et, k0, x, Y0, ga, gb, L, on, colp, msum); break;
         }
     }
 }

@@ -175,7 +175,7 @@ __device__ __forceinline__ double nz_trip(const NzEntry *__restrict__ L, int n, 
 
 #define PLL_PARTS 4
 template <int MODE, typename TZ = double>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ? 3 : 2, MODE == 3 ? 3 : 2)))
 k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__restrict__ recs,
               const int *__restrict__ owner, const int4 *__restrict__ pbox, const int64_t *__restrict__ offsets,
               const TZ *__restrict__ data, const double *__restrict__ nelec, int H, int W,
@@ -284,24 +284,22 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
             if (split && chunk % PLL_PARTS != part) continue;
             const int xi = X0 + col;
             const bool on = xi < ev.y;
+            if (MODE != 3) {
 #pragma unroll
-            for (int r = 0; r < HW_TH / 2; r++) acc[r * 64 + lane] = 0.0;
+                for (int r = 0; r < HW_TH / 2; r++) acc[r * 64 + lane] = 0.0;
+            }
             bool direct;
             const int Kk = hw_build(T, lc, rec, lane, dropmode, Tdrop, log_floor, Y0, X0, min(ev.y, X0 + HW_TW) - 1, 0, rb, direct, &cj);
-            hw_walk(T, et, Kk, (double)xi, Y0, 0, rb, on, direct, acc, lane);
-            __syncthreads();
-            if (MODE != 3) {
-                lt[lane] = lt_ic;
-                lt[64 + lane] = lt_lc;
-                __syncthreads();
-            }
             if (MODE == 3) {
-#pragma unroll
-                for (int r = 0; r < HW_TH / 2; r++)
-                    if (on && 2 * r + half < rb) m += acc[r * 64 + lane];
-                __syncthreads();
+                // the stamp's mass wants no tile: every lane sums what it evaluates (its columns' rows of its groups), in a fixed order
+                hw_walk<true>(T, et, Kk, (double)xi, Y0, 0, rb, on, direct, nullptr, lane, &m);
                 continue;
             }
+            hw_walk(T, et, Kk, (double)xi, Y0, 0, rb, on, direct, acc, lane);
+            __syncthreads();
+            lt[lane] = lt_ic;
+            lt[64 + lane] = lt_lc;
+            __syncthreads();
             // the chunk's patch data, 16 rows of loads in flight at a time (addresses clamped into
             // the chunk instead of predicated), issued only once the walk's registers are free
             const int64_t zo = (int64_t)(Y0 - bx.z) * zpitch + (min(xi, ev.y - 1) - bx.x);

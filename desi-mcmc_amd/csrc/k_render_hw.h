@@ -34,9 +34,12 @@ __host__ __device__ inline double quad_max_rect_hw(double a, double b, double c,
     return m * 1.00001;
 }
 
-template <int G, int STRIDE = HW_TW>   // STRIDE = doubles between consecutive rows of the accumulator tile
+// SUM: nothing is written to a tile; the rows' sums are added to *msum (this lane's share of the source's total on the
+// rectangle: the stamp-mass kernel needs no accumulator tile at all)
+template <int G, int STRIDE = HW_TW, bool SUM = false>   // STRIDE = doubles between consecutive rows of the accumulator tile
 __device__ inline void rec_group_hw(const CompTab &T, const double *__restrict__ et, int k0, double x,
-                                    int Y0, int ra, int rb, int L, bool on, double *__restrict__ acc_col) {
+                                    int Y0, int ra, int rb, int L, bool on, double *__restrict__ acc_col,
+                                    double *__restrict__ msum = nullptr) {
     double g[G], r[G], q[G];
     const double aon = on ? 1.0 : 0.0;
     for (int sa = ra; sa < rb; sa += L) {
@@ -75,14 +78,18 @@ __device__ inline void rec_group_hw(const CompTab &T, const double *__restrict__
                 g[i] = g1[i] * r1[i];
                 r[i] = r1[i] * q[i];
             }
-            lds_add(&acc_col[row * STRIDE], s0);
-            lds_add(&acc_col[(row + 1) * STRIDE], s1);
+            if (SUM) { *msum += s0; *msum += s1; }
+            else {
+                lds_add(&acc_col[row * STRIDE], s0);
+                lds_add(&acc_col[(row + 1) * STRIDE], s1);
+            }
         }
         if (row < sb) {
             double s0 = g[0];
 #pragma unroll
             for (int i = 1; i < G; i++) s0 += g[i];
-            lds_add(&acc_col[row * STRIDE], s0);
+            if (SUM) *msum += s0;
+            else lds_add(&acc_col[row * STRIDE], s0);
         }
     }
 }
