@@ -149,7 +149,9 @@ int cel_ctx_get_option(cel_ctx *ctx, int key, double *value);
 /* Replaces constructing B FitsImage objects (fits_image.py:48-155) as far as the path reads them. */
 int cel_images_create(cel_ctx *ctx, int B, int H, int W, const cel_band *bands, cel_images **out);
 int cel_images_destroy(cel_images *img);
-/* nelec: B*H*W observed electron counts, FitsImage.nelec (fits_image.py:86-93); stays on device */
+/* nelec: B*H*W observed electron counts, FitsImage.nelec (fits_image.py:86-93); stays on device.  The call also reduces the
+ * image's range on the device (one pass, synchronous): images within 0 ... 65 535 let cel_photon_split keep its photons-left
+ * plane in 16 bits (a seventh wave per CU); any other image takes the 32-bit instantiation, with the same draws */
 int cel_images_set_nelec(cel_images *img, const double *nelec, int mem);
 /* Gibbs resamples the sky level (models.py:156-160) */
 int cel_images_set_epsilon(cel_images *img, int band, double eps);
