@@ -373,6 +373,64 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
 #undef PLL_PUT
 }
 
+// A galaxy's 42 components are 3 x 14: covariance v_j W + P_k about the same centre for the 14 profile variances v_j of PSF
+// component k.  In the basis that diagonalises the pair (W, P_k) -- M_k with M^T W M = I, M^T P_k M = diag(l1, l2) -- every
+// one of the 14 quadratic forms is a1^2 / (v_j + l1) + a2^2 / (v_j + l2) with a = M_k^T (x - centre_k): the rotated
+// coordinates are formed once per (PSF component, photon) (6 instructions) and a component's exponent is ONE multiply and
+// ONE fma (both terms <= 0: nothing cancels) instead of the five fma of the general quadratic -- 15 VALU per (component,
+// photon) instead of 19.  gk: per PSF component p0 p1 p2 q0 q1 q2 (a1 = p0 + p1 X + p2 Y, a2 likewise; 8 doubles apart);
+// gc: per component s1 s2 A (s = -1/2 * 64/ln2 / (v_j + l); 4 doubles apart), PSF-major like the lanes.
+template <int P>
+__device__ __forceinline__ double nz_trip_gal(const NzEntry *__restrict__ L, int n, int i0, int lane,
+                                              const double *__restrict__ gk, const double *__restrict__ gc,
+                                              const double *__restrict__ ltq, const double *__restrict__ et,
+                                              double px, double py, double counts) {
+    double X[P], Y[P], v[P], z[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int i = i0 + 64 * p + lane;
+        const NzEntry en = L[min(i, n - 1)];
+        X[p] = (double)(en.xy & 0xffff) - px;
+        Y[p] = (double)((unsigned)en.xy >> 16) - py;
+        z[p] = (i < n) ? (double)en.z : 0.0;
+        v[p] = 0.0;
+    }
+    // (rolled loops with their table reads inside: unrolled, the compiler hoists all 144 table values out of the trip loop
+    // into registers it does not have -- 1 KB of scratch per lane)
+#pragma nounroll
+    for (int k = 0; k < K_PSF; k++) {
+        asm volatile("" ::: "memory");
+        const double *g = gk + 8 * k;
+        const double p0 = g[0], p1 = g[1], p2 = g[2], q0 = g[3], q1 = g[4], q2 = g[5];
+        double r1[P], r2[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const double a1 = fma(p1, X[p], fma(p2, Y[p], p0));
+            const double a2 = fma(q1, X[p], fma(q2, Y[p], q0));
+            r1[p] = a1 * a1;
+            r2[p] = a2 * a2;
+        }
+#pragma nounroll
+        for (int j = 0; j < K_PROF; j++) {
+            asm volatile("" ::: "memory");
+            const double *c = gc + 4 * (k * K_PROF + j);
+            const double s1 = c[0], s2 = c[1], A = c[2];
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const double e = fma(s1, r1[p], s2 * r2[p]);
+                v[p] = fma(A, exp_tab64_p4(e, et), v[p]);
+            }
+        }
+    }
+    double a = 0.0;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const double m = counts * v[p];
+        if (z[p] != 0.0 && m > 0.0) a += log_tab(m, ltq) * z[p];
+    }
+    return a;
+}
+
 // ---- mode 0 at the photons ---------------------------------------------------------------------------------
 // sum over a patch's photon list (k_nz_compact) of z log(counts * stamp(x, y)) - counts * sum(psf weights): the same
 // value k_patch_ll_hw<0> forms over the photon rectangle, where only pixels with z > 0 contribute.  Every lane takes
@@ -393,6 +451,7 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     __shared__ double et[64];
     __shared__ double ltq[128];
     __shared__ double cq[8 * K_GAL];
+    __shared__ double gq[32 + 4 * K_GAL];      // a galaxy's table in the rotated form (nz_trip_gal): 3 x 8 + 42 x 4 doubles
     const int lane = threadIdx.x;
     const int64_t jslot = blockIdx.x;
     if (job_count && jslot >= *job_count) return;
@@ -419,6 +478,7 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     if (bx.y - bx.x <= 0 || bx.w - bx.z <= 0) done = true;                              // no sample image in this band
     else if (rec.type == -3) { mass_only = -counts * wsum; done = true; }               // psf_ns is None (sources.py:160-163)
     const int K = (rec.type == 0 || rec.type == -1) ? K_PSF : K_GAL;
+    bool use_gal = false;
     if (!done) {
         if (rec.type < 0) rec.type = (rec.type == -2) ? 1 : 0;
         rec.scale = 1.0;
@@ -426,7 +486,7 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
         ltq[lane] = c_log_ic[lane];
         ltq[64 + lane] = c_log_lc[lane];
         const LaneConst lc = lane_consts(lane, bd);
-        bool alive = false;
+        bool alive = false, gal_ok = true;
         if (lane < K) {
             const Comp c = make_comp_lc(lc, rec);
             // exactly 0 on the whole photon rectangle (exp underflows below -745.2): only the mass term is left, as in the dense kernel
@@ -443,8 +503,35 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
             cq[8 * lane + 5] = -0.5 * qc;
             cq[8 * lane + 6] = c.A;
             cq[8 * lane + 7] = 0.0;
+            if (K == K_GAL) {
+                // the pair (W, P_k) diagonalised: W = L L^T, C = L^-1 P_k L^-T, one Jacobi rotation of C (nz_trip_gal)
+                const double l11 = sqrt(rec.w00), l21 = rec.w01 / l11, d22 = rec.w11 - l21 * l21, l22 = sqrt(d22);
+                const double ia = 1.0 / l11, ic = 1.0 / l22, ib = -l21 * ia * ic;
+                const double C11 = ia * ia * lc.g_cxx, C12 = ia * (ib * lc.g_cxx + ic * lc.g_cxy);
+                const double C22 = ib * ib * lc.g_cxx + 2.0 * ib * ic * lc.g_cxy + ic * ic * lc.g_cyy;
+                double cs = 1.0, sn = 0.0, lam1 = C11, lam2 = C22;
+                if (C12 != 0.0) {
+                    const double tau = (C22 - C11) / (2.0 * C12);
+                    const double t = copysign(1.0, tau) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    cs = 1.0 / sqrt(1.0 + t * t); sn = t * cs;
+                    lam1 = C11 - t * C12; lam2 = C22 + t * C12;
+                }
+                const double d1 = lc.g_var + lam1, d2 = lc.g_var + lam2;
+                const double gs1 = -0.5 * EXP_SCALE / d1, gs2 = -0.5 * EXP_SCALE / d2;
+                const double al1 = cs * ia - sn * ib, be1 = -sn * ic, al2 = sn * ia + cs * ib, be2 = cs * ic;
+                const double g0 = -(al1 * ux + be1 * uy), g3 = -(al2 * ux + be2 * uy);
+                gq[32 + 4 * lane + 0] = gs1; gq[32 + 4 * lane + 1] = gs2; gq[32 + 4 * lane + 2] = c.A;
+                if (lane % K_PROF == 0) {
+                    double *g = gq + 8 * (lane / K_PROF);
+                    g[0] = g0; g[1] = al1; g[2] = be1; g[3] = g3; g[4] = al2; g[5] = be2;
+                }
+                gal_ok = (rec.w00 > 0.0) && (d22 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (gs1 == gs1) && (gs2 == gs2) &&
+                         (g0 == g0) && (g3 == g3) && (fabs(g0) < 1e300) && (fabs(g3) < 1e300);
+            }
         }
         if (__ballot(alive) == 0ull) { mass_only = -counts * wsum; done = true; }
+        // a galaxy whose decomposition is sound on every lane takes the rotated form: the table is rewritten in its layout
+        use_gal = (K == K_GAL) && (__ballot(lane < K && !gal_ok) == 0ull);
     }
     if (done) {
         if (split) { if (lane == 0) outp[part] = (part == 0) ? mass_only : 0.0; }
@@ -464,7 +551,11 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
         if (split && cls != part) continue;
         const int left = n - i0;
         double a;
-        if (left > 128) a = nz_trip<4>(L, n, i0, lane, K, cq, ltq, et, rec.px, rec.py, counts);
+        if (use_gal) {
+            if (left > 128) a = nz_trip_gal<4>(L, n, i0, lane, gq, gq + 32, ltq, et, rec.px, rec.py, counts);
+            else if (left > 64) a = nz_trip_gal<2>(L, n, i0, lane, gq, gq + 32, ltq, et, rec.px, rec.py, counts);
+            else a = nz_trip_gal<1>(L, n, i0, lane, gq, gq + 32, ltq, et, rec.px, rec.py, counts);
+        } else if (left > 128) a = nz_trip<4>(L, n, i0, lane, K, cq, ltq, et, rec.px, rec.py, counts);
         else if (left > 64) a = nz_trip<2>(L, n, i0, lane, K, cq, ltq, et, rec.px, rec.py, counts);
         else a = nz_trip<1>(L, n, i0, lane, K, cq, ltq, et, rec.px, rec.py, counts);
 #pragma unroll
