@@ -789,6 +789,13 @@ def test_photon_lists_agree_with_the_dense_form_fuzz(cel):
         edge = rs.rand(S) < 0.2
         src["radec"][edge] = synth.pixel2equa(f.bands[0], np.column_stack([rs.choice([-3.0, 1.5, W - 2.0, W + 2.5], edge.sum()),
                                                                            rs.uniform(0, H, edge.sum())]))
+        if seed == 5:
+            # the older per-profile route (type 2: shape = theta, W00, W01, W11): a positive definite W takes the kernel's
+            # rotated form like any galaxy, a rank-1 W (no Cholesky factor) its general form
+            gal = np.nonzero(src["type"] == 1)[0][:6]
+            src["type"][gal] = 2
+            src["shape"][gal[:3], 1:] = [[9.0, 2.0, 4.0], [2.5, -1.0, 6.0], [30.0, 12.0, 8.0]]
+            src["shape"][gal[3:], 1:] = [[9.0, 6.0, 4.0], [1.0, 1.0, 1.0], [16.0, -8.0, 4.0]]
         f.sources.set(src["type"], src["radec"], src["counts"], src["shape"])
         f.images.render(f.sources)
         f.images.set_nelec(rs.poisson(f.images.model_images()).astype(np.float64))
