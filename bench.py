@@ -278,13 +278,19 @@ def run_render(args, env):
     def after_warmup():
         if reducer is not None:
             reducer.drain()
-        ctx.profile(True)
+        # the dominant kernel is timed live over the whole timed region (HIP events attached to its dispatches); the three
+        # small kernels around it are timed in a few extra steps afterwards (an event pair costs the host ~10 us per launch:
+        # bracketing all four kernels made the step itself 3 % longer)
+        ctx.profile(2)
 
     def finish():
         if reducer is not None:
             last["llb"] = reducer.drain()[-1]
     dt = Timer(dist, torch).run(step, args.warmup, args.steps, after_warmup, finish, prime=100)
     t_render, n_render, render_kernel = ctx.profile_render()
+    ctx.profile(1)
+    for _ in range(20):                 # untimed: prep / binning / reduction durations for `kernels_ms`
+        field.images.render(field.sources, loglik=True)
     t_bin, _ = ctx.profile_get("bin")
     t_prep, _ = ctx.profile_get("prep")
     t_red, _ = ctx.profile_get("reduce")
@@ -469,7 +475,7 @@ def secondary_legs(args, env, field):
         S, B, H, W, fg = synth.CONFIGS[name]
         for _ in range(30):
             f.images.render(f.sources, loglik=True)
-        ctx.profile(True)
+        ctx.profile(2)                  # the render kernel only (see run_render)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -553,7 +559,7 @@ def run_fields(args, env):
         if reducer is not None:
             reducer.drain()
         for cx in ctxs:
-            cx.profile(True)
+            cx.profile(2)               # the render kernel only (see run_render)
 
     def finish():
         if reducer is not None:

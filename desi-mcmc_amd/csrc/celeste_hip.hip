@@ -110,7 +110,7 @@ struct cel_ctx {
     bool own_stream = false;
     int variant = 1;
     double tail_T = 32.0;
-    bool profile = false;
+    int profile = 0;          // CEL_OPT_PROFILE: 0 off, 1 every kernel, 2 the evaluating kernels only
     int star_tiles = (getenv("CEL_STAR_TILES") && atoi(getenv("CEL_STAR_TILES")) >= 0 && atoi(getenv("CEL_STAR_TILES")) <= 2)
                          ? atoi(getenv("CEL_STAR_TILES")) : 1;       // CEL_OPT_STAR_TILES (the env var: the initial value, for test runs)
     int tile_order = 1;       // 0 = launch k_render tiles in index order, 1 = heaviest first by the last render's measured tile durations (estimate when none), 2 = heaviest first by the estimate only
@@ -223,6 +223,12 @@ struct cel_sources {
     double *d_radec = nullptr, *d_counts = nullptr, *d_shape = nullptr;
 };
 
+// The launch order of the tiles matters only when there are more tiles than the chip runs at once (2048 waves of the
+// general kernel): below that every tile starts at once whatever the order, and a sort + its launch is all cost.
+static inline int tile_order_of(const cel_ctx *c, const cel_images *im) {
+    return ((int64_t)im->B * im->ntx * im->nty > 2048) ? c->tile_order : 0;
+}
+
 static bool prof_alloc(Prof &p) {
     if (p.ev) return true;
     p.ev = (hipEvent_t *)calloc(2 * Prof::PAIRS, sizeof(hipEvent_t));
@@ -248,6 +254,9 @@ static bool prof_harvest_one(Prof &p, bool wait) {
 // reserve a pair for kernel k; returns the index of its first event, -1 when profiling is off
 static int prof_slot(cel_ctx *c, int k) {
     if (!c->profile) return -1;
+    // level 2: the small kernels around a render (prep, binning, reduction) go unbracketed -- an event pair costs the host
+    // ~10 us per launch, 3 % of a 1.35 ms step when every kernel carries one
+    if (c->profile == 2 && (k == CEL_K_PREP || k == CEL_K_BIN || k == CEL_K_REDUCE)) return -1;
     Prof &p = c->prof;
     if (!prof_alloc(p)) return -1;
     if (p.count == Prof::PAIRS) prof_harvest_one(p, true);
@@ -433,8 +442,9 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         c->tail_T = v;
         return CEL_OK;
     case CEL_OPT_PROFILE:
+        if (v != 0.0 && v != 1.0 && v != 2.0) return fail(CEL_ERR_INVALID, "CEL_OPT_PROFILE must be 0, 1 or 2");
         if (v != 0.0 && !prof_alloc(c->prof)) return fail(CEL_ERR_HIP, "CEL_OPT_PROFILE: cannot create the timing events");
-        c->profile = (v != 0.0);
+        c->profile = (int)v;
         return CEL_OK;
     case CEL_OPT_TILE_ORDER:
         if (v != 0.0 && v != 1.0 && v != 2.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TILE_ORDER must be 0, 1 or 2");
@@ -478,7 +488,7 @@ int cel_ctx_get_option(cel_ctx *c, int key, double *v) {
     switch (key) {
     case CEL_OPT_KERNEL: *v = c->variant; return CEL_OK;
     case CEL_OPT_TAIL_LOG: *v = c->tail_T; return CEL_OK;
-    case CEL_OPT_PROFILE: *v = c->profile ? 1.0 : 0.0; return CEL_OK;
+    case CEL_OPT_PROFILE: *v = (double)c->profile; return CEL_OK;
     case CEL_OPT_TILE_ORDER: *v = (double)c->tile_order; return CEL_OK;
     case CEL_OPT_TILE_ROWS: *v = c->tile_rows; return CEL_OK;
     case CEL_OPT_TILE_TIMING: *v = c->tile_timing ? 1.0 : 0.0; return CEL_OK;
@@ -834,44 +844,52 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         if (rc) return rc;
     }
     const int NS = im->B * im->nsx * im->nsy;
+    const int tile_order = tile_order_of(c, im);
+    // a small catalogue is binned by one wave per tile into per-tile segments of S entries (k_bin_direct)
+    const bool bin_direct = S > 0 && S <= BIN_DIRECT_MAX_S && (int64_t)T * S <= ((int64_t)1 << 25);
+    if (bin_direct && (rc = ensure_lists(im, (int64_t)T * S))) return rc;
     for (int attempt = 0; attempt < 8; attempt++) {
         // d_cursor: [0] fine cursor, [1] fine overflow, [2] coarse cursor, [3] coarse overflow;
         // zeroed by k_prep (no memset in the queue), by hand only when that did not run or on a retry
         if (attempt > 0 || S * im->B == 0) HIP_TRY(hipMemsetAsync(im->d_cursor, 0, sizeof(unsigned long long) * 4, st));
         // one event pair over the binning kernels: start on the first, stop on the last
         int pi = prof_slot(c, CEL_K_BIN);
-        // one binning kernel while no super-tile holds more than BIN_CH candidates; the two-level form after that
-        if (im->bin_two_level)
-            LAUNCH_EV(k_bin_coarse, dim3(NS), dim3(64 * COARSE_WAVES), st, EV0(c, pi), (hipEvent_t) nullptr, im->d_boxes, S, im->nsx, im->nsy,
-                      im->d_sup_cnt, im->d_sup_off, im->d_cursor + 2, im->d_clist, im->clist_cap, (int *)(im->d_cursor + 3));
         // the order by the previous render's measured durations was sorted behind that render's readback
         // (below): nothing to do here then
-        const bool order_ready = (c->tile_order == 1 && im->order_S == S && im->cost_S == S);
-        const hipEvent_t bin_ev1 = (c->tile_order && !order_ready) ? (hipEvent_t) nullptr : EV1(c, pi);
-        if (im->bin_two_level)
+        const bool order_ready = (tile_order == 1 && im->order_S == S && im->cost_S == S);
+        const hipEvent_t bin_ev1 = (tile_order && !order_ready) ? (hipEvent_t) nullptr : EV1(c, pi);
+        // a small catalogue: one wave per tile (k_bin_direct).  Otherwise one binning kernel while no super-tile holds more
+        // than BIN_CH candidates, the two-level form after that
+        if (bin_direct) {
+            LAUNCH_EV(k_bin_direct, dim3(T), dim3(64), st, EV0(c, pi), bin_ev1, im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
+                      im->d_tile_cnt, im->d_tile_nstar, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists);
+        } else if (im->bin_two_level) {
+            LAUNCH_EV(k_bin_coarse, dim3(NS), dim3(64 * COARSE_WAVES), st, EV0(c, pi), (hipEvent_t) nullptr, im->d_boxes, S, im->nsx, im->nsy,
+                      im->d_sup_cnt, im->d_sup_off, im->d_cursor + 2, im->d_clist, im->clist_cap, (int *)(im->d_cursor + 3));
             LAUNCH_EV(k_bin_fine_blk<false>, dim3(NS), dim3(64 * FINE_WAVES), st, (hipEvent_t) nullptr, bin_ev1,
                       im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
                       im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
                       im->d_tile_nstar, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
                       (int *)(im->d_cursor + 1), (int *)(im->d_cursor + 3));
-        else
+        } else {
             LAUNCH_EV(k_bin_fine_blk<true>, dim3(NS), dim3(64 * FINE_WAVES), st, EV0(c, pi), bin_ev1,
                       im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
                       im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
                       im->d_tile_nstar, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
                       (int *)(im->d_cursor + 1), (int *)(im->d_cursor + 3));
-        if (c->tile_order && !order_ready)
+        }
+        if (tile_order && !order_ready)
             // heaviest first: by the durations the tiles had in the previous render when that was
             // of the same source count (an MCMC chain changes little from one evaluation to the
             // next), by the binning pass's estimate otherwise.  The order never changes results.
             LAUNCH_EV(k_order, dim3(1), dim3(1024), st, (hipEvent_t) nullptr, EV1(c, pi),
-                      (const int *)((im->cost_S == S && c->tile_order == 1) ? im->d_tile_cost : im->d_tile_work), T, im->d_order);
+                      (const int *)((im->cost_S == S && tile_order == 1) ? im->d_tile_cost : im->d_tile_work), T, im->d_order);
         RenderArgs a;
         a.bands = im->d_bands; a.recs = im->d_recs; a.lists = im->d_lists; a.tile_cnt = im->d_tile_cnt;
         a.tile_nstar = im->d_tile_nstar;
         a.tile_off = im->d_tile_off; a.nelec = im->d_nelec; a.lambda = lambda_out ? lambda_out : im->d_lambda; a.partials = im->d_partials;
         a.S = S; a.capacity = im->lists_cap; a.B = im->B; a.H = im->H; a.W = im->W; a.ntx = im->ntx; a.nty = im->nty;
-        a.flags = flags | (c->debug << 8); a.variant = c->variant; a.tail_T = c->tail_T; a.order = c->tile_order ? im->d_order : nullptr;
+        a.flags = flags | (c->debug << 8); a.variant = c->variant; a.tail_T = c->tail_T; a.order = tile_order ? im->d_order : nullptr;
         a.timing = nullptr;
         a.cost = (im->TW == HW_TW || im->TW == QW_TW) ? im->d_tile_cost : nullptr;
         if (c->tile_timing) {
@@ -910,7 +928,7 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         // An MCMC chain renders the same number of sources again: sort this render's tile durations into
         // the next render's launch order NOW, behind the readback the host is waiting for, instead of
         // in front of the next render (13 us + a launch gap per step).  The host waits for the copy only.
-        const bool post_order = (c->tile_order == 1 && a.cost != nullptr);
+        const bool post_order = (tile_order == 1 && a.cost != nullptr);
         if (post_order) {
             if (!im->ev_step) HIP_TRY(hipEventCreateWithFlags(&im->ev_step, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(im->ev_step, st));
@@ -1728,7 +1746,7 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         a.win_y0 = im->win_y0; a.full_H = im->full_H;
         a.noise_y0 = im->noise_y0; a.noise_y1 = im->noise_y1;
         a.rate_img = im->d_rate; a.tail_T = c->tail_T; a.nz = fused_nz ? im->d_snz : nullptr;
-        a.order = (hw && c->tile_order) ? im->d_order : nullptr;
+        a.order = (hw && tile_order_of(c, im)) ? im->d_order : nullptr;
         a.sums = fused_nz ? im->d_ssum : nullptr;
         a.nnz = lists ? im->d_nnz : nullptr;
         a.debug = c->debug;
@@ -1867,7 +1885,7 @@ int cel_estep_stats(cel_images *im, cel_sources *src, double *xtilde, double *ma
             // the gather adds a source's entries in tile order
             EstepArgs ea;
             ea.bands = im->d_bands; ea.recs = im->d_recs; ea.lists = im->d_lists; ea.tile_cnt = im->d_tile_cnt;
-            ea.tile_off = im->d_tile_off; ea.order = c->tile_order ? im->d_order : nullptr;
+            ea.tile_off = im->d_tile_off; ea.order = tile_order_of(c, im) ? im->d_order : nullptr;
             ea.nelec = im->d_nelec; ea.lambda = im->d_lambda; ea.partial = d_part; ea.noise_partial = im->d_partials;
             ea.S = S; ea.capacity = im->lists_cap; ea.B = B; ea.H = im->H; ea.W = im->W; ea.ntx = im->ntx; ea.nty = im->nty;
             ea.tail_T = c->tail_T;

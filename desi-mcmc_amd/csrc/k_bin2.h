@@ -254,3 +254,78 @@ k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int
         }
     }
 }
+
+// ---- small catalogues: one wave per render tile, no super-tiles ----------------------------------------------
+// With a few thousand sources the two-level machinery above is all latency (sixteen-wave blocks, three barriers, a global
+// cursor: 35 us for 1 000 stars on 640 tiles, a third of that step).  Here every tile's wave tests the band's S boxes itself
+// (S / 64 trips, the boxes from L2) and writes its list into a segment of its own, tile * S entries into the buffer: no
+// atomics on list positions, no prefix sum between tiles, the same list format (stars first, each kind in source order),
+// the same counts and work estimates.  The host takes it while S <= BIN_DIRECT_MAX_S and the segments fit the list buffer.
+#define BIN_DIRECT_MAX_S 4096
+__global__ void __launch_bounds__(64)
+k_bin_direct(const int4 *__restrict__ boxes, const int *__restrict__ kind, int64_t S, int ntx, int nty, int TH, int TW,
+             int *__restrict__ tile_cnt, int *__restrict__ tile_nstar, int *__restrict__ tile_work, int64_t *__restrict__ tile_off,
+             unsigned long long *cursor, int *__restrict__ lists) {
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int per_band = ntx * nty;
+    const int b = tile / per_band;
+    const int t = tile - b * per_band;
+    const int ty = t / ntx, tx = t - ty * ntx;
+    const int X0 = tx * TW, X1 = X0 + TW, Y0 = ty * TH, Y1 = Y0 + TH;
+    const int4 *bx = boxes + (int64_t)b * S;
+    const int *kd = kind + (int64_t)b * S;
+    const int64_t base = (int64_t)tile * S;
+    constexpr int U = 8;                    // box loads in flight per lane
+    int cnt = 0, nst = 0, work = 0;
+    for (int64_t s0 = 0; s0 < S; s0 += 64 * U) {
+        int4 q[U];
+        int k[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t s = min(s0 + 64 * u + lane, S - 1);
+            q[u] = bx[s];
+            k[u] = kd[s];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool hit = (s0 + 64 * u + lane < S) && box_hits(q[u], X0, X1, Y0, Y1);
+            if (hit) work += k[u] * (min(q[u].w, Y1) - max(q[u].z, Y0) + 18);
+            cnt += __popcll(__ballot(hit));
+            nst += __popcll(__ballot(hit && k[u] == K_PSF));
+        }
+    }
+    int run = 0, rung = 0;
+    for (int64_t s0 = 0; s0 < S && cnt > 0; s0 += 64 * U) {
+        int4 q[U];
+        int k[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t s = min(s0 + 64 * u + lane, S - 1);
+            q[u] = bx[s];
+            k[u] = kd[s];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t s = s0 + 64 * u + lane;
+            const bool hit = (s < S) && box_hits(q[u], X0, X1, Y0, Y1);
+            const bool star = hit && k[u] == K_PSF;
+            const unsigned long long mk = __ballot(hit), ms = __ballot(star);
+            if (hit) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                // stars fill the head of the segment, everything else follows them
+                const int64_t at = star ? base + run + __popcll(ms & below) : base + nst + rung + __popcll((mk & ~ms) & below);
+                lists[at] = (int)s;
+            }
+            run += __popcll(ms);
+            rung += __popcll(mk & ~ms);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) work += __shfl_down(work, o);
+    if (lane == 0) {
+        tile_cnt[tile] = cnt;
+        tile_nstar[tile] = nst;
+        tile_work[tile] = work;
+        tile_off[tile] = base;
+        if (cnt) atomicAdd(cursor, (unsigned long long)cnt);      // the total list length, for cel_field_stats
+    }
+}

@@ -68,7 +68,9 @@ class Context(object):
         self.set_option(L.CEL_OPT_TAIL_LOG, T)
 
     def profile(self, on=True):
-        self.set_option(L.CEL_OPT_PROFILE, 1.0 if on else 0.0)
+        """HIP-event timing of the kernels: True / 1 = every kernel, 2 = the evaluating kernels only (the small launches
+        around a render go unbracketed: an event pair costs the host ~10 us per launch), False / 0 = off.  Resets the sums."""
+        self.set_option(L.CEL_OPT_PROFILE, float(int(on)))
         L.check(L.lib().cel_profile_reset(self._h))
 
     def profile_get(self, kernel):

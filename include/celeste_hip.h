@@ -65,7 +65,9 @@ enum {
                               conditional log-likelihood, the E-step sums) use the same T against
                               the source's own smallest value on the tile instead of eps: the
                               relative error of every pixel stays below n_components * e^-T    */
-    CEL_OPT_PROFILE = 3,   /* 1 = bracket every kernel launch with HIP events              */
+    CEL_OPT_PROFILE = 3,   /* 1 = bracket every kernel launch with HIP events; 2 = the evaluating kernels only (render,
+                              conditional likelihoods, split, mass, E-step: not the prep / binning / reduction launches
+                              around a render -- an event pair costs the host ~10 us per launch)            */
     CEL_OPT_TILE_ORDER = 4,/* launch order of the render tiles; never changes results.  0 = index order,
                               1 (default) = heaviest first by the durations the tiles had in the previous
                               render of the same number of sources (the binning pass's estimate when there
@@ -372,7 +374,7 @@ int cel_bounding_radius(const double *w, const double *mu, const double *cov, in
                         const double *center, double *out);
 
 /* ---- measurement -------------------------------------------------------------------------- */
-/* With CEL_OPT_PROFILE = 1 every launch of kernel `k` is bracketed by HIP events on the
+/* With CEL_OPT_PROFILE = 1 (2: see the option) every launch of kernel `k` is bracketed by HIP events on the
  * context's stream; cel_profile_get synchronises and returns the mean duration. */
 int cel_profile_reset(cel_ctx *ctx);
 int cel_profile_get(cel_ctx *ctx, int kernel, double *mean_ms, int64_t *launches);
