@@ -502,7 +502,7 @@ def secondary_legs(args, env, field):
             g.log_likelihood()
         for k in g.timing:
             g.timing[k] = 0
-        ctx.profile(True)
+        ctx.profile(2)        # the evaluating kernels (likelihoods, split, mass, render), not the 46 k_prep launches of a sweep
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(sweeps):
@@ -732,7 +732,7 @@ def run_gibbs(args, env):
             reducer.drain()
         for k in g.timing:
             g.timing[k] = 0
-        ctx.profile(True)
+        ctx.profile(2)        # the evaluating kernels (likelihoods, split, mass, render), not the 46 k_prep launches of a sweep
 
     def finish():
         if reducer is not None:

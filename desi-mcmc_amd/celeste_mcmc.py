@@ -211,7 +211,6 @@ class ModelGibbs(object):
         self.deal = deal
         if deal is not None and deal.S != self.S:
             raise ValueError("the deal is over %d sources, the catalogue has %d" % (deal.S, self.S))
-        self._pool = None               # one worker thread: device calls that run beside host-side draws
         self.noise_sums = None
         self.active = np.ones(self.S, dtype=bool)
 
@@ -311,36 +310,40 @@ class ModelGibbs(object):
 
         mine = None if self.deal is None or self.deal.world == 1 else self.deal.mine
 
-        def rates():        # the device's part (a ctypes call: runs beside the host's draws below)
-            psf_sums = np.zeros((self.S, 5))
-            for f in self.fields:
-                if mine is None:
-                    mass = f.iset.stamp_mass(f.sset) * f.has_patch      # sum of the unit stamp on its own box
-                else:                   # this rank's sources only; a (source, band) value does not depend on the batch
-                    from . import field as _field
-                    if getattr(f, "sub", None) is None or f.sub.capacity < mine.size:
-                        f.sub = _field.SourceSet(f.iset.ctx, max(mine.size, 1), f.iset.B)
-                    f.sub.set(self.typ[mine], self.u[mine], self.counts(f, idx=mine), self.shape[mine])
-                    mass = np.zeros((self.S, f.iset.B))
-                    mass[mine] = f.iset.stamp_mass(f.sub) * f.has_patch[mine]
-                for b in range(f.iset.B):
-                    psf_sums[:, f.band_index[b]] += mass[:, b] * (f.kappa[b] / f.calib[b])
-            return self.flux_b_0 + psf_sums
+        # The device's part -- the sum of every source's unit stamp on its own box -- runs beside the host's draws: the last
+        # field's kernel is queued (stamp_mass_begin), the Gamma variates are drawn, then its values are collected.  (Fields
+        # before the last are summed synchronously: two pending calls may not share a context.  Round 2 used a worker thread
+        # for the overlap: its hand-over through the interpreter lock made the step vary between 2 and 4 ms.)
+        def field_sources(f):
+            if mine is None:
+                return f.sset
+            from . import field as _field          # this rank's sources only; a (source, band) value does not depend on the batch
+            if getattr(f, "sub", None) is None or f.sub.capacity < mine.size:
+                f.sub = _field.SourceSet(f.iset.ctx, max(mine.size, 1), f.iset.B)
+            f.sub.set(self.typ[mine], self.u[mine], self.counts(f, idx=mine), self.shape[mine])
+            return f.sub
 
-        if self._pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=1)
-        fut = self._pool.submit(rates)
+        def add_mass(psf_sums, f, m):
+            if mine is None:
+                mass = m * f.has_patch
+            else:
+                mass = np.zeros((self.S, f.iset.B))
+                mass[mine] = m * f.has_patch[mine]
+            for b in range(f.iset.B):
+                psf_sums[:, f.band_index[b]] += mass[:, b] * (f.kappa[b] / f.calib[b])
+
+        psf_sums = np.zeros((self.S, 5))
+        for f in self.fields[:-1]:
+            add_mass(psf_sums, f, f.iset.stamp_mass(field_sources(f)))
+        last = self.fields[-1]
+        last.iset.stamp_mass_begin(field_sources(last))
         try:
             # Gamma(a_n, 1 / b_n) = standard Gamma(a_n) * (1 / b_n); every (source, band) draws from its own stream
             g = gamma_by_stream(a_n.ravel(), self.seed * 15485863 + self.sweeps, np.arange(self.S * 5)).reshape(self.S, 5)
         finally:
-            # a Context is not thread-safe (scratch slots, the profile ring, the records are shared): whatever
-            # the host draw does, nobody touches this one again before the worker's device call has returned
-            worker_error = fut.exception()          # blocks until the worker is done
-        if worker_error is not None:
-            raise worker_error
-        new = g * (1. / fut.result())
+            m_last = last.iset.stamp_mass_end()     # whatever the host draw does, the pending call is collected
+        add_mass(psf_sums, last, m_last)
+        new = g * (1. / (self.flux_b_0 + psf_sums))
         self.fluxes = np.where(self.active[:, None], new, self.fluxes)       # rows of other ranks' sources: merged at the sweep's end
         self.timing["flux"] += time.perf_counter() - t0
         return self.fluxes

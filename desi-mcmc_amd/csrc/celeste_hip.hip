@@ -169,6 +169,8 @@ struct cel_images {
     int *d_tile_cost = nullptr;   // measured duration of every tile in the last render (the next render's launch order)
     int64_t cost_S = -1;          // number of sources that render had (-1: nothing measured yet)
     bool bin_two_level = false;   // a super-tile once held more than BIN_CH candidates: coarse lists in global memory from then on
+    int64_t mass_pending = -1;       // doubles waiting in d_mass between cel_stamp_mass_begin and _end (-1: none)
+    double *d_mass = nullptr;        // (a scratch slot of the context: not owned)
     bool nelec_u16 = false;          // every observed pixel in 0 ... 65 535: the split's 16-bit photons-left plane
     bool star_one_segment = false;   // every band passes star_setup's test: k_render_stars may take star tiles
     int64_t order_S = -1;         // d_order already holds the heaviest-first order of those costs (sorted behind that render's readback)
@@ -1255,14 +1257,15 @@ int cel_patch_loglik(cel_images *im, cel_sources *src, const int32_t *boxes, con
     return cel_patch_loglik_multi(im, src, nullptr, 1, boxes, offsets, data, mem, mode, ll_out);
 }
 
-int cel_stamp_mass(cel_images *im, cel_sources *src, double *mass) {
-    if (!im || !src || !mass) return fail(CEL_ERR_INVALID, "cel_stamp_mass: null argument");
+int cel_stamp_mass_begin(cel_images *im, cel_sources *src) {
+    if (!im || !src) return fail(CEL_ERR_INVALID, "cel_stamp_mass: null argument");
     if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
     cel_ctx *c = im->ctx;
     HIP_TRY(hipSetDevice(c->device));
     const int B = im->B;
     const int64_t S = src->S;
-    if (S == 0) return CEL_OK;
+    im->mass_pending = -1;
+    if (S == 0) { im->mass_pending = 0; return CEL_OK; }
     int rc = run_prep(im, src);
     if (rc) return rc;
     double *d_out = nullptr;
@@ -1273,7 +1276,26 @@ int cel_stamp_mass(cel_images *im, cel_sources *src, double *mass) {
                        (const double *)nullptr, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
     prof_end(c, pi);
     HIP_TRY(hipGetLastError());
-    return copy_out(mass, d_out, sizeof(double) * S * B, CEL_HOST, c->stream);
+    im->mass_pending = S * B;
+    im->d_mass = d_out;
+    return CEL_OK;
+}
+
+int cel_stamp_mass_end(cel_images *im, double *mass) {
+    if (!im || !mass) return fail(CEL_ERR_INVALID, "cel_stamp_mass_end: null argument");
+    if (im->mass_pending < 0) return fail(CEL_ERR_INVALID, "cel_stamp_mass_end without a cel_stamp_mass_begin");
+    cel_ctx *c = im->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t n = im->mass_pending;
+    im->mass_pending = -1;
+    if (n == 0) return CEL_OK;
+    return copy_out(mass, im->d_mass, sizeof(double) * n, CEL_HOST, c->stream);
+}
+
+int cel_stamp_mass(cel_images *im, cel_sources *src, double *mass) {
+    if (!mass) return fail(CEL_ERR_INVALID, "cel_stamp_mass: null argument");
+    int rc = cel_stamp_mass_begin(im, src);
+    return rc ? rc : cel_stamp_mass_end(im, mass);
 }
 
 // ---- lock-step slice sampling of the locations, on the device -----------------------------------

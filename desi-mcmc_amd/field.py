@@ -376,6 +376,17 @@ class ImageSet(object):
         L.check(L.lib().cel_stamp_mass(self._h, sources._h, L.dptr(out)))
         return out
 
+    def stamp_mass_begin(self, sources):
+        """queue stamp_mass and return: the device sums the stamps while the host does something else (no other call on
+        this context before stamp_mass_end)"""
+        L.check(L.lib().cel_stamp_mass_begin(self._h, sources._h))
+        self._mass_shape = (sources.S, self.B)
+
+    def stamp_mass_end(self):
+        out = np.zeros(self._mass_shape)
+        L.check(L.lib().cel_stamp_mass_end(self._h, L.dptr(out)))
+        return out
+
     def estep_stats(self, sources):
         """E-step reductions (celeste_em.py:38-91) -> (xtilde[S,B], mass[S,B], noise[B])."""
         S = sources.S

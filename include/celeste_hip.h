@@ -262,6 +262,11 @@ int cel_patch_loglik_multi(cel_images *img, cel_sources *src, const int32_t *own
  * Source.resample_fluxes multiplies by kappa/calib for the rate of its Gamma conditional
  * (CelestePy/sources.py:336-339) and celeste_em's sum_fs (celeste_em.py:89).  0 without a stamp.  Host output. */
 int cel_stamp_mass(cel_images *img, cel_sources *src, double *mass);
+/* The same in two halves: _begin queues the kernel and returns, _end waits and copies the S*B values out -- so that the host
+ * can draw its Gamma variates while the device sums the stamps (the flux step of a Gibbs sweep) without a second thread.
+ * No other call on this context may come between the two (they share one of its scratch buffers). */
+int cel_stamp_mass_begin(cel_images *img, cel_sources *src);
+int cel_stamp_mass_end(cel_images *img, double *mass);
 
 /* Source.resample_location (CelestePy/sources.py:308-319) for EVERY source of `src` at once: slicesample
  * (CelestePy/util/infer/slicesample.py:89-227) with the options of that call -- component-wise, no stepping
