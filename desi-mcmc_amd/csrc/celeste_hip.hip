@@ -1241,7 +1241,7 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
         for (int b = 0; b < B; b++) {                       // band order, like the reference's image loop
             const double *q = hout.data() + (size_t)(p * B + b) * nparts;
             double x = q[0];
-            for (int k = 1; k < nparts; k++) x += q[k];     // a job's parts first, in order (as k_slice_consume does)
+            for (int k = 1; k < nparts; k++) x += q[k];     // a job's parts first, in order (as k_slice_step does)
             s += x;
         }
         ll_out[p] = s;
@@ -1373,7 +1373,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         HIP_TRY(hipMemcpyAsync(d_ids, chain_ids, sizeof(int) * S, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(int) * 4, st));
+    HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(int) * 11, st));      // [0..3] and [10]: see k_slice.h; the rest is set where it is used
     const unsigned g256 = (unsigned)((S + 255) / 256);
     hipLaunchKernelGGL(k_slice_init, dim3(g256), dim3(256), 0, st, ss, S, src->d_radec, chain_ids ? d_ids : (const int *)nullptr,
                        im->d_soff, B, (unsigned long long)seed, sigma, d_owner);
@@ -1423,7 +1423,8 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         const bool use_live = live_dense >= 0 && (live_dense + live_nz) * 4 < (n_dense + n_nz) * 3;
         const int64_t gd = use_live ? live_dense : n_dense, gn = !use_nz ? 0 : (use_live ? live_nz : n_nz);
         for (int k = 0; k < nb; k++) {
-            hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags, queued == 0 ? 1 : 0);
+            // the first round's points; every later round's were named by the step kernel of the round before
+            if (queued == 0) hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags);
             prop->gen = ++g_source_gen;
             if ((rc = run_prep(im, prop, d_owner, 1))) return rc;      // the patch limits are fixed: no boxes
             if (c->variant == 0) {
@@ -1447,7 +1448,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
                               (const int *)(use_live ? d_live_nz : d_jobs_nz), (const int *)nullptr);
                 }
             }
-            hipLaunchKernelGGL(k_slice_consume, dim3(g256), dim3(256), 0, st, ss, S, B, ostr, d_ll, sigma, d_flags, d_flags + 1);
+            hipLaunchKernelGGL(k_slice_step, dim3(g256), dim3(256), 0, st, ss, S, B, ostr, d_ll, sigma, d_flags, (int)queued, prop->d_radec, d_owner);
             queued++;
         }
         if (c->variant != 0) {          // the running chains' blocks, for the next batch; few chains left: every job dealt
@@ -1456,10 +1457,10 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
                                (const int *)(use_nz ? im->d_nzmode : nullptr), d_live_nz, d_flags + 5, (const int *)im->d_nnz,
                                (const int4 *)im->d_snz, (live * B <= SLICE_SPLIT_JOBS) ? 1 : 0);
         }
-        HIP_TRY(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 6, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 11, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
-        const int running = h_flags[0], err = h_flags[1];
+        const int running = h_flags[((queued - 1) & 1) ? 10 : 0], err = h_flags[1];      // the last round's slot
         live = running;
         if (c->variant != 0) { live_dense = h_flags[4]; live_nz = h_flags[5]; }
         if (err & 1) return fail(CEL_ERR_INVALID, "Slice sampler got a NaN");

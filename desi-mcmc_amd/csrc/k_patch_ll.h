@@ -461,7 +461,7 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     if (job_order) { split = (job & 1) != 0; part = (int)((job >> 1) & 3); job >>= 3; }
     // The trips of a list fall into PLL_PARTS classes (trip t -> class t mod PLL_PARTS) that are ALWAYS summed apart: a
     // whole job writes the four class sums to its four slots, a dealt job's block its class to its slot, and whoever
-    // adds the slots in order (k_slice_consume, the host loop of cel_patch_loglik_multi) gets the same bits either way.
+    // adds the slots in order (k_slice_step, the host loop of cel_patch_loglik_multi) gets the same bits either way.
     double *const outp = out + job * PLL_PARTS;
     const int b = (int)(job % B);
     const int64_t p = job / B;

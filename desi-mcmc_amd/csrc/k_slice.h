@@ -3,8 +3,8 @@
 // Source.resample_location (CelestePy/sources.py:308-319) = slicesample(u, location_likelihood, ...)
 // (CelestePy/util/infer/slicesample.py:89-227) with the options that call uses: component-wise,
 // no stepping out.  One chain per source; every round each unfinished chain names the point it
-// needs next (k_slice_propose writes it into the proposal set's radec), cel_patch_loglik's kernels
-// score all of them against the resident photon patches, and k_slice_consume advances the chains.
+// needs next (written into the proposal set's radec), cel_patch_loglik's kernels score all of them against
+// the resident photon patches, and k_slice_step advances the chains and names their next points.
 // Nothing but one counter crosses PCIe per round.
 //
 // The arithmetic and the random streams are those of the host engine
@@ -77,19 +77,9 @@ k_slice_init(SliceState st, int64_t S, const double *__restrict__ radec, const i
     owner[s] = has_patch ? (int)s : -1;
 }
 
-// the point every unfinished chain needs next -> the proposal set's radec; owner[s] = -1 retires a chain
-__global__ void __launch_bounds__(256)
-k_slice_propose(SliceState st, int64_t S, double *__restrict__ prop_radec, int *__restrict__ owner, int *__restrict__ n_active,
-                int first) {
+// the point an unfinished chain needs next -> the proposal set's radec; owner[s] = -1 retires a chain
+__device__ __forceinline__ void sl_propose_chain(const SliceState &st, int64_t s, double *__restrict__ prop_radec, int *__restrict__ owner) {
 #pragma clang fp contract(off)
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s == 0) {
-        // n_active[3] counts the rounds that had a chain to score: the host queues rounds in batches and
-        // reads the flags once per batch, so it cannot count them itself
-        if (first || *n_active > 0) n_active[3] += 1;
-        *n_active = 0;
-    }
-    if (s >= S) return;
     const int ph = st.phase[s];
     if (ph == SL_FINAL) { owner[s] = -1; return; }
     double z = 0.0;
@@ -105,12 +95,37 @@ k_slice_propose(SliceState st, int64_t S, double *__restrict__ prop_radec, int *
     owner[s] = (int)s;
 }
 
-// consume the round's log-likelihoods (per (chain, band), summed in band order as the host sums them)
+// Flags of a call (ints): [0] / [10] chains still running after the last even / odd round, [1] error bits, [2] likelihood
+// evaluations so far, [3] rounds that had a chain to score.  The host queues rounds in batches and reads the flags once per
+// batch, so the device counts: round r's consume kernel adds its running chains to slot r & 1, and -- the other slot holding
+// the complete count of round r - 1 -- books round r as a round with work when that count is positive, then clears it for
+// round r + 1.
+
+// the first round of a call: every chain's first point
 __global__ void __launch_bounds__(256)
-k_slice_consume(SliceState st, int64_t S, int B, int nparts /* blocks per (chain, band) job: their partial sums are added first, in order */,
-                const double *__restrict__ ll_pb, double sigma, int *__restrict__ n_active, int *__restrict__ err) {
+k_slice_propose(SliceState st, int64_t S, double *__restrict__ prop_radec, int *__restrict__ owner, int *__restrict__ flags) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0) { flags[3] += 1; flags[0] = 0; flags[10] = 0; }
+    if (s >= S) return;
+    sl_propose_chain(st, s, prop_radec, owner);
+}
+
+// Consume round `round`'s log-likelihoods (per (chain, band), summed in band order as the host sums them) and name the
+// point every chain that is still running needs next: one kernel per round instead of a consume and a propose (a chain's
+// next point depends on its own state only).
+__global__ void __launch_bounds__(256)
+k_slice_step(SliceState st, int64_t S, int B, int nparts /* blocks per (chain, band) job: their partial sums are added first, in order */,
+             const double *__restrict__ ll_pb, double sigma, int *__restrict__ flags, int round,
+             double *__restrict__ prop_radec, int *__restrict__ owner) {
 #pragma clang fp contract(off)
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int *const n_active = flags + ((round & 1) ? 10 : 0);
+    int *const err = flags + 1;
+    if (s == 0 && round > 0) {
+        int *const prev = flags + ((round & 1) ? 0 : 10);        // complete: round - 1's kernel has finished
+        if (*prev > 0) flags[3] += 1;
+        *prev = 0;                                               // round + 1 adds here
+    }
     bool active = false, scored = false;
     if (s < S) {
         const int ph = st.phase[s];
@@ -161,6 +176,7 @@ k_slice_consume(SliceState st, int64_t S, int B, int nparts /* blocks per (chain
     const unsigned long long m = __ballot(active), me = __ballot(scored);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_active, __popcll(m));
     if ((threadIdx.x & 63) == 0 && me) atomicAdd(err + 1, __popcll(me));         // evaluations so far (int: < 2^31 per call)
+    if (s < S) sl_propose_chain(st, s, prop_radec, owner);                       // the next round's point (a finished chain retires)
 }
 
 // the (chain, band) jobs of the chains that are still running, in no particular order (they all start at once:
