@@ -171,6 +171,7 @@ struct cel_images {
     bool bin_two_level = false;   // a super-tile once held more than BIN_CH candidates: coarse lists in global memory from then on
     int64_t mass_pending = -1;       // doubles waiting in d_mass between cel_stamp_mass_begin and _end (-1: none)
     double *d_mass = nullptr;        // (a scratch slot of the context: not owned)
+    long long *d_btot = nullptr;     // per-1024-entries totals of the patch / list layout scans
     bool nelec_u16 = false;          // every observed pixel in 0 ... 65 535: the split's 16-bit photons-left plane
     bool star_one_segment = false;   // every band passes star_setup's test: k_render_stars may take star tiles
     int64_t order_S = -1;         // d_order already holds the heaviest-first order of those costs (sorted behind that render's readback)
@@ -510,7 +511,7 @@ int cel_images_destroy(cel_images *im) {
     void *ptrs[] = {im->d_bands, im->d_nelec, im->d_lambda, im->d_partials, im->d_llband, im->d_recs,
                     im->d_boxes, im->d_kind, im->d_status, im->d_tile_cnt, im->d_tile_nstar, im->d_tile_work, im->d_tile_cost, im->d_order, im->d_tile_off, im->d_lists, im->d_stats,
                     im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff, im->d_rate, im->d_snz, im->d_ssum,
-                    im->d_nnz, im->d_nzmode, im->d_nzoff, im->d_nzlist};
+                    im->d_nnz, im->d_nzmode, im->d_nzoff, im->d_nzlist, im->d_btot};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (im->d_slice) (void)hipFree(im->d_slice);
@@ -1723,9 +1724,17 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
             HIP_TRY(hipMalloc((void **)&im->d_nnz, sizeof(int) * cap));
             HIP_TRY(hipMalloc((void **)&im->d_nzmode, sizeof(int) * cap));
             HIP_TRY(hipMalloc((void **)&im->d_nzoff, sizeof(int64_t) * cap));
+            if (im->d_btot) (void)hipFree(im->d_btot);
+            im->d_btot = nullptr;
+            HIP_TRY(hipMalloc((void **)&im->d_btot, sizeof(long long) * (size_t)(cap / 1024 + 2)));
             im->slay_cap = cap;
         }
-        hipLaunchKernelGGL(k_samp_layout, dim3(1), dim3(1024), 0, c->stream, im->d_recs, S, B, im->d_sbox, im->d_soff);
+        {
+            const unsigned nblk = (unsigned)((n + 1023) / 1024);
+            hipLaunchKernelGGL(k_samp_layout, dim3(nblk), dim3(1024), 0, c->stream, im->d_recs, S, B, im->d_sbox, im->d_soff, im->d_btot);
+            hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, c->stream, im->d_btot, (int)nblk, im->d_soff + n);
+            hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(1024), 0, c->stream, im->d_soff, n, (const long long *)im->d_btot);
+        }
         HIP_TRY(hipMemcpyAsync(c->pinned + MAX_BANDS + 2, im->d_soff + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         memcpy(&total, c->pinned + MAX_BANDS + 2, sizeof(total));
@@ -1790,8 +1799,13 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
             hipLaunchKernelGGL(k_patch_nzbox<int>, dim3((unsigned)n), dim3(64), 0, c->stream, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_snz);
     }
     if (lists)      // where each patch's photon list starts, and whether its likelihood is cheaper at the photons or densely
-        hipLaunchKernelGGL(k_nz_layout, dim3(1), dim3(1024), 0, c->stream, (const int *)im->d_nnz, (const int4 *)im->d_snz,
-                           (const int *)src->d_type, S, B, c->nz_force, c->nz_bias, im->d_nzoff, im->d_nzmode);
+    {
+        const unsigned nblk = (unsigned)((n + 1023) / 1024);
+        hipLaunchKernelGGL(k_nz_layout, dim3(nblk), dim3(1024), 0, c->stream, (const int *)im->d_nnz, (const int4 *)im->d_snz,
+                           (const int *)src->d_type, S, B, c->nz_force, c->nz_bias, im->d_nzoff, im->d_nzmode, im->d_btot);
+        hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, c->stream, im->d_btot, (int)nblk, im->d_nzoff + n);
+        hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(1024), 0, c->stream, im->d_nzoff, n, (const long long *)im->d_btot);
+    }
     HIP_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
     if (lists) HIP_TRY(hipMemcpyAsync(c->pinned + MAX_BANDS + 2, im->d_nzoff + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     if (!resident && mem != CEL_DEVICE && total > 0)

@@ -222,37 +222,50 @@ __device__ __forceinline__ long long block_scan_1024(long long v, long long *__r
     return v + before;
 }
 
+// Three launches instead of one block walking the table: every block of 1024 scans its own entries (k_*_layout: local
+// exclusive prefix + the block's total), one block scans the totals (k_scan_totals), every block adds its offset
+// (k_scan_apply).  The single block took 0.15 + 0.11 ms per sweep for the two tables, all of it load latency in sequence.
 __global__ void __launch_bounds__(1024)
 k_samp_layout(const SrcRec *__restrict__ recs, int64_t S, int B, int4 *__restrict__ sbox /* S*B: x0,x1,y0,y1 */,
-              int64_t *__restrict__ soff /* S*B + 1 */) {
+              int64_t *__restrict__ soff /* S*B + 1: the block-local exclusive prefix (k_scan_apply finishes it) */,
+              long long *__restrict__ btot /* per block: its total */) {
     __shared__ long long wtot[16];
-    const int tid = threadIdx.x;
     const int64_t n = S * B;
-    // one block walks the table in chunks of 1024; a chunk's records are requested while the previous chunk is scanned
-    auto fetch = [&](int64_t i, int4 &bx, long long &area) {       // i = s*B + b
-        bx = make_int4(0, 0, 0, 0); area = 0;
-        if (i < n) {
-            const int64_t s = i / B;
-            const int b = (int)(i - s * B);
-            const SrcRec &r = recs[(int64_t)b * S + s];
-            if (r.type >= 0) { bx = make_int4(r.x0, r.x1, r.y0, r.y1); area = (long long)(r.x1 - r.x0) * (r.y1 - r.y0); }
-        }
-    };
-    long long carry = 0;               // the same in every thread
-    int4 bx_next;
-    long long area_next;
-    fetch(tid, bx_next, area_next);
-    for (int64_t base = 0; base < n; base += 1024) {
-        const int64_t i = base + tid;
-        const int4 bx = bx_next;
-        const long long area = area_next;
-        fetch(i + 1024, bx_next, area_next);
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;       // i = s*B + b
+    int4 bx = make_int4(0, 0, 0, 0);
+    long long area = 0;
+    if (i < n) {
+        const int64_t s = i / B;
+        const int b = (int)(i - s * B);
+        const SrcRec &r = recs[(int64_t)b * S + s];
+        if (r.type >= 0) { bx = make_int4(r.x0, r.x1, r.y0, r.y1); area = (long long)(r.x1 - r.x0) * (r.y1 - r.y0); }
+    }
+    long long total;
+    const long long incl = block_scan_1024(area, wtot, total);
+    if (i < n) { sbox[i] = bx; soff[i] = incl - area; }
+    if (threadIdx.x == 0) btot[blockIdx.x] = total;
+}
+
+// exclusive scan of up to 1024 * 1024 block totals in place (one block; chunks of 1024 with a carry), grand total -> *out_total
+__global__ void __launch_bounds__(1024)
+k_scan_totals(long long *__restrict__ btot, int nb, int64_t *__restrict__ out_total) {
+    __shared__ long long wtot[16];
+    long long carry = 0;
+    for (int base = 0; base < nb; base += 1024) {
+        const int j = base + threadIdx.x;
+        const long long v = (j < nb) ? btot[j] : 0;
         long long total;
-        const long long incl = block_scan_1024(area, wtot, total);
-        if (i < n) { sbox[i] = bx; soff[i] = carry + incl - area; }      // exclusive
+        const long long incl = block_scan_1024(v, wtot, total);
+        if (j < nb) btot[j] = carry + incl - v;
         carry += total;
     }
-    if (tid == 0) soff[n] = carry;
+    if (threadIdx.x == 0) *out_total = carry;
+}
+
+__global__ void __launch_bounds__(1024)
+k_scan_apply(int64_t *__restrict__ off, int64_t n, const long long *__restrict__ btot) {
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) off[i] += btot[blockIdx.x];
 }
 
 template <typename TS>
@@ -302,36 +315,26 @@ __global__ void __launch_bounds__(1024)
 k_nz_layout(const int *__restrict__ nnz, const int4 *__restrict__ nzbox, const int *__restrict__ type /* per source */,
             int64_t S, int B, int force /* 0 = estimate, 1 = every patch at its photons, 2 = every patch densely */,
             double bias /* force 0: at the photons unless that is estimated more than `bias` times the dense cost */,
-            int64_t *__restrict__ loff /* S*B + 1: list offsets */, int *__restrict__ mode /* S*B: 1 = evaluate at the photons */) {
+            int64_t *__restrict__ loff /* S*B + 1: list offsets -- block-local here, finished by k_scan_totals / k_scan_apply */,
+            int *__restrict__ mode /* S*B: 1 = evaluate at the photons */, long long *__restrict__ btot) {
     __shared__ long long wtot[16];
-    const int tid = threadIdx.x;
     const int64_t n = S * B;
-    auto fetch = [&](int64_t i, long long &cnt, int &md) {
-        cnt = 0; md = 0;
-        if (i < n) {
-            cnt = nnz[i];
-            const int4 q = nzbox[i];
-            const int K = (type[i / B] == 0) ? K_PSF : K_GAL;
-            const long long chunks = (cnt > 0) ? (long long)((q.y - q.x + HW_TW - 1) / HW_TW) * ((q.w - q.z + HW_TH - 1) / HW_TH) : 0;
-            const long long sparse_cost = ((cnt + 63) / 64) * K * 17 + 150;
-            const long long dense_cost = chunks * ((K == K_PSF) ? 1900 : 6800);
-            md = (force == 1) ? 1 : (force == 2) ? 0 : ((double)sparse_cost < bias * (double)dense_cost ? 1 : 0);
-        }
-    };
-    long long carry = 0, cnt_next;
-    int md_next;
-    fetch(tid, cnt_next, md_next);
-    for (int64_t base = 0; base < n; base += 1024) {      // a chunk's inputs are requested while the previous chunk is scanned
-        const int64_t i = base + tid;
-        const long long cnt = cnt_next;
-        const int md = md_next;
-        fetch(i + 1024, cnt_next, md_next);
-        long long total;
-        const long long incl = block_scan_1024(cnt, wtot, total);
-        if (i < n) { mode[i] = md; loff[i] = carry + incl - cnt; }
-        carry += total;
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    long long cnt = 0;
+    int md = 0;
+    if (i < n) {
+        cnt = nnz[i];
+        const int4 q = nzbox[i];
+        const int K = (type[i / B] == 0) ? K_PSF : K_GAL;
+        const long long chunks = (cnt > 0) ? (long long)((q.y - q.x + HW_TW - 1) / HW_TW) * ((q.w - q.z + HW_TH - 1) / HW_TH) : 0;
+        const long long sparse_cost = ((cnt + 63) / 64) * K * 17 + 150;
+        const long long dense_cost = chunks * ((K == K_PSF) ? 1900 : 6800);
+        md = (force == 1) ? 1 : (force == 2) ? 0 : ((double)sparse_cost < bias * (double)dense_cost ? 1 : 0);
     }
-    if (tid == 0) loff[n] = carry;
+    long long total;
+    const long long incl = block_scan_1024(cnt, wtot, total);
+    if (i < n) { mode[i] = md; loff[i] = incl - cnt; }
+    if (threadIdx.x == 0) btot[blockIdx.x] = total;
 }
 
 __global__ void __launch_bounds__(64)
