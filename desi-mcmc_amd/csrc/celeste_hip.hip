@@ -1766,7 +1766,8 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
     if (fused_nz) HIP_TRY(hipMemsetAsync(im->d_ssum, 0, sizeof(double) * n, c->stream));
     if (lists) HIP_TRY(hipMemsetAsync(im->d_nnz, 0, sizeof(int) * n, c->stream));
     if (fused_nz)
-        hipLaunchKernelGGL(k_samp_prepare<int>, dim3((unsigned)n), dim3(64), 0, c->stream, im->d_sbox, im->d_soff, im->d_samp, im->d_snz);
+        hipLaunchKernelGGL(k_samp_prepare<int>, dim3((unsigned)((n + 4 * SAMP_PREP_PER_WAVE - 1) / (4 * SAMP_PREP_PER_WAVE))), dim3(256), 0, c->stream,
+                           im->d_sbox, im->d_soff, im->d_samp, im->d_snz, n);
     else if (total > 0)
         HIP_TRY(hipMemsetAsync(d_samp, 0, (resident ? sizeof(int) : sizeof(double)) * total, c->stream));
     {

@@ -288,18 +288,22 @@ k_patch_sums(const int64_t *__restrict__ soff, const TS *__restrict__ samp, doub
 // Before a resident split on the recurrence kernel: that kernel writes every pixel strictly inside
 // a box exactly once, so only the first row and column of each patch need zeroing (not the whole
 // 3.2 GB buffer), and the photon rectangles it will reduce with atomics need their identity.
+#define SAMP_PREP_PER_WAVE 4      // patches per wave (one wave per patch was 50 000 blocks of a few stores: launch-bound)
 template <typename TS>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_samp_prepare(const int4 *__restrict__ sbox, const int64_t *__restrict__ soff, TS *__restrict__ samp,
-               int4 *__restrict__ nz) {
-    const int64_t i = blockIdx.x;
-    const int4 bx = sbox[i];
-    const int nx = bx.y - bx.x, ny = bx.w - bx.z;
-    if (threadIdx.x == 0) nz[i] = make_int4(INT_MAX, 0, INT_MAX, 0);      // x0, x1, y0, y1: empty
-    if (nx <= 0 || ny <= 0) return;
-    TS *p = samp + soff[i];
-    for (int x = threadIdx.x; x < nx; x += 64) p[x] = (TS)0;
-    for (int y = threadIdx.x; y < ny; y += 64) p[(int64_t)y * nx] = (TS)0;
+               int4 *__restrict__ nz, int64_t n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t first = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * SAMP_PREP_PER_WAVE;
+    for (int64_t i = first; i < first + SAMP_PREP_PER_WAVE && i < n; i++) {
+        const int4 bx = sbox[i];
+        const int nx = bx.y - bx.x, ny = bx.w - bx.z;
+        if (lane == 0) nz[i] = make_int4(INT_MAX, 0, INT_MAX, 0);      // x0, x1, y0, y1: empty
+        if (nx <= 0 || ny <= 0) continue;
+        TS *p = samp + soff[i];
+        for (int x = lane; x < nx; x += 64) p[x] = (TS)0;
+        for (int y = lane; y < ny; y += 64) p[(int64_t)y * nx] = (TS)0;
+    }
 }
 
 // ---- photon lists: the pixels of a sample patch that hold a photon ------------------------------------
