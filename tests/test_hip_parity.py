@@ -1456,6 +1456,30 @@ def test_star_tile_kernel_vs_oracle_and_general_kernel(cel, ctx, orc, seed):
         ctx.profile(False)
 
 
+@pytest.mark.parametrize("S", [4096, 4097])
+def test_binning_forms_at_the_small_catalogue_limit(cel, ctx, orc, S):
+    """k_bin_direct (one wave per tile, per-tile list segments) takes catalogues of up to 4096 sources, the super-tile
+    kernels everything larger: the same crowded mixed field at 4096 and at 4097 sources, both against the oracle -- model
+    pixels, log-likelihoods, the number of source-pixels -- and the tile lists' total length by both forms."""
+    from desi_mcmc_amd import synth
+    f = synth.SyntheticField(ctx, S, 2, 200, 232, frac_gal=0.3, seed=11)
+    ll, llb = f.images.render(f.sources, loglik=True)
+    o_lam, o_ll, o_st = orc.render_field(oracle_bands(f), f.H, f.W, f.src["type"], f.src["radec"], f.src["counts"],
+                                         f.src["shape"], f.nelec)
+    np.testing.assert_allclose(f.images.model_images(), o_lam, rtol=RT_LAM)
+    np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
+    st = f.images.stats()
+    assert st["n_srcpix"] == o_st["n_srcpix"]
+    # the first 4096 sources through the other form give the same lists' length as a 4096-source catalogue
+    if S == 4097:
+        sub = cel.SourceSet(ctx, 4096, 2).set(f.src["type"][:4096], f.src["radec"][:4096], f.src["counts"][:4096], f.src["shape"][:4096])
+        f.images.render(sub)
+        n_direct = f.images.stats()["n_tile_entries"]
+        f.images.render(f.sources)
+        n_super = f.images.stats()["n_tile_entries"]
+        assert n_super >= n_direct > 0
+
+
 def test_bench_line_contract_on_the_small_star_workload():
     """bench.py end to end on BASELINE configs[1] (stars1k_512): one JSON line with the contract's keys,
     a roofline object measured live, the extra legs, and a bounded cpu_baseline"""
