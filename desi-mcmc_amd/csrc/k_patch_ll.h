@@ -161,7 +161,7 @@ __device__ __forceinline__ double nz_trip(const NzEntry *__restrict__ L, int n, 
             e = fma(c3, XX[p], e);
             e = fma(c4, XY[p], e);
             e = fma(c5, YY[p], e);
-            v[p] = fma(A, exp_tab64_p4(e, et), v[p]);      // e is finite; far tails flush to 0 inside
+            v[p] = fma(A, exp_tab256_p3(e, et), v[p]);     // e is finite; far tails flush to 0 inside; et: the 256-entry table
         }
     }
     double a = 0.0;
@@ -418,7 +418,7 @@ __device__ __forceinline__ double nz_trip_gal(const NzEntry *__restrict__ L, int
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 const double e = fma(s1, r1[p], s2 * r2[p]);
-                v[p] = fma(A, exp_tab64_p4(e, et), v[p]);
+                v[p] = fma(A, exp_tab256_p3(e, et), v[p]);
             }
         }
     }
@@ -448,7 +448,7 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
               double *__restrict__ out /* PLL_PARTS doubles per job */,
               const int *__restrict__ job_order /* per BLOCK: job << 3 | part << 1 | split, or nullptr: block = job, whole */,
               const int *__restrict__ job_count) {
-    __shared__ double et[64];
+    __shared__ double et[256];                 // 2^(j/256): the photon kernel's exponentials take a cubic on it (exp_tab256_p3)
     __shared__ double ltq[128];
     __shared__ double cq[8 * K_GAL];
     __shared__ double gq[32 + 4 * K_GAL];      // a galaxy's table in the rotated form (nz_trip_gal): 3 x 8 + 42 x 4 doubles
@@ -482,7 +482,13 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
     if (!done) {
         if (rec.type < 0) rec.type = (rec.type == -2) ? 1 : 0;
         rec.scale = 1.0;
-        et[lane] = exp2((double)lane * (1.0 / 64.0));
+        {   // 2^(j/256), j = 4 lane + k: the 64-entry value times 2^(k/256)
+            const double e64 = exp2((double)lane * (1.0 / 64.0));
+            et[4 * lane + 0] = e64;
+            et[4 * lane + 1] = e64 * 1.0027112750502025;      // 2^(1/256)
+            et[4 * lane + 2] = e64 * 1.0054299011128027;      // 2^(2/256)
+            et[4 * lane + 3] = e64 * 1.0081558981184175;      // 2^(3/256)
+        }
         ltq[lane] = c_log_ic[lane];
         ltq[64 + lane] = c_log_lc[lane];
         const LaneConst lc = lane_consts(lane, bd);
@@ -494,7 +500,7 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
                                               (double)ev.z - c.my, (double)(ev.w - 1) - c.my);
             alive = !(0.5 * qmin > 750.0);
             const double ux = c.mx - rec.px, uy = c.my - rec.py;         // the component's centre seen from the source
-            const double qa = c.qa * EXP_SCALE, qb = c.qb * EXP_SCALE, qc = c.qc * EXP_SCALE;
+            const double qa = c.qa * EXP_SCALE256, qb = c.qb * EXP_SCALE256, qc = c.qc * EXP_SCALE256;
             cq[8 * lane + 0] = -0.5 * (qa * ux * ux + 2.0 * qb * ux * uy + qc * uy * uy);
             cq[8 * lane + 1] = qa * ux + qb * uy;
             cq[8 * lane + 2] = qb * ux + qc * uy;
@@ -517,7 +523,7 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
                     lam1 = C11 - t * C12; lam2 = C22 + t * C12;
                 }
                 const double d1 = lc.g_var + lam1, d2 = lc.g_var + lam2;
-                const double gs1 = -0.5 * EXP_SCALE / d1, gs2 = -0.5 * EXP_SCALE / d2;
+                const double gs1 = -0.5 * EXP_SCALE256 / d1, gs2 = -0.5 * EXP_SCALE256 / d2;
                 const double al1 = cs * ia - sn * ib, be1 = -sn * ic, al2 = sn * ia + cs * ib, be2 = cs * ic;
                 const double g0 = -(al1 * ux + be1 * uy), g3 = -(al2 * ux + be2 * uy);
                 gq[32 + 4 * lane + 0] = gs1; gq[32 + 4 * lane + 1] = gs2; gq[32 + 4 * lane + 2] = c.A;

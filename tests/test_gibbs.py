@@ -817,8 +817,10 @@ def test_photon_lists_agree_with_the_dense_form_fuzz(cel):
             finally:
                 ctx.set_option(_lib.CEL_OPT_PHOTON_LISTS, 0)
         assert np.all(np.isfinite(out[2]))
-        np.testing.assert_allclose(out[1], out[2], rtol=1e-12)
-        np.testing.assert_allclose(out[0], out[2], rtol=1e-12)
+        # 1e-12 of the value -- or 1e-9 absolute where the photon term and the mass term nearly cancel (a value of -1 from terms
+        # of 1e3: the photon kernel's exponential is a cubic on a 256-entry table, good to 1.4e-13 of a pixel's value)
+        np.testing.assert_allclose(out[1], out[2], rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(out[0], out[2], rtol=1e-12, atol=1e-9)
         boxes, offs, data = f.images.fetch_samples()
         nnz = np.array([np.count_nonzero(data[offs[i]:offs[i + 1]]) for i in range(S * 5)])
         longest = max(longest, int(nnz.max()))
