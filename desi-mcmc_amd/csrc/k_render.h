@@ -235,25 +235,9 @@ __device__ inline double exp_tab64(double t, const double *__restrict__ et) {
     return ldexp(et[ni & 63] * p, ni >> 6);
 }
 
-// the same with a degree-4 polynomial (truncation r^5/120 < 4e-14 relative): one fma less, for the evaluations at
-// the photons (k_patch_ll_nz), whose instruction stream is 19 VALU per (component, photon) with it
-__device__ inline double exp_tab64_p4(double t, const double *__restrict__ et) {
-    const double c1 = 1.0830424696249145e-02;     // (ln2/64)
-    const double c2 = 5.864904955056169e-05;      // (ln2/64)^2 / 2
-    const double c3 = 2.1173137155464774e-07;     // (ln2/64)^3 / 6
-    const double c4 = 5.732851688640402e-10;      // (ln2/64)^4 / 24
-    double n = rint(t);
-    double f = t - n;
-    int ni = (int)n;                              // saturates for t << 0: ldexp flushes to 0
-    double p = fma(f, c4, c3);
-    p = fma(p, f, c2);
-    p = fma(p, f, c1);
-    p = fma(p, f, 1.0);
-    return ldexp(et[ni & 63] * p, ni >> 6);
-}
-
 // the same on a 256-entry table (t in units of ln2/256) with a cubic: |r| <= ln2/512, truncation r^4/24 < 1.4e-13 relative --
-// one fma less again, for the evaluations at the photons, whose log-likelihood sums are tested to 1e-12
+// two fma less, for the evaluations at the photons (k_patch_ll_nz: 14 VALU per galaxy component and photon with it), whose
+// log-likelihood sums are tested to 1e-12
 #define EXP_SCALE256 369.32993046757462703   // 256 / ln 2
 __device__ inline double exp_tab256_p3(double t, const double *__restrict__ et256) {
     const double c1 = 2.7076061740622863e-03;     // (ln2/256)
