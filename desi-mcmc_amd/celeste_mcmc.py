@@ -15,6 +15,26 @@ from . import celeste as _celeste
 from .sources import SamplePatch
 
 
+_M64 = (1 << 64) - 1
+# one tag per randomised step of a sweep: no two steps share a stream key for any seed (with seed = 0 the plain
+# `seed * prime + sweep` forms all collapsed to `sweep`, and a source's location, shape and flux draws were one sequence)
+STEP_TAGS = dict(split=0x53504C4954000001, flux=0x464C555800000002, location=0x4C4F434154000003, shape=0x5348415045000004)
+
+
+def _mix64(z):
+    """SplitMix64's finaliser on a Python int"""
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def step_seed(seed, step, sweep, k=0):
+    """the stream seed of one step (`split`, `flux`, `location`, `shape`) of sweep number `sweep` (of field k): a hash of
+    all of them, so that the Gibbs blocks draw from unrelated streams whatever the chain's seed is"""
+    return _mix64((_mix64(_mix64(int(seed) & _M64) ^ STEP_TAGS[step]) + int(sweep)) & _M64 ^ (int(k) * 0xD6E8FEB86659FD93 & _M64))
+
+
 def _flux_counts(src, image):
     return (src.flux_dict[image.band] / image.calib) * image.kappa      # celeste.py:80-81,94
 
@@ -253,6 +273,9 @@ class ModelGibbs(object):
                       dtype=np.float64).reshape(S, 4)
         return cls(fields, typ, u, fl, sh, **kw)
 
+    def step_seed(self, step, k=0):
+        return step_seed(self.seed, step, self.sweeps, k)
+
     def counts(self, f, fluxes=None, idx=None):
         """flux in nanomaggies -> expected photons in every image of field f  (sources.py:120-129)"""
         fl = self.fluxes if fluxes is None else fluxes
@@ -273,13 +296,14 @@ class ModelGibbs(object):
         self.noise_sums = []
         any_patch = np.zeros(self.S, dtype=bool)
         for k, f in enumerate(self.fields):
-            seed = (self.seed * 1000003 + self.sweeps * 8191 + k) & (2 ** 64 - 1)
+            seed = self.step_seed("split", k)
             noise = f.iset.photon_split_resident(self._sources(f), seed)
             if self.deal is not None and self.deal.kind == "strips":
                 # this rank split its window and counted its strip's sky photons: the frame's sum over the ranks; and its own
                 # sources' boxes have to lie inside the window (their patches must be complete)
-                noise = self.deal.rank_sum(noise)
-                self.deal.check_boxes(*f.iset.source_boxes(f.sset))
+                # (one collective for both; every rank raises if any rank's window cuts a box)
+                bx, stt = f.iset.source_boxes(f.sset)
+                noise = self.deal.check_boxes(bx, stt, extra=noise)
             f.sums = f.iset.sample_sums()                              # photons per (source, image)
             f.has_patch = f.iset.sample_box_areas() > 0
             any_patch |= f.has_patch.any(axis=1)
@@ -339,7 +363,7 @@ class ModelGibbs(object):
         last.iset.stamp_mass_begin(field_sources(last))
         try:
             # Gamma(a_n, 1 / b_n) = standard Gamma(a_n) * (1 / b_n); every (source, band) draws from its own stream
-            g = gamma_by_stream(a_n.ravel(), self.seed * 15485863 + self.sweeps, np.arange(self.S * 5)).reshape(self.S, 5)
+            g = gamma_by_stream(a_n.ravel(), self.step_seed("flux"), np.arange(self.S * 5)).reshape(self.S, 5)
         finally:
             m_last = last.iset.stamp_mass_end()     # whatever the host draw does, the pending call is collected
         add_mass(psf_sums, last, m_last)
@@ -399,7 +423,7 @@ class ModelGibbs(object):
         t0 = time.perf_counter()
         mine = self.active if self.deal is None else (self.active & self.deal.mask)
         gal = np.nonzero(mine & (self.typ == 1))[0]
-        seed = self.seed * 104729 + self.sweeps
+        seed = self.step_seed("shape")
         if self._shape_engine_on_device():
             # the state machine on the device (cel_slice_sample): the directions are drawn here, from each chain's
             # normal stream, exactly as the host engine draws them; nothing but counters crosses PCIe per round
@@ -458,7 +482,7 @@ class ModelGibbs(object):
             sset = self._sources(f)                        # the catalogue with the fluxes just drawn (other ranks' rows are
             # stale until the merge: a chain reads only its own source's counts)
             ids = None if self.deal is None or self.deal.world == 1 else self.deal.chain_ids()
-            new_u, _, st = f.iset.slice_locations(sset, self.slice_args.get("sigma", 1.0), self.seed * 7919 + self.sweeps,
+            new_u, _, st = f.iset.slice_locations(sset, self.slice_args.get("sigma", 1.0), self.step_seed("location"),
                                                   chain_ids=ids)
             self.u = new_u
             self.timing["rounds"] += st["rounds"]
@@ -473,7 +497,7 @@ class ModelGibbs(object):
         if act.size:
             st = {}
             new_u, _ = slicesample_lockstep(self.u[act], lambda i, U: self.location_loglik(act[i], U),
-                                            seed=self.seed * 7919 + self.sweeps, chain_ids=act, stats=st,
+                                            seed=self.step_seed("location"), chain_ids=act, stats=st,
                                             **self.slice_args)
             self.u[act] = new_u
             self.timing["rounds"] += st["rounds"]

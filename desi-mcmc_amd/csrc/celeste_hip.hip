@@ -1328,8 +1328,6 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     }
     if (!im->slice_prop || im->slice_prop->cap < S) {
         if (im->slice_prop) cel_sources_destroy(im->slice_prop);
-    if (im->sgen_prop) cel_sources_destroy(im->sgen_prop);
-    if (im->d_sgen) (void)hipFree(im->d_sgen);
         im->slice_prop = nullptr;
         int rc0 = cel_sources_create(c, S + S / 4 + 16, B, &im->slice_prop);
         if (rc0) return rc0;

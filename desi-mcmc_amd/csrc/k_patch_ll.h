@@ -10,8 +10,8 @@
 //   mode 1:  sum log(m + eps) * z  -  sum (m + eps)
 //   mode 2:  sum_{m>0} log(m) * z  -  sum m        (galaxy_source_like, celeste_galaxy_conditionals.py:15-42,
 //            on given limits; a pixel the model does not reach contributes nothing)
-//   mode 4:  sum_{z>=0, m+bg>0} log(m + bg) * z - (m + bg)   on a given BACKGROUND: the patch data is two planes,
-//            z then bg (everything else in the field rendered on the box); z < 0 marks a masked pixel.  The
+//   mode 4:  sum_{z unmasked, m+bg>0} log(m + bg) * z - (m + bg)   on a given BACKGROUND: the patch data is two planes,
+//            z then bg (everything else in the field rendered on the box); a NaN z marks a masked pixel (a negative count is data).  The
 //            image_like closure of the star <-> galaxy move (sources.py:277-291).
 // z = the patch data (photons attributed to the source, or nelec for the isolated form).
 //
@@ -81,7 +81,7 @@ k_patch_ll(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__
             if (v > 0.0) a += log(v) * zi;
         } else if (mode == 4) {
             v += (double)zd[(int64_t)n + (int64_t)yy * zpitch + xx];         // the background plane follows the data plane
-            if (v > 0.0 && zi >= 0.0) { a += log(v) * zi; m += v; }
+            if (v > 0.0 && zi == zi) { a += log(v) * zi; m += v; }       // a NaN count marks a masked pixel
         } else if (mode == 2) {
             if (v > 0.0) { a += log(v) * zi; m += v; }
         } else {
@@ -334,7 +334,7 @@ k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
                             if (v > 0.0) { a += log_tab(v, lt) * zz[r]; m += v; }
                         } else if (MODE == 4) {
                             v += bg[r];
-                            if (v > 0.0 && zz[r] >= 0.0) { a += log_tab(v, lt) * zz[r]; m += v; }
+                            if (v > 0.0 && zz[r] == zz[r]) { a += log_tab(v, lt) * zz[r]; m += v; }    // NaN: masked
                         } else {
                             v += eps;
                             a += log_tab(v, lt) * zz[r];

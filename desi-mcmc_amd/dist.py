@@ -120,6 +120,9 @@ class StripDeal(SourceDeal):
 
     def __init__(self, rows, H, world=1, rank=0, halo=0, device=None):
         rows = np.asarray(rows, dtype=np.float64)
+        if int(world) > -(-int(H) // TILE_ROWS):
+            raise ValueError("StripDeal: %d ranks for a frame of %d rows = %d tile rows: a rank would own no rows"
+                             % (world, H, -(-int(H) // TILE_ROWS)))
         edges = np.array([strip_rows(H, world, r)[1] for r in range(world)])
         owner = np.minimum(np.searchsorted(edges, np.clip(np.floor(rows), 0, H - 1), side="right"), world - 1)
         SourceDeal.__init__(self, rows.shape[0], world, rank, device=device, owner=owner)
@@ -132,16 +135,27 @@ class StripDeal(SourceDeal):
         """the strip's rows inside the window (window-relative): what the split's noise sums count"""
         return self.strip[0] - self.window[0], self.strip[1] - self.window[0]
 
-    def check_boxes(self, boxes, status):
-        """boxes (B, S, 4) = y0, y1, x0, x1 relative to the window, status (B, S): an own source's box must not be cut by
-        the window (it may end at the frame's edge)"""
+    def boxes_cut(self, boxes, status):
+        """boxes (B, S, 4) = y0, y1, x0, x1 relative to the window, status (B, S) -> how many of this rank's source boxes the
+        window cuts (a box may end at the frame's edge)"""
         y0, y1 = boxes[:, self.mine, 0], boxes[:, self.mine, 1]
         has = status[:, self.mine] > 0
         top_cut = has & (y0 <= 0) & (self.window[0] > 0)
         bot_cut = has & (y1 >= self.window[1] - self.window[0]) & (self.window[1] < self.H)
-        if top_cut.any() or bot_cut.any():
-            raise RuntimeError("StripDeal: %d of this rank's source boxes reach beyond the window rows %s: enlarge the halo"
-                               % (int(top_cut.sum() + bot_cut.sum()), self.window))
+        return int(top_cut.sum() + bot_cut.sum())
+
+    def check_boxes(self, boxes, status, extra=None):
+        """COLLECTIVE: every rank calls it in every sweep.  The ranks' cut counts are summed (riding with `extra`, a small
+        vector the caller wants summed anyway) and EVERY rank raises when any rank's window cuts one of its boxes -- a rank
+        raising alone would leave the others blocked in the sweep's next collective.
+        -> the rank sum of `extra` (or None)"""
+        cut = self.boxes_cut(boxes, status)
+        vec = np.append(np.atleast_1d(np.asarray(extra, dtype=np.float64)) if extra is not None else np.zeros(0), float(cut))
+        tot = self.rank_sum(vec)
+        if tot[-1] > 0:
+            raise RuntimeError("StripDeal: %d source boxes reach beyond their rank's window (%d on rank %d, window rows %s): "
+                               "enlarge the halo" % (int(tot[-1]), cut, self.rank, self.window))
+        return tot[:-1] if extra is not None else None
 
 
 def init_from_env(backend=None):

@@ -419,9 +419,9 @@ class ImageSet(object):
         return out
 
     def patch_loglik_planes(self, sources, boxes, planes):
-        """mode 4 of cel_patch_loglik: sum over bands of sum_{z>=0, m+bg>0} log(m + bg) z - (m + bg) for each of the
+        """mode 4 of cel_patch_loglik: sum over bands of sum_{z unmasked, m+bg>0} log(m + bg) z - (m + bg) for each of the
         P proposals in `sources`.  boxes (B,4) y0,y1,x0,x1 (empty: band not scored); planes[b] = (2, ny, nx): the
-        observed counts (negative = masked pixel) and the background everything else contributes.  -> ll[P]
+        observed counts (NaN = masked pixel; negative counts are data) and the background everything else contributes.  -> ll[P]
         (poisson_loglike of sources.py:6-12 as the star <-> galaxy move uses it, :277-291)"""
         boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(self.B, 4)
         offs = np.zeros(self.B + 1, dtype=np.int64)

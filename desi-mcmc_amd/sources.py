@@ -297,7 +297,7 @@ class Source(object):
     # the bounding box and sums a masked Poisson term in numpy (the closure of :277-291, twice per image).
     # Here every candidate (current, proposed, or any number of proposals of either type) is scored on
     # every image of a same-shape group by ONE call of cel_patch_loglik in mode 4: the observed box and
-    # the stored background cross the ABI as two planes per band, masked pixels marked by a negative count.
+    # the stored background cross the ABI as two planes per band, masked pixels marked by a NaN count.
     def image_like_batch(self, candidates, images):
         """sum over `images` of poisson_loglike(observed box, background + candidate's model patch, invvar mask)
         for each SrcParams of `candidates` (stars and galaxies may be mixed)  -> (P,)"""
@@ -320,7 +320,7 @@ class Source(object):
                     obs = np.array(im.nelec[y0:y1, x0:x1], dtype=np.float64)
                     invvar = getattr(im, "invvar", None)
                     if invvar is not None:
-                        obs[invvar[y0:y1, x0:x1] == 0] = -1.0
+                        obs[invvar[y0:y1, x0:x1] == 0] = np.nan        # the mask is its own signal: a negative count is data (sources.py:9)
                     planes[k] = np.stack([obs, np.asarray(self.background_image_dict[im], dtype=np.float64)])
                 flux_counts = lambda q, im: (q.flux_dict[im.band] / im.calib) * im.kappa      # noqa: E731  (sources.py:393-394)
                 typ, radec, counts_part, shape = _celeste._source_arrays(list(candidates), part, counts_fn=flux_counts)

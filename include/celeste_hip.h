@@ -241,10 +241,10 @@ int cel_render_stamps(cel_images *img, cel_sources *src, int band, int scaled, c
  *   mode 1   ll = sum_b [ sum log(m + eps_b) z - sum (m + eps_b) ]
  *   mode 2   ll = sum_b [ sum_{m>0} log(m) z - sum m ]   -- galaxy_source_like
  *            (celeste_galaxy_conditionals.py:15-42) on given limits
- *   mode 4   ll = sum_b [ sum_{z>=0, m+bg>0} log(m + bg) z - (m + bg) ]   -- poisson_loglike of the observed box
+ *   mode 4   ll = sum_b [ sum_{z unmasked, m+bg>0} log(m + bg) z - (m + bg) ]   -- poisson_loglike of the observed box
  *            against background + model, the image_like closure of the star <-> galaxy move
  *            (CelestePy/sources.py:6-12,277-291).  Each band's patch data is TWO planes, z then bg
- *            (offsets[b+1]-offsets[b] = 2 x box area); z < 0 marks a masked pixel (invvar == 0)
+ *            (offsets[b+1]-offsets[b] = 2 x box area); a NaN z marks a masked pixel (invvar == 0); negative counts are data
  *   ll_out   P doubles (host) */
 int cel_patch_loglik(cel_images *img, cel_sources *src, const int32_t *boxes, const int64_t *offsets,
                      const double *data, int mem, int mode, double *ll_out);

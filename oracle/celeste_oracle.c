@@ -488,9 +488,9 @@ double orc_patch_loglik(const orc_band *b, int H, int W, int type, const double 
         } else if (mode == 4) {
             /* image_like of calculate_acceptance_logprob (sources.py:277-291): poisson_loglike (:6-12) of the
              * observed box against background_img + model_img; data = [observed (n), background (n)], an observed
-             * value < 0 stands for mask == 0 */
+             * value that is NaN stands for mask == 0 (a negative count, as in sky-subtracted data, is kept: :9) */
             m += data[n + i];
-            if (m > 0. && data[i] >= 0.) {
+            if (m > 0. && data[i] == data[i]) {
                 a += (long double)(log(m) * data[i]);
                 msum += (long double)m;
             }
@@ -555,16 +555,25 @@ void orc_galaxy_psf_mixture_params(const double thetas[2], const double W[4], co
  * tables (what `.amp` / `.var[:,0,0]` of :155-156 mean).  bound with ERROR = 1e-5 about v_s (:160-161),
  * int() box (:166-167) unless lims = {y0,y1,x0,x1} is given (:162-164); values by gmm_like_2d (:173-176).
  * box = {y0,y1,x0,x1} out; patch may be NULL to query the box.  Returns the number of patch pixels. */
+static int64_t prof_psf_image_W(const orc_band *b, int H, int W_, int prof, const double Wm[4], const double u[2],
+                               const int *lims, int box[4], double *patch);
+
 int64_t orc_galaxy_prof_psf_image(const orc_band *b, int H, int W_, int prof, const double R[4], const double u[2],
                                   const int *lims, int box[4], double *patch) {
+    /* np.dot(R, R.T) */
+    double Wm[4] = {R[0] * R[0] + R[1] * R[1], R[0] * R[2] + R[1] * R[3], R[2] * R[0] + R[3] * R[1], R[2] * R[2] + R[3] * R[3]};
+    return prof_psf_image_W(b, H, W_, prof, Wm, u, lims, box, patch);
+}
+
+/* the same from W = R R^T on (what :151 forms and everything after it reads) */
+static int64_t prof_psf_image_W(const orc_band *b, int H, int W_, int prof, const double Wm[4], const double u[2],
+                               const int *lims, int box[4], double *patch) {
     double ea[K_EXP], ev[K_EXP], da[K_DEV], dv[K_DEV];
     orc_profile_tables(ea, ev, da, dv);
     const double *amp = prof == 0 ? ea : da, *sig = prof == 0 ? ev : dv;
     const int J = prof == 0 ? K_EXP : K_DEV;
     double v_s[2];
     orc_equa2pixel(b, u, v_s);
-    /* np.dot(R, R.T) */
-    double Wm[4] = {R[0] * R[0] + R[1] * R[1], R[0] * R[2] + R[1] * R[3], R[2] * R[0] + R[3] * R[1], R[2] * R[2] + R[3] * R[3]};
     double weights[K_PSF * K_DEV], means[2 * K_PSF * K_DEV], covars[4 * K_PSF * K_DEV];
     orc_galaxy_prof_psf_mixture_params(Wm, v_s, b->w, &b->mu[0][0], &b->cov[0][0][0], K_PSF, amp, sig, J, weights, means, covars);
     if (lims) {
@@ -612,6 +621,88 @@ double orc_galaxy_source_like(const orc_band *b, int H, int W_, const double th[
     }
     free(fe); free(fd);
     return (double)(a - m);
+}
+
+/* The terms of orc_patch_loglik's mode 0 (Source.log_likelihood, sources.py:134-183) APART, for tests that must not
+ * lose the photon term's digits where it cancels against the mass term:
+ *   out[0] = sum_{m>0} log(m) z      out[1] = sum_{m>0} |log(m) z|   (the scale its rounding is relative to)
+ *   out[2] = counts * sum(psf weights)                                (ll = out[0] - out[2])
+ *   out[3] = what the SUBNORMAL range is worth in the photon term.  Where the unit stamp lies below 2^-1022 (a proposal
+ *            hundreds of pixels from its photons: exponents between -708 and -750) every evaluator -- the reference's two
+ *            included, mog_loglike's exp(logsumexp) and gmm_like_2d's sum of exp -- holds it to a few quanta of 2^-1074
+ *            only; log() turns n quanta of error into n 2^-1074 / stamp, and below a handful of quanta whether a pixel
+ *            counts at all (m > 0) depends on the order of the arithmetic.  With L = the stamp's logarithm formed in the
+ *            log domain: a pixel with L < log(2^-1074) - log 64 adds nothing (zero everywhere), one with
+ *            L < log(2^-1074) + log 64 its whole term |L + log counts| z, any other subnormal one 64 quanta.
+ * type 0 star, 1 galaxy (shape = theta, sigma, phi, rho), 2 the older per-profile route's source as the product's ABI takes
+ * it: shape = theta, W00, W01, W11 with W = R R^T of celeste_galaxy_conditionals.py:151 (constant Ups_n), the unit stamp
+ * theta f_exp + (1 - theta) f_dev (:34-36) on the limits. */
+void orc_patch_loglik_terms(const orc_band *b, int H, int W, int type, const double u[2], const double shape[4],
+                            double counts, const int box[4], const double *data, double out[4]) {
+    double wsum = (b->w[0] + b->w[1]) + b->w[2];
+    out[0] = out[1] = out[3] = 0.0;
+    out[2] = counts * wsum;
+    int64_t n = (int64_t)(box[1] - box[0]) * (box[3] - box[2]);
+    if (n <= 0) { out[2] = 0.0; return; }
+    double *patch = (double *)malloc(sizeof(double) * (size_t)n);
+    /* the same mixture as (pis, means, icovs, dets), for the log-domain value */
+    double pis[K_GAL], means[2 * K_GAL], covs[4 * K_GAL], icovs[4 * K_GAL], dets[K_GAL], scratch[K_GAL];
+    int K = K_GAL;
+    if (type == 0) {
+        double v[2];
+        int own[4];
+        if (!orc_star_box(b, H, W, u, v, own)) { free(patch); return; }     /* psf_ns is None (:160-163) */
+        orc_star_patch(b, v, box, patch);
+        K = K_PSF;
+        for (int k = 0; k < K_PSF; k++) {
+            pis[k] = b->w[k];
+            means[2 * k] = b->mu[k][0] + v[0];
+            means[2 * k + 1] = b->mu[k][1] + v[1];
+            memcpy(covs + 4 * k, &b->cov[k][0][0], sizeof(double) * 4);
+        }
+    } else if (type == 1) {
+        double pxy[2], Tinv[4];
+        orc_galaxy_table(b, shape, u, pis, means, covs, pxy, Tinv);
+        orc_galaxy_patch(pis, means, covs, box, patch);
+    } else {
+        double Wm[4] = {shape[1], shape[2], shape[2], shape[3]};
+        double *fd = (double *)malloc(sizeof(double) * (size_t)n);
+        int bx[4];
+        prof_psf_image_W(b, H, W, 0, Wm, u, box, bx, patch);
+        prof_psf_image_W(b, H, W, 1, Wm, u, box, bx, fd);
+        for (int64_t i = 0; i < n; i++) patch[i] = shape[0] * patch[i] + (1. - shape[0]) * fd[i];
+        free(fd);
+        double ea[K_EXP], ev[K_EXP], da[K_DEV], dv[K_DEV], v_s[2];
+        orc_profile_tables(ea, ev, da, dv);
+        orc_equa2pixel(b, u, v_s);
+        orc_galaxy_prof_psf_mixture_params(Wm, v_s, b->w, &b->mu[0][0], &b->cov[0][0][0], K_PSF, ea, ev, K_EXP, pis, means, covs);
+        orc_galaxy_prof_psf_mixture_params(Wm, v_s, b->w, &b->mu[0][0], &b->cov[0][0][0], K_PSF, da, dv, K_DEV,
+                                           pis + K_PSF * K_EXP, means + 2 * K_PSF * K_EXP, covs + 4 * K_PSF * K_EXP);
+        for (int k = 0; k < K_GAL; k++) pis[k] *= (k < K_PSF * K_EXP) ? shape[0] : (1. - shape[0]);
+    }
+    for (int k = 0; k < K; k++) inv2(covs + 4 * k, icovs + 4 * k, dets + k);
+    const double LOG_Q = -744.44007192138126;          /* log(2^-1074) */
+    const double LOG_64 = 4.1588830833596715;
+    const int nx = box[3] - box[2];
+    long double a = 0.0L, aa = 0.0L, qq = 0.0L;
+    for (int64_t i = 0; i < n; i++) {
+        double m = counts * patch[i];
+        if (m > 0.) {
+            double t = log(m) * data[i];
+            a += (long double)t;
+            aa += (long double)fabs(t);
+        }
+        if (patch[i] < 2.2250738585072014e-308 && data[i] != 0.) {
+            double L = mog_loglike_pt((double)(box[2] + (int)(i % nx)), (double)(box[0] + (int)(i / nx)), means, icovs, dets, pis, K, scratch);
+            if (L < LOG_Q - LOG_64) continue;
+            if (L < LOG_Q + LOG_64) qq += (long double)(fabs(L + log(counts)) * fabs(data[i]));
+            else qq += (long double)(fabs(data[i]) * 64.0 * exp(LOG_Q - L));
+        }
+    }
+    free(patch);
+    out[0] = (double)a;
+    out[1] = (double)aa;
+    out[3] = (double)qq;
 }
 
 /* The reductions celeste_em.py:38-91 takes of gen_src_prob_layers (celeste.py:222-234):

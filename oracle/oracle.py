@@ -234,6 +234,21 @@ def patch_loglik(band, H, W, typ, u, shape, counts, box, data, mode=0):
                                   box.ctypes.data_as(_ip), dp, C.c_int(int(mode)))
 
 
+def patch_loglik_terms(band, H, W, typ, u, shape, counts, box, data):
+    """mode 0's terms apart -> (sum_{m>0} log(m) z, sum_{m>0} |log(m) z|, counts * sum(psf weights), the worth of one
+    subnormal quantum in the photon term where the unit stamp is a subnormal number); type 2 takes
+    shape = (theta, W00, W01, W11), the per-profile route's source as the product's ABI holds it"""
+    b, bp = _d(band)
+    u, up = _d(u)
+    sh, sp = _d(shape)
+    box = np.ascontiguousarray(box, dtype=np.int32)
+    data, dp = _d(data)
+    out = np.zeros(4)
+    lib().orc_patch_loglik_terms(bp, C.c_int(H), C.c_int(W), C.c_int(int(typ)), up, sp, C.c_double(float(counts)),
+                                 box.ctypes.data_as(_ip), dp, out.ctypes.data_as(_dp))
+    return out
+
+
 def galaxy_prof_psf_mixture_params(W, v_s, image_ws, image_means, image_covars, amp, sigs):
     """celeste_fast.pyx:100-140 -> (weights, means, covars), PSF-major"""
     W, Wp = _d(W)

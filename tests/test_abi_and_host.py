@@ -311,3 +311,23 @@ def test_mog_sampling_api(built):
     np.testing.assert_allclose(m.var(), .3 * m.covs[0] + .7 * m.covs[1])
     np.random.seed(5)
     assert mog.mog_samples(3, m.means, m.chols, m.pis).shape == (3, 2)      # the global generator, as the reference
+
+
+def test_step_seeds_are_unrelated_for_every_chain_seed():
+    """the sweep's randomised steps draw from unrelated streams for ANY chain seed -- with `seed * prime + sweep` seeds a
+    chain seeded 0 handed the location, shape and flux steps one and the same uniform sequence"""
+    from desi_mcmc_amd import celeste_mcmc
+    from desi_mcmc_amd.util.infer.slicesample import ChainStreams
+    for seed in (0, 1, 4, 2 ** 63 + 5):
+        seen = {}
+        for sweep in range(3):
+            for step in ("split", "flux", "location", "shape"):
+                for k in range(2):
+                    sd = celeste_mcmc.step_seed(seed, step, sweep, k)
+                    assert 0 <= sd < 2 ** 64 and sd not in seen, (seed, step, sweep, k, seen.get(sd))
+                    seen[sd] = (step, sweep, k)
+        first = {}
+        for step in ("flux", "location", "shape"):
+            st = ChainStreams(celeste_mcmc.step_seed(seed, step, 0), np.arange(50))
+            first[step] = st.uniform(np.arange(50))
+        assert not np.any(first["flux"] == first["location"]) and not np.any(first["shape"] == first["location"])

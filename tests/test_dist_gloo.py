@@ -150,11 +150,21 @@ def _strip_worker(rank, world, port, out_dir):
     Hw = deal.window[1] - deal.window[0]
     boxes = np.zeros((2, S, 4), dtype=np.int32)
     boxes[:, :, 0], boxes[:, :, 1] = 5, Hw - 5
-    deal.check_boxes(boxes, np.ones((2, S), dtype=np.int32))               # inside the window: fine
-    if deal.window[0] > 0 and deal.mine.size:
-        boxes[0, deal.mine[0], 0] = 0                                       # an own box cut by the window's first row
-        with pytest.raises(RuntimeError, match="halo"):
-            deal.check_boxes(boxes, np.ones((2, S), dtype=np.int32))
+    ones = np.ones((2, S), dtype=np.int32)
+    assert deal.check_boxes(boxes, ones) is None                          # inside every window: fine (a collective)
+    got = deal.check_boxes(boxes, ones, extra=np.array([1.0, float(rank)]))
+    assert got.tolist() == [float(world), float(sum(range(world)))]         # the caller's vector rides along, summed
+    # ONE rank's window cuts one of its boxes: every rank raises (a rank raising alone would leave the others blocked in
+    # the sweep's next collective)
+    assert deal.boxes_cut(boxes, ones) == 0
+    if rank == 1:
+        assert deal.window[0] > 0 and deal.mine.size
+        boxes[0, deal.mine[0], 0] = 0
+        assert deal.boxes_cut(boxes, ones) == 1
+    with pytest.raises(RuntimeError, match="halo"):
+        deal.check_boxes(boxes, ones)
+    with pytest.raises(ValueError, match="own no rows"):
+        dist.StripDeal(rows, 64, world, rank)                             # 2 tile rows for 3 ranks
     np.savez(os.path.join(out_dir, "strip_%d.npz" % rank), state=state, owner=deal.owner)
     dist.barrier()
     import torch.distributed as td

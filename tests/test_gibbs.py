@@ -137,7 +137,7 @@ def test_model_gibbs_conserves_photons_and_draws_the_gamma_conditionals(cel):
         # (source, band) drawn from its own stream -- re-drawn here from the same streams
         mass = f.iset.stamp_mass(f.sset)
         fl = g.resample_fluxes().copy()
-        std = celeste_mcmc.gamma_by_stream((5. + f.sums).ravel(), g.seed * 15485863 + g.sweeps, np.arange(20)).reshape(4, 5)
+        std = celeste_mcmc.gamma_by_stream((5. + f.sums).ravel(), g.step_seed("flux"), np.arange(20)).reshape(4, 5)
         np.testing.assert_allclose(fl, std / (.005 + mass * (f.kappa / f.calib)[None, :]), rtol=1e-12)
         g.resample_locations()
         g.sweeps += 1
@@ -276,11 +276,22 @@ def test_background_patch_and_image_like(cel, orc):
     # masked pixels (invvar == 0) drop out of both sums
     img.invvar = np.ones_like(img.nelec)
     img.invvar[ylim[0] + 3:ylim[0] + 20, xlim[0] + 5:xlim[0] + 30] = 0.0
+    nel0 = img.nelec
     try:
         mask = img.invvar[ylim[0]:ylim[1], xlim[0]:xlim[1]]
         np.testing.assert_allclose(src.image_like(src, img), orc.poisson_loglike(obs, bg + model, mask), rtol=1e-11)
+        # a NEGATIVE observed count (sky-subtracted data) is data, not a mask: poisson_loglike keeps it (sources.py:9)
+        neg = nel0.copy()
+        neg[ylim[0] + 25:ylim[0] + 28, xlim[0] + 2:xlim[0] + 9] = -3.0
+        neg[ylim[0] + 5, xlim[0] + 7] = -1.0                        # masked AND negative
+        img.nelec = neg                                             # (the move reads the observed box from the image object)
+        obs2 = neg[ylim[0]:ylim[1], xlim[0]:xlim[1]]
+        want = orc.poisson_loglike(obs2, bg + model, mask)
+        assert abs(want - orc.poisson_loglike(obs, bg + model, mask)) > 1.0
+        np.testing.assert_allclose(src.image_like(src, img), want, rtol=1e-11)
     finally:
         del img.invvar
+        img.nelec = nel0
 
 
 class _FlatPrior(object):
@@ -560,6 +571,27 @@ def test_config5_full_size_sweeps(cel, orc):
             p, _, _ = orc.source_patch(band, f.H, f.W, gd.typ[s], gd.u[s], gd.shape[s])
             want = 0.0 if p is None else p.sum()
             np.testing.assert_allclose(mass[s, b], want, rtol=1e-10, atol=1e-300)
+    # the location step's likelihood at the chain's state against the oracle, on BOTH routes: every patch at its photons
+    # (k_patch_ll_nz) and every patch densely (k_patch_ll_hw<0>) -- the same split (same seed: same photons) laid out twice
+    from desi_mcmc_amd import _lib
+    rs = np.random.RandomState(8)
+    idx = np.sort(rs.choice(np.nonzero(gd.active)[0], 200, replace=False))
+    U = gd.u[idx] + rs.normal(0, 3e-5, size=(200, 2))
+    gfd = gd.fields[0]
+    gfd._counts = None
+    terms = None
+    for route in (1, 2):
+        ctx.set_option(_lib.CEL_OPT_PHOTON_LISTS, route)
+        try:
+            f.images.photon_split_resident(sset, seed=77)
+            got = gd.location_loglik(idx, U)
+        finally:
+            ctx.set_option(_lib.CEL_OPT_PHOTON_LISTS, 0)
+        if terms is None:
+            boxes, offs, data = f.images.fetch_samples()
+            terms, _ = _oracle_terms(orc, f, gd.typ[idx], U, gd.counts(gfd, idx=idx), gd.shape[idx], idx, boxes, offs, data)
+            del data
+        _assert_terms(got, terms, "route %d" % route)
 
 
 @pytest.mark.parametrize("engine", ["device", "host"])
@@ -726,7 +758,8 @@ def test_shape_step_device_engine_follows_the_host_engine(cel, shape_args):
     assert not custom._shape_engine_on_device()
 
 
-def test_one_chain_partitioned_by_row_strips(cel, tmp_path):
+@pytest.mark.parametrize("S,size,sweeps", [(600, 512, 3), (10000, 2048, 2)], ids=["600x512", "config5_full_size"])
+def test_one_chain_partitioned_by_row_strips(cel, tmp_path, S, size, sweeps):
     """SURVEY 8e, config 5, the spatial partition: two child ranks (sharing GPU 0, gloo) each hold the images on their row
     strip plus a halo, split only those rows' photons, own the sources whose row lies in their strip, count their strip's
     sky photons (the sums are added over the ranks) and add their strip's log-likelihood to the trace (dist.StripDeal).
@@ -741,7 +774,6 @@ def test_one_chain_partitioned_by_row_strips(cel, tmp_path):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from _dealt_chain_rank import run_chain
-    S, size, sweeps = 600, 512, 3
     one = run_chain(S, size, sweeps, "device")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -766,6 +798,10 @@ def test_one_chain_partitioned_by_row_strips(cel, tmp_path):
     np.testing.assert_allclose(got[0]["fluxes"][0], one["fluxes"][0], rtol=1e-9)
     np.testing.assert_allclose(got[0]["eps"][0], one["eps"][0], rtol=1e-12)
     np.testing.assert_allclose(got[0]["ll"][0], one["ll"][0], rtol=1e-10)
+    # the field's log-likelihood trace over all sweeps: 1e-12 (the window's row origin enters the arithmetic: rounding)
+    np.testing.assert_allclose(got[0]["ll"], one["ll"], rtol=1e-12)
+    for k in range(sweeps):                                               # conservation over the ranks in EVERY sweep
+        assert own_sums[k].sum() <= got[0]["nelec_sum"].sum()
     assert 0.25 < (got[0]["sums"][0].sum() / own_sums[0].sum()) < 0.75    # the ranks shared the sources about evenly
 
 
@@ -828,6 +864,101 @@ def test_photon_lists_agree_with_the_dense_form_fuzz(cel):
     assert longest > 3 * 2048 and shortest < 64                   # lists dealt to four blocks, and lists shorter than one step
 
 
+def _oracle_terms(orc, f, typ, U, counts, shape, own, boxes, offs, data, threads=8):
+    """orc_patch_loglik_terms of proposal p on its owner's photon patches, summed over the bands -> (P, 3), (P,) photons"""
+    from concurrent.futures import ThreadPoolExecutor
+    B = f.B
+    bands = [f.bands[b].copy() for b in range(B)]
+    for b in range(B):
+        bands[b][36] = f.images.band(b)[36]              # R as the library computed it (pinned to the reference's elsewhere)
+
+    def one(p):
+        t, nph = np.zeros(4), 0.0
+        o = int(own[p])
+        for b in range(B):
+            bx = boxes[o, b]
+            z = data[offs[o * B + b]:offs[o * B + b + 1]]
+            t += orc.patch_loglik_terms(bands[b], f.H, f.W, typ[p], U[p], shape[p], counts[p, b], bx, z)
+            nph += z.sum()
+        return t, nph
+    with ThreadPoolExecutor(threads) as ex:
+        res = list(ex.map(one, range(len(own))))
+    return np.array([r[0] for r in res]), np.array([r[1] for r in res])
+
+
+def _assert_terms(got, terms, what=""):
+    """got = photon term - mass term of the HIP path against the oracle's terms (P, 4) = (photon, |photon|, mass, quantum): the
+    photon term to 1e-11 of the scale its rounding is relative to (sum |z log m|; the mass term, counts * sum w, is formed
+    alike on both sides), and the value itself to rtol = 1e-11 -- no atol -- wherever the two terms do not cancel.
+    `quantum`: where the unit stamp is a SUBNORMAL number (a proposal hundreds of pixels from its photons, exponents between
+    -708 and -750) every evaluator -- the reference's two included -- holds it to a few of the range's quanta only; the
+    oracle prices that (orc_patch_loglik_terms: 64 quanta through log(), the whole term within 64 quanta of zero)."""
+    pt, apt, mass, quantum = terms[:, 0], terms[:, 1], terms[:, 2], terms[:, 3]
+    err = np.abs((got + mass) - pt)
+    bound = 1e-11 * apt + 8 * np.finfo(float).eps * mass + quantum
+    bad = np.nonzero(err > bound)[0]
+    assert bad.size == 0, "%s photon term off at %s: err %s, bound %s" % (what, bad[:5], err[bad[:5]], bound[bad[:5]])
+    want = pt - mass
+    clean = (np.abs(want) >= 0.01 * (apt + mass)) & (quantum == 0)
+    assert clean.sum() >= 0.7 * clean.size
+    np.testing.assert_allclose(got[clean], want[clean], rtol=1e-11, atol=0)
+
+
+def test_photon_list_route_vs_oracle(cel, orc):
+    """The conditional likelihood read AT THE PHOTONS (k_patch_ll_nz, CEL_OPT_PHOTON_LISTS = 1: every patch takes that route)
+    directly against the oracle's Source.log_likelihood (sources.py:134-183) on the split's photon patches fetched to the
+    host -- stars (general form), galaxies (rotated basis, cubic table exponential), per-profile sources with a positive
+    definite and with a rank-1 W (rotated / general form), sources on the frame's edge and off it, proposals from a fraction
+    of a pixel to hundreds of pixels away (the far shortcut: -counts * sum w), photon lists from under 64 to over 8 192
+    entries (whole jobs and jobs dealt to four blocks, in calls of 7 and of hundreds of proposals)."""
+    from desi_mcmc_amd import _lib, synth
+    ctx = cel.default_context(0)
+    shortest, longest, far = 1 << 30, 0, 0
+    for seed in range(3):
+        rs = np.random.RandomState(300 + seed)
+        S, H, W = 48, int(rs.choice([192, 256])), int(rs.choice([224, 320]))
+        f = synth.SyntheticField(ctx, S, 5, H, W, frac_gal=0.6, seed=400 + seed, with_nelec=False)
+        src = f.src
+        src["counts"] = src["counts"] * np.exp(rs.uniform(np.log(0.02), np.log(60.0), size=(S, 1)))     # 20 ... 5e6 photons
+        src["shape"][:, 1] = np.exp(rs.uniform(np.log(0.05), np.log(6.0), S))                            # r_e 0.05" ... 6"
+        edge = rs.rand(S) < 0.2
+        src["radec"][edge] = synth.pixel2equa(f.bands[0], np.column_stack([rs.choice([-3.0, 1.5, W - 2.0, W + 2.5], edge.sum()),
+                                                                           rs.uniform(0, H, edge.sum())]))
+        gal = np.nonzero(src["type"] == 1)[0][:6]
+        if seed >= 1:           # type 2: shape = theta, W00, W01, W11 -- three positive definite, three rank-1 (no Cholesky factor)
+            src["type"][gal] = 2
+            src["shape"][gal[:3], 1:] = [[9.0, 2.0, 4.0], [2.5, -1.0, 6.0], [30.0, 12.0, 8.0]]
+            src["shape"][gal[3:], 1:] = [[9.0, 6.0, 4.0], [1.0, 1.0, 1.0], [16.0, -8.0, 4.0]]
+        f.sources.set(src["type"], src["radec"], src["counts"], src["shape"])
+        f.images.render(f.sources)
+        f.images.set_nelec(rs.poisson(f.images.model_images()).astype(np.float64))
+        P = 4
+        own = np.repeat(np.arange(S, dtype=np.int32), P)
+        jit = rs.normal(0, 1.0, size=(S * P, 2)) * np.repeat(rs.choice([3e-6, 3e-5, 4e-4, 2e-2, 6e-2], S), P)[:, None]
+        typ, U = np.repeat(src["type"], P), np.repeat(src["radec"], P, axis=0) + jit
+        cts, shp = np.repeat(src["counts"], P, axis=0), np.repeat(src["shape"], P, axis=0)
+        prop = cel.SourceSet(ctx, S * P, 5).set(typ, U, cts, shp)
+        ctx.set_option(_lib.CEL_OPT_PHOTON_LISTS, 1)
+        try:
+            f.images.photon_split_resident(f.sources, seed=seed)
+            got = f.images.patch_loglik_resident(prop, own)
+            few = cel.SourceSet(ctx, 7, 5).set(typ[11:18], U[11:18], cts[11:18], shp[11:18])       # 35 jobs: every job dealt
+            assert np.array_equal(f.images.patch_loglik_resident(few, own[11:18]), got[11:18])
+        finally:
+            ctx.set_option(_lib.CEL_OPT_PHOTON_LISTS, 0)
+        boxes, offs, data = f.images.fetch_samples()
+        for i in range(S * 5):
+            n = int(np.count_nonzero(data[offs[i]:offs[i + 1]]))
+            if offs[i + 1] > offs[i]:
+                shortest, longest = min(shortest, n), max(longest, n)
+        terms, nph = _oracle_terms(orc, f, typ, U, cts, shp, own, boxes, offs, data)
+        assert np.all(np.isfinite(got))
+        _assert_terms(got, terms, "seed %d" % seed)
+        far += int(np.sum((terms[:, 1] == 0) & (nph > 0)))       # the model is exactly 0 on every photon: only the mass term
+    assert shortest < 64 and longest > 8192, (shortest, longest)
+    assert far >= 3
+
+
 def test_slice_sample_and_planes_error_paths(cel):
     """bad arguments of the round-3 entry points come back as ValueError (CEL_ERR_INVALID), never as a crash"""
     from desi_mcmc_amd import synth
@@ -859,3 +990,42 @@ def test_slice_sample_and_planes_error_paths(cel):
         f.images.patch_loglik_planes(one, boxes, [None, None, np.zeros((20, 30)), None, None])
     ll = f.images.patch_loglik_planes(one, boxes, [None, None, np.stack([np.full((20, 30), 3.0), np.full((20, 30), 400.0)]), None, None])
     assert np.isfinite(ll[0])
+
+
+def test_the_two_device_samplers_in_either_order(cel):
+    """cel_slice_sample, then cel_slice_locations, then cel_slice_sample again on ONE image set: each sampler owns its state
+    (round 3 freed the general sampler's state inside the first cel_slice_locations call: a use-after-free on the next
+    cel_slice_sample and a double free at destroy).  The second shape call must reproduce a fresh image set's."""
+    from desi_mcmc_amd import synth
+    ctx = cel.default_context(0)
+    dirs = np.tile(np.eye(4)[None, :2, :], (60, 1, 1))
+
+    def run(order):
+        f = synth.SyntheticField(ctx, 60, 5, 192, 192, frac_gal=0.5, seed=21)
+        f.images.photon_split_resident(f.sources, seed=5)
+        out = []
+        for what in order:
+            if what == "shape":
+                th, llh, _ = f.images.slice_sample(f.sources, 1, 1.0, seed=9, dirs=dirs)
+                out.append(th)
+            else:
+                u, _, _ = f.images.slice_locations(f.sources, 1e-3, seed=4)
+                out.append(u)
+                f.sources.set(f.src["type"], f.src["radec"], f.src["counts"], f.src["shape"])     # back to the start
+        del f
+        return out
+    a = run(["shape", "loc", "shape", "loc"])
+    b = run(["loc", "shape"])
+    assert np.array_equal(a[0], a[2]) and np.array_equal(a[0], b[1])
+    assert np.array_equal(a[1], a[3]) and np.array_equal(a[1], b[0])
+    # a catalogue that outgrows the location sampler's proposal set after the general sampler ran
+    f = synth.SyntheticField(ctx, 40, 5, 160, 160, frac_gal=0.5, seed=22)
+    f.images.photon_split_resident(f.sources, seed=5)
+    f.images.slice_sample(f.sources, 0, 1e-3, seed=1, step_out=False)
+    f.images.slice_locations(f.sources, 1e-3, seed=4)
+    big = synth.SyntheticField(ctx, 400, 5, 160, 160, frac_gal=0.5, seed=23)
+    f.images.photon_split_resident(big.sources, seed=5)
+    f.images.slice_sample(big.sources, 0, 1e-3, seed=1, step_out=False)
+    f.images.slice_locations(big.sources, 1e-3, seed=4)
+    x, _, st = f.images.slice_sample(big.sources, 0, 1e-3, seed=1, step_out=False)
+    assert x.shape == (400, 2) and st["evals"] >= 4 * 400

@@ -258,6 +258,13 @@ def test_source_conditional_loglik_golden():
                     data = zs[j] if mode == 0 else g["nelec"][b, boxes[j, 0]:boxes[j, 1], boxes[j, 2]:boxes[j, 3]]
                     ll += orc.patch_loglik(B[b], H, W, kind, us[p], sh[p], counts, boxes[j], data, mode)
                 np.testing.assert_allclose(ll, exp[p], rtol=1e-12)
+                if mode == 0:       # the same value from its terms taken apart (what the photon-list GPU test compares)
+                    tt = np.zeros(4)
+                    for j, b in enumerate(used):
+                        tt += orc.patch_loglik_terms(B[b], H, W, kind, us[p], sh[p], fl[p, b] / g["calib"][b] * g["kappa"][b],
+                                                     boxes[j], zs[j])
+                    np.testing.assert_allclose(tt[0] - tt[2], exp[p], rtol=1e-12)
+                    assert tt[1] >= abs(tt[0]) and tt[3] == 0.0
         if kind == 0:
             assert g["c%d_ll0" % ci][-1] < 0     # the overlap-miss proposal: -flux * sum(weights) only
 
@@ -389,3 +396,26 @@ def test_galaxy_source_like_oracle_matches_a_numpy_statement(bands):
         ok = lam > 0
         want = np.sum(Z[ok] * np.log(lam[ok])) - np.sum(lam[ok])
         np.testing.assert_allclose(orc.galaxy_source_like(band, 51, 51, th, u, flux, box, Z), want, rtol=1e-12)
+
+
+def test_patch_loglik_terms_of_a_per_profile_source():
+    """type 2 of orc_patch_loglik_terms (shape = theta, W00, W01, W11) is galaxy_source_like's photon term
+    (celeste_galaxy_conditionals.py:15-42: the value at Z minus the value at Z = 0) when W = R R^T of the same shape"""
+    g = load_golden("mini_field.npz")
+    B = orc.pack_bands(g)
+    H, W = int(g["H"]), int(g["W"])
+    rs = np.random.RandomState(7)
+    th = np.array([0.35, 1.4, 50.0, 0.55])
+    u = g["radec"][int(np.nonzero(g["is_gal"])[0][0])]
+    for b in (0, 2, 4):
+        R = orc.galaxy_tinv(th[1], th[3], th[2], B[b][28:32].reshape(2, 2))
+        Wm = R @ R.T
+        v = orc.equa2pixel(B[b], u)
+        x0, y0 = int(v[0]) - 9, int(v[1]) - 7
+        box = np.array([max(y0, 0), min(y0 + 17, H), max(x0, 0), min(x0 + 21, W)], dtype=np.int32)
+        Z = rs.poisson(3.0, size=(box[1] - box[0], box[3] - box[2])).astype(np.float64)
+        a = orc.galaxy_source_like(B[b], H, W, th, u, 900.0, box, Z)
+        a0 = orc.galaxy_source_like(B[b], H, W, th, u, 900.0, box, np.zeros_like(Z))
+        t = orc.patch_loglik_terms(B[b], H, W, 2, u, [th[0], Wm[0, 0], Wm[0, 1], Wm[1, 1]], 900.0, box, Z)
+        np.testing.assert_allclose(t[0], a - a0, rtol=1e-11)
+        np.testing.assert_allclose(t[2], 900.0 * B[b][3:6].sum(), rtol=1e-15)
