@@ -26,6 +26,10 @@ config1.npz        config 1: real stamps, catalogue sources, gen_model_image + c
 source_ll.npz      (f)1 Source.log_likelihood / log_likelihood_isolated (sources.py:134-237)
 estep.npz          (f)4 gen_src_prob_layers reductions (celeste_em.py:38-91)
 slicesample.npz    config 5: slicesample (util/infer/slicesample.py:89-227) with every draw it made recorded
+real_fields.npz    configs 1 / 4 on EVERY real field the reference ships (data/stamps 11, data/stamp_catalog 63,
+                   data/galaxy_stamps 25, data/real 1 = 100 fields, 500 images, 221 catalogue sources): FitsImage
+                   records + nelec, the catalogue as util/misc/init_utils.py:42-60 loads it, gen_model_image,
+                   celeste_likelihood[_multi_image], every source's box, star stamps and gen_galaxy_psf_image patches
 """
 import os
 import sys
@@ -577,7 +581,103 @@ def gen_slicesample():
     save("slicesample.npz", **out)
 
 
+REAL_DIRS = ("stamps", "stamp_catalog", "galaxy_stamps", "real")
+
+
+def real_field_list():
+    """[(dir, tag, stamp template, catalogue file)] of every field with five band images and a catalogue, in sorted order
+    (what load_imgs_and_catalog, util/misc/init_utils.py:9-40, is handed as a sorted glob of cat*.fits)"""
+    import glob
+    out = []
+    for d in REAL_DIRS:
+        D = os.path.join(_refload.REF_ROOT, "data", d)
+        for c in sorted(glob.glob(os.path.join(D, "cat*.fits"))):
+            base = os.path.basename(c)[:-5]
+            tag = base.split("cat-")[1] if "cat-" in base else ""
+            tmpl = os.path.join(D, "stamp-%s-" + tag + ".fits") if tag else os.path.join(D, "stamp-%s.fits")
+            if all(os.path.exists(tmpl % b) for b in BANDS):
+                out.append((d, tag, tmpl, c))
+    return out
+
+
+def catalogue_sources(cat_file):
+    """get_sources_from_catalog (util/misc/init_utils.py:42-60): a row with any negative flux is skipped"""
+    _, cat = _refload.fits_bintable(cat_file)
+    srcs = []
+    for row in cat:
+        fl = dict(zip(BANDS, [float(row["psfflux_" + b]) for b in BANDS]))
+        if any(v < 0 for v in fl.values()):
+            continue
+        srcs.append(SrcParams(u=np.array([row["ra"], row["dec"]], dtype=np.float64), fluxes=fl))
+    return srcs
+
+
+def gen_real_fields():
+    """real_fields.npz: the reference's own FitsImage / gen_model_image / celeste_likelihood[_multi_image] /
+    gen_point_source_psf_image / gen_galaxy_psf_image on every real field in its tree.  Model images are stored whole for
+    data/stamps and data/real (12 fields), every 4th pixel of every 4th row for the others (the log-likelihoods pin the rest);
+    star stamps for the r band of those 12 fields; one galaxy patch per field of data/stamps and data/galaxy_stamps."""
+    fields = real_field_list()
+    rs = np.random.RandomState(2024)
+    recs, names, HW, nel, cat_off, cat_radec, cat_flux = [], [], [], [], [0], [], []
+    lam_full, lam_sub, ll_band, ll = [], [], [], []
+    src_box, src_none = [], []
+    st_field, st_src, st_box, st_patch = [], [], [], []
+    g_field, g_band, g_u, g_th, g_box, g_patch = [], [], [], [], [], []
+    for fi, (d, tag, tmpl, catf) in enumerate(fields):
+        imgs = [ref_fits.FitsImage(b, fits_file_template=tmpl) for b in BANDS]
+        srcs = catalogue_sources(catf)
+        H, W = imgs[0].nelec.shape
+        assert all(im.nelec.shape == (H, W) for im in imgs)
+        names.append("%s/%s" % (d, tag))
+        HW.append([H, W])
+        recs.append(stack_bands(imgs))
+        ne = np.array([im.nelec for im in imgs])
+        assert np.array_equal(ne, np.rint(ne)) and np.abs(ne).max() < 2 ** 31
+        nel.append(ne.astype(np.int32).ravel())
+        cat_off.append(cat_off[-1] + len(srcs))
+        cat_radec += [s.u for s in srcs]
+        cat_flux += [[s.fluxes[b] for b in BANDS] for s in srcs]
+        lam = np.array([ref_cel.gen_model_image(srcs, im) for im in imgs])
+        ll_band.append([ref_cel.celeste_likelihood(srcs, im) for im in imgs])
+        ll.append(ref_cel.celeste_likelihood_multi_image(srcs, imgs))
+        whole = d in ("stamps", "real")
+        (lam_full if whole else lam_sub).append((lam if whole else lam[:, ::4, ::4]).ravel())
+        for si, s in enumerate(srcs):
+            for bi, im in enumerate(imgs):
+                patch, yl, xl = ref_cel.gen_point_source_psf_image(s.u, im)
+                src_none.append(int(patch is None))
+                src_box.append([0, 0, 0, 0] if patch is None else [yl[0], yl[1], xl[0], xl[1]])
+                if whole and bi == 2 and patch is not None:
+                    st_field.append(fi); st_src.append(si); st_box.append([yl[0], yl[1], xl[0], xl[1]]); st_patch.append(patch)
+        if d in ("stamps", "galaxy_stamps") and srcs:
+            # a galaxy at the brightest catalogue source's place, on this field's PSF and WCS
+            bi = fi % 5
+            s = max(srcs, key=lambda q: q.fluxes["r"])
+            th = np.array([rs.uniform(0.05, 0.95), np.exp(rs.uniform(np.log(0.3), np.log(3.0))), rs.uniform(0, 180), rs.uniform(0.2, 0.95)])
+            patch, yl, xl = ref_gal.gen_galaxy_psf_image(th, s.u, imgs[bi])
+            g_field.append(fi); g_band.append(bi); g_u.append(s.u); g_th.append(th)
+            g_box.append([yl[0], yl[1], xl[0], xl[1]]); g_patch.append(patch)
+    out = {k: np.array([r[k] for r in recs], dtype=np.float64) for k in recs[0]}        # (F, 5, ...)
+    st_flat, st_offs, st_shapes = pack_ragged(st_patch)
+    g_flat, g_offs, g_shapes = pack_ragged(g_patch)
+    out.update(names=np.array(names), HW=np.array(HW, dtype=np.int64), nelec=np.concatenate(nel),
+               cat_off=np.array(cat_off, dtype=np.int64), cat_radec=np.array(cat_radec, dtype=np.float64),
+               cat_flux=np.array(cat_flux, dtype=np.float64), lam_full=np.concatenate(lam_full), lam_sub=np.concatenate(lam_sub),
+               ll_band=np.array(ll_band, dtype=np.float64), ll=np.array(ll, dtype=np.float64),
+               src_box=np.array(src_box, dtype=np.int64).reshape(-1, 5, 4), src_none=np.array(src_none, dtype=np.int8).reshape(-1, 5),
+               st_field=np.array(st_field), st_src=np.array(st_src), st_box=np.array(st_box, dtype=np.int64),
+               st_flat=st_flat, st_offs=st_offs, st_shapes=st_shapes,
+               g_field=np.array(g_field), g_band=np.array(g_band), g_u=np.array(g_u), g_th=np.array(g_th),
+               g_box=np.array(g_box, dtype=np.float64), g_flat=g_flat, g_offs=g_offs, g_shapes=g_shapes)
+    save("real_fields.npz", **out)
+    print("real fields: %d fields, %d sources, sum of ll = %.4f" % (len(fields), cat_off[-1], float(np.sum(ll))))
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["real_fields"]:
+        gen_real_fields()
+        sys.exit(0)
     if sys.argv[1:] == ["slicesample"]:
         gen_slicesample()
         sys.exit(0)
@@ -592,3 +692,4 @@ if __name__ == "__main__":
     gen_source_ll()
     gen_estep()
     gen_slicesample()
+    gen_real_fields()

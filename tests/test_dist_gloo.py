@@ -64,6 +64,53 @@ def _worker(rank, world, port, mode, out_dir):
     td.destroy_process_group()
 
 
+def _real_set_worker(rank, world, port, out_dir):
+    """the real-data field set (tests/golden/real_fields.npz) dealt to the ranks: each rank scores ITS fields (the oracle
+    stands in for the GPU here) and one all-reduce of the 5 per-band sums gives every rank the survey's log-likelihood"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import real_fields
+    from desi_mcmc_amd import dist
+    from oracle import oracle as orc
+    dist.init_from_env(backend="gloo")
+    _, fields = real_fields()
+    mine = dist.field_shard(len(fields), world, rank)
+    part = np.zeros(5)
+    for k in mine:
+        f = fields[k]
+        S = len(f["radec"])
+        _, ll, _ = orc.render_field(orc.pack_bands(f["rec"]), f["H"], f["W"], np.zeros(S, np.int32), f["radec"].reshape(S, 2),
+                                    (f["flux"] * f["rec"]["kappa"][None, :]).reshape(S, 5), np.zeros((S, 4)), f["nelec"])
+        part += ll
+    tot = dist.allreduce_loglik(part)
+    tot_det = dist.allreduce_loglik(part, deterministic=True)
+    np.save(os.path.join(out_dir, "realset_%d.npy" % rank), np.stack([tot, tot_det, part, np.full(5, float(len(mine)))]))
+    dist.barrier()
+    import torch.distributed as td
+    td.destroy_process_group()
+
+
+def test_real_field_set_world2_gloo(tmp_path):
+    """BASELINE configs[3] on the real data the reference ships: 100 fields dealt round-robin to two ranks, one all-reduce;
+    the sum is the reference's own (celeste_likelihood per image of every field, summed)"""
+    import torch.multiprocessing as mp
+    from conftest import real_fields
+    world = 2
+    mp.spawn(_real_set_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), "realset_%d.npy" % r)) for r in range(world)]
+    _, fields = real_fields()
+    want = np.sum([f["ll_band"] for f in fields], axis=0)
+    for r in range(world):
+        np.testing.assert_allclose(res[r][0], want, rtol=1e-12)
+        np.testing.assert_allclose(res[r][1], want, rtol=1e-12)
+        assert np.array_equal(res[r][1], res[0][1])
+        assert res[r][3][0] == 50.0
+    np.testing.assert_allclose(res[0][2] + res[1][2], want, rtol=1e-12)
+    assert not np.allclose(res[0][2], res[1][2])
+
+
 def _deal_target(idx, P):
     """a per-chain log-density (chain c is a Gaussian about (c, -c) of width 1 + c / 10): the stand-in for the
     conditional likelihood of source c given the photon split"""

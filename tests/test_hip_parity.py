@@ -235,6 +235,94 @@ def test_config1_real_stamps(cel, stamp_images):
 
 
 # ------------------------------------------------------------------------------------------
+# every real field the reference ships (tests/golden/real_fields.npz: its own run on all of them)
+# ------------------------------------------------------------------------------------------
+def _real_images(cel, f):
+    return [cel.FitsImage.from_record(BANDS[b], f["rec"], b, f["nelec"][b]) for b in range(5)]
+
+
+def _real_sources(cel, f):
+    return [cel.SrcParams(u=f["radec"][s], fluxes=dict(zip(BANDS, f["flux"][s]))) for s in range(len(f["radec"]))]    # a = None (Q2)
+
+
+def test_every_real_field_through_the_reference_api(cel):
+    """configs[0] on ALL the real data in the reference's tree: 100 fields (data/stamps 11, data/stamp_catalog 63,
+    data/galaxy_stamps 25, data/real 1: 500 SDSS images, 221 catalogue sources loaded as util/misc/init_utils.py:9-60 loads
+    them) through the drop-in API -- FitsImage's derived fields, gen_model_image, celeste_likelihood[_multi_image] (celeste.py:203-252),
+    every source's box from gen_point_source_psf_image, the star stamps and gen_galaxy_psf_image
+    (celeste_galaxy_conditionals.py:185-214) on each field's own PSF and WCS -- against the reference's own run."""
+    from conftest import real_fields
+    from desi_mcmc_amd import celeste
+    from desi_mcmc_amd import celeste_galaxy_conditionals as gal
+    g, fields = real_fields()
+    assert len(fields) == 100
+    imgs_of = {}
+    for f in fields:
+        imgs = imgs_of[f["index"]] = _real_images(cel, f)
+        srcs = _real_sources(cel, f)
+        for b, im in enumerate(imgs):
+            np.testing.assert_allclose(im.R, f["rec"]["R"][b], rtol=1e-13)
+            np.testing.assert_allclose(im.invcovars, f["rec"]["invcovars"][b], rtol=1e-12)
+            np.testing.assert_allclose(im.logdets, f["rec"]["logdets"][b], rtol=1e-12)
+            lam = celeste.gen_model_image(srcs, im)
+            if f["lam"] is not None:
+                np.testing.assert_allclose(lam, f["lam"][b], rtol=RT_LAM, err_msg=f["name"])
+            else:
+                np.testing.assert_allclose(lam[::4, ::4], f["lam_sub"][b], rtol=RT_LAM, err_msg=f["name"])
+            np.testing.assert_allclose(celeste.celeste_likelihood(srcs, im), f["ll_band"][b], rtol=RT_LL, err_msg=f["name"])
+            for s, q in enumerate(srcs):
+                patch, yl, xl = celeste.gen_point_source_psf_image(q.u, im)
+                assert (patch is None) == bool(f["src_none"][s, b])
+                if patch is not None:
+                    assert (yl[0], yl[1], xl[0], xl[1]) == tuple(int(t) for t in f["src_box"][s, b]), (f["name"], s, b)
+        np.testing.assert_allclose(celeste.celeste_likelihood_multi_image(srcs, imgs), f["ll"], rtol=RT_LL, err_msg=f["name"])
+    by_index = {f["index"]: f for f in fields}
+    for k, want in enumerate(unpack_ragged(g["st_flat"], g["st_offs"], g["st_shapes"])):
+        f = by_index[int(g["st_field"][k])]
+        patch, yl, xl = celeste.gen_point_source_psf_image(f["radec"][int(g["st_src"][k])], imgs_of[f["index"]][2])
+        assert (yl[0], yl[1], xl[0], xl[1]) == tuple(int(t) for t in g["st_box"][k])
+        np.testing.assert_allclose(patch, want, rtol=RT_STAMP, atol=1e-300)
+    for k, want in enumerate(unpack_ragged(g["g_flat"], g["g_offs"], g["g_shapes"])):
+        img = imgs_of[int(g["g_field"][k])][int(g["g_band"][k])]
+        patch, yl, xl = gal.gen_galaxy_psf_image(g["g_th"][k], g["g_u"][k], img)
+        assert (yl[0], yl[1], xl[0], xl[1]) == tuple(g["g_box"][k]) and isinstance(yl[0], float)
+        np.testing.assert_allclose(patch, want, rtol=RT_STAMP, atol=1e-300)
+
+
+def test_real_field_set_dealt_to_the_ranks(cel, ctx):
+    """BASELINE configs[3] on the only real data that exists (the Stripe-82 set is absent from the reference tree,
+    .MISSING_LARGE_BLOBS:2-4): the 99 51 x 51 real fields as ONE field set dealt by dist.field_shard -- world 1 here, on the
+    GPU, through the resident ImageSet / SourceSet path bench.py --workload fields8_2048 runs; world 2 on gloo in
+    tests/test_dist_gloo.py -- every field's per-band log-likelihoods and the job's all-reduced sum equal the reference's."""
+    from conftest import real_fields
+    from desi_mcmc_amd import dist, field
+    g, fields = real_fields()
+    fields = [f for f in fields if (f["H"], f["W"]) == (51, 51)]
+    assert len(fields) == 99
+    mine = dist.field_shard(len(fields), 1, 0)
+    assert mine == list(range(99))
+    total, want = np.zeros(5), np.zeros(5)
+    sets = []
+    for k in mine:
+        f = fields[k]
+        iset = cel.ImageSet(ctx, field.pack_bands(f["rec"]), 51, 51, nelec=f["nelec"])
+        S = len(f["radec"])
+        sset = cel.SourceSet(ctx, max(S, 1), 5).set(np.zeros(S, np.int32), f["radec"].reshape(S, 2),
+                                                    (f["flux"] * f["rec"]["kappa"][None, :]).reshape(S, 5), np.zeros((S, 4)))
+        sets.append((iset, sset))
+    for rep in range(2):                                   # resident: a second pass re-renders without any upload
+        total[:] = 0.0
+        for k, (iset, sset) in zip(mine, sets):
+            _, llb = iset.render(sset, loglik=True)
+            np.testing.assert_allclose(llb, fields[k]["ll_band"], rtol=RT_LL, err_msg=fields[k]["name"])
+            total += llb
+    for k in mine:
+        want += fields[k]["ll_band"]
+    np.testing.assert_allclose(dist.allreduce_loglik(total), want, rtol=RT_LL)
+    np.testing.assert_allclose(total.sum(), sum(f["ll"] for f in fields), rtol=RT_LL)
+
+
+# ------------------------------------------------------------------------------------------
 # seeded synthetic fields against the CPU oracle
 # ------------------------------------------------------------------------------------------
 def oracle_bands(field):

@@ -419,3 +419,46 @@ def test_patch_loglik_terms_of_a_per_profile_source():
         t = orc.patch_loglik_terms(B[b], H, W, 2, u, [th[0], Wm[0, 0], Wm[0, 1], Wm[1, 1]], 900.0, box, Z)
         np.testing.assert_allclose(t[0], a - a0, rtol=1e-11)
         np.testing.assert_allclose(t[2], 900.0 * B[b][3:6].sum(), rtol=1e-15)
+
+
+def test_every_real_field_the_reference_ships():
+    """tests/golden/real_fields.npz: the reference's own run on all 100 real fields in its tree (500 images, 221 catalogue
+    sources as util/misc/init_utils.py:42-60 loads them) -- model images at 1e-10 (whole for data/stamps + data/real, every
+    4th pixel of every 4th row elsewhere), per-image and multi-image log-likelihoods at 1e-12, every source's box exact,
+    star stamps and gen_galaxy_psf_image patches (float limits, celeste_galaxy_conditionals.py:185-214)."""
+    from conftest import real_fields
+    g, fields = real_fields()
+    assert len(fields) == 100 and sum(len(f["radec"]) for f in fields) == 221
+    for f in fields:
+        B = orc.pack_bands(f["rec"])
+        S = len(f["radec"])
+        counts = f["flux"] * f["rec"]["kappa"][None, :]          # a is None: kappa * flux (celeste.py:52-55, Q2)
+        lam, ll, _ = orc.render_field(B, f["H"], f["W"], np.zeros(S, np.int32), f["radec"].reshape(S, 2), counts.reshape(S, 5),
+                                      np.zeros((S, 4)), f["nelec"])
+        if f["lam"] is not None:
+            np.testing.assert_allclose(lam, f["lam"], rtol=RTOL, err_msg=f["name"])
+        else:
+            np.testing.assert_allclose(lam[:, ::4, ::4], f["lam_sub"], rtol=RTOL, err_msg=f["name"])
+        np.testing.assert_allclose(ll, f["ll_band"], rtol=1e-12, err_msg=f["name"])
+        np.testing.assert_allclose(ll.sum(), f["ll"], rtol=1e-12)
+        for s in range(S):
+            for b in range(5):
+                ok, v, box = orc.star_box(B[b], f["H"], f["W"], f["radec"][s])
+                assert (not ok) == bool(f["src_none"][s, b])
+                if ok:
+                    assert list(box) == list(f["src_box"][s, b]), (f["name"], s, b)
+    by_index = {f["index"]: f for f in fields}
+    stamps = unpack_ragged(g["st_flat"], g["st_offs"], g["st_shapes"])
+    assert len(stamps) >= 40
+    for k, want in enumerate(stamps):
+        f = by_index[int(g["st_field"][k])]
+        p, yl, xl = orc.source_patch(orc.pack_bands(f["rec"])[2], f["H"], f["W"], 0, f["radec"][int(g["st_src"][k])])
+        assert [yl[0], yl[1], xl[0], xl[1]] == list(g["st_box"][k])
+        np.testing.assert_allclose(p, want, rtol=RTOL)
+    gal = unpack_ragged(g["g_flat"], g["g_offs"], g["g_shapes"])
+    assert len(gal) == 36
+    for k, want in enumerate(gal):
+        f = by_index[int(g["g_field"][k])]
+        p, yl, xl = orc.source_patch(orc.pack_bands(f["rec"])[int(g["g_band"][k])], f["H"], f["W"], 1, g["g_u"][k], g["g_th"][k])
+        assert [float(yl[0]), float(yl[1]), float(xl[0]), float(xl[1])] == list(g["g_box"][k])
+        np.testing.assert_allclose(p, want, rtol=RTOL)
