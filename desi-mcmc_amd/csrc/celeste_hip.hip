@@ -82,6 +82,7 @@ static int fail(int code, const char *fmt, ...) {
 #include "k_render.h"
 #include "k_render_hw.h"
 #include "k_render_stars.h"
+#include "k_small_stars.h"
 #include "k_render_qw.h"
 #include "k_misc.h"
 #include "k_patch_ll.h"
@@ -111,7 +112,7 @@ struct cel_ctx {
     int variant = 1;
     double tail_T = 32.0;
     int profile = 0;          // CEL_OPT_PROFILE: 0 off, 1 every kernel, 2 the evaluating kernels only
-    int star_tiles = (getenv("CEL_STAR_TILES") && atoi(getenv("CEL_STAR_TILES")) >= 0 && atoi(getenv("CEL_STAR_TILES")) <= 2)
+    int star_tiles = (getenv("CEL_STAR_TILES") && atoi(getenv("CEL_STAR_TILES")) >= 0 && atoi(getenv("CEL_STAR_TILES")) <= 3)
                          ? atoi(getenv("CEL_STAR_TILES")) : 1;       // CEL_OPT_STAR_TILES (the env var: the initial value, for test runs)
     int tile_order = 1;       // 0 = launch k_render tiles in index order, 1 = heaviest first by the last render's measured tile durations (estimate when none), 2 = heaviest first by the estimate only
     int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created
@@ -212,6 +213,11 @@ struct cel_images {
     cel_sources *sgen_prop = nullptr;
     int64_t last_S = 0;
     double last_entries = 0;
+    // the one-launch path of a small star field (k_small_stars.h): per-block partials + per-band arrival counters
+    double *d_small = nullptr, *h_small = nullptr;      // one buffer: pinned host memory and its device address
+    unsigned long long small_seq = 0;
+    bool llband_on_host = false;  // the last render's per-band sums were formed on the host (the small path)
+    bool small_off = false;       // a part once held more stars than the kernel stages: the general path from then on
 };
 
 static std::atomic<uint64_t> g_source_gen{0};
@@ -469,7 +475,7 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         c->nz_force = (int)v;
         return CEL_OK;
     case CEL_OPT_STAR_TILES:
-        if (v != 0.0 && v != 1.0 && v != 2.0) return fail(CEL_ERR_INVALID, "CEL_OPT_STAR_TILES must be 0, 1 or 2");
+        if (v != 0.0 && v != 1.0 && v != 2.0 && v != 3.0) return fail(CEL_ERR_INVALID, "CEL_OPT_STAR_TILES must be 0, 1, 2 or 3");
         c->star_tiles = (int)v;
         return CEL_OK;
     case CEL_OPT_DEBUG:
@@ -518,6 +524,7 @@ int cel_images_destroy(cel_images *im) {
     if (im->slice_prop) cel_sources_destroy(im->slice_prop);
     if (im->sgen_prop) cel_sources_destroy(im->sgen_prop);
     if (im->d_sgen) (void)hipFree(im->d_sgen);
+    if (im->h_small) (void)hipHostFree(im->h_small);
     if (im->ev_step) (void)hipEventDestroy(im->ev_step);
     delete im;
     return CEL_OK;
@@ -814,11 +821,75 @@ static int host_boxes(cel_images *im, cel_sources *src) {
 // internal render flag: sources take part only strictly inside their boxes on the low side
 // (x > x0, y > y0), the photon split's membership rule (celeste_sample_sources.pyx:50-51)
 #define CEL_RENDER_STRICT 4
+// internal render flag: the caller reads the tile lists afterwards (the E-step's tile walk): the general path
+#define CEL_RENDER_KEEP_LISTS 16
 static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_band, double *ll_total, double *lambda_out);
 
 int cel_render_field(cel_images *im, cel_sources *src, int flags, double *ll_band, double *ll_total) {
     if (flags & ~(CEL_RENDER_LOGLIK | CEL_RENDER_NO_STORE)) return fail(CEL_ERR_INVALID, "cel_render_field: unknown flag bits");
     return render_impl(im, src, flags, ll_band, ll_total, nullptr);
+}
+
+// A small star field in one launch (k_small_stars.h): prep, binning, render and the per-band reduction.  *done = false when a
+// part of a tile held more stars than the kernel stages (the caller then takes the general path, from now on).
+static int render_small_stars(cel_images *im, cel_sources *src, int flags, bool *done) {
+    cel_ctx *c = im->ctx;
+    hipStream_t st = c->stream;
+    const int64_t S = src->S;
+    const int B = im->B;
+    *done = false;
+    int rc = ensure_recs(im, S * B);
+    if (rc) return rc;
+    const int nblk = B * im->ntx * im->nty * SMALL_NP, nblk_band = im->ntx * im->nty * SMALL_NP;
+    if (!im->h_small) {
+        // the blocks' partials and the overflow word behind them live in pinned, device-mapped, coherent HOST memory: the
+        // kernel stores them over PCIe itself (20 KB at configs[1]) and the step needs no copy command behind the kernel
+        // -- a D2H copy of this size cost the step ~8 us of queue latency
+        HIP_TRY(hipHostMalloc((void **)&im->h_small, sizeof(double) * (nblk + 1), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(im->h_small, 0, sizeof(double) * (nblk + 1));
+        HIP_TRY(hipHostGetDevicePointer((void **)&im->d_small, im->h_small, 0));
+    }
+    RenderArgs a;
+    memset(&a, 0, sizeof(a));
+    a.bands = im->d_bands; a.recs = im->d_recs; a.nelec = im->d_nelec; a.lambda = im->d_lambda; a.partials = im->d_small;
+    a.S = S; a.B = B; a.H = im->H; a.W = im->W; a.ntx = im->ntx; a.nty = im->nty;
+    a.flags = flags; a.variant = c->variant; a.tail_T = c->tail_T;
+    SmallArgs x;
+    x.radec = src->d_radec; x.counts = src->d_counts;
+    x.recs = im->d_recs; x.boxes = im->d_boxes; x.kind = im->d_kind; x.status = im->d_status;
+    x.partials = im->d_small;
+    x.flag = reinterpret_cast<unsigned long long *>(im->d_small + nblk);
+    x.stamp = 0x8000000000000000ull | ++im->small_seq;
+    x.full_H = im->full_H; x.win_y0 = im->win_y0;
+    int pi = prof_slot(c, CEL_K_RENDER_STARS);
+    LAUNCH_EV(k_small_stars, dim3((unsigned)nblk), dim3(64), st, EV0(c, pi), EV1(c, pi), a, x);
+    const bool ll = (flags & CEL_RENDER_LOGLIK) != 0;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    unsigned long long cur0;
+    memcpy(&cur0, im->h_small + nblk, sizeof(cur0));
+    if (cur0 == x.stamp) { im->small_off = true; return CEL_OK; }
+    if (ll) {
+        // a band's partials in index order, Kahan: the same bits whatever order the blocks ran in
+        for (int b = 0; b < B; b++) {
+            const double *pb = im->h_small + (size_t)b * nblk_band;
+            double sum = 0.0, comp = 0.0;
+            for (int i = 0; i < nblk_band; i++) {
+                const double y = pb[i] - comp;
+                const double t = sum + y;
+                comp = (t - sum) - y;
+                sum = t;
+            }
+            c->pinned[b] = sum;
+        }
+        im->llband_on_host = true;              // d_llband does not hold this render's sums (cel_images_loglik_device uploads them)
+    }
+    im->recs_gen = src->gen;                    // the kernel wrote k_prep's records, boxes and status words
+    im->last_S = S;
+    im->cost_S = -1; im->order_S = -1;
+    im->last_entries = 0;
+    *done = true;
+    return CEL_OK;
 }
 
 static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_band, double *ll_total, double *lambda_out) {
@@ -834,7 +905,29 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
     hipStream_t st = c->stream;
     const int64_t S = src->S;
     const int T = im->B * im->ntx * im->nty;
-    int rc = run_prep(im, src);
+    int rc;
+    // a small star field (configs[1]): one launch instead of four (k_small_stars.h) -- unless a caller needs the tile lists
+    // (the photon split, the E-step), an image of its own or the diagnostics
+    const bool keep_lists = (flags & CEL_RENDER_KEEP_LISTS) != 0;
+    flags &= ~CEL_RENDER_KEEP_LISTS;
+    if (S > 0 && S <= SMALL_MAX_S && T <= STAR_TILES_MIN && im->TW == HW_TW && c->variant != 0 && c->star_tiles == 1 &&
+        !c->tile_timing && !(c->debug & ~64) && src->n_gal == 0 && im->star_one_segment && !im->small_off && !lambda_out &&
+        !keep_lists && !(flags & CEL_RENDER_STRICT)) {
+        bool done = false;
+        if ((rc = render_small_stars(im, src, flags, &done))) return rc;
+        if (done) {
+            if (flags & CEL_RENDER_LOGLIK) {
+                double tot = 0.0;
+                for (int b = 0; b < im->B; b++) {
+                    if (ll_band) ll_band[b] = c->pinned[b];
+                    tot += c->pinned[b];
+                }
+                if (ll_total) *ll_total = tot;
+            }
+            return CEL_OK;
+        }
+    }
+    rc = run_prep(im, src);
     if (rc) return rc;
     if (im->lists_cap == 0) {
         // first guess: every (band, source) touches ~6 tiles; grown on overflow below
@@ -904,7 +997,7 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         // instantiation with counters / time stamps / ablations exists for the general kernel only
         const bool diag = a.timing || (c->debug & ~64);
         const bool stars_only = im->TW == HW_TW && !diag && c->star_tiles && src->n_gal == 0 && im->star_one_segment &&
-                                c->variant != 0 && (c->star_tiles == 2 || T > STAR_TILES_MIN);
+                                c->variant != 0 && (c->star_tiles == 2 || T > STAR_TILES_MIN);    // (1 and 3: the rule; 3 = without the one-launch small path)
         pi = prof_slot(c, stars_only ? CEL_K_RENDER_STARS : CEL_K_RENDER);
         if (im->TW == QW_TW)
             LAUNCH_EV(k_render_qw, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
@@ -922,6 +1015,7 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         if (flags & CEL_RENDER_LOGLIK) {
             pi = prof_slot(c, CEL_K_REDUCE);
             LAUNCH_EV(k_reduce, dim3(im->B), dim3(256), st, EV0(c, pi), EV1(c, pi), (const double *)im->d_partials, im->ntx * im->nty, im->d_llband);
+            im->llband_on_host = false;
         }
         // the per-band sums, the total list length and the overflow flags ride back in ONE copy
         HIP_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * MAX_BANDS + sizeof(unsigned long long) * 4,
@@ -1890,7 +1984,7 @@ int cel_estep_stats(cel_images *im, cel_sources *src, double *xtilde, double *ma
     if (!im->have_nelec) return fail(CEL_ERR_INVALID, "cel_estep_stats needs cel_images_set_nelec first");
     cel_ctx *c = im->ctx;
     // lambda for exactly these sources must be resident (this also runs k_prep for them)
-    int rc = cel_render_field(im, src, 0, nullptr, nullptr);
+    int rc = render_impl(im, src, CEL_RENDER_KEEP_LISTS, nullptr, nullptr, nullptr);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     const int B = im->B;

@@ -27,6 +27,55 @@ __device__ inline double comp_radius(double cxx, double cxy, double cyy, double 
     return maj + dist;
 }
 
+// ---- pieces of k_prep that the fused small-field kernel (k_small_stars.h) evaluates itself: the same expressions, so the
+// same positions and boxes ----
+// equa2pixel (fits_image.py:166-174); cphi = cos(phi_1 pi / 180)
+__device__ __forceinline__ void prep_pixel(const BandDev &bd, double ra, double dec, double cphi, double &px, double &py) {
+    double s0 = (ra - bd.phi[0]) * cphi, s1 = dec - bd.phi[1];
+    px = (bd.ups_inv[0] * s0 + bd.ups_inv[1] * s1) + bd.rho[0];
+    py = (bd.ups_inv[2] * s0 + bd.ups_inv[3] * s1) + bd.rho[1];
+}
+
+// a star's record fields from its pixel position: celeste.py:130-140, the overlap test (with the reference's axis mix-up,
+// Q1) + the int() box on the H x W frame; type 0, or -3 where the reference returns (None, None, None)
+__device__ __forceinline__ void prep_star_box(const BandDev &bd, double px, double py, int H, int W, SrcRec &r) {
+    const double BIG = 1073741824.0;
+    bool miss = (px < -50 || px > 2.0 * H || py < -50 || px > 2.0 * W);
+    if (miss || !(px == px) || !(py == py)) {
+        r.type = -3;    // the reference returns (None, None, None) here, whatever the limits
+    } else {
+        double bound = bd.R;
+        int lx = (int)clampd(px - bound, -BIG, BIG), hx = (int)clampd(px + bound + 1, -BIG, BIG);
+        int ly = (int)clampd(py - bound, -BIG, BIG), hy = (int)clampd(py + bound + 1, -BIG, BIG);
+        r.x0 = max(0, lx); r.x1 = min(hx, W);
+        r.y0 = max(0, ly); r.y1 = min(hy, H);
+    }
+}
+
+// row window [win_y0, win_y0 + win_h) of the H-row frame (strip partition across GPUs): boxes are formed against the FULL
+// frame, then cut to the window and re-based, so a strip renders the same pixels the whole frame would; a record without
+// a contribution gets an empty box and remembers its kind in a negative type
+__device__ __forceinline__ void prep_window(SrcRec &r, double py, int win_y0, int win_h) {
+    r.y0 = max(r.y0, win_y0) - win_y0;
+    r.y1 = min(r.y1, win_y0 + win_h) - win_y0;
+    r.py = py - (double)win_y0;
+    if (r.type < 0 || r.x1 <= r.x0 || r.y1 <= r.y0) {
+        r.x0 = r.x1 = r.y0 = r.y1 = 0;
+        if (r.type >= 0) r.type = -1 - r.type;   // remember the kind, mark "no contribution"
+    }
+}
+
+// what k_prep leaves for one (band, source) besides the record
+__device__ __forceinline__ void prep_store(const SrcRec &r, int64_t i, SrcRec *__restrict__ recs, int4 *__restrict__ boxes,
+                                           int *__restrict__ kind, int *__restrict__ status) {
+    recs[i] = r;
+    boxes[i] = make_int4(r.x0, r.x1, r.y0, r.y1);
+    kind[i] = r.type < 0 ? 0 : (r.type == 0 ? K_PSF : K_GAL);
+    // what cel_stamp_boxes / cel_source_boxes report: 1 = has a stamp, 0 = empty box, -1 = the
+    // reference's overlap test fails (celeste.py:130-135)
+    status[i] = r.type >= 0 ? 1 : (r.type == -3 ? -1 : 0);
+}
+
 __global__ void __launch_bounds__(256)
 k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int win_h, int64_t S,
        const int *__restrict__ type, const double *__restrict__ radec,
@@ -52,25 +101,14 @@ k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int w
     double ra = radec[2 * s], dec = radec[2 * s + 1];
     // equa2pixel (fits_image.py:166-174)
     double cphi = cos(bd.phi[1] / 180.0 * PI_D);
-    double s0 = (ra - bd.phi[0]) * cphi, s1 = dec - bd.phi[1];
-    double px = (bd.ups_inv[0] * s0 + bd.ups_inv[1] * s1) + bd.rho[0];
-    double py = (bd.ups_inv[2] * s0 + bd.ups_inv[3] * s1) + bd.rho[1];
+    double px, py;
+    prep_pixel(bd, ra, dec, cphi, px, py);
     r.px = px; r.py = py;
     r.scale = counts[s * B + b];
     r.type = t;
     const double BIG = 1073741824.0;
     if (t == 0) {
-        // celeste.py:130-140: overlap test (with the reference's axis mix-up, Q1) + int() box
-        bool miss = (px < -50 || px > 2.0 * H || py < -50 || px > 2.0 * W);
-        if (miss || !(px == px) || !(py == py)) {
-            r.type = -3;    // the reference returns (None, None, None) here, whatever the limits
-        } else {
-            double bound = bd.R;
-            int lx = (int)clampd(px - bound, -BIG, BIG), hx = (int)clampd(px + bound + 1, -BIG, BIG);
-            int ly = (int)clampd(py - bound, -BIG, BIG), hy = (int)clampd(py + bound + 1, -BIG, BIG);
-            r.x0 = max(0, lx); r.x1 = min(hx, W);
-            r.y0 = max(0, ly); r.y1 = min(hy, H);
-        }
+        prep_star_box(bd, px, py, H, W, r);
     } else if (t == 1) {
         double theta = shape[4 * s], sig = shape[4 * s + 1], phi_s = shape[4 * s + 2], rho_s = shape[4 * s + 3];
         // cd_at_pixel (fits_image.py:196-216): 10-px finite difference of pixel2equa
@@ -149,22 +187,8 @@ k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int w
     } else {
         r.type = -1;
     }
-    // row window [win_y0, win_y0 + win_h) of the H-row frame (strip partition across GPUs):
-    // boxes are formed against the FULL frame exactly as above, then cut to the window and
-    // re-based, so a strip renders the same pixels the whole frame would.
-    r.y0 = max(r.y0, win_y0) - win_y0;
-    r.y1 = min(r.y1, win_y0 + win_h) - win_y0;
-    r.py = py - (double)win_y0;
-    if (r.type < 0 || r.x1 <= r.x0 || r.y1 <= r.y0) {
-        r.x0 = r.x1 = r.y0 = r.y1 = 0;
-        if (r.type >= 0) r.type = -1 - r.type;   // remember the kind, mark "no contribution"
-    }
-    recs[i] = r;
-    boxes[i] = make_int4(r.x0, r.x1, r.y0, r.y1);
-    kind[i] = r.type < 0 ? 0 : (r.type == 0 ? K_PSF : K_GAL);
-    // what cel_stamp_boxes / cel_source_boxes report: 1 = has a stamp, 0 = empty box, -1 = the
-    // reference's overlap test fails (celeste.py:130-135)
-    status[i] = r.type >= 0 ? 1 : (r.type == -3 ? -1 : 0);
+    prep_window(r, py, win_y0, win_h);
+    prep_store(r, i, recs, boxes, kind, status);
 }
 
 // Gibbs resamples the sky level (models.py:156-160): one scalar, passed as a kernel argument so

@@ -88,8 +88,11 @@ enum {
                                came from host memory): 0 = the general one (k_render_hw); 1 (default) = k_render_stars
                                -- the same 32 x 64 tiles taken in two column halves, 8 KB of accumulator instead of 16,
                                three waves per SIMD instead of two -- when the frame has more than 2048 tiles (the
-                               general kernel's wave slots; fewer do not fill the extra waves); 2 = k_render_stars at
-                               any size.  Tile layout 1 and the row-recurrence only.  The two kernels add a pixel's stars in different orders: values
+                               general kernel's wave slots; fewer do not fill the extra waves), and for a catalogue of at
+                               most 4096 stars on at most 2048 tiles (BASELINE configs[1]) ONE launch that prepares,
+                               bins, renders and reduces (k_small_stars: every quarter of a tile's columns a wave of
+                               its own, no tile lists); 2 = k_render_stars at any size; 3 = rule 1 without the
+                               one-launch path.  Tile layout 1 and the row-recurrence only.  The two kernels add a pixel's stars in different orders: values
                                agree to rounding (1e-15), and which one runs depends on the call's inputs only */
     CEL_OPT_DEBUG = 8       /* diagnostics.  The shipped library accepts two result-preserving bits: 64 = the E-step
                                takes its per-source form, 128 = CEL_OPT_TILE_TIMING's third word carries the

@@ -1011,7 +1011,7 @@ def test_the_two_device_samplers_in_either_order(cel):
             else:
                 u, _, _ = f.images.slice_locations(f.sources, 1e-3, seed=4)
                 out.append(u)
-                f.sources.set(f.src["type"], f.src["radec"], f.src["counts"], f.src["shape"])     # back to the start
+            f.sources.set(f.src["type"], f.src["radec"], f.src["counts"], f.src["shape"])     # back to the start (both samplers update the catalogue in place)
         del f
         return out
     a = run(["shape", "loc", "shape", "loc"])

@@ -1481,7 +1481,7 @@ def test_star_tile_kernel_vs_oracle_and_general_kernel(cel, ctx, orc, seed):
     try:
         assert ctx.get_option(L.CEL_OPT_STAR_TILES) == 1.0
         with pytest.raises(ValueError):
-            ctx.set_option(L.CEL_OPT_STAR_TILES, 3)
+            ctx.set_option(L.CEL_OPT_STAR_TILES, 4)
         ctx.set_option(L.CEL_OPT_STAR_TILES, 0)
         iset.render(ss)
         ob = f_bands.copy()
@@ -1492,12 +1492,42 @@ def test_star_tile_kernel_vs_oracle_and_general_kernel(cel, ctx, orc, seed):
         ll0, llb0, ns0, ng0 = run(0)
         lam0 = iset.model_images()
         assert (ns0, ng0) == (0, 1)
-        ll1, llb1, ns1, ng1 = run(1)                 # default: a frame of this size keeps the general kernel
+        ll1, llb1, ns1, ng1 = run(3)                 # the tile-count rule alone: a frame of this size keeps the general kernel
         assert (ns1, ng1) == (0, 1) and ll1 == ll0
+        # the default: at most 4096 stars on at most 2048 tiles take the ONE-launch path (k_small_stars: prep, binning, render
+        # and the partials of the per-band sums in one kernel; counted in the star kernel's profile slot)
+        iset.render(cel.SourceSet(ctx, 1, 5).set(typ[:1], radec[:1], counts[:1]))
+        ll5, llb5, ns5, ng5 = run(1)
+        lam5 = iset.model_images()
+        # (1, 1): a part of a tile held more candidate stars than the kernel stages (900 stars on a small frame): the call was
+        # rendered again on the general path, as is every later one on this image set
+        fell_back = (ns5, ng5) == (1, 1)
+        assert (ns5, ng5) == ((0, 1) if seed in (3, 4) else (1, 0)) or (fell_back and S >= 256)
+        o_lam, o_ll, o_st = orc.render_field(ob, H, W, typ, radec, counts, np.zeros((S, 4)), nelec)
+        np.testing.assert_allclose(lam5, o_lam, rtol=RT_LAM)
+        np.testing.assert_allclose(llb5, o_ll, rtol=RT_LL)
+        np.testing.assert_allclose(lam5, lam0, rtol=1e-13)
+        np.testing.assert_allclose(llb5, llb0, rtol=1e-13)
+        st = iset.stats()                             # the kernel left k_prep's records behind: work counters, boxes, status
+        assert st["n_srcpix"] == o_st["n_srcpix"] and st["n_gauss"] == o_st["n_gauss"]
+        bx5, st5 = iset.source_boxes(ss)
+        ctx.set_option(L.CEL_OPT_STAR_TILES, 0)
+        ss0 = cel.SourceSet(ctx, S, 5).set(typ, radec, counts)       # (a set of its own: boxes are cached per set)
+        iset.render(ss0)
+        bx0, st0 = iset.source_boxes(ss0)
+        assert np.array_equal(bx5, bx0) and np.array_equal(st5, st0)
+        again = run(1)
+        assert again[1].tolist() == llb5.tolist()                     # run to run: the same bits
+        assert again[2:] == ((0, 1) if (fell_back or seed in (3, 4)) else (1, 0))
+        ll6, llb6, ns6, _ = run(1, store=False)                       # log-likelihood only
+        assert llb6.tolist() == llb5.tolist()
+        ctx.set_option(L.CEL_OPT_STAR_TILES, 1)
+        iset.render(cel.SourceSet(ctx, 1, 5).set(typ[:1], radec[:1], counts[:1]))
+        iset.render(ss)                                               # model images only
+        np.testing.assert_array_equal(iset.model_images(), lam5)
         ll2, llb2, ns2, ng2 = run(2)
         lam2 = iset.model_images()
         assert (ns2, ng2) == ((0, 1) if seed in (3, 4) else (1, 0))      # 3, 4: exponents beyond the one-segment bound
-        o_lam, o_ll, _ = orc.render_field(ob, H, W, typ, radec, counts, np.zeros((S, 4)), nelec)
         np.testing.assert_allclose(lam2, o_lam, rtol=RT_LAM)
         np.testing.assert_allclose(llb2, o_ll, rtol=RT_LL)
         np.testing.assert_allclose(lam2, lam0, rtol=1e-13)
