@@ -470,12 +470,14 @@ def secondary_legs(args, env, field):
     torch, cel, dist, synth, ctx = env["torch"], env["cel"], env["dist"], env["synth"], env["ctx"]
     from desi_mcmc_amd import celeste_mcmc
     sec = {}
-    for name, steps in (("stars10k_2048", 100), ("stars2k_4096", 100), ("stars1k_512", 200)):
+    for name, steps in (("stars10k_2048", 100), ("stars2k_4096", 100), ("stars1k_512", 400)):
         f = synth.SyntheticField.from_config(ctx, name, seed=42)
         S, B, H, W, fg = synth.CONFIGS[name]
         for _ in range(30):
             f.images.render(f.sources, loglik=True)
-        ctx.profile(2)                  # the render kernel only (see run_render)
+        # the render kernel only (see run_render); a step of a few tens of microseconds (configs[1]: one 26 us launch) carries
+        # the event pair -- ~10 us of host time -- on every FOURTH launch: a sample of the timed region's launches
+        ctx.profile(3 if name == "stars1k_512" else 2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -490,6 +492,9 @@ def secondary_legs(args, env, field):
                      "roofline": {"bound": "hbm", "achieved": alg / (t_render * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": alg / (t_render * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": render_kernel, "kernel_ms": t_render,
                                   "launches": n_render, "algorithmic_bytes_per_launch": alg}}
+        if render_kernel == "k_small_stars":
+            sec[name]["roofline"]["note"] = ("k_small_stars is the WHOLE step in one launch (source prep, tile binning, render, Poisson partials): "
+                                             "kernel_ms is that launch; HIP events on every 4th of the %d timed steps" % steps)
         del f
     S, B, H, W = field.S, field.B, field.H, field.W
     gf = celeste_mcmc.GibbsField(field.images, list(range(B)), field.bands[:, 2], field.bands[:, 1], H * W)

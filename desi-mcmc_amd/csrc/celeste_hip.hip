@@ -103,6 +103,7 @@ struct Prof {
     int head = 0, count = 0;    // next pair to hand out; pairs handed out and not yet read
     double sum_ms[CEL_K_COUNT] = {0};
     int64_t n[CEL_K_COUNT] = {0};
+    unsigned seen[CEL_K_COUNT] = {0};   // launches of each kernel since the reset (level 3 times every fourth)
 };
 
 struct cel_ctx {
@@ -215,6 +216,7 @@ struct cel_images {
     double last_entries = 0;
     // the one-launch path of a small star field (k_small_stars.h): per-block partials + per-band arrival counters
     double *d_small = nullptr, *h_small = nullptr;      // one buffer: pinned host memory and its device address
+    double *d_small_consts = nullptr;
     unsigned long long small_seq = 0;
     bool llband_on_host = false;  // the last render's per-band sums were formed on the host (the small path)
     bool small_off = false;       // a part once held more stars than the kernel stages: the general path from then on
@@ -265,7 +267,10 @@ static int prof_slot(cel_ctx *c, int k) {
     if (!c->profile) return -1;
     // level 2: the small kernels around a render (prep, binning, reduction) go unbracketed -- an event pair costs the host
     // ~10 us per launch, 3 % of a 1.35 ms step when every kernel carries one
-    if (c->profile == 2 && (k == CEL_K_PREP || k == CEL_K_BIN || k == CEL_K_REDUCE)) return -1;
+    if (c->profile >= 2 && (k == CEL_K_PREP || k == CEL_K_BIN || k == CEL_K_REDUCE)) return -1;
+    // level 3: a SAMPLE of the evaluating launches -- every fourth of a kernel -- for steps so short that the pair's ~10 us
+    // of host time is a fifth of what is being measured (configs[1]: a 44 us step)
+    if (c->profile == 3 && (c->prof.seen[k]++ & 3) != 0) return -1;
     Prof &p = c->prof;
     if (!prof_alloc(p)) return -1;
     if (p.count == Prof::PAIRS) prof_harvest_one(p, true);
@@ -451,7 +456,7 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         c->tail_T = v;
         return CEL_OK;
     case CEL_OPT_PROFILE:
-        if (v != 0.0 && v != 1.0 && v != 2.0) return fail(CEL_ERR_INVALID, "CEL_OPT_PROFILE must be 0, 1 or 2");
+        if (v != 0.0 && v != 1.0 && v != 2.0 && v != 3.0) return fail(CEL_ERR_INVALID, "CEL_OPT_PROFILE must be 0, 1, 2 or 3");
         if (v != 0.0 && !prof_alloc(c->prof)) return fail(CEL_ERR_HIP, "CEL_OPT_PROFILE: cannot create the timing events");
         c->profile = (int)v;
         return CEL_OK;
@@ -525,6 +530,7 @@ int cel_images_destroy(cel_images *im) {
     if (im->sgen_prop) cel_sources_destroy(im->sgen_prop);
     if (im->d_sgen) (void)hipFree(im->d_sgen);
     if (im->h_small) (void)hipHostFree(im->h_small);
+    if (im->d_small_consts) (void)hipFree(im->d_small_consts);
     if (im->ev_step) (void)hipEventDestroy(im->ev_step);
     delete im;
     return CEL_OK;
@@ -848,6 +854,9 @@ static int render_small_stars(cel_images *im, cel_sources *src, int flags, bool 
         HIP_TRY(hipHostMalloc((void **)&im->h_small, sizeof(double) * (nblk + 1), hipHostMallocMapped | hipHostMallocCoherent));
         memset(im->h_small, 0, sizeof(double) * (nblk + 1));
         HIP_TRY(hipHostGetDevicePointer((void **)&im->d_small, im->h_small, 0));
+        // the bands' star-pass constants, once (the PSF and the WCS of an image set do not change)
+        HIP_TRY(hipMalloc((void **)&im->d_small_consts, sizeof(double) * SMALL_CONSTS * B));
+        hipLaunchKernelGGL(k_small_consts, dim3(B), dim3(64), 0, st, (const BandDev *)im->d_bands, im->d_small_consts);
     }
     RenderArgs a;
     memset(&a, 0, sizeof(a));
@@ -861,26 +870,47 @@ static int render_small_stars(cel_images *im, cel_sources *src, int flags, bool 
     x.flag = reinterpret_cast<unsigned long long *>(im->d_small + nblk);
     x.stamp = 0x8000000000000000ull | ++im->small_seq;
     x.full_H = im->full_H; x.win_y0 = im->win_y0;
-    int pi = prof_slot(c, CEL_K_RENDER_STARS);
+    x.consts = im->d_small_consts;
+    x.stamps = nullptr;
+    static const char *stamp_path = getenv("CEL_SMALL_STAMPS");     // diagnostic: dump every block's phase stamps of each call
+    unsigned long long *d_stamps = nullptr;
+    if (stamp_path) { HIP_TRY(hipMalloc((void **)&d_stamps, sizeof(unsigned long long) * 8 * nblk)); x.stamps = d_stamps; }
+    int pi = prof_slot(c, CEL_K_SMALL_STARS);
     LAUNCH_EV(k_small_stars, dim3((unsigned)nblk), dim3(64), st, EV0(c, pi), EV1(c, pi), a, x);
     const bool ll = (flags & CEL_RENDER_LOGLIK) != 0;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
+    if (d_stamps) {
+        std::vector<unsigned long long> hs((size_t)8 * nblk);
+        (void)hipMemcpy(hs.data(), d_stamps, sizeof(unsigned long long) * 8 * nblk, hipMemcpyDeviceToHost);
+        (void)hipFree(d_stamps);
+        if (FILE *fp = fopen(stamp_path, "wb")) { fwrite(hs.data(), sizeof(unsigned long long), hs.size(), fp); fclose(fp); }
+    }
     unsigned long long cur0;
     memcpy(&cur0, im->h_small + nblk, sizeof(cur0));
     if (cur0 == x.stamp) { im->small_off = true; return CEL_OK; }
     if (ll) {
-        // a band's partials in index order, Kahan: the same bits whatever order the blocks ran in
+        // a band's partials in a fixed order -- eight interleaved Kahan sums (index mod 8: independent chains for the host's
+        // pipeline; one chain of 512 dependent adds per band was 13 us of the step), added in order: the same bits
+        // whatever order the blocks ran in
         for (int b = 0; b < B; b++) {
             const double *pb = im->h_small + (size_t)b * nblk_band;
-            double sum = 0.0, comp = 0.0;
-            for (int i = 0; i < nblk_band; i++) {
-                const double y = pb[i] - comp;
-                const double t = sum + y;
-                comp = (t - sum) - y;
-                sum = t;
+            double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, comp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int i = 0;
+            for (; i + 8 <= nblk_band; i += 8)
+                for (int k = 0; k < 8; k++) {
+                    const double y = pb[i + k] - comp[k];
+                    const double t = sum[k] + y;
+                    comp[k] = (t - sum[k]) - y;
+                    sum[k] = t;
+                }
+            for (int k = 0; i < nblk_band; i++, k++) {
+                const double y = pb[i] - comp[k];
+                const double t = sum[k] + y;
+                comp[k] = (t - sum[k]) - y;
+                sum[k] = t;
             }
-            c->pinned[b] = sum;
+            c->pinned[b] = ((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7]));
         }
         im->llband_on_host = true;              // d_llband does not hold this render's sums (cel_images_loglik_device uploads them)
     }
@@ -2192,7 +2222,7 @@ int cel_profile_reset(cel_ctx *c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->prof.head = 0;
     c->prof.count = 0;
-    for (int k = 0; k < CEL_K_COUNT; k++) { c->prof.sum_ms[k] = 0.0; c->prof.n[k] = 0; }
+    for (int k = 0; k < CEL_K_COUNT; k++) { c->prof.sum_ms[k] = 0.0; c->prof.n[k] = 0; c->prof.seen[k] = 0; }
     return CEL_OK;
 }
 

@@ -208,9 +208,13 @@ __device__ __forceinline__ void star_stage(const RenderArgs &a, StarTab &ST, con
     __syncthreads();
 }
 
+// `own` (optional, 64 * CW bytes of LDS): the star of every task, written once per batch by the stars' lanes (CW byte stores
+// each) -- a step then finds its lane's star with ONE LDS read instead of a six-step bisection of the prefix sums (six
+// dependent reads, a quarter of a short step's cycles); meant for narrow parts (k_small_stars: CW = 8)
 template <bool DIAG, int CW>
 __device__ __forceinline__ void star_walk(const RenderArgs &a, StarTab &ST, const double *__restrict__ et, double *__restrict__ acc,
-                                          int nb, int lane, int Xa, int Y0, int strict, unsigned &dbg_halfrows) {
+                                          int nb, int lane, int Xa, int Y0, int strict, unsigned &dbg_halfrows,
+                                          unsigned char *__restrict__ own = nullptr) {
     double cqa[K_PSF], cqb[K_PSF], cqc[K_PSF], ceq[K_PSF], cA0[K_PSF], cmx[K_PSF], cmy[K_PSF];
 #pragma unroll
     for (int k = 0; k < K_PSF; k++) {
@@ -233,6 +237,11 @@ __device__ __forceinline__ void star_walk(const RenderArgs &a, StarTab &ST, cons
     }
     const int total = __builtin_amdgcn_readlane(incl, 63);
     ST.cum[lane] = (lane < nb) ? incl - w : 0x3fffffff;
+    if (own) {
+#pragma unroll
+        for (int cidx = 0; cidx < CW; cidx++)
+            if (cidx < w) own[incl - w + cidx] = (unsigned char)lane;
+    }
     __syncthreads();
     for (int t0 = 0; t0 < total && !(dbg & 2); t0 += 64) {
         const int t = t0 + lane;
@@ -240,9 +249,13 @@ __device__ __forceinline__ void star_walk(const RenderArgs &a, StarTab &ST, cons
         // the star this task belongs to: the last j with cum[j] <= t (stars without a column share their
         // successor's cum and are passed over; entries behind the batch hold a sentinel)
         int j = 0;
+        if (own) {
+            j = own[min(t, total - 1)];
+        } else {
 #pragma unroll
-        for (int step = 32; step > 0; step >>= 1)
-            if (ST.cum[min(j + step, 63)] <= t && j + step < 64) j += step;
+            for (int step = 32; step > 0; step >>= 1)
+                if (ST.cum[min(j + step, 63)] <= t && j + step < 64) j += step;
+        }
         const double px = ST.px[j], py = ST.py[j];
         const int4 bx = ST.box[j];
         const int bx0 = max(bx.x + strict, Xa), by0 = bx.z + strict;

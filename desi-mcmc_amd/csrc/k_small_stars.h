@@ -36,8 +36,32 @@ struct SmallArgs {
     double *partials;                         // out: one Poisson partial per block (band-major); the host sums them
     unsigned long long *flag;                 // set to `stamp` when a part holds more than SMALL_CAP stars
     unsigned long long stamp;
+    const double *consts;                     // per band SMALL_CONSTS doubles: what every block used to compute for itself (k_small_consts)
+    unsigned long long *stamps;               // diagnostic (CEL_SMALL_STAMPS): 6 wall-clock stamps (100 MHz) + XCC/CU id per block, or nullptr
     int full_H, win_y0;
 };
+
+// Per-band constants of the star pass, formed ONCE per image set by k_small_consts with the device's own arithmetic (so a
+// block that loads them holds the bits it would have computed): the star table's 21 doubles (star_setup), cos(phi_1),
+// the 2^(j/64) table and the two log tables.  2 560 blocks each spent ~3 us of dependent fp64 library code (exp2, cos, a
+// division, a square root) on them before touching a star.
+#define SMALL_CONSTS (21 + 1 + 64 + 128)
+__global__ void __launch_bounds__(64) k_small_consts(const BandDev *__restrict__ bands, double *__restrict__ out) {
+    __shared__ StarTab ST;
+    __shared__ double et[64];
+    const int lane = threadIdx.x, b = blockIdx.x;
+    et[lane] = exp2((double)lane * (1.0 / 64.0));
+    __syncthreads();
+    star_setup(ST, bands + b, et, lane);
+    double *o = out + (int64_t)b * SMALL_CONSTS;
+    if (lane < 21) o[lane] = (&ST.qa[0])[lane];          // qa, qb, qc, eq, A0, mux, muy: contiguous at the table's end
+    if (lane == 0) o[21] = cos(bands[b].phi[1] / 180.0 * PI_D);
+    o[22 + lane] = et[lane];
+    o[86 + lane] = c_log_ic[lane];
+    o[150 + lane] = c_log_lc[lane];
+}
+static_assert(offsetof(StarTab, muy) - offsetof(StarTab, qa) == 18 * sizeof(double), "the star table's constants must be contiguous");
+
 
 // k_prep's record of one star (position, counts, box on the window, type / status)
 __device__ __forceinline__ void small_prep(const RenderArgs &a, const SmallArgs &x, const BandDev &bd, double cphi, int b, int64_t s,
@@ -53,8 +77,8 @@ __device__ __forceinline__ void small_prep(const RenderArgs &a, const SmallArgs 
 }
 
 // one batch of the part's hit list into the star table, sorted by the rows a star has on this part (star_stage's rule:
-// descending, ties by list position; a star without a row or a column here sorts last).  A hit's position comes from the
-// scan's LDS tables, its box is k_prep's expressions on that position, its counts are the one global load.
+// descending, ties by list position; a star without a row or a column here sorts last).  A hit's position comes
+// from the scan's LDS tables, its box is k_prep's expressions on that position; its counts are the one global load.
 __device__ __forceinline__ void small_stage(const RenderArgs &a, const SmallArgs &x, StarTab &ST, const unsigned short *__restrict__ hits,
                                             const double *__restrict__ cpx, const double *__restrict__ cpy,
                                             int base, int nb, int lane, int b, const BandDev &bd, int Xa, int Y0) {
@@ -64,8 +88,7 @@ __device__ __forceinline__ void small_stage(const RenderArgs &a, const SmallArgs
     int4 bx4 = make_int4(0, 0, 0, 0);
     int nrows = -1;
     if (lane < nb) {
-        const int64_t s = hits[base + lane];
-        sc = x.counts[s * a.B + b];
+        sc = x.counts[(int64_t)hits[base + lane] * a.B + b];
         SrcRec r;
         r.x0 = r.x1 = r.y0 = r.y1 = 0;
         r.type = 0;
@@ -94,7 +117,7 @@ __device__ __forceinline__ void small_stage(const RenderArgs &a, const SmallArgs
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_small_stars(RenderArgs a, SmallArgs x) {
     __shared__ double acc[HW_TH * SMALL_CW];
     __shared__ StarTab ST;
@@ -102,6 +125,7 @@ k_small_stars(RenderArgs a, SmallArgs x) {
     __shared__ double lt[128];
     __shared__ unsigned short hits[SMALL_CAP];
     __shared__ double cpx[SMALL_CAP], cpy[SMALL_CAP];      // the candidates' pixel positions (full-frame rows)
+    __shared__ unsigned char own[64 * SMALL_CW];           // the star of every (star, column) task of a batch (star_walk)
     const int lane = threadIdx.x;
     const int per_band = a.ntx * a.nty;
     const int nblk_band = per_band * SMALL_NP;
@@ -113,35 +137,50 @@ k_small_stars(RenderArgs a, SmallArgs x) {
     const int Xa = X0 + p * SMALL_CW;
     const BandDev *bd = a.bands + b;
     const BandDev &bdr = *bd;
+    const int S = (int)a.S;
+    unsigned long long tstamp[6];
+    if (x.stamps) tstamp[0] = wall_clock64();
 
-    et[lane] = exp2((double)lane * (1.0 / 64.0));
-    lt[lane] = c_log_ic[lane];
-    lt[64 + lane] = c_log_lc[lane];
-    __syncthreads();
-    star_setup(ST, bd, et, lane);               // the host checked the one-segment condition for every band
+    // ---- nearly everything this block reads from global memory is requested NOW -- the band's constants, the first 1024
+    // stars' positions, the part's observed pixels -- in one round trip
+    const double *sc = x.consts + (int64_t)b * SMALL_CONSTS;
+    const double v_st = sc[min(lane, 20)], v_et = sc[22 + lane], v_l0 = sc[86 + lane], v_l1 = sc[150 + lane];
+    const double cphi = sc[21];
+    constexpr int U = 16;                       // stars per lane in flight
+    double ra[U], de[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int s = min(64 * u + lane, S - 1);
+        const double2 rd = *reinterpret_cast<const double2 *>(x.radec + 2 * (int64_t)s);
+        ra[u] = rd.x; de[u] = rd.y;
+    }
+    const bool in_frame = (X0 + HW_TW <= a.W) && (Y0 + HW_TH <= a.H);
+    const bool inside = in_frame && (a.flags & CEL_RENDER_LOGLIK);
+    const bool store = !(a.flags & CEL_RENDER_NO_STORE);
+    double ne[HW_TH * SMALL_CW / 64];
+    if (inside && !(SMALL_ABL & 4)) stars_nelec<SMALL_CW, true>(a, b, Xa, Y0, lane, ne);
+
+#pragma unroll
+    for (int r = 0; r < HW_TH * SMALL_CW / 64; r++) acc[r * 64 + lane] = 0.0;
+    et[lane] = v_et;
+    lt[lane] = v_l0;
+    lt[64 + lane] = v_l1;
+    if (lane < 21) (&ST.qa[0])[lane] = v_st;    // star_setup's values (the host checked the one-segment condition for every band)
     const double eps = bd->eps;
-    const double cphi = cos(bdr.phi[1] / 180.0 * PI_D);
+    __syncthreads();
 
+    if (x.stamps) tstamp[1] = wall_clock64();
     // ---- the band's stars against this part's rectangle.  Pass 1, every star: the pixel position only (six flops) against
     // the rectangle grown by the star radius + 3 -- the int() box reaches less than R + 2 from the position, so no star
-    // whose box meets the rectangle is lost; the candidates' indices go to LDS in ascending order.  Pass 2, the candidates
-    // (a few dozen): k_prep's exact box against the rectangle.
+    // whose box meets the rectangle is lost; the candidates' indices and positions go to LDS in ascending order.  Pass 2,
+    // the candidates (a few dozen): k_prep's exact box against the rectangle.
     int nh = 0;
     {
         const double grow = bdr.R + 3.0;
         const double xlo = (double)Xa - grow, xhi = (double)(Xa + SMALL_CW) + grow;
         const double ylo = (double)(Y0 + x.win_y0) - grow, yhi = (double)(Y0 + x.win_y0 + HW_TH) + grow;
-        constexpr int U = 16;                   // positions per lane in flight: one round trip for a thousand stars
         int nc = 0;
-        const int S = (int)a.S;
         for (int s0 = 0; s0 < S && !(SMALL_ABL & 1); s0 += 64 * U) {
-            double ra[U], de[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int s = min(s0 + 64 * u + lane, S - 1);
-                const double2 rd = *reinterpret_cast<const double2 *>(x.radec + 2 * (int64_t)s);
-                ra[u] = rd.x; de[u] = rd.y;
-            }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int s = s0 + 64 * u + lane;
@@ -155,6 +194,14 @@ k_small_stars(RenderArgs a, SmallArgs x) {
                 }
                 nc += __popcll(m);
             }
+            if (s0 + 64 * U < S) {              // a catalogue of more than 1024 stars: the next 1024
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int s = min(s0 + 64 * U + 64 * u + lane, S - 1);
+                    const double2 rd = *reinterpret_cast<const double2 *>(x.radec + 2 * (int64_t)s);
+                    ra[u] = rd.x; de[u] = rd.y;
+                }
+            }
         }
         if (nc > SMALL_CAP) {                   // the host renders this call again on the general path
             if (lane == 0) *x.flag = x.stamp;
@@ -163,8 +210,8 @@ k_small_stars(RenderArgs a, SmallArgs x) {
         __syncthreads();
         for (int c0 = 0; c0 < nc; c0 += 64) {   // exact test (no loads); the tables are compacted in place (writes trail reads)
             const int i = c0 + lane, ic = min(i, nc - 1);
-            const int s = hits[ic];
             const double px = cpx[ic], py = cpy[ic];
+            const unsigned short sh = hits[ic];
             SrcRec r;
             r.x0 = r.x1 = r.y0 = r.y1 = 0;
             r.type = 0;
@@ -175,7 +222,7 @@ k_small_stars(RenderArgs a, SmallArgs x) {
             __syncthreads();
             if (hit) {
                 const int at = nh + __popcll(m & ((1ull << lane) - 1ull));
-                hits[at] = (unsigned short)s; cpx[at] = px; cpy[at] = py;
+                hits[at] = sh; cpx[at] = px; cpy[at] = py;
             }
             nh += __popcll(m);
             __syncthreads();
@@ -183,26 +230,21 @@ k_small_stars(RenderArgs a, SmallArgs x) {
     }
 
     // ---- the part's stars into its accumulator
-#pragma unroll
-    for (int r = 0; r < HW_TH * SMALL_CW / 64; r++) acc[r * 64 + lane] = 0.0;
+    if (x.stamps) tstamp[2] = wall_clock64();
     unsigned d0 = 0;
     for (int base = 0; base < nh; base += 64) {
         const int nb = min(64, nh - base);
         small_stage(a, x, ST, hits, cpx, cpy, base, nb, lane, b, bdr, Xa, Y0);
-        if (!(SMALL_ABL & 2)) star_walk<false, SMALL_CW>(a, ST, et, acc, nb, lane, Xa, Y0, 0, d0);
+        if (!(SMALL_ABL & 2)) star_walk<false, SMALL_CW>(a, ST, et, acc, nb, lane, Xa, Y0, 0, d0, own);
     }
     __syncthreads();
 
     // ---- epilogue: lambda = eps + acc written once, the Poisson terms of the part
+    if (x.stamps) tstamp[3] = wall_clock64();
     double part = 0.0;
-    const bool in_frame = (X0 + HW_TW <= a.W) && (Y0 + HW_TH <= a.H);
-    const bool inside = in_frame && (a.flags & CEL_RENDER_LOGLIK);
-    const bool store = !(a.flags & CEL_RENDER_NO_STORE);
-    double ne[HW_TH * SMALL_CW / 64];
     if (SMALL_ABL & 4) {
         part = acc[lane];
     } else if (inside) {
-        stars_nelec<SMALL_CW, true>(a, b, Xa, Y0, lane, ne);
         part = store ? stars_epilogue<SMALL_CW, true, true>(a, acc, lt, eps, b, Xa, Y0, lane, ne)
                      : stars_epilogue<SMALL_CW, true, false>(a, acc, lt, eps, b, Xa, Y0, lane, ne);
     } else if (in_frame) {                      // model images only: stores, none of them under a condition
@@ -222,6 +264,7 @@ k_small_stars(RenderArgs a, SmallArgs x) {
         if (lane == 0) x.partials[(int64_t)b * nblk_band + q] = part;
     }
 
+    if (x.stamps) tstamp[4] = wall_clock64();
     // ---- k_prep's outputs: block q writes the records of sources [64 k, 64 k + 64), k = q, q + nblk_band, ...
     for (int64_t s = (int64_t)q * 64 + lane; s - lane < a.S; s += (int64_t)nblk_band * 64) {
         if (s < a.S) {
@@ -229,5 +272,12 @@ k_small_stars(RenderArgs a, SmallArgs x) {
             small_prep(a, x, bdr, cphi, b, s, r);
             prep_store(r, (int64_t)b * a.S + s, x.recs, x.boxes, x.kind, x.status);
         }
+    }
+    if (x.stamps && lane == 0) {
+        tstamp[5] = wall_clock64();
+        unsigned long long *o = x.stamps + (int64_t)blockIdx.x * 8;
+        for (int k = 0; k < 6; k++) o[k] = tstamp[k];
+        o[6] = (unsigned long long)nh;
+        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) /* XCC_ID */;
     }
 }

@@ -80,9 +80,13 @@ class Context(object):
 
     def profile_render(self):
         """(mean ms, launches, kernel name) of the field render since the last reset: k_render_stars when the star-tile
-        kernel took the launches (CEL_OPT_STAR_TILES; a catalogue without galaxies), the general kernel otherwise"""
+        kernel took the launches (CEL_OPT_STAR_TILES; a catalogue without galaxies), k_small_stars when the one-launch path
+        of a small star field did (that kernel is the whole step: prep, binning, render, partial sums), the general kernel otherwise"""
         ms_s, n_s = self.profile_get("render_stars")
         ms_g, n_g = self.profile_get("render")
+        ms_f, n_f = self.profile_get("small_stars")
+        if n_f > max(n_s, n_g):
+            return ms_f, n_f, "k_small_stars"
         if n_s > n_g:
             return ms_s, n_s, "k_render_stars"
         return ms_g, n_g, "k_render_hw"

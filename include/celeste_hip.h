@@ -67,7 +67,8 @@ enum {
                               relative error of every pixel stays below n_components * e^-T    */
     CEL_OPT_PROFILE = 3,   /* 1 = bracket every kernel launch with HIP events; 2 = the evaluating kernels only (render,
                               conditional likelihoods, split, mass, E-step: not the prep / binning / reduction launches
-                              around a render -- an event pair costs the host ~10 us per launch)            */
+                              around a render -- an event pair costs the host ~10 us per launch); 3 = as 2 on a SAMPLE of
+                              the launches, every fourth of a kernel (for steps of a few tens of microseconds)     */
     CEL_OPT_TILE_ORDER = 4,/* launch order of the render tiles; never changes results.  0 = index order,
                               1 (default) = heaviest first by the durations the tiles had in the previous
                               render of the same number of sources (the binning pass's estimate when there
@@ -113,7 +114,8 @@ enum {
     CEL_K_MASS = 8,         /* cel_stamp_mass */
     CEL_K_ESTEP = 9,        /* cel_estep_stats */
     CEL_K_RENDER_STARS = 10,/* k_render_stars: the field render of a catalogue without galaxies (CEL_OPT_STAR_TILES) */
-    CEL_K_COUNT = 11
+    CEL_K_SMALL_STARS = 11,/* k_small_stars: a small star field's whole step in one launch (CEL_OPT_STAR_TILES = 1) */
+    CEL_K_COUNT = 12
 };
 
 typedef struct cel_ctx cel_ctx;

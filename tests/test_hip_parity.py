@@ -1474,7 +1474,7 @@ def test_star_tile_kernel_vs_oracle_and_general_kernel(cel, ctx, orc, seed):
         ctx.set_option(L.CEL_OPT_STAR_TILES, mode)
         ctx.profile(True)
         ll, llb = iset.render(sources, loglik=True, store=store)
-        n_star, n_gen = ctx.profile_get("render_stars")[1], ctx.profile_get("render")[1]
+        n_star, n_gen = ctx.profile_get("render_stars")[1] + ctx.profile_get("small_stars")[1], ctx.profile_get("render")[1]
         ctx.profile(False)
         return ll, llb, n_star, n_gen
 

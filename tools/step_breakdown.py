@@ -18,7 +18,7 @@ f = synth.SyntheticField.from_config(ctx, name)
 for _ in range(100):
     f.images.render(f.sources, loglik=True)
 out = {}
-for level in (0, 2, 1):
+for level in (0, 3, 2, 1):
     ctx.profile(level if level else False)
     for _ in range(20):
         f.images.render(f.sources, loglik=True)
@@ -33,4 +33,5 @@ for level in (0, 2, 1):
         parts = {k: ctx.profile_get(k) for k in ("prep", "bin", "reduce")}
         print("kernels (mean ms per launch): render[%s] %.4f" % (kname, tr), " ".join("%s %.4f" % (k, t) for k, (t, n) in parts.items()))
     ctx.profile(False)
-print("%s: step unprofiled %.4f ms, render-only events %.4f ms, all events %.4f ms; ll %.6f" % (name, out[0], out[2], out[1], ll))
+print("%s: step unprofiled %.4f ms, render events on every 4th launch %.4f ms, on every launch %.4f ms, all kernels' events %.4f ms; ll %.6f"
+      % (name, out[0], out[3], out[2], out[1], ll))
