@@ -792,7 +792,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="mixed10k_2048")
     ap.add_argument("--kernel", default="recurrence", choices=["direct", "recurrence"])
-    ap.add_argument("--tail-log", type=float, default=32.0)
+    ap.add_argument("--tail-log", type=float, default=None,
+                    help="CEL_OPT_TAIL_LOG for every kernel; default: the library's defaults (24 for the field render, 32 for the per-source kernels)")
     ap.add_argument("--tile-rows", type=int, default=32, choices=[32, 64])
     ap.add_argument("--tile-order", type=int, default=1, choices=[0, 1, 2])
     ap.add_argument("--layout", type=int, default=1, choices=[0, 1, 2],
@@ -856,7 +857,9 @@ def main():
     torch.cuda.set_device(local)
     ctx = cel.Context(local)
     ctx.set_kernel(args.kernel)
-    ctx.set_tail_log(args.tail_log)
+    if args.tail_log is not None:
+        ctx.set_tail_log(args.tail_log)
+    args.tail_log = ctx.get_option(_lib.CEL_OPT_TAIL_LOG)        # the field render's threshold (what the headline kernel runs at)
     ctx.set_option(_lib.CEL_OPT_TILE_ROWS, args.tile_rows)
     ctx.set_option(_lib.CEL_OPT_TILE_LAYOUT, args.layout)
     ctx.set_option(_lib.CEL_OPT_TILE_ORDER, args.tile_order)

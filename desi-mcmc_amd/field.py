@@ -63,8 +63,10 @@ class Context(object):
         self.set_option(L.CEL_OPT_KERNEL, {"direct": 0, "recurrence": 1}[name])
 
     def set_tail_log(self, T):
-        """drop threshold T of CEL_OPT_TAIL_LOG; "default" (32) or "fast" (20, 1e-6 parity only) name the presets"""
-        T = {"default": L.TAIL_LOG_DEFAULT, "fast": L.TAIL_LOG_FAST}.get(T, T)
+        """drop threshold T of CEL_OPT_TAIL_LOG (a number sets the field render's AND the per-source kernels'); presets:
+        "default" = the library's defaults (24 for the field render, 32 for the per-source kernels), "strict" = 32 for both
+        (what the 1e-10 parity tests run at), "fast" = 20 (1e-6 parity only)"""
+        T = {"default": float("nan"), "strict": L.TAIL_LOG_STRICT, "fast": L.TAIL_LOG_FAST}.get(T, T)
         self.set_option(L.CEL_OPT_TAIL_LOG, T)
 
     def profile(self, on=True):
