@@ -49,9 +49,10 @@ FLOP_PER_GAUSS = 35.0        # SURVEY 8d accounting: 10 arithmetic + exp counted
 #   traffic = 2 * FETCH_SIZE + WRITE_SIZE (gfx950 correction, re-calibrated with tools/calib_traffic.hip)
 #   valu    = SQ_INSTS_VALU (wave-instructions), busy = waves per SIMD * SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES
 PMC_PROFILES = {   # (workload, kernel, tail_log, layout) -> committed summary
-    ("mixed10k_2048", "recurrence", 32.0, 1): "profiles/r03_final_pmc.json",
-    ("stars10k_2048", "recurrence", 32.0, 1): "profiles/r03_stars_pmc.json",
+    ("mixed10k_2048", "recurrence", 24.0, 1): "profiles/r04_final_pmc.json",
+    ("stars10k_2048", "recurrence", 24.0, 1): "profiles/r04_stars_pmc.json",
 }
+GIBBS_PMC_PROFILE = "profiles/r04_aux_pmc.json"     # bench.py --workload gibbs10k under the counters
 
 
 def library_sha256():
@@ -83,6 +84,29 @@ def load_pmc(key, kernel="k_render"):
     waves_per_simd = 3.0 if "k_render_stars" in name else 2.0       # resident waves per SIMD (kernel-resource-usage)
     return {"traffic": 2.0 * last("FETCH_SIZE") * 1024.0 + last("WRITE_SIZE") * 1024.0, "valu_insts": last("SQ_INSTS_VALU"),
             "valu_busy": waves_per_simd * last("SQ_ACTIVE_INST_VALU") / last("SQ_WAVE_CYCLES"), "source": rel}
+
+
+def load_gibbs_pmc():
+    """HBM traffic of ONE round of the Gibbs location step (its one or two likelihood launches) from the committed counter
+    passes of `bench.py --workload gibbs10k`, under the same library-hash check as load_pmc
+    -> dict(traffic, source) or dict(stale=reason)"""
+    path = os.path.join(ROOT, GIBBS_PMC_PROFILE)
+    if not os.path.exists(path):
+        return {"stale": "%s not present" % GIBBS_PMC_PROFILE}
+    prof = json.load(open(path))
+    have, want = prof.get("library_sha256"), library_sha256()
+    if have != want:
+        return {"stale": "%s was taken with library sha256 %s..., loaded is %s...: re-run tools/profile_r04.sh"
+                         % (GIBBS_PMC_PROFILE, str(have)[:12], want[:12])}
+    ks = [k for k in prof["kernels"] if "k_patch_ll_nz" in k or "k_patch_ll_hw<0" in k]
+    if not ks:
+        return {"stale": "%s holds no likelihood launches" % GIBBS_PMC_PROFILE}
+    rounds = max(prof["kernels"][k]["FETCH_SIZE"]["launches"] for k in ks)       # every round launches the photon-list kernel
+    tot = 0.0
+    for k in ks:
+        c = prof["kernels"][k]
+        tot += (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0 * c["FETCH_SIZE"]["launches"]
+    return {"traffic": tot / rounds, "source": GIBBS_PMC_PROFILE, "kernels": ks}
 
 
 CPU_THREADS_MAX = 16         # the GPU box's CPU share for one GPU
@@ -438,10 +462,38 @@ def extra_render_legs(args, env, field, out):
     out["python_api_ms"] = (time.perf_counter() - t0) / n * 1e3
     plist = [cel.SrcParams(u=p.u.copy(), a=p.a, fluxes=p.fluxes.copy(), theta=p.theta, sigma=p.sigma, phi=p.phi, rho=p.rho)
              for p in cat]
+    # A plain LIST of SrcParams, as celeste_em.py:25,159, celeste_mcmc.py:130 and the moves of
+    # util/infer/mcmc_transitions.py:37-152 pass it: (a) every source assigned to since the last call -- the whole list is
+    # gathered again; (b) ONE source moved between calls -- the caller's usual case: its row is re-read and uploaded;
+    # (c) nothing changed.  (SrcParams.__setattr__ stamps an object; celeste._cached_list_arrays.)
     t0 = time.perf_counter()
     for _ in range(3):
+        for p in plist:
+            p.u = p.u                        # an assignment stamps the object
         ll_list = celeste.celeste_likelihood_multi_image(plist, imgs)
-    out["python_api_list_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+    t_all = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter()
+    for _ in range(3):
+        for p in plist:
+            p.u = p.u
+    t_assign = (time.perf_counter() - t0) / 3
+    out["python_api_list_ms"] = (t_all - t_assign) * 1e3
+    u0 = plist[23].u.copy()
+    ll_moved = None
+    t0 = time.perf_counter()
+    for k in range(n):
+        pos = plist[23].u                    # the reference's moves: edit in place, then assign (mcmc_transitions.py:49-51)
+        pos[0] = u0[0] + 1e-6 * ((k % 5) - 2)
+        plist[23].u = pos
+        ll_moved = celeste.celeste_likelihood_multi_image(plist, imgs)
+    out["python_api_list_one_changed_ms"] = (time.perf_counter() - t0) / n * 1e3
+    plist[23].u = u0
+    ll_list2 = celeste.celeste_likelihood_multi_image(plist, imgs)
+    assert ll_moved != ll_list2 and ll_list2 == ll_list, (ll_moved, ll_list2, ll_list)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        celeste.celeste_likelihood_multi_image(plist, imgs)
+    out["python_api_list_unchanged_ms"] = (time.perf_counter() - t0) / n * 1e3
     views = cel.SrcCatalog.from_params(plist).views()         # a LIST of per-source objects backed by one catalogue
     ll_views = celeste.celeste_likelihood_multi_image(views, imgs)
     views[17].u = views[17].u + 1e-5                          # a write through a view is seen by the next call
@@ -454,7 +506,9 @@ def extra_render_legs(args, env, field, out):
     assert moved != ll_views and abs(ll_views - ll_api) <= 1e-12 * abs(ll_api)
     out["python_api_note"] = ("celeste_likelihood_multi_image(srcs, imgs) end to end, images resident after the first call: "
                               "srcs = SrcCatalog (arrays; python_api_ms) / a plain list of %d SrcParams objects "
-                              "(python_api_list_ms: the per-object attribute gather dominates) / the list SrcCatalog.views() "
+                              "(python_api_list_ms: every object assigned to since the last call, the whole list gathered again; "
+                              "python_api_list_one_changed_ms: one source moved between calls -- its row re-read and uploaded; "
+                              "python_api_list_unchanged_ms) / the list SrcCatalog.views() "
                               "hands out: per-source objects with SrcParams' attributes, backed by the catalogue's arrays "
                               "(python_api_views_ms)" % len(plist))
     out["python_api_loglik_rel_diff"] = float(abs(ll_api - out["loglik"]) / abs(out["loglik"])) if out["loglik"] else None
@@ -520,9 +574,39 @@ def secondary_legs(args, env, field):
         ctx.profile(False)
         sec["gibbs10k"] = dict({"value": float(g.active.sum()) * sweeps / dt, "unit": "source updates (samples)/s", "steps": sweeps,
                                 "ms_per_step": dt / sweeps * 1e3, "slice_sigma_deg": g.slice_args.get("sigma", 1.0)}, **rep)
+        if args.cpu_sample > 0:
+            from oracle import oracle as orc      # cpu_baseline leg only
+            sec["gibbs10k"]["cpu_baseline"] = gibbs_cpu_baseline(field, g, gf, orc, n_sources=32)
     finally:
         for b in range(B):                      # the sweeps redrew the sky levels: the headline field gets its own back
             field.images.set_epsilon(b, eps0[b])
+    # BASELINE configs[3]'s stand-in (the Stripe-82 set is absent from the reference tree): 8 fields of the configs[2]
+    # population as ONE field set on this GPU, 3 timed steps (what `bench.py --workload fields8_2048` reports on more)
+    K, steps = 8, 3
+    fields = [field] + [synth.SyntheticField.from_config(ctx, "mixed10k_2048", seed=42 + 1000 * k) for k in range(1, K)]
+    for f in fields:
+        f.images.render(f.sources, loglik=True)
+    ctx.profile(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        llb = np.zeros(B)
+        for f in fields:
+            llb += f.images.render(f.sources, loglik=True)[1]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t_render, n_render, render_kernel = ctx.profile_render()
+    ctx.profile(False)
+    npx = sum(f.images.stats()["n_srcpix"] for f in fields)
+    alg = 16.0 * B * H * W + 128.0 * S * B
+    sec["fields8_2048"] = {"value": npx * steps / dt, "unit": "source-pixel evals/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+                           "n_fields": K, "loglik_field_set": float(llb.sum()),
+                           "roofline": {"bound": "hbm", "achieved": alg / (t_render * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": alg / (t_render * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": render_kernel, "kernel_ms": t_render,
+                                        "launches": n_render, "algorithmic_bytes_per_launch": alg},
+                           "note": "a step renders and scores all 8 fields (one launch of the render kernel per field); N > 1 deals the fields "
+                                   "to the ranks and all-reduces the 5 per-band sums (bench.py --workload fields8_2048 --gpus N)"}
+    del fields
     return sec
 
 
@@ -670,10 +754,11 @@ def gibbs_report(g, gf, ctx, steps, dt, S, B):
     round_ms = t_ll * n_ll / rounds
     achieved = (alg_bytes / (round_ms * 1e-3) / 1e9) if (round_ms > 0 and not shapes_ran) else None
     known = g.timing["split"] + g.timing["flux"] + g.timing["location"] + g.timing.get("shape", 0.0) + g.timing.get("merge", 0.0)
+    pmc = load_gibbs_pmc()
     return {
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "k_patch_ll_nz + k_patch_ll_hw<0> (one slice round of every running chain)",
+                     "traffic": pmc.get("traffic"), "traffic_source": pmc.get("source") or pmc.get("stale"), "kernel": "k_patch_ll_nz + k_patch_ll_hw<0> (one slice round of every running chain)",
                      "kernel_ms": round_ms, "launches": rounds, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "one launch = one round of the location step (its one or two dispatches); kernel_ms: HIP events attached to "
                              "the dispatches, summed per round and averaged over the timed sweeps' rounds; bytes: per evaluation and band "

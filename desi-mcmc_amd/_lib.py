@@ -57,6 +57,7 @@ SYMBOLS = [
     ("cel_sources_create", C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_void_pp]),
     ("cel_sources_destroy", C.c_int, [C.c_void_p]),
     ("cel_sources_set", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    ("cel_sources_set_rows", C.c_int, [C.c_void_p, C.c_int64, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p]),
     ("cel_render_field", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_double_p, c_double_p]),
     ("cel_field_stats", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     ("cel_debug_tile_timing", C.c_int, [C.c_void_p, C.c_void_p, c_int64_p]),

@@ -151,14 +151,18 @@ def expected_photons(src, image):
 
 
 def _gather_fluxes(srcs, images, bidx, fls=None):
-    """(S, B) fluxes in the images' bands: one pass over the sources, not S x B calls"""
+    """(S, B) fluxes in the images' bands: one C-level pass over the sources (itemgetter + fromiter: a nest of Python
+    subscripts cost 8x as much at 10 000 sources), not S x B calls"""
     S = len(srcs)
     if fls is None:
         fls = [s.fluxes for s in srcs]
     kinds = set(map(type, fls))
     if kinds == {dict}:
         names = [im.band for im in images]
-        return np.array([[f[n] for n in names] for f in fls], dtype=np.float64).reshape(S, len(images))
+        if len(names) == 1:
+            return np.fromiter(map(operator.itemgetter(names[0]), fls), dtype=np.float64, count=S).reshape(S, 1)
+        return np.fromiter(itertools.chain.from_iterable(map(operator.itemgetter(*names), fls)), dtype=np.float64,
+                           count=S * len(names)).reshape(S, len(names))
     if dict not in kinds:
         if kinds == {np.ndarray}:
             return np.concatenate(fls).astype(np.float64, copy=False).reshape(S, -1)[:, bidx]
@@ -209,17 +213,33 @@ def _source_arrays(srcs, images, counts_fn=expected_photons):
             counts = (fl / calib[None, :]) * kappa[None, :]          # flux_dict convention (celeste.py:80-81,94)
         typ = (a == 1).astype(np.int32)
         return typ, u, counts, np.where((a == 1)[:, None], sh, 0.0)
+    if type(srcs) is list and len(srcs) >= _LIST_CACHE_MIN:
+        return _cached_list_arrays(srcs, images, counts_fn, bidx, calib, kappa)
+    return _gather_plain(srcs, images, counts_fn, bidx, calib, kappa)
+
+
+def _attr_column(srcs, name, S):
+    """one attribute of every source as an object array: a single C-level pass"""
+    return np.fromiter(map(operator.attrgetter(name), srcs), dtype=object, count=S)
+
+
+def _gather_plain(srcs, images, counts_fn, bidx, calib, kappa):
+    """the arrays of a plain sequence of SrcParams: one C-level pass per attribute when every source takes the same flux
+    convention, source by source otherwise"""
+    B = len(images)
     S = len(srcs)
     radec = np.zeros((S, 2))
     shape = np.zeros((S, 4))
     counts = np.zeros((S, B))
-    # one pass for what decides the route: type, temperature, flux container
+    # what decides the route: type, temperature, flux container
+    a_col = _attr_column(srcs, "a", S)
+    f_col = _attr_column(srcs, "fluxes", S)
     try:
-        head = list(map(operator.attrgetter("a", "fluxes", "t"), srcs))
+        t_col = _attr_column(srcs, "t", S)
     except AttributeError:                      # records without a temperature attribute
-        head = [(s.a, s.fluxes, getattr(s, "t", None)) for s in srcs]
-    typ = np.fromiter((1 if h[0] == 1 else 0 for h in head), dtype=np.int32, count=S)
-    simple = counts_fn is not expected_photons or not any(h[2] for h in head)
+        t_col = np.array([getattr(s, "t", None) for s in srcs], dtype=object)
+    typ = (a_col == 1).astype(np.int32)
+    simple = counts_fn is not expected_photons or not any(t_col.tolist())
     if S and simple:
         us = list(map(operator.attrgetter("u"), srcs))
         if set(map(type, us)) == {np.ndarray} and us[0].shape == (2,):
@@ -231,14 +251,15 @@ def _source_arrays(srcs, images, counts_fn=expected_photons):
             pick = srcs if gal.size == S else [srcs[i] for i in gal]
             shape[gal] = np.fromiter(itertools.chain.from_iterable(map(operator.attrgetter("theta", "sigma", "phi", "rho"), pick)),
                                      dtype=np.float64, count=4 * gal.size).reshape(gal.size, 4)
+        fls = f_col.tolist()
         if counts_fn is expected_photons:
-            if any(h[0] is None and h[1] is None for h in head):
+            untyped = np.equal(a_col, None)
+            if any(f is None for f, u_ in zip(fls, untyped.tolist()) if u_):
                 raise Exception("No way to compute expected photons without at least fluxes or brightness")
-            fl = _gather_fluxes(srcs, images, bidx, [h[1] for h in head])
-            untyped = np.fromiter((h[0] is None for h in head), dtype=bool, count=S)
+            fl = _gather_fluxes(srcs, images, bidx, fls)
             counts = np.where(untyped[:, None], kappa[None, :] * fl, fl / calib[None, :] * kappa[None, :])
         else:
-            fl = _gather_fluxes(srcs, images, bidx, [h[1] for h in head])      # flux_dict = the same numbers by band letter
+            fl = _gather_fluxes(srcs, images, bidx, fls)      # flux_dict = the same numbers by band letter
             counts = (fl / calib[None, :]) * kappa[None, :]
         return typ, radec, counts, shape
     for s, src in enumerate(srcs):
@@ -248,6 +269,103 @@ def _source_arrays(srcs, images, counts_fn=expected_photons):
         for b, im in enumerate(images):
             counts[s, b] = counts_fn(src, im)
     return typ, radec, counts, shape
+
+
+# ---- a LIST of SrcParams evaluated again and again -------------------------------------------------------------------
+# celeste_em.py:25,159, celeste_mcmc.py:130 and every move of util/infer/mcmc_transitions.py:37-152 call
+# celeste_likelihood*(list_of_SrcParams, ...) after changing ONE source.  The arrays gathered from a list are kept (per list
+# object, image group and flux convention); on the next call with the same list -- the same objects in the same places,
+# one C-level identity pass -- only the objects whose modification stamp moved (celeste_src.SrcParams.__setattr__) are read
+# again, and only their rows go to the device (cel_sources_set_rows).  A container changed IN PLACE without an attribute
+# assignment afterwards is not seen: celeste_src.touch(src) (the reference's own moves assign, mcmc_transitions.py:49-51).
+_LIST_CACHE_MIN = 64          # shorter lists are gathered every time (cheaper than the bookkeeping)
+_LIST_CACHE = collections.OrderedDict()   # (id(list), image ids, counts_fn) -> _ListEntry; a handful of lists
+_LIST_CACHE_MAX = 4
+_ENTRY_OF = {}                # id(typ array) -> entry: how _device_sources recognises cached arrays
+
+
+class _ListEntry(object):
+    __slots__ = ("srcs", "objs", "stamps", "clock", "imgkey", "typ", "radec", "counts", "shape", "version", "log")
+
+    def rows_since(self, version):
+        """rows changed after `version`, or None when the log no longer reaches back that far"""
+        if version == self.version:
+            return np.zeros(0, dtype=np.int64)
+        if not self.log or self.log[0][0] > version + 1:
+            return None
+        return np.unique(np.concatenate([r for v, r in self.log if v > version]))
+
+
+def _stamp_column(srcs, S):
+    try:
+        return np.fromiter(map(operator.attrgetter("_stamp"), srcs), dtype=np.int64, count=S)
+    except AttributeError:       # objects that are not SrcParams (no stamps): never cached
+        return None
+
+
+def _cached_list_arrays(srcs, images, counts_fn, bidx, calib, kappa):
+    from .celeste_src import clock
+    S = len(srcs)
+    key = (id(srcs), tuple(map(id, images)), counts_fn)
+    imgkey = (tuple(bidx), tuple(calib.tolist()), tuple(kappa.tolist()))
+    ent = _LIST_CACHE.get(key)
+    if ent is not None and ent.srcs is srcs and len(ent.objs) == S and ent.imgkey == imgkey and all(map(operator.is_, srcs, ent.objs)):
+        _LIST_CACHE.move_to_end(key)
+        now = clock()
+        if now != ent.clock:                   # some SrcParams somewhere was assigned to since the last look
+            stamps = _stamp_column(srcs, S)
+            rows = np.nonzero(stamps != ent.stamps)[0]
+            if rows.size > max(S // 8, 16):
+                ent = None                      # most of the list moved: gather it whole
+            else:
+                if rows.size:
+                    t, r, c, sh = _gather_plain([srcs[i] for i in rows], images, counts_fn, bidx, calib, kappa)
+                    ent.typ[rows], ent.radec[rows], ent.counts[rows], ent.shape[rows] = t, r, c, sh
+                    ent.version += 1
+                    ent.log.append((ent.version, rows))
+                    del ent.log[:-16]
+                ent.stamps, ent.clock = stamps, now
+        if ent is not None:
+            return ent.typ, ent.radec, ent.counts, ent.shape
+    now = clock()
+    stamps = _stamp_column(srcs, S)
+    arrs = _gather_plain(srcs, images, counts_fn, bidx, calib, kappa)
+    if stamps is None:
+        return arrs
+    old = _LIST_CACHE.pop(key, None)
+    if old is not None:
+        _ENTRY_OF.pop(id(old.typ), None)
+    ent = _ListEntry()
+    ent.srcs, ent.objs, ent.stamps, ent.clock, ent.imgkey = srcs, list(srcs), stamps, now, imgkey
+    ent.typ, ent.radec, ent.counts, ent.shape = arrs
+    ent.version, ent.log = 0, []
+    _LIST_CACHE[key] = ent
+    _ENTRY_OF[id(ent.typ)] = ent
+    while len(_LIST_CACHE) > _LIST_CACHE_MAX:
+        _, gone = _LIST_CACHE.popitem(last=False)
+        _ENTRY_OF.pop(id(gone.typ), None)
+    return arrs
+
+
+def _device_sources(iset, arrs):
+    """the SourceSet of `iset` holding these arrays.  Arrays that came from the list cache go up row by changed row -- or
+    not at all when the device copy is current."""
+    typ, radec, counts, shape = arrs
+    ent = _ENTRY_OF.get(id(typ))
+    if ent is None or ent.typ is not typ:
+        return iset._sources(typ, radec, counts, shape)
+    state = getattr(iset, "_list_state", None)
+    sset = iset._srcs
+    if state is not None and state[0] is ent and sset is not None and sset.S == typ.shape[0]:
+        rows = ent.rows_since(state[1])
+        if rows is not None and rows.size <= 256:
+            if rows.size:
+                sset.set_rows(rows, typ[rows], radec[rows], counts[rows], shape[rows])
+            iset._list_state = (ent, ent.version)
+            return sset
+    sset = iset._sources(typ, radec, counts, shape)
+    iset._list_state = (ent, ent.version)
+    return sset
 
 
 def _one_stamp(image, typ, u, shape, xlim=None, ylim=None, scale=1.0):
@@ -349,7 +467,7 @@ def gen_model_image(srcs, image):
     """pixel-wise mean counts: epsilon + sum of source images  -- celeste.py:203-219"""
     iset = _image_set((image,))
     typ, radec, counts, shape = _source_arrays(srcs, (image,))
-    iset.render(iset._sources(typ, radec, counts, shape), loglik=False)
+    iset.render(_device_sources(iset, (typ, radec, counts, shape)), loglik=False)
     return iset.model_images()[0]
 
 
@@ -400,7 +518,7 @@ def celeste_likelihood(srcs, image):
     """Poisson log-likelihood sum(nelec*log(lambda) - lambda)  -- celeste.py:237-240"""
     iset = _image_set((image,))
     typ, radec, counts, shape = _source_arrays(srcs, (image,))
-    total, _ = iset.render(iset._sources(typ, radec, counts, shape), loglik=True)
+    total, _ = iset.render(_device_sources(iset, (typ, radec, counts, shape)), loglik=True)
     return total
 
 
@@ -417,7 +535,7 @@ def celeste_likelihood_multi_image(srcs, images):
         group = tuple(images[i:j])
         iset = _image_set(group)
         typ, radec, counts, shape = _source_arrays(srcs, group)
-        total, _ = iset.render(iset._sources(typ, radec, counts, shape), loglik=True)
+        total, _ = iset.render(_device_sources(iset, (typ, radec, counts, shape)), loglik=True)
         ll += total
         i = j
     return ll

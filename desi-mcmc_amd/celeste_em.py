@@ -20,11 +20,6 @@ import numpy as np
 from . import celeste as _celeste
 
 
-def printif(statement, condition):
-    if condition:
-        print(statement)
-
-
 def _expected_brightness(planck):
     def f(t, b, band):             # planck.py:155-158
         lens_watts = planck.lens_area * b * planck.sun_wattage / (planck.m_per_ly ** 2)
@@ -43,53 +38,55 @@ def celeste_em(srcs, imgs, maxiter=20, debug=False, verbose=True, planck=None):
     hook = getattr(planck, "photons_expected_brightness", None) or _expected_brightness(planck)
     old_hook = _celeste.photons_expected_brightness
     _celeste.photons_expected_brightness = hook
+    say = (lambda msg, level=1: print(msg)) if verbose else (lambda msg, level=1: None)
+    detail = verbose > 1
     try:
         prev_ll = _celeste.celeste_likelihood_multi_image(srcs, imgs)
         ll_trace = [prev_ll]
         imgbands = np.array([img.band for img in imgs])
         uniquebands = np.unique(imgbands)
-        printif("Initial Log Likelihood = %2.2f" % prev_ll, verbose)
+        # lens_watts per unit brightness: what turns photons per joule into expected photons (planck.py:155-158)
+        fac = 1. / (planck.lens_area * planck.exposure_duration * planck.sun_wattage / (planck.m_per_ly ** 2))
+
+        def band_efficiency(t):
+            """photons per joule of a black body at temperature t in every image's band (celeste_em.py:96-106)"""
+            I_ts = np.zeros(len(imgbands))
+            for b in uniquebands:
+                I_ts[imgbands == b] = planck.photons_per_joule(t, b)
+            return I_ts
+
+        say("EM start: log-likelihood %.2f over %d images, %d sources" % (prev_ll, len(imgs), len(srcs)))
         em_iter = -1
         for em_iter in range(maxiter):
-            printif("============================================", verbose)
-            # E-step: the three reductions of the responsibility layers (celeste_em.py:38-58, 85, 89)
-            printif("  iter %d E-step" % em_iter, verbose)
+            # E-step: the three reductions of the responsibility layers (celeste_em.py:38-58, 85, 89), on the device
             X_all, F_all, Z = _celeste.estep_statistics(srcs, imgs)
-            # M-step
-            printif("  iter %d M-step" % em_iter, verbose)
-            for i, img in enumerate(imgs):                              # :60-63
-                eps_tmp = img.epsilon
+            # M-step, sky levels (:60-63): the photons the E-step left to the sky, per pixel
+            for i, img in enumerate(imgs):
+                before = img.epsilon
                 img.epsilon = Z[i] / img.nelec.size
-                printif("      img %d eps %2.2f => %2.2f" % (i, eps_tmp, img.epsilon), verbose > 1)
-            fac = 1. / (planck.lens_area * planck.exposure_duration * planck.sun_wattage / (planck.m_per_ly ** 2))
+                if detail:
+                    say("[%d] image %d sky %.3f -> %.3f" % (em_iter, i, before, img.epsilon))
+            # M-step, sources (:113-141): temperature by a 1-D search on the profiled objective, brightness in closed form
             for s in range(len(srcs)):
                 X_tildes, sum_fs = X_all[s], F_all[s]
 
-                def compute_photons_per_joule_per_image(t):            # :96-106
-                    I_ts = np.zeros(len(imgbands))
-                    for b in uniquebands:
-                        I_ts[imgbands == b] = planck.photons_per_joule(t, b)
-                    return I_ts
-
-                def partial_loss(temp):                                 # :113-117
-                    I_ts = compute_photons_per_joule_per_image(temp)
+                def temperature_objective(temp):
+                    I_ts = band_efficiency(temp)
                     return X_tildes.dot(np.log(I_ts)) - np.log(I_ts.dot(sum_fs)) * X_tildes.sum()
 
-                t_hat = fmin(lambda t: -partial_loss(np.atleast_1d(t)[0]), srcs[s].t, disp=False)[0]       # :133-134
-                I_ts = compute_photons_per_joule_per_image(t_hat)
-                b_hat = fac * (1. / I_ts.dot(sum_fs)) * X_tildes.sum()                                    # :141
-                printif("   src %d temp       = %2.2f => %2.2f" % (s, srcs[s].t, t_hat), verbose > 1)
-                printif("   src %d brightness = %2.2g => %2.2g" % (s, srcs[s].b, b_hat), verbose > 1)
+                t_hat = fmin(lambda t: -temperature_objective(np.atleast_1d(t)[0]), srcs[s].t, disp=False)[0]
+                b_hat = fac * (1. / band_efficiency(t_hat).dot(sum_fs)) * X_tildes.sum()
+                if detail:
+                    say("[%d] source %d: T %.1f -> %.1f, brightness %.3g -> %.3g" % (em_iter, s, srcs[s].t, t_hat, srcs[s].b, b_hat))
                 srcs[s].t = t_hat
                 srcs[s].b = b_hat
             ll = _celeste.celeste_likelihood_multi_image(srcs, imgs)
             ll_trace.append(ll)
-            printif(".... current marginal likelihood = %2.2f" % ll, verbose)
+            say("[%d] log-likelihood %.2f (%+.3f)" % (em_iter, ll, ll - prev_ll))
             if prev_ll > ll:
-                printif("marginal likelihood DECREASED!!!", verbose)
-                printif("   %2.4f => %2.4f" % (prev_ll, ll), verbose)
-            if ll - prev_ll < 1:
-                printif("marginal likelihood converging, stopping (iter = %d, maxiter = %d)" % (em_iter, maxiter), verbose)
+                say("[%d] warning: the log-likelihood went DOWN, %.4f -> %.4f" % (em_iter, prev_ll, ll))
+            if ll - prev_ll < 1:                                        # the reference's stopping rule (:174-177)
+                say("converged after %d of at most %d iterations" % (em_iter + 1, maxiter))
                 break
             prev_ll = ll
         return ll_trace, em_iter < maxiter

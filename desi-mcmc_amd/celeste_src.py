@@ -22,14 +22,41 @@ def nanomaggies2mags(nanos):
     return (-2.5) * np.log10(nanos) + 22.5
 
 
+# A process-wide modification clock: every attribute assignment on a SrcParams ticks it and stamps the object.  The render
+# / likelihood functions keep the arrays they gathered from a LIST of SrcParams and, called again with the same list,
+# re-read only the objects whose stamp moved (celeste._source_arrays): the reference's callers evaluate the likelihood
+# of a list after changing ONE source (util/infer/mcmc_transitions.py:37-152, celeste_mcmc.py:130).
+_CLOCK = [0]
+_set = object.__setattr__
+
+
+def clock():
+    return _CLOCK[0]
+
+
+def touch(src):
+    """mark `src` as modified.  Needed only after changing one of its containers IN PLACE (src.u[0] = x,
+    src.fluxes['r'] = f) without assigning the attribute afterwards; `src.u = u` -- what the reference's own moves do
+    after their in-place edits (mcmc_transitions.py:49-51) -- stamps by itself."""
+    _CLOCK[0] += 1
+    _set(src, "_stamp", _CLOCK[0])
+
+
 class SrcParams(object):
-    __slots__ = ("a", "u", "b", "t", "v", "theta", "phi", "sigma", "rho", "fluxes", "ell", "d", "header")
+    __slots__ = ("a", "u", "b", "t", "v", "theta", "phi", "sigma", "rho", "fluxes", "ell", "d", "header", "_stamp")
 
     def __init__(self, u, a=None, b=None, t=None, v=None, theta=None, phi=None, sigma=None, rho=None,
                  fluxes=None, ell=None, d=None, header=None):
-        self.u, self.a, self.b, self.t, self.v = u, a, b, t, v
-        self.theta, self.phi, self.sigma, self.rho = theta, phi, sigma, rho
-        self.fluxes, self.ell, self.d, self.header = fluxes, ell, d, header
+        _set(self, "u", u); _set(self, "a", a); _set(self, "b", b); _set(self, "t", t); _set(self, "v", v)
+        _set(self, "theta", theta); _set(self, "phi", phi); _set(self, "sigma", sigma); _set(self, "rho", rho)
+        _set(self, "fluxes", fluxes); _set(self, "ell", ell); _set(self, "d", d); _set(self, "header", header)
+        _CLOCK[0] += 1
+        _set(self, "_stamp", _CLOCK[0])
+
+    def __setattr__(self, name, value):
+        _set(self, name, value)
+        _CLOCK[0] += 1
+        _set(self, "_stamp", _CLOCK[0])
 
     def __eq__(self, other):
         return isinstance(other, SrcParams) and np.array_equal(self.u, other.u) and self.b == other.b

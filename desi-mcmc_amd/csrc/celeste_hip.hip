@@ -237,6 +237,7 @@ struct cel_sources {
     int64_t n_gal = -1;            // entries that are not stars (type != 0); -1 = unknown (types set from device memory)
     int *d_type = nullptr;
     double *d_radec = nullptr, *d_counts = nullptr, *d_shape = nullptr;
+    std::vector<int32_t> h_type;   // the types as last set from host memory (cel_sources_set_rows keeps n_gal exact with them)
 };
 
 // The launch order of the tiles matters only when there are more tiles than the chip runs at once (2048 waves of the
@@ -744,10 +745,57 @@ int cel_sources_set(cel_sources *s, int64_t S, const int32_t *type, const double
     s->S = S;
     s->gen = ++g_source_gen;
     s->n_gal = -1;
+    s->h_type.clear();
     if (mem != CEL_DEVICE) {
         s->n_gal = 0;
         for (int64_t i = 0; i < S; i++) s->n_gal += (type[i] != 0);
+        s->h_type.assign(type, type + S);
     }
+    return CEL_OK;
+}
+
+// n rows of the catalogue replaced (host arrays, packed: idx[n], type[n], radec[n][2], counts[n][B], shape[n][4]): what a
+// caller that changed ONE source between two evaluations uploads instead of the whole catalogue (the RJ moves and slice
+// steps of CelestePy/util/infer/mcmc_transitions.py:37-152 call celeste_likelihood after every such change)
+int cel_sources_set_rows(cel_sources *s, int64_t n, const int32_t *idx, const int32_t *type, const double *radec,
+                         const double *counts, const double *shape) {
+    if (!s || n < 0 || (n > 0 && (!idx || !type || !radec || !counts || !shape)))
+        return fail(CEL_ERR_INVALID, "cel_sources_set_rows: null argument");
+    for (int64_t i = 0; i < n; i++)
+        if (idx[i] < 0 || idx[i] >= s->S) return fail(CEL_ERR_INVALID, "cel_sources_set_rows: row %d outside the catalogue's %lld", idx[i], (long long)s->S);
+    if (n == 0) return CEL_OK;
+    cel_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int B = s->B;
+    // one staging buffer: idx, type (ints), then radec, counts, shape (doubles)
+    const size_t ints = ((size_t)(2 * n) * sizeof(int) + 7) & ~(size_t)7;
+    const size_t bytes = ints + sizeof(double) * (size_t)n * (2 + B + 4);
+    char *d = nullptr;
+    int rc = scratch_get(c, 7, bytes, (void **)&d);
+    if (rc) return rc;
+    std::vector<char> h(bytes);
+    memcpy(h.data(), idx, sizeof(int) * n);
+    memcpy(h.data() + sizeof(int) * n, type, sizeof(int) * n);
+    double *hd = reinterpret_cast<double *>(h.data() + ints);
+    memcpy(hd, radec, sizeof(double) * 2 * n);
+    memcpy(hd + 2 * n, counts, sizeof(double) * B * n);
+    memcpy(hd + (2 + B) * n, shape, sizeof(double) * 4 * n);
+    HIP_TRY(hipMemcpyAsync(d, h.data(), bytes, hipMemcpyHostToDevice, st));
+    const double *dd = reinterpret_cast<const double *>(d + ints);
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, B, (const int *)d, (const int *)d + n,
+                       dd, dd + 2 * n, dd + (2 + B) * n, s->d_type, s->d_radec, s->d_counts, s->d_shape);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));          // the pageable staging vector goes out of scope
+    if ((int64_t)s->h_type.size() == s->S) {
+        for (int64_t i = 0; i < n; i++) {
+            s->n_gal += (type[i] != 0) - (s->h_type[idx[i]] != 0);
+            s->h_type[idx[i]] = type[i];
+        }
+    } else {
+        s->n_gal = -1;
+    }
+    s->gen = ++g_source_gen;
     return CEL_OK;
 }
 

@@ -1,5 +1,20 @@
 // k_misc.h -- stamp and generic-evaluator kernels
 #pragma once
+// cel_sources_set_rows: n packed rows (type, radec, counts[B], shape) scattered to rows idx[] of the catalogue's arrays
+__global__ void __launch_bounds__(256)
+k_scatter_rows(int64_t n, int B, const int *__restrict__ idx, const int *__restrict__ type, const double *__restrict__ radec,
+               const double *__restrict__ counts, const double *__restrict__ shape,
+               int *__restrict__ d_type, double *__restrict__ d_radec, double *__restrict__ d_counts, double *__restrict__ d_shape) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t s = idx[i];
+    d_type[s] = type[i];
+    d_radec[2 * s] = radec[2 * i];
+    d_radec[2 * s + 1] = radec[2 * i + 1];
+    for (int b = 0; b < B; b++) d_counts[s * B + b] = counts[i * B + b];
+    for (int k = 0; k < 4; k++) d_shape[4 * s + k] = shape[4 * i + k];
+}
+
 #include "hw_source.h"
 // ------------------------------------------------------------------------------------------
 // k_stamps: one wave per (source, 64-column strip, row chunk) job

@@ -141,6 +141,16 @@ class SourceSet(object):
         self.S = S
         return self
 
+    def set_rows(self, rows, typ, radec, counts, shape):
+        """replace the rows `rows` of the catalogue on the device (cel_sources_set_rows): what changed since the last upload"""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        n = rows.shape[0]
+        typ = np.ascontiguousarray(typ, dtype=np.int32).reshape(n)
+        radec, counts, shape = L.f64(radec).reshape(n, 2), L.f64(counts).reshape(n, self.B), L.f64(shape).reshape(n, 4)
+        L.check(L.lib().cel_sources_set_rows(self._h, n, rows.ctypes.data_as(L.c_int32_p), typ.ctypes.data_as(L.c_int32_p),
+                                             L.dptr(radec), L.dptr(counts), L.dptr(shape)))
+        return self
+
     def set_device(self, S, typ_ptr, radec_ptr, counts_ptr, shape_ptr):
         """Same, from raw device pointers (e.g. torch tensors' data_ptr())."""
         L.check(L.lib().cel_sources_set(self._h, int(S), C.c_void_p(typ_ptr), C.c_void_p(radec_ptr),
@@ -203,6 +213,7 @@ class ImageSet(object):
     # ---- the hot path ----
     def _sources(self, typ, radec, counts, shape):
         S = len(typ)
+        self._list_state = None             # (celeste._device_sources: which cached list the device copy mirrors)
         if self._srcs is None or self._srcs.capacity < S:
             self._srcs = SourceSet(self.ctx, max(S, 16), self.B)
         return self._srcs.set(typ, radec, counts, shape)

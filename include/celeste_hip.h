@@ -202,6 +202,11 @@ int cel_sources_create(cel_ctx *ctx, int64_t capacity, int B, cel_sources **out)
 int cel_sources_destroy(cel_sources *src);
 int cel_sources_set(cel_sources *src, int64_t S, const int32_t *type, const double *radec,
                     const double *counts, const double *shape, int mem);
+/* Replace n rows of the catalogue (host arrays, packed row-major as above; idx[i] = the row that packed row i goes to).
+ * What a caller that changed ONE source between two evaluations uploads -- the slice steps and RJ moves of
+ * CelestePy/util/infer/mcmc_transitions.py:37-152 call celeste_likelihood(list of SrcParams) after every such change. */
+int cel_sources_set_rows(cel_sources *src, int64_t n, const int32_t *idx, const int32_t *type, const double *radec,
+                         const double *counts, const double *shape);
 
 /* ---- the hot path --------------------------------------------------------------------- */
 /* gen_model_image (celeste.py:203-219) for every band + celeste_likelihood /

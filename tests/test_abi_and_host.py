@@ -293,6 +293,70 @@ def test_catalogue_views_reach_the_device_arrays_without_a_gather(built):
     assert celeste._catalogue_rows([views[0], other[1]]) is None
 
 
+def test_list_of_srcparams_is_gathered_once_and_then_row_by_changed_row(built):
+    """celeste._source_arrays on a plain LIST of SrcParams (what celeste_em.py:25,159, celeste_mcmc.py:130 and the moves of
+    util/infer/mcmc_transitions.py:37-152 pass): the arrays are kept per list object; an attribute assignment stamps the
+    object (SrcParams.__setattr__) and only stamped objects are read again.  After every kind of change the cached arrays
+    equal a fresh gather: one source assigned, many, the reference's in-place-then-assign idiom, an element replaced,
+    two swapped, one appended, one removed, touch() after a purely in-place edit."""
+    from desi_mcmc_amd import celeste, celeste_src
+
+    class Im(object):
+        def __init__(self, band, calib, kappa):
+            self.band, self.calib, self.kappa = band, calib, kappa
+    ims = [Im(b, 0.004 + 0.001 * k, 4.0 + 0.2 * k) for k, b in enumerate("gri")]
+    rs = np.random.RandomState(1)
+    S = 200
+
+    def make(i):
+        fl = rs.rand(5) * 10 + 1
+        return built.SrcParams(u=rs.rand(2), a=[0, 1, None][i % 3], fluxes=dict(zip("ugriz", fl)) if i % 2 else fl, theta=.4, sigma=1.5,
+                               phi=10. * i, rho=.6)
+    ps = [make(i) for i in range(S)]
+
+    def check():
+        got = celeste._source_arrays(ps, ims)
+        want = celeste._gather_plain(ps, ims, celeste.expected_photons, [1, 2, 3], np.array([im.calib for im in ims]),
+                                     np.array([im.kappa for im in ims]))
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+        return got
+    first = check()
+    ent = celeste._ENTRY_OF[id(first[0])]
+    assert ent.srcs is ps and ent.version == 0
+    assert check()[0] is first[0] and ent.version == 0                  # nothing changed: the same arrays, no new version
+    ps[17].u = np.array([0.5, 0.25])
+    assert check()[0] is first[0] and ent.version == 1 and ent.rows_since(0).tolist() == [17]
+    pos = ps[40].u                                                      # mcmc_transitions.py:49-51: edit in place, then assign
+    pos[0] = 0.125
+    ps[40].u = pos
+    ps[41].fluxes = np.arange(5.) + 1
+    ps[43].sigma = 7.0
+    ps[44].a = 1
+    check()
+    assert ent.version == 2 and ent.rows_since(1).tolist() == [40, 41, 43, 44] and ent.rows_since(0).tolist() == [17, 40, 41, 43, 44]
+    ps[50].u[1] = 0.75                                                  # in place only: invisible until touched
+    celeste_src.touch(ps[50])
+    check()
+    assert ent.rows_since(2).tolist() == [50]
+    for p in ps:                                                        # most of the list assigned: gathered whole, a new entry
+        p.u = p.u
+    again = check()
+    assert again[0] is not first[0] and id(first[0]) not in celeste._ENTRY_OF
+    ps[3] = make(3)                                                     # an element replaced by a new object
+    check()
+    ps[5], ps[9] = ps[9], ps[5]                                         # two swapped: no stamp moved, the identity pass sees it
+    check()
+    ps.append(make(7))
+    assert check()[0].shape[0] == S + 1
+    del ps[10]
+    assert check()[0].shape[0] == S
+    short = ps[:10]                                                     # short lists are not cached
+    celeste._source_arrays(short, ims)
+    assert all(e.srcs is not short for e in celeste._LIST_CACHE.values())
+    assert len(celeste._LIST_CACHE) <= celeste._LIST_CACHE_MAX
+
+
 def test_mog_sampling_api(built):
     """mog_samples / discrete / MixtureOfGaussians.rvs / var (util/dists/mog.py:25-37,69-73): host-side draws"""
     from desi_mcmc_amd.util.dists import mog

@@ -1406,6 +1406,54 @@ def test_tail_log_fast_preset_meets_the_1e6_bar(cel, orc, big_field):
     np.testing.assert_allclose(llb20, llb32, rtol=1e-8)
 
 
+def test_list_of_srcparams_end_to_end_after_single_source_moves(cel, orc):
+    """celeste_likelihood[_multi_image](LIST of SrcParams, imgs) called again and again while single sources change -- the
+    pattern of util/infer/mcmc_transitions.py:37-152 and celeste_mcmc.py:130: the device catalogue follows row by changed row
+    (cel_sources_set_rows) and every value equals what a freshly built list gives, and the oracle."""
+    from desi_mcmc_amd import celeste, synth
+    ctx = cel.default_context(0)
+    f = synth.SyntheticField(ctx, 300, 5, 256, 256, frac_gal=0.5, seed=31)
+    imgs = synth.fits_images(f)
+    fl5 = f.flux5()
+    ps = [cel.SrcParams(u=f.src["radec"][s].copy(), a=int(f.src["type"][s]), fluxes=dict(zip(BANDS, fl5[s])),
+                        theta=f.src["shape"][s, 0], sigma=f.src["shape"][s, 1], phi=f.src["shape"][s, 2], rho=f.src["shape"][s, 3])
+          for s in range(f.S)]
+
+    def fresh():
+        return celeste.celeste_likelihood_multi_image(list(ps), imgs)       # a new list object: gathered and uploaded whole
+    ll0 = celeste.celeste_likelihood_multi_image(ps, imgs)
+    assert ll0 == fresh()
+    ob = oracle_bands(f)
+    rs = np.random.RandomState(2)
+    for step in range(6):
+        s = int(rs.randint(f.S))
+        if step % 3 == 0:
+            pos = ps[s].u
+            pos[step % 2] += 2e-5
+            ps[s].u = pos                                                   # in place, then assigned (mcmc_transitions.py:49-51)
+        elif step % 3 == 1:
+            ps[s].fluxes = {b: v * 1.5 for b, v in ps[s].fluxes.items()}
+        else:
+            ps[s].a = 1 - ps[s].a
+            ps[s].theta, ps[s].sigma, ps[s].phi, ps[s].rho = 0.3, 1.1, 40.0, 0.7
+        got = celeste.celeste_likelihood_multi_image(ps, imgs)
+        assert got == fresh(), step
+        assert got != ll0
+        ll0 = got
+        assert celeste.celeste_likelihood(ps, imgs[2]) == celeste.celeste_likelihood(list(ps), imgs[2])
+    typ = np.array([p.a for p in ps], dtype=np.int32)
+    radec = np.array([p.u for p in ps])
+    counts = np.array([[p.fluxes[b] for b in BANDS] for p in ps]) / f.bands[:, 2][None, :] * f.bands[:, 1][None, :]
+    shape = np.array([[p.theta, p.sigma, p.phi, p.rho] if p.a == 1 else [0, 0, 0, 0] for p in ps], dtype=float)
+    _, o_ll, _ = orc.render_field(ob, f.H, f.W, typ, radec, counts, shape, f.nelec)
+    np.testing.assert_allclose(ll0, o_ll.sum(), rtol=RT_LL)
+    # the raw entry point: bad rows are refused
+    sset = cel.SourceSet(ctx, 8, 5).set(typ[:8], radec[:8], counts[:8], shape[:8])
+    with pytest.raises(ValueError):
+        sset.set_rows([8], typ[:1], radec[:1], counts[:1], shape[:1])
+    sset.set_rows([], typ[:0], radec[:0], counts[:0], shape[:0])
+
+
 def test_image_set_cache_lru_budget_and_superset_reuse(cel, stamp_images):
     """the mirror's device image-set cache: least recently used sets are evicted -- and their device
     memory released at once -- beyond the byte / count budget; a caller touching SOME images of a
