@@ -294,7 +294,7 @@ def run_render(args, env):
     def step():
         ll, llb = field.images.render(field.sources, loglik=True)
         if reducer is not None:
-            reducer.submit(llb)
+            reducer.submit_device([field.images])     # the sums go from the library's device memory straight into the collective
             if len(reducer.pending) > 1:
                 llb = reducer.result()
         last["llb"] = llb
@@ -639,7 +639,7 @@ def run_fields(args, env):
         for i in range(len(fields)):
             llb += per[i % n_str][i // n_str]
         if reducer is not None:
-            reducer.submit(llb)
+            reducer.submit_device([f.images for f in fields])     # summed on the device, then all-reduced: no host hop before the collective
             if len(reducer.pending) > 1:
                 llb = reducer.result()
         last["llb"] = llb

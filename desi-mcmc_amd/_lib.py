@@ -54,6 +54,7 @@ SYMBOLS = [
     ("cel_images_get_band", C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     ("cel_images_get_lambda", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("cel_images_device_ptrs", C.c_int, [C.c_void_p, c_void_pp, c_void_pp]),
+    ("cel_images_loglik_device", C.c_int, [C.c_void_p, c_void_pp]),
     ("cel_sources_create", C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_void_pp]),
     ("cel_sources_destroy", C.c_int, [C.c_void_p]),
     ("cel_sources_set", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

@@ -223,7 +223,8 @@ struct cel_images {
     double *d_small = nullptr, *h_small = nullptr;      // one buffer: pinned host memory and its device address
     double *d_small_consts = nullptr;
     unsigned long long small_seq = 0;
-    bool llband_on_host = false;  // the last render's per-band sums were formed on the host (the small path)
+    bool llband_on_host = false;  // the last render's per-band sums were formed on the host (the small path): in h_llband
+    double h_llband[MAX_BANDS] = {0};
     bool small_off = false;       // a part once held more stars than the kernel stages: the general path from then on
 };
 
@@ -696,6 +697,21 @@ int cel_images_device_ptrs(cel_images *im, void **nelec, void **lambda) {
     return CEL_OK;
 }
 
+int cel_images_loglik_device(cel_images *im, void **ll_band) {
+    if (!im || !ll_band) return fail(CEL_ERR_INVALID, "cel_images_loglik_device: null argument");
+    if (im->llband_on_host) {
+        // the one-launch path of a small star field adds its blocks' partials on the host: put the sums where every other
+        // render leaves them
+        cel_ctx *c = im->ctx;
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipMemcpyAsync(im->d_llband, im->h_llband, sizeof(double) * im->B, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        im->llband_on_host = false;
+    }
+    *ll_band = im->d_llband;
+    return CEL_OK;
+}
+
 // ---- sources --------------------------------------------------------------------------------
 int cel_sources_destroy(cel_sources *s) {
     if (!s) return CEL_OK;
@@ -966,6 +982,7 @@ static int render_small_stars(cel_images *im, cel_sources *src, int flags, bool 
                 sum[k] = t;
             }
             c->pinned[b] = ((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7]));
+            im->h_llband[b] = c->pinned[b];
         }
         im->llband_on_host = true;              // d_llband does not hold this render's sums (cel_images_loglik_device uploads them)
     }

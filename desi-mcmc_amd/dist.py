@@ -59,21 +59,40 @@ class SourceDeal(object):
         self.mask = np.zeros(self.S, dtype=bool)
         self.mask[self.mine] = True
         self.per_rank = max([r.size for r in self.rows_of] + [1])         # rows every rank contributes (padded)
+        self._bufs = {}                                                   # (n, k) -> persistent pinned / device tensors of _gather
 
     def chain_ids(self):
         """cel_slice_locations' chain_ids: a source's own index where it is this rank's, -1 elsewhere"""
         return np.where(self.mask, np.arange(self.S), -1).astype(np.int32)
 
     def _gather(self, send):
-        """(n, k) of this rank -> (world, n, k) of every rank (one all_gather_into_tensor)"""
+        """(n, k) of this rank -> (world, n, k) of every rank (one all_gather_into_tensor).  Under RCCL the send / receive
+        tensors and their pinned host mirrors are allocated once per shape and the copies are asynchronous on the current
+        stream: the rows themselves are formed on the host (the flux conditionals' Gamma draws are host-side), so one
+        pinned H2D of this rank's rows (110 KB at config 5 on 8 ranks) is inherent; nothing is staged through pageable memory."""
         import torch
         import torch.distributed as dist
-        t = torch.from_numpy(np.ascontiguousarray(send, dtype=np.float64))
-        if dist.get_backend() == "nccl":
-            t = t.cuda(self.device if self.device is not None else torch.cuda.current_device())
-        recv = torch.empty((self.world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)      # rank-major concatenation
-        dist.all_gather_into_tensor(recv, t)
-        return recv.cpu().numpy().reshape(self.world, t.shape[0], t.shape[1])
+        send = np.ascontiguousarray(send, dtype=np.float64)
+        if dist.get_backend() != "nccl":
+            t = torch.from_numpy(send)
+            recv = torch.empty((self.world * t.shape[0], t.shape[1]), dtype=t.dtype)      # rank-major concatenation
+            dist.all_gather_into_tensor(recv, t)
+            return recv.numpy().reshape(self.world, t.shape[0], t.shape[1])
+        key = send.shape
+        buf = self._bufs.get(key)
+        if buf is None:
+            dev = torch.device("cuda", self.device if self.device is not None else torch.cuda.current_device())
+            buf = (torch.empty(key, dtype=torch.float64, pin_memory=True), torch.empty(key, dtype=torch.float64, device=dev),
+                   torch.empty((self.world * key[0], key[1]), dtype=torch.float64, device=dev),
+                   torch.empty((self.world * key[0], key[1]), dtype=torch.float64, pin_memory=True))
+            self._bufs[key] = buf
+        h_send, d_send, d_recv, h_recv = buf
+        h_send.numpy()[...] = send
+        d_send.copy_(h_send, non_blocking=True)
+        dist.all_gather_into_tensor(d_recv, d_send)
+        h_recv.copy_(d_recv, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return h_recv.numpy().reshape(self.world, key[0], key[1]).copy()
 
     def merge(self, arr):
         """arr (S, k) with this rank's rows up to date -> (S, k) with every row taken from its owner"""
@@ -203,6 +222,18 @@ def allreduce_loglik(ll_band, device=None, deterministic=False, force=False):
     return t.cpu().numpy()
 
 
+class _DeviceDoubles(object):
+    """n doubles at a raw device address, for torch.as_tensor (zero copy through __cuda_array_interface__)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def _fetch_device_doubles(ptr, n):
+    import torch
+    return torch.as_tensor(_DeviceDoubles(ptr, n), device="cuda").cpu().numpy()
+
+
 class LoglikReducer(object):
     """The same all-reduce, pipelined: submit() starts the sum of one evaluation's B per-band
     doubles and returns at once; result() hands back the oldest outstanding sum.  With fields
@@ -246,6 +277,34 @@ class LoglikReducer(object):
             work = dist.all_reduce(self.dev_t[s], op=dist.ReduceOp.SUM, async_op=True)
         else:
             work = dist.all_reduce(self.host_t[s], op=dist.ReduceOp.SUM, async_op=True)
+        self.pending.append((s, work))
+
+    def submit_device(self, image_sets):
+        """The same for sums that are ALREADY on the device: the per-band log-likelihoods the last render of each of
+        `image_sets` left in the library's memory (ImageSet.loglik_device_ptr; their renders have returned, i.e. their
+        stream was synchronised).  Under RCCL the sums are added into this reducer's device slot by device-to-device
+        operations and all-reduced from there: nothing crosses PCIe before the collective.  Without a GPU process group
+        (gloo rigs, one rank) the values are fetched and take submit()'s path."""
+        image_sets = list(image_sets)
+        if not (self.active and self.gpu):
+            tot = np.zeros(self.B)
+            for iset in image_sets:
+                tot += _fetch_device_doubles(iset.loglik_device_ptr(), self.B)
+            return self.submit(tot)
+        if len(self.pending) >= self.depth:
+            raise RuntimeError("LoglikReducer: %d sums outstanding, call result() first" % len(self.pending))
+        import torch
+        import torch.distributed as dist
+        s = self.slot
+        self.slot = (s + 1) % self.depth
+        slot = self.dev_t[s]
+        for k, iset in enumerate(image_sets):
+            src = torch.as_tensor(_DeviceDoubles(iset.loglik_device_ptr(), self.B), device=self.dev)
+            if k == 0:
+                slot.copy_(src)
+            else:
+                slot.add_(src)
+        work = dist.all_reduce(slot, op=dist.ReduceOp.SUM, async_op=True)
         self.pending.append((s, work))
 
     def result(self):

@@ -210,6 +210,13 @@ class ImageSet(object):
         L.check(L.lib().cel_images_device_ptrs(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def loglik_device_ptr(self):
+        """device address of the B per-band log-likelihoods of the last render(loglik=True): what dist.LoglikReducer
+        all-reduces without a trip through host memory"""
+        p = C.c_void_p()
+        L.check(L.lib().cel_images_loglik_device(self._h, C.byref(p)))
+        return p.value
+
     # ---- the hot path ----
     def _sources(self, typ, radec, counts, shape):
         S = len(typ)

@@ -185,6 +185,10 @@ int cel_images_get_lambda(cel_images *img, double *out, int mem);
  * the caller may write the observed image in place: it stops assuming the range cel_images_set_nelec found (the photon split's
  * 16-bit photons-left plane) until the next cel_images_set_nelec */
 int cel_images_device_ptrs(cel_images *img, void **nelec, void **lambda);
+/* device pointer of the B per-band log-likelihoods of the LAST render with CEL_RENDER_LOGLIK (doubles, valid until the next
+ * render of this image set; the stream has been synchronised when the render returned): what a multi-GPU caller hands to
+ * its all-reduce without a trip through host memory (the one collective of the path). */
+int cel_images_loglik_device(cel_images *img, void **ll_band);
 
 /* ---- sources ------------------------------------------------------------------------ */
 /* Replaces a python list of SrcParams (celeste_src.py:57-94) as far as the path reads them:

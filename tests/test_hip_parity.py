@@ -1766,6 +1766,36 @@ for k in range(4):
         got.append(red.result())
 got += red.drain()
 assert len(got) == 4 and all(np.array_equal(g, x * (k + 1)) for k, g in enumerate(got))
+# sums straight from the library's device memory (ImageSet.loglik_device_ptr): two fields' per-band log-likelihoods added on
+# the device and all-reduced, pipelined one step deep -- nothing crosses PCIe before the collective; a small star field
+# (sums formed on the host by the one-launch path) comes the same way
+import desi_mcmc_amd as cel
+from desi_mcmc_amd import synth
+ctx = cel.default_context(0)
+fa = synth.SyntheticField(ctx, 120, 5, 200, 240, frac_gal=0.5, seed=3)
+fb = synth.SyntheticField(ctx, 90, 5, 160, 224, frac_gal=0.0, seed=4)
+red = dist.LoglikReducer(5, device=0, depth=2, force=True)
+want, got = [], []
+for k in range(3):
+    la = fa.images.render(fa.sources, loglik=True)[1]
+    lb = fb.images.render(fb.sources, loglik=True)[1]
+    want.append(la + lb)
+    red.submit_device([fa.images, fb.images])
+    if len(red.pending) > 1:
+        got.append(red.result())
+got += red.drain()
+assert len(got) == 3 and all(np.array_equal(g, w) for g, w in zip(got, want)), (got, want)
+assert ctx.profile_get("small_stars")[1] == 0
+ctx.profile(True)
+fb.images.render(fb.sources, loglik=True)
+assert ctx.profile_get("small_stars")[1] == 1          # the star field did take the one-launch path
+ctx.profile(False)
+# the dealt chain's exchange on persistent pinned / device buffers
+deal = dist.SourceDeal(7, 1, 0, device=0)
+deal.world = 1
+X = np.arange(21.0).reshape(7, 3)
+g1 = deal._gather(X); g2 = deal._gather(X + 1)
+assert np.array_equal(g1[0], X) and np.array_equal(g2[0], X + 1) and len(deal._bufs) == 1
 td.barrier()
 td.destroy_process_group()
 print("rccl one-rank ok")
