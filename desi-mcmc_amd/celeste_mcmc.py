@@ -284,10 +284,21 @@ class ModelGibbs(object):
         return fl[:, f.band_index] / f.calib[None, :] * f.kappa[None, :]
 
     def _sources(self, f):
+        """the catalogue at the chain's current state on the device.  It is uploaded only when it differs from what the
+        device holds (three calls per sweep ask for it, one has anything new): besides the copies saved, an unchanged
+        SourceSet keeps its identity, which is what lets the next photon split take its totals image from the trace
+        render's model image instead of rendering it again (CEL_OPT_SPLIT_REUSE)."""
         from . import field as _field
         if f.sset is None or f.sset.capacity < self.S:
             f.sset = _field.SourceSet(f.iset.ctx, max(self.S, 1), f.iset.B)
-        return f.sset.set(self.typ, self.u, self.counts(f), self.shape)
+            f._uploaded = None
+        cur = (self.typ, self.u, self.counts(f), self.shape)
+        last = getattr(f, "_uploaded", None)
+        if last is not None and f.sset.S == self.S and all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(cur, last)):
+            return f.sset
+        f.sset.set(*cur)
+        f._uploaded = tuple(np.array(a, copy=True) for a in cur)
+        return f.sset
 
     # -- Field.resample_photons: models.py:123-160 ---------------------------------------------------
     def resample_photons(self):
@@ -436,6 +447,7 @@ class ModelGibbs(object):
                                              max_steps_out=a.get("max_steps_out", 1000), phi_max=self.phi_period, chain_ids=ids)
             new[:, 2] = np.where(ids >= 0, (new[:, 2] + self.phi_period) % self.phi_period, new[:, 2])
             self.shape = new
+            f._uploaded = None                                 # (the device holds the unwrapped angles)
             self.timing["shape_rounds"] += st["rounds"]
             self.timing["shape_evals"] += st["evals"]
             self.timing["shape"] += time.perf_counter() - t0
@@ -485,6 +497,8 @@ class ModelGibbs(object):
             new_u, _, st = f.iset.slice_locations(sset, self.slice_args.get("sigma", 1.0), self.step_seed("location"),
                                                   chain_ids=ids)
             self.u = new_u
+            if getattr(f, "_uploaded", None) is not None:      # the device's catalogue moved with the chains: it IS the new state
+                f._uploaded = (f._uploaded[0], new_u.copy(), f._uploaded[2], f._uploaded[3])
             self.timing["rounds"] += st["rounds"]
             self.timing["evals"] += st["evals"]
             self.timing["loc_bytes"] = self.timing.get("loc_bytes", 0) + st["algorithmic_bytes"]

@@ -83,6 +83,7 @@ static int fail(int code, const char *fmt, ...) {
 #include "k_render_hw.h"
 #include "k_render_stars.h"
 #include "k_small_stars.h"
+#include "k_border.h"
 #include "k_render_qw.h"
 #include "k_misc.h"
 #include "k_patch_ll.h"
@@ -124,6 +125,7 @@ struct cel_ctx {
     int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created
     bool tile_timing = false; // diagnostic: k_render stamps each tile's start/end wall clock
     double nz_bias = getenv("CEL_NZ_BIAS") ? atof(getenv("CEL_NZ_BIAS")) : 4.0;   // see k_nz_layout (the env var: experiments only)
+    int split_reuse = (getenv("CEL_SPLIT_REUSE") && atoi(getenv("CEL_SPLIT_REUSE")) == 0) ? 0 : 1;      // CEL_OPT_SPLIT_REUSE (the env var: the initial value, for A/B runs): the split's totals from a model image already on the device (k_border.h)
     int nz_force = 0;         // CEL_OPT_PHOTON_LISTS: 0 = per patch, whichever is estimated cheaper; 1 = every patch at its photons; 2 = never
     int debug = 0;            // CEL_OPT_DEBUG: timing-only ablation bits handed to the render kernel (results are wrong when set)
     int tile_layout = 1;      // 0: 64 x tile_rows tiles, one lane per column (k_render)
@@ -170,6 +172,9 @@ struct cel_images {
     // and the host copy of their boxes / status that cel_stamp_boxes / cel_source_boxes hand out:
     // a stamp call (boxes, then stamps) runs k_prep and the D2H once, not twice
     uint64_t recs_gen = 0, hbox_gen = 0;
+    // which sources the model image in d_lambda (full boxes, the current sky levels) and the tile lists belong to: what lets
+    // the photon split take its totals from that image (k_border.h); 0 = not valid
+    uint64_t lambda_gen = 0, lists_gen = 0;
     std::vector<int4> h_boxes;
     std::vector<int> h_status;
     int *d_tile_cnt = nullptr, *d_tile_nstar = nullptr, *d_tile_work = nullptr, *d_order = nullptr;
@@ -488,6 +493,10 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         if (v != 0.0 && v != 1.0 && v != 2.0) return fail(CEL_ERR_INVALID, "CEL_OPT_PHOTON_LISTS must be 0, 1 or 2");
         c->nz_force = (int)v;
         return CEL_OK;
+    case CEL_OPT_SPLIT_REUSE:
+        if (v != 0.0 && v != 1.0) return fail(CEL_ERR_INVALID, "CEL_OPT_SPLIT_REUSE must be 0 or 1");
+        c->split_reuse = (int)v;
+        return CEL_OK;
     case CEL_OPT_STAR_TILES:
         if (v != 0.0 && v != 1.0 && v != 2.0 && v != 3.0) return fail(CEL_ERR_INVALID, "CEL_OPT_STAR_TILES must be 0, 1, 2 or 3");
         c->star_tiles = (int)v;
@@ -518,6 +527,7 @@ int cel_ctx_get_option(cel_ctx *c, int key, double *v) {
     case CEL_OPT_TILE_LAYOUT: *v = c->tile_layout; return CEL_OK;
     case CEL_OPT_PHOTON_LISTS: *v = c->nz_force; return CEL_OK;
     case CEL_OPT_STAR_TILES: *v = c->star_tiles; return CEL_OK;
+    case CEL_OPT_SPLIT_REUSE: *v = c->split_reuse; return CEL_OK;
     case CEL_OPT_DEBUG: *v = c->debug; return CEL_OK;
     }
     return fail(CEL_ERR_INVALID, "unknown option %d", key);
@@ -654,6 +664,7 @@ int cel_images_set_epsilon(cel_images *im, int band, double eps) {
     if (!im || band < 0 || band >= im->B) return fail(CEL_ERR_INVALID, "cel_images_set_epsilon: bad band");
     HIP_TRY(hipSetDevice(im->ctx->device));
     im->hb[band].eps = eps;
+    im->lambda_gen = 0;                   // the model image on the device was rendered with the old sky level
     // stream-ordered, no host synchronisation (Gibbs calls this per band per sweep)
     hipLaunchKernelGGL(k_set_eps, dim3(1), dim3(1), 0, im->ctx->stream, im->d_bands, band, eps);
     HIP_TRY(hipGetLastError());
@@ -667,6 +678,7 @@ int cel_images_set_window(cel_images *im, int y0, int full_H) {
     im->win_y0 = y0;
     im->full_H = full_H;
     im->recs_gen = im->hbox_gen = 0;      // boxes are cut to the window
+    im->lambda_gen = im->lists_gen = 0;
     return CEL_OK;
 }
 
@@ -987,6 +999,8 @@ static int render_small_stars(cel_images *im, cel_sources *src, int flags, bool 
         im->llband_on_host = true;              // d_llband does not hold this render's sums (cel_images_loglik_device uploads them)
     }
     im->recs_gen = src->gen;                    // the kernel wrote k_prep's records, boxes and status words
+    im->lists_gen = 0;                          // ... and no tile lists
+    if (!(flags & CEL_RENDER_NO_STORE)) im->lambda_gen = 0;
     im->last_S = S;
     im->cost_S = -1; im->order_S = -1;
     im->last_entries = 0;
@@ -1029,6 +1043,8 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
             return CEL_OK;
         }
     }
+    im->lists_gen = 0;
+    if (!lambda_out && !(flags & CEL_RENDER_NO_STORE)) im->lambda_gen = 0;
     rc = run_prep(im, src);
     if (rc) return rc;
     if (im->lists_cap == 0) {
@@ -1142,7 +1158,12 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         const bool too_dense = (cur[3] & 2ull) != 0;        // a super-tile with more candidates than the one-kernel form stages
         const bool coarse_ok = (cur[3] & 0xffffffffull) == 0 && (int64_t)cur[2] <= im->clist_cap;
         if (coarse_ok) im->last_entries = (double)cur[0];
-        if (fine_ok && coarse_ok) { im->cost_S = a.cost ? S : -1; im->order_S = post_order ? S : -1; break; }
+        if (fine_ok && coarse_ok) {
+            im->cost_S = a.cost ? S : -1; im->order_S = post_order ? S : -1;
+            im->lists_gen = src->gen;
+            if (!lambda_out && !(flags & (CEL_RENDER_NO_STORE | CEL_RENDER_STRICT)) && im->TW == HW_TW && c->variant != 0) im->lambda_gen = src->gen;
+            break;
+        }
         im->cost_S = -1;
         im->order_S = -1;
         // rerun with room (a truncated coarse list also truncates the fine counts)
@@ -1161,6 +1182,13 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         if (ll_total) *ll_total = tot;
     }
     return CEL_OK;
+}
+
+int cel_debug_split_rates(cel_images *im, double *out) {
+    if (!im || !out) return fail(CEL_ERR_INVALID, "cel_debug_split_rates: null argument");
+    if (!im->d_rate) return fail(CEL_ERR_INVALID, "no totals image: cel_photon_split on the recurrence kernels has not run");
+    HIP_TRY(hipSetDevice(im->ctx->device));
+    return copy_out(out, im->d_rate, sizeof(double) * (size_t)im->B * im->H * im->W, CEL_HOST, im->ctx->stream);
 }
 
 int cel_debug_tile_timing(cel_images *im, uint64_t *out, int64_t *n_tiles) {
@@ -1608,7 +1636,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     // are queued SLICE_BATCH at a time and the flags read once per batch: the queue does not drain
     // while the host takes its turn.  A round queued after the last chain has finished scores nothing
     // (every job retires at its first instruction) and is not counted.
-    const int SLICE_BATCH = 4;
+    const int SLICE_BATCH = 4;                       // (6, 8 and 12 measure the same sweep: the batch boundary is not where the step's gaps are)
     const int ostr = (c->variant != 0) ? SLICE_SPLIT : 1;        // slots per job in d_ll: the recurrence kernels always fill all four
     // the blocks of the coming batch: the full heaviest-first lists while (nearly) every chain runs, afterwards the running
     // chains' blocks (k_slice_live_jobs, built behind the batch before: their counts came back with its flags)
@@ -1886,7 +1914,21 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
     int rc;
     if (hw) {
         if (!im->d_rate) HIP_TRY(hipMalloc((void **)&im->d_rate, sizeof(double) * (size_t)im->B * im->H * im->W));
-        rc = render_impl(im, src, CEL_RENDER_STRICT, nullptr, nullptr, im->d_rate);
+        if (c->split_reuse && src->gen != 0 && im->lambda_gen == src->gen && im->lists_gen == src->gen && im->recs_gen == src->gen) {
+            // the model image, records and tile lists of exactly these sources are on the device (the chain's trace render
+            // came last): the totals are that image minus every source's first box row and column (k_border.h)
+            RenderArgs a;
+            memset(&a, 0, sizeof(a));
+            a.bands = im->d_bands; a.recs = im->d_recs; a.lists = im->d_lists; a.tile_cnt = im->d_tile_cnt; a.tile_off = im->d_tile_off;
+            a.lambda = im->d_lambda; a.S = src->S; a.capacity = im->lists_cap; a.B = im->B; a.H = im->H; a.W = im->W;
+            a.ntx = im->ntx; a.nty = im->nty;
+            int pi = prof_slot(c, CEL_K_TOTALS);
+            LAUNCH_EV(k_strict_totals, dim3((unsigned)(im->B * im->ntx * im->nty)), dim3(64), c->stream, EV0(c, pi), EV1(c, pi), a, im->d_rate);
+            HIP_TRY(hipGetLastError());
+            rc = CEL_OK;
+        } else {
+            rc = render_impl(im, src, CEL_RENDER_STRICT, nullptr, nullptr, im->d_rate);
+        }
     } else {
         rc = cel_render_field(im, src, 0, nullptr, nullptr);
     }

@@ -625,7 +625,9 @@ k_photon_split_hw(SplitArgs a) {
     const SrcRec *recs = a.recs + (int64_t)b * a.S;
     const int dropmode = (a.tail_T > 0.0 && eps > 0.0) ? HW_DROP_SKY : HW_DROP_NONE;
     const double log_sky = (eps > 0.0) ? (double)__logf((float)eps) : 0.0;
+#ifndef SPLIT_LC_PER_SOURCE
     const LaneConst lc = lane_consts(lane, bd);
+#endif
     const int nent = (Y0 < a.H) ? (int)min((int64_t)cnt, a.capacity > off ? a.capacity - off : (int64_t)0) : 0;
     int idx64 = (lane < nent) ? a.lists[off + lane] : 0;
     int s_next = __builtin_amdgcn_readlane(idx64, 0);
@@ -650,6 +652,10 @@ k_photon_split_hw(SplitArgs a) {
         if (ra >= rb || xa > xb) continue;          // touches the tile's other half only (wave-uniform)
         const bool on = (xi >= xa) && (xi <= xb);
         bool direct;
+#ifdef SPLIT_LC_PER_SOURCE
+        asm volatile("" ::: "memory");      // the band's lane constants are read again per source instead of living in 28 VGPRs across the walk
+        const LaneConst lc = lane_consts(lane, bd);
+#endif
         const int Kk = hw_build(T, lc, rec, lane, dropmode, a.tail_T, log_sky, Y0, xa, xb, ra, rb, direct, nullptr, et);
         if (!(SPLIT_ABLATE(a) & 4)) hw_walk(T, et, Kk, x, Y0, ra, rb, on, direct, one, lane);
         __syncthreads();

@@ -243,6 +243,12 @@ class ImageSet(object):
         L.check(L.lib().cel_images_get_lambda(self._h, out.ctypes.data, L.CEL_HOST))
         return out
 
+    def split_rates(self):
+        """the totals image the last photon split drew from (B, H, W): diagnostic (cel_debug_split_rates)"""
+        out = np.empty((self.B, self.H, self.W))
+        L.check(L.lib().cel_debug_split_rates(self._h, L.dptr(out)))
+        return out
+
     def stats(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         L.check(L.lib().cel_field_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))

@@ -100,6 +100,12 @@ enum {
                                its own, no tile lists); 2 = k_render_stars at any size; 3 = rule 1 without the
                                one-launch path.  Tile layout 1 and the row-recurrence only.  The two kernels add a pixel's stars in different orders: values
                                agree to rounding (1e-15), and which one runs depends on the call's inputs only */
+    CEL_OPT_SPLIT_REUSE = 11,/* cel_photon_split's totals image (every pixel's rate under the split's strict boxes): 1 (default) =
+                               when the model image of exactly these sources and sky levels is on the device -- the chain's
+                               trace render came last -- it is formed from that image by subtracting the sources' first
+                               box row and column (k_strict_totals: 0.35 ms instead of a 1.3 ms render at configs[4]);
+                               0 = always rendered from scratch.  The two agree to ~1e-10 of a pixel's rate on those
+                               pixels (exactly elsewhere): equal in distribution, not photon for photon */
     CEL_OPT_DEBUG = 8       /* diagnostics.  The shipped library accepts two result-preserving bits: 64 = the E-step
                                takes its per-source form, 128 = CEL_OPT_TILE_TIMING's third word carries the
                                row-waste counters of tools/row_waste.py.  The timing-only ABLATION bits (render:
@@ -120,7 +126,8 @@ enum {
     CEL_K_ESTEP = 9,        /* cel_estep_stats */
     CEL_K_RENDER_STARS = 10,/* k_render_stars: the field render of a catalogue without galaxies (CEL_OPT_STAR_TILES) */
     CEL_K_SMALL_STARS = 11,/* k_small_stars: a small star field's whole step in one launch (CEL_OPT_STAR_TILES = 1) */
-    CEL_K_COUNT = 12
+    CEL_K_TOTALS = 12,     /* k_strict_totals: the photon split's totals image from the model image on the device (CEL_OPT_SPLIT_REUSE) */
+    CEL_K_COUNT = 13
 };
 
 typedef struct cel_ctx cel_ctx;
@@ -227,6 +234,9 @@ int cel_field_stats(cel_images *img, double *n_srcpix, double *n_gauss, double *
 /* diagnostic (CEL_OPT_TILE_TIMING): per launched render block i, out[3i] = start, out[3i+1] = end
  * (100 MHz wall clock ticks), out[3i+2] = (tile index << 32) | list length.  out == NULL: only
  * *n_tiles is returned.  Never enabled in a timed run. */
+/* the totals image the last cel_photon_split on the recurrence kernels drew from (every pixel's rate under the split's
+ * strict boxes), B*H*W doubles to host memory: what the tests compare between the two ways of forming it (CEL_OPT_SPLIT_REUSE) */
+int cel_debug_split_rates(cel_images *img, double *out);
 int cel_debug_tile_timing(cel_images *img, uint64_t *out, int64_t *n_tiles);
 
 /* ---- stamps --------------------------------------------------------------------------- */

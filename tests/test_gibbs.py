@@ -1029,3 +1029,61 @@ def test_the_two_device_samplers_in_either_order(cel):
     f.images.slice_locations(big.sources, 1e-3, seed=4)
     x, _, st = f.images.slice_sample(big.sources, 0, 1e-3, seed=1, step_out=False)
     assert x.shape == (400, 2) and st["evals"] >= 4 * 400
+
+
+def test_split_totals_from_the_trace_image(cel):
+    """CEL_OPT_SPLIT_REUSE: when the model image of exactly these sources and sky levels is on the device (a chain's trace
+    render came last), the photon split forms its totals image -- every pixel's rate under the strict-box rule of
+    celeste_sample_sources.pyx:50-51 -- from that image by subtracting each source's first box row and column
+    (k_strict_totals) instead of rendering it again.  The two images agree to 1e-9 on every pixel (exactly off the border
+    pixels); both splits conserve every photon; a changed sky level, a changed catalogue or the option send the split back
+    to the render; a whole sweep of ModelGibbs takes the short way from its second sweep on."""
+    from desi_mcmc_amd import _lib, celeste_mcmc, synth
+    ctx = cel.default_context(0)
+    f = synth.SyntheticField(ctx, 400, 5, 384, 416, frac_gal=0.5, seed=17)
+    nel = f.nelec.reshape(5, -1).sum(axis=1)
+
+    def split(expect_short):
+        ctx.profile(True)
+        noise = f.images.photon_split_resident(f.sources, seed=7)
+        n_short, n_render = ctx.profile_get("totals")[1], ctx.profile_get("render")[1]
+        ctx.profile(False)
+        assert (n_short, n_render) == ((1, 0) if expect_short else (0, 1)), (n_short, n_render)
+        sums = f.images.sample_sums()
+        assert np.array_equal(sums.sum(axis=0) + noise, nel)
+        return sums, noise, f.images.split_rates()
+    try:
+        f.images.render(f.sources, loglik=True)                 # the trace render: full boxes, model image stored
+        s_short, n_short, r_short = split(True)
+        ctx.set_option(_lib.CEL_OPT_SPLIT_REUSE, 0)
+        f.images.render(f.sources, loglik=True)
+        s_full, n_full, r_full = split(False)
+        ctx.set_option(_lib.CEL_OPT_SPLIT_REUSE, 1)
+        np.testing.assert_allclose(r_short, r_full, rtol=1e-9)
+        same = r_short == r_full
+        assert same.mean() > 0.5                                 # off the border pixels: the very same numbers
+        lam = f.images.model_images()
+        assert np.all(r_full <= lam * (1 + 1e-12)) and np.any(r_full < lam * (1 - 1e-6))     # strict boxes: something was taken away
+        assert np.mean(s_short == s_full) > 0.999 and abs(s_short - s_full).sum() <= 8        # the same draws but for a rare flip
+        split(True)                                              # the render of the totals left the model image alone: still valid
+    finally:
+        ctx.set_option(_lib.CEL_OPT_SPLIT_REUSE, 1)
+        ctx.profile(False)
+    f.images.render(f.sources, loglik=True)
+    f.images.set_epsilon(2, f.bands[2, 0] * 1.01)                # a new sky level: the image on the device is stale
+    split(False)
+    f.images.render(f.sources, loglik=True)
+    f.sources.set(f.src["type"], f.src["radec"], f.src["counts"], f.src["shape"])      # a new catalogue (same numbers, nobody knows)
+    split(False)
+    f.images.render(f.sources, loglik=False)                     # a render without the log-likelihood stores the image too
+    split(True)
+    # a chain: from the second sweep on the split follows the trace render of the sweep before
+    gf = celeste_mcmc.GibbsField(f.images, list(range(5)), f.bands[:, 2], f.bands[:, 1], f.H * f.W)
+    g = celeste_mcmc.ModelGibbs([gf], f.src["type"], f.src["radec"], f.flux5(), f.src["shape"], seed=3)
+    ctx.profile(True)
+    for k in range(3):
+        g.sweep()
+        assert np.array_equal(gf.sums.sum(axis=0) + g.noise_sums[0], nel)
+        g.log_likelihood()
+    assert ctx.profile_get("totals")[1] == 2 and ctx.profile_get("render")[1] == 1 + 3
+    ctx.profile(False)
