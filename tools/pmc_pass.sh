@@ -26,7 +26,7 @@ for k in per:
     res[k] = {c: [per[k][c][d] for d in sorted(per[k][c])] for c in sorted(per[k])}
 json.dump(res, open("%s/gpurun_out/pmc_%s.json" % (root, tag), "w"), indent=1)
 for k in sorted(res):
-    if not any(t in k for t in ("k_render", "k_patch", "k_photon", "k_estep")):
+    if not any(t in k for t in ("k_render", "k_patch", "k_photon", "k_estep", "k_small", "k_strict")):
         continue
     print(k)
     for c in sorted(res[k]):
