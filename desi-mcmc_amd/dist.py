@@ -304,6 +304,9 @@ class LoglikReducer(object):
                 slot.copy_(src)
             else:
                 slot.add_(src)
+        # the library's buffers are rewritten by the next render on ITS stream: the device-to-device copies above (a few
+        # microseconds on torch's stream) must have run before this call returns; the collective itself stays asynchronous
+        torch.cuda.current_stream(self.dev).synchronize()
         work = dist.all_reduce(slot, op=dist.ReduceOp.SUM, async_op=True)
         self.pending.append((s, work))
 

@@ -642,14 +642,18 @@ def test_full_size_gibbs_kernels_properties(cel, ctx, big_field):
     np.testing.assert_allclose(nz, nz_d, rtol=1e-12)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_strips_tile_the_frame(cel, ctx, world):
+@pytest.mark.parametrize("world,frac_gal", [(2, 0.5), (3, 0.5), (3, 0.0)])
+def test_row_strips_tile_the_frame(cel, ctx, world, frac_gal):
     """strong-scaling partition on ONE gpu: strips rendered through cel_images_set_window must
-    reproduce the whole frame's model pixels, and their ll partials must add up"""
+    reproduce the whole frame's model pixels, and their ll partials must add up.  frac_gal = 0: a star-only catalogue on a
+    small frame -- frame and strips take the one-launch path (k_small_stars), whose blocks apply the window themselves"""
     from desi_mcmc_amd import dist, synth
     H, W = 200, 300
-    f = synth.SyntheticField(ctx, 300, 2, H, W, frac_gal=0.5, seed=11)
+    f = synth.SyntheticField(ctx, 300, 2, H, W, frac_gal=frac_gal, seed=11)
+    ctx.profile(True)
     ll, llb = f.images.render(f.sources, loglik=True)
+    assert ctx.profile_get("small_stars")[1] == (1 if frac_gal == 0.0 else 0)
+    ctx.profile(False)
     lam = f.images.model_images()
     parts = np.zeros(2)
     for r in range(world):
