@@ -31,7 +31,13 @@ import os
 import sys
 import time
 
-import numpy as np
+# The GPU boxes show every core of the host (256) and grant a share of 16: thread pools sized by the core count (OpenMP,
+# BLAS, torch's intra-op pool) then oversubscribe the share and the cgroup throttles the whole process -- the sweeps' host
+# side (launches, flag reads) slowed by 10-25 % in such runs.  Nothing here needs more than the share.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    os.environ.setdefault(_v, "16")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -562,7 +568,7 @@ def secondary_legs(args, env, field):
             g.log_likelihood()
         for k in g.timing:
             g.timing[k] = 0
-        ctx.profile(2)        # the evaluating kernels (likelihoods, split, mass, render), not the 46 k_prep launches of a sweep
+        ctx.profile(int(os.environ.get("CEL_BENCH_PROFILE", "2")))        # the evaluating kernels (likelihoods, split, mass, render), not the 46 k_prep launches of a sweep
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(sweeps):
@@ -823,7 +829,7 @@ def run_gibbs(args, env):
             reducer.drain()
         for k in g.timing:
             g.timing[k] = 0
-        ctx.profile(2)        # the evaluating kernels (likelihoods, split, mass, render), not the 46 k_prep launches of a sweep
+        ctx.profile(int(os.environ.get("CEL_BENCH_PROFILE", "2")))        # the evaluating kernels (likelihoods, split, mass, render), not the 46 k_prep launches of a sweep
 
     def finish():
         if reducer is not None:
@@ -924,6 +930,7 @@ def main():
         raise SystemExit("unknown workload %r (render: %s; also fields8_2048, gibbs10k)" % (args.workload, ", ".join(RENDER_WORKLOADS)))
 
     import torch
+    torch.set_num_threads(min(16, max(1, torch.get_num_threads())))
 
     import desi_mcmc_amd as cel
     from desi_mcmc_amd import _lib, dist, synth

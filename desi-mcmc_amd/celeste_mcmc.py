@@ -233,6 +233,10 @@ class ModelGibbs(object):
             raise ValueError("the deal is over %d sources, the catalogue has %d" % (deal.S, self.S))
         self.noise_sums = None
         self.active = np.ones(self.S, dtype=bool)
+        # the flux conditionals' Gamma variates: on the device (cel_gamma_streams) or, host_gamma=True, by the numpy form of
+        # the same sampler (gamma_by_stream: the same streams and decisions, values equal to rounding)
+        import os
+        self.host_gamma = os.environ.get("CEL_HOST_GAMMA") == "1"
 
     # -- helpers ---------------------------------------------------------------------------------
     SLICE_INTENDED = dict(step_out=False, sigma=1e-3)
@@ -373,10 +377,16 @@ class ModelGibbs(object):
         last = self.fields[-1]
         last.iset.stamp_mass_begin(field_sources(last))
         try:
-            # Gamma(a_n, 1 / b_n) = standard Gamma(a_n) * (1 / b_n); every (source, band) draws from its own stream
-            g = gamma_by_stream(a_n.ravel(), self.step_seed("flux"), np.arange(self.S * 5)).reshape(self.S, 5)
+            # Gamma(a_n, 1 / b_n) = standard Gamma(a_n) * (1 / b_n); every (source, band) draws from its own stream -- on the
+            # device, queued behind the mass kernel (cel_gamma_streams: gamma_by_stream's sampler, streams and decisions, ~10 us;
+            # the numpy draws beside the kernel took 1.7 ms on an idle host and 3.5 ms on a busy one: the step's time moved
+            # with the host)
+            if self.host_gamma:
+                g = gamma_by_stream(a_n.ravel(), self.step_seed("flux"), np.arange(self.S * 5)).reshape(self.S, 5)
+            else:
+                g = last.iset.ctx.gamma_streams(a_n.ravel(), self.step_seed("flux")).reshape(self.S, 5)
         finally:
-            m_last = last.iset.stamp_mass_end()     # whatever the host draw does, the pending call is collected
+            m_last = last.iset.stamp_mass_end()     # whatever the draw does, the pending call is collected
         add_mass(psf_sums, last, m_last)
         new = g * (1. / (self.flux_b_0 + psf_sums))
         self.fluxes = np.where(self.active[:, None], new, self.fluxes)       # rows of other ranks' sources: merged at the sweep's end

@@ -1482,6 +1482,10 @@ int cel_patch_loglik(cel_images *im, cel_sources *src, const int32_t *boxes, con
     return cel_patch_loglik_multi(im, src, nullptr, 1, boxes, offsets, data, mem, mode, ll_out);
 }
 
+// (Round 4 measured this kernel on a SECOND stream beside the photon split -- its inputs are ready before the split when the
+// chain's trace render came last: the split slowed down by 1.35 ms for the 1.7 ms taken off the flux step and the sweep was
+// 0.9 ms LONGER than with the two kernels one behind the other; two VALU- and LDS-bound kernels have nothing to give each
+// other.  Removed again.)
 int cel_stamp_mass_begin(cel_images *im, cel_sources *src) {
     if (!im || !src) return fail(CEL_ERR_INVALID, "cel_stamp_mass: null argument");
     if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
@@ -1515,6 +1519,24 @@ int cel_stamp_mass_end(cel_images *im, double *mass) {
     im->mass_pending = -1;
     if (n == 0) return CEL_OK;
     return copy_out(mass, im->d_mass, sizeof(double) * n, CEL_HOST, c->stream);
+}
+
+// celeste_mcmc.gamma_by_stream on the device (k_gamma_streams): n standard Gamma(a[i]) variates, element i from its own
+// streams keyed by (seed, i).  Host arrays in and out.
+int cel_gamma_streams(cel_ctx *c, int64_t n, const double *a, uint64_t seed, double *out) {
+    if (!c || n < 0 || (n > 0 && (!a || !out))) return fail(CEL_ERR_INVALID, "cel_gamma_streams: bad argument");
+    if (n == 0) return CEL_OK;
+    for (int64_t i = 0; i < n; i++)
+        if (!(a[i] > 0.0) || !(a[i] < 1e300)) return fail(CEL_ERR_INVALID, "cel_gamma_streams: shape parameter %lld is not positive and finite", (long long)i);
+    HIP_TRY(hipSetDevice(c->device));
+    double *d = nullptr;
+    int rc = scratch_get(c, 6, sizeof(double) * 2 * n, (void **)&d);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d, a, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_gamma_streams, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, (const double *)d,
+                       (unsigned long long)seed, d + n);
+    HIP_TRY(hipGetLastError());
+    return copy_out(out, d + n, sizeof(double) * n, CEL_HOST, c->stream);
 }
 
 int cel_stamp_mass(cel_images *im, cel_sources *src, double *mass) {

@@ -41,6 +41,7 @@ k_strict_totals(RenderArgs a /* lambda: the full-box model image (in); lists / r
         for (int r = 0; r < HW_TH * HW_TW / 64; r++) acc[r * 64 + lane] = 0.0;
         const LaneConst lc = lane_consts(lane, bd);
         const SrcRec *recs = a.recs + (int64_t)b * a.S;
+        const double log_eps = (bd->eps > 0.0) ? (double)__logf((float)bd->eps) : -700.0;
         __syncthreads();
         for (int e = 0; e < nent; e++) {
             const int s = a.lists[off + e];
@@ -52,18 +53,35 @@ k_strict_totals(RenderArgs a /* lambda: the full-box model image (in); lists / r
             if (!row_here && !col_here) continue;
             const int K = (rec.type == 0) ? K_PSF : K_GAL;
             __syncthreads();            // the previous source's table has been read
+            // The border lies where the source has faded to 1e-5 / 1e-3 of its mass: most of a galaxy's 42 components are
+            // nothing there.  A component is kept when it can exceed eps e^-40 somewhere on the box's first row or column
+            // (the form's minimum along the line y = y0, resp. x = x0: q_min = d^2 det / q_other): what is left out is below
+            // 42 e^-40 = 2e-16 of the sky level per pixel.  Kept components are compacted (ballot + prefix count).
+            bool keep = false;
+            Comp c;
             if (lane < K) {
-                const Comp c = make_comp_lc(lc, rec);
-                tA[lane] = c.A; tmx[lane] = c.mx; tmy[lane] = c.my;
-                tqa[lane] = c.qa * EXP_SCALE; tqb[lane] = c.qb * EXP_SCALE; tqc[lane] = c.qc * EXP_SCALE;
+                c = make_comp_lc(lc, rec);
+                const double dy = (double)rec.y0 - c.my, dx = (double)rec.x0 - c.mx;
+                const double det = c.qa * c.qc - c.qb * c.qb;
+                const double qrow = dy * dy * det / c.qa, qcol = dx * dx * det / c.qc;
+                const double lim = 2.0 * (40.0 + (double)__logf((float)fmax(fabs(c.A), 1e-300)) - log_eps);
+                keep = (fmin(qrow, qcol) <= lim) || !(lim == lim);
+            }
+            const unsigned long long km = __ballot(keep);
+            const int Kk = __popcll(km);
+            if (keep) {
+                const int p = __popcll(km & ((1ull << lane) - 1ull));
+                tA[p] = c.A; tmx[p] = c.mx; tmy[p] = c.my;
+                tqa[p] = c.qa * EXP_SCALE; tqb[p] = c.qb * EXP_SCALE; tqc[p] = c.qc * EXP_SCALE;
             }
             __syncthreads();
+            if (Kk == 0) continue;
             any = true;
             if (row_here) {             // row y0: the tile's 32 columns, the components dealt to the two half-waves
                 const double x = (double)(X0 + col), y = (double)rec.y0;
                 const bool on = (X0 + col >= rec.x0) && (X0 + col < rec.x1);
                 double v = 0.0;
-                for (int k = half; k < K; k += 2) {
+                for (int k = half; k < Kk; k += 2) {
                     const double dx = x - tmx[k], dy = y - tmy[k];
                     const double q = tqa[k] * dx * dx + (2.0 * tqb[k] * dx + tqc[k] * dy) * dy;
                     v = fma(tA[k], exp_tab64(-0.5 * q, et), v);
@@ -75,7 +93,7 @@ k_strict_totals(RenderArgs a /* lambda: the full-box model image (in); lists / r
                 const double x = (double)rec.x0, y = (double)yi;
                 const bool on = (yi > rec.y0) && (yi < rec.y1);
                 double v = 0.0;
-                for (int k = 0; k < K; k++) {
+                for (int k = 0; k < Kk; k++) {
                     const double dx = x - tmx[k], dy = y - tmy[k];
                     const double q = tqa[k] * dx * dx + (2.0 * tqb[k] * dx + tqc[k] * dy) * dy;
                     v = fma(tA[k], exp_tab64(-0.5 * q, et), v);

@@ -93,6 +93,14 @@ class Context(object):
             return ms_s, n_s, "k_render_stars"
         return ms_g, n_g, "k_render_hw"
 
+    def gamma_streams(self, a, seed):
+        """standard Gamma(a[i]) variates, element i from its own streams keyed by (seed, i), drawn on the device
+        (cel_gamma_streams; celeste_mcmc.gamma_by_stream(a, seed, arange(n)) is the same sampler on the host)"""
+        a = L.f64(a).ravel()
+        out = np.empty_like(a)
+        L.check(L.lib().cel_gamma_streams(self._h, a.shape[0], L.dptr(a), C.c_uint64(int(seed) & (2 ** 64 - 1)), L.dptr(out)))
+        return out
+
     def gmm_like_2d(self, x, ws, mus, sigs, probs=None):
         """probs[n] = sum_k ws[k] N(x[n]; mus[k], sigs[k])  (gmm_like_fast.pyx:130-176)."""
         x, ws, mus, sigs = L.f64(x), L.f64(ws), L.f64(mus), L.f64(sigs)
@@ -403,6 +411,7 @@ class ImageSet(object):
     def stamp_mass(self, sources):
         """sum of every source's unit stamp over its own box -> (S, B)  (sources.py:336-339)"""
         out = np.zeros((sources.S, self.B))
+        self._mass_pending = False              # (a call queued earlier and never collected is dropped)
         L.check(L.lib().cel_stamp_mass(self._h, sources._h, L.dptr(out)))
         return out
 
@@ -411,9 +420,11 @@ class ImageSet(object):
         this context before stamp_mass_end)"""
         L.check(L.lib().cel_stamp_mass_begin(self._h, sources._h))
         self._mass_shape = (sources.S, self.B)
+        self._mass_pending = True
 
     def stamp_mass_end(self):
         out = np.zeros(self._mass_shape)
+        self._mass_pending = False
         L.check(L.lib().cel_stamp_mass_end(self._h, L.dptr(out)))
         return out
 

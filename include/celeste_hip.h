@@ -193,7 +193,8 @@ int cel_images_get_lambda(cel_images *img, double *out, int mem);
  * 16-bit photons-left plane) until the next cel_images_set_nelec */
 int cel_images_device_ptrs(cel_images *img, void **nelec, void **lambda);
 /* device pointer of the B per-band log-likelihoods of the LAST render with CEL_RENDER_LOGLIK (doubles, valid until the next
- * render of this image set; the stream has been synchronised when the render returned): what a multi-GPU caller hands to
+ * render, photon split or E-step call on this image set -- they reduce into the same buffer; the stream has been synchronised
+ * when the render returned): what a multi-GPU caller hands to
  * its all-reduce without a trip through host memory (the one collective of the path). */
 int cel_images_loglik_device(cel_images *img, void **ll_band);
 
@@ -290,6 +291,10 @@ int cel_patch_loglik_multi(cel_images *img, cel_sources *src, const int32_t *own
 /* Sum of every source's UNIT stamp over its own box, in every band: mass[s*B + b] -- what
  * Source.resample_fluxes multiplies by kappa/calib for the rate of its Gamma conditional
  * (CelestePy/sources.py:336-339) and celeste_em's sum_fs (celeste_em.py:89).  0 without a stamp.  Host output. */
+/* n standard Gamma(a[i]) variates, element i from its own counter-based streams keyed by (seed, i): the flux conditionals'
+ * draws of Source.resample_fluxes (CelestePy/sources.py:341-345) for a whole catalogue (celeste_mcmc.gamma_by_stream is the
+ * host form: the same streams and decisions, values equal to rounding).  Host arrays. */
+int cel_gamma_streams(cel_ctx *ctx, int64_t n, const double *a, uint64_t seed, double *out);
 int cel_stamp_mass(cel_images *img, cel_sources *src, double *mass);
 /* The same in two halves: _begin queues the kernel and returns, _end waits and copies the S*B values out -- so that the host
  * can draw its Gamma variates while the device sums the stamps (the flux step of a Gibbs sweep) without a second thread.

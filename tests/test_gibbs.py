@@ -1087,3 +1087,29 @@ def test_split_totals_from_the_trace_image(cel):
         g.log_likelihood()
     assert ctx.profile_get("totals")[1] == 2 and ctx.profile_get("render")[1] == 1 + 3
     ctx.profile(False)
+
+
+def test_device_gamma_streams_are_the_host_sampler(cel):
+    """cel_gamma_streams (k_gamma_streams: the flux conditionals' Gamma draws of Source.resample_fluxes, sources.py:341-345, for a
+    whole catalogue on the device) against celeste_mcmc.gamma_by_stream, the numpy form of the same sampler -- the same
+    per-element SplitMix64 streams, the same Marsaglia-Tsang decisions: values equal to rounding (cos and log are the
+    device's), shapes from 0.05 (the boosted branch) to 1e7, order-free; bad shapes are refused."""
+    from desi_mcmc_amd.celeste_mcmc import gamma_by_stream
+    ctx = cel.default_context(0)
+    rs = np.random.RandomState(0)
+    a = np.concatenate([np.exp(rs.uniform(np.log(0.05), np.log(1e7), 60000)), [1.0, 0.999999, 1.0 / 3.0 + 1e-9, 5.0, 1e-3]])
+    for seed in (0, 11, 2 ** 63 + 12345):
+        dev = ctx.gamma_streams(a, seed)
+        host = gamma_by_stream(a, seed, np.arange(a.shape[0]))
+        assert np.all(dev[a >= 0.05] > 0) and np.all(np.isfinite(dev)) and np.all(dev >= 0)      # (a = 1e-3: u^1000 may underflow, on the host too)
+        close = np.abs(dev - host) <= 1e-12 * np.abs(host)
+        assert close.mean() > 0.99999, close.mean()          # (an accept / reject decision within rounding of its boundary may differ)
+    assert np.array_equal(ctx.gamma_streams(a, 11), ctx.gamma_streams(a, 11))
+    assert np.array_equal(ctx.gamma_streams(a[:100], 11), ctx.gamma_streams(a, 11)[:100])     # element i depends on (seed, i) only
+    big = ctx.gamma_streams(np.full(200000, 2.5), 3)
+    assert abs(big.mean() - 2.5) < 0.02 and abs(big.var() - 2.5) < 0.06
+    with pytest.raises(ValueError):
+        ctx.gamma_streams(np.array([1.0, -2.0]), 1)
+    with pytest.raises(ValueError):
+        ctx.gamma_streams(np.array([1.0, np.nan]), 1)
+    assert ctx.gamma_streams(np.zeros(0), 1).shape == (0,)
