@@ -28,6 +28,16 @@ __global__ void __launch_bounds__(64) k_rate(const double *__restrict__ in, doub
             a[i] = __builtin_fma(a[i], b[i], b[i]);
 #elif VARIANT == 3
             a[i] = a[i] * b[i]; b[i] = b[i] * a[(i + 1) % N];   // two dependent-free multiplies with mixed operands
+#elif VARIANT == 4
+            a[i] = __builtin_rint(a[i] * 1.0000001);            // v_mul_f64 + v_rndne_f64
+#elif VARIANT == 5
+            a[i] = (double)((int)(a[i]) + 1);                   // v_cvt_i32_f64 + v_add_u32 + v_cvt_f64_i32
+#elif VARIANT == 6
+            a[i] = __builtin_ldexp(a[i], (t & 1) ? 1 : -1);     // v_ldexp_f64
+#elif VARIANT == 7
+            a[i] = (a[i] + 6755399441055744.0) - 6755399441055743.0;   // the magic-number rounding: two v_add_f64
+#elif VARIANT == 8
+            a[i] = __builtin_amdgcn_frexp_mant(a[i]) + b[i];    // v_frexp_mant_f64 + v_add_f64
 #endif
         }
     }
@@ -52,7 +62,7 @@ int main() {
         (void)hipEventRecord(b);
         (void)hipEventSynchronize(b);
         float ms; (void)hipEventElapsedTime(&ms, a, b);
-        double ninstr = (double)blocks * iters * N * (VARIANT == 3 ? 2 : 1);
+        double ninstr = (double)blocks * iters * N * ((VARIANT == 3 || VARIANT == 4 || VARIANT == 7 || VARIANT == 8) ? 2 : (VARIANT == 5 ? 3 : 1));
         printf("variant %d lds %d: %.3f ms, %.2f cycles per wave-instruction per SIMD at 2.4 GHz\n", VARIANT, LDS_BYTES, ms,
                ms * 1e-3 * 2.4e9 / (ninstr / 1024.0));
     }
