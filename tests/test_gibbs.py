@@ -1113,3 +1113,39 @@ def test_device_gamma_streams_are_the_host_sampler(cel):
     with pytest.raises(ValueError):
         ctx.gamma_streams(np.array([1.0, np.nan]), 1)
     assert ctx.gamma_streams(np.zeros(0), 1).shape == (0,)
+
+
+def test_gibbs_sweeps_on_a_real_sdss_field(cel):
+    """BASELINE configs[4] on real data: ModelGibbs over the five SDSS images of data/stamps 253.1147-11.6072 (the reference's
+    own FitsImage fields and catalogue, tests/golden/real_fields.npz), the catalogue's sources as stars.  Every observed
+    photon of every band goes to exactly one source or to the sky in every sweep; the device and the host engine follow the
+    same trajectory bit for bit; the sky levels stay near their catalogued values; the chain's log-likelihood settles above
+    the reference's own celeste_likelihood_multi_image value for the raw catalogue."""
+    from conftest import real_fields
+    from desi_mcmc_amd import celeste, celeste_mcmc
+    _, fields = real_fields(dirs=("stamps",))
+    f = [q for q in fields if q["name"].endswith("253.1147-11.6072")][0]
+    imgs = [cel.FitsImage.from_record(BANDS[b], f["rec"], b, f["nelec"][b]) for b in range(5)]
+    params = [cel.SrcParams(u=f["radec"][s].copy(), a=0, fluxes=dict(zip(BANDS, np.maximum(f["flux"][s], 1e-3)))) for s in range(len(f["radec"]))]
+    nel = f["nelec"].reshape(5, -1).sum(axis=1)
+    out = {}
+    for eng in ("host", "device"):
+        for im, e in zip(imgs, f["rec"]["eps"]):
+            im.epsilon = float(e)
+        g = celeste_mcmc.ModelGibbs.from_images([dict(zip(BANDS, imgs))], params, seed=6, engine=eng)
+        trace = []
+        for sweep in range(4):
+            g.sweep()
+            gf = g.fields[0]
+            assert np.array_equal(gf.sums.sum(axis=0) + g.noise_sums[0], nel), (eng, sweep)
+            trace.append((g.u.copy(), g.fluxes.copy(), gf.epsilon.copy(), g.log_likelihood()))
+        out[eng] = trace
+    for a, b in zip(out["host"], out["device"]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    u, fl, eps, ll = out["device"][-1]
+    assert np.all(np.abs(eps / f["rec"]["eps"] - 1.0) < 0.05)                 # sky levels: SKY * GAIN of the headers
+    # the chain fits fluxes and sky to the pixels: it ends above the reference's log-likelihood of the raw catalogue (whose
+    # untyped rows take the kappa * flux convention, celeste.py:52-55) and has settled (sweep to sweep within 1e-3)
+    lls = np.array([t[3] for t in out["device"]])
+    assert ll > f["ll"] and np.all(np.abs(np.diff(lls)) < 1e-3 * abs(ll))
+    assert np.all(np.abs(u - f["radec"]) < 2e-3) and np.all(fl > 0)

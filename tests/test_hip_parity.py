@@ -289,6 +289,31 @@ def test_every_real_field_through_the_reference_api(cel):
         np.testing.assert_allclose(patch, want, rtol=RT_STAMP, atol=1e-300)
 
 
+def test_small_star_path_scans_a_catalogue_of_thousands(cel, ctx, orc):
+    """k_small_stars with more stars than one scan pass holds (1 024: 16 per lane): 3 000 stars on 5 x 384 x 448 -- the second
+    and third pass of the position filter, ~60 candidates per part -- against the oracle and the general kernel"""
+    from desi_mcmc_amd import synth
+    L = cel._lib
+    f = synth.SyntheticField(ctx, 3000, 5, 384, 448, frac_gal=0.0, seed=5)
+    ctx.profile(True)
+    ll, llb = f.images.render(f.sources, loglik=True)
+    assert ctx.profile_get("small_stars")[1] == 1 and ctx.profile_get("render")[1] == 0
+    ctx.profile(False)
+    lam = f.images.model_images()
+    o_lam, o_ll, o_st = orc.render_field(oracle_bands(f), f.H, f.W, f.src["type"], f.src["radec"], f.src["counts"], f.src["shape"], f.nelec)
+    np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM)
+    np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
+    st = f.images.stats()
+    assert st["n_srcpix"] == o_st["n_srcpix"]
+    ctx.set_option(L.CEL_OPT_STAR_TILES, 0)
+    try:
+        ll0, llb0 = f.images.render(f.sources, loglik=True)
+        np.testing.assert_allclose(f.images.model_images(), lam, rtol=1e-13)
+        np.testing.assert_allclose(llb0, llb, rtol=1e-13)
+    finally:
+        ctx.set_option(L.CEL_OPT_STAR_TILES, 1)
+
+
 def test_real_field_set_dealt_to_the_ranks(cel, ctx):
     """BASELINE configs[3] on the only real data that exists (the Stripe-82 set is absent from the reference tree,
     .MISSING_LARGE_BLOBS:2-4): the 99 51 x 51 real fields as ONE field set dealt by dist.field_shard -- world 1 here, on the
