@@ -929,7 +929,7 @@ static int render_small_stars(cel_images *im, cel_sources *src, int flags, bool 
     *done = false;
     int rc = ensure_recs(im, S * B);
     if (rc) return rc;
-    const int nblk = B * im->ntx * im->nty * SMALL_NP, nblk_band = im->ntx * im->nty * SMALL_NP;
+    const int nblk = B * im->ntx * im->nty * SMALL_NB, nblk_band = im->ntx * im->nty * SMALL_NB;
     if (!im->h_small) {
         // the blocks' partials and the overflow word behind them live in pinned, device-mapped, coherent HOST memory: the
         // kernel stores them over PCIe itself (20 KB at configs[1]) and the step needs no copy command behind the kernel
@@ -959,7 +959,7 @@ static int render_small_stars(cel_images *im, cel_sources *src, int flags, bool 
     unsigned long long *d_stamps = nullptr;
     if (stamp_path) { HIP_TRY(hipMalloc((void **)&d_stamps, sizeof(unsigned long long) * 8 * nblk)); x.stamps = d_stamps; }
     int pi = prof_slot(c, CEL_K_SMALL_STARS);
-    LAUNCH_EV(k_small_stars, dim3((unsigned)nblk), dim3(64), st, EV0(c, pi), EV1(c, pi), a, x);
+    LAUNCH_EV(k_small_stars, dim3((unsigned)nblk), dim3(64 * SMALL_NWV), st, EV0(c, pi), EV1(c, pi), a, x);
     const bool ll = (flags & CEL_RENDER_LOGLIK) != 0;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));

@@ -1,4 +1,6 @@
-"""Per-block phase timeline of k_small_stars (diagnostic): CEL_SMALL_STAMPS=file makes the library dump, per block, six
+"""Per-block phase timeline of k_small_stars (diagnostic; needs a library built with -DSMALL_STAMPS, e.g.
+    hipcc <Makefile flags> -DSMALL_STAMPS -o tools/bin/libcel_stamps.so desi-mcmc_amd/csrc/celeste_hip.hip
+and CEL_HIP_LIBRARY pointing at it): CEL_SMALL_STAMPS=file makes the library dump, per block, six
 100 MHz wall-clock stamps (start, tables ready, scan done, walk done, epilogue done, end), the star count and the XCC id.
     python tools/small_stamps.py [workload]"""
 import os, sys
@@ -26,4 +28,4 @@ for k, nm in enumerate(["loads+tables", "scan", "stage+walk", "epilogue", "recor
 dur = us[:, 5] - us[:, 0]
 print("block duration: mean %.2f median %.2f p95 %.2f max %.2f us; block end: median %.2f p95 %.2f max %.2f" %
       (dur.mean(), np.median(dur), np.percentile(dur, 95), dur.max(), np.median(us[:, 5]), np.percentile(us[:, 5], 95), us[:, 5].max()))
-print("stars per part: mean %.1f max %d; corr(duration, stars) %.2f" % (st[:, 6].mean(), st[:, 6].max(), np.corrcoef(dur, st[:, 6])[0, 1]))
+print("stars per block: mean %.1f max %d; corr(duration, stars) %.2f" % (st[:, 6].mean(), st[:, 6].max(), np.corrcoef(dur, st[:, 6])[0, 1]))
