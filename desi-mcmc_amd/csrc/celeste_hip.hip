@@ -44,6 +44,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <new>
 #include <vector>
@@ -131,7 +132,8 @@ struct cel_ctx {
     int tile_layout = 1;      // 0: 64 x tile_rows tiles, one lane per column (k_render)
                               // 1: 32 x 64 tiles, two component groups per column (k_render_hw)
     Prof prof;
-    double *pinned = nullptr;   // MAX_BANDS + 8 doubles of pinned host memory for readbacks
+    double *pinned = nullptr;   // MAX_BANDS + 16 doubles of pinned host memory for readbacks
+    hipEvent_t slice_ev[2] = {nullptr, nullptr};     // cel_slice_locations: one per batch of rounds in flight
     // grow-only device scratch for the small per-call buffers of the stamp / patch-ll entry
     // points (a hipMalloc + hipFree pair per call costs more than the kernels they bracket)
     void *scratch[8] = {nullptr};
@@ -399,7 +401,7 @@ int cel_ctx_create(int device, void *stream, cel_ctx **out) {
         if (e != hipSuccess) { delete c; return fail(CEL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->own_stream = true;
     }
-    hipError_t e = hipHostMalloc((void **)&c->pinned, sizeof(double) * (MAX_BANDS + 8), hipHostMallocDefault);
+    hipError_t e = hipHostMalloc((void **)&c->pinned, sizeof(double) * (MAX_BANDS + 16), hipHostMallocDefault);
     if (e != hipSuccess) { delete c; return fail(CEL_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
     // profile constants, normalised as mixture_profiles.py:13,19
     double amp[K_PROF], var[K_PROF], se = 0.0, sd = 0.0;
@@ -429,6 +431,7 @@ int cel_ctx_destroy(cel_ctx *c) {
         for (int i = 0; i < 2 * Prof::PAIRS; i++)
             if (c->prof.ev[i]) (void)hipEventDestroy(c->prof.ev[i]);
     free(c->prof.ev);
+    for (int k = 0; k < 2; k++) if (c->slice_ev[k]) (void)hipEventDestroy(c->slice_ev[k]);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (void *p : c->scratch)
         if (p) (void)hipFree(p);
@@ -932,7 +935,7 @@ static int render_small_stars(cel_images *im, cel_sources *src, int flags, bool 
     const int nblk = B * im->ntx * im->nty * SMALL_NB, nblk_band = im->ntx * im->nty * SMALL_NB;
     if (!im->h_small) {
         // the blocks' partials and the overflow word behind them live in pinned, device-mapped, coherent HOST memory: the
-        // kernel stores them over PCIe itself (20 KB at configs[1]) and the step needs no copy command behind the kernel
+        // kernel stores them over PCIe itself (5 KB at configs[1]) and the step needs no copy command behind the kernel
         // -- a D2H copy of this size cost the step ~8 us of queue latency
         HIP_TRY(hipHostMalloc((void **)&im->h_small, sizeof(double) * (nblk + 1), hipHostMallocMapped | hipHostMallocCoherent));
         memset(im->h_small, 0, sizeof(double) * (nblk + 1));
@@ -954,6 +957,17 @@ static int render_small_stars(cel_images *im, cel_sources *src, int flags, bool 
     x.stamp = 0x8000000000000000ull | ++im->small_seq;
     x.full_H = im->full_H; x.win_y0 = im->win_y0;
     x.consts = im->d_small_consts;
+    {
+        int mul = (int)(nblk_band * 0.381966) | 1;
+        auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+        while (mul > 1 && gcd(mul, nblk_band) != 1) mul += 2;
+        if (nblk_band < 4) mul = 1;
+        x.perm_mul = mul % nblk_band ? mul % nblk_band : 1;
+        x.perm_add = nblk_band / 3 + 1;
+    }
+    // (Dealing the tiles to the block slots by the star counts of the call before -- heaviest first, each to the free slot of
+    // its band whose CU holds the least -- was built on top of the shuffle and measured 23.1-23.3 us against 23.4-23.7: a
+    // block's duration correlates with its star count at 0.3 only.  Removed.)
     x.stamps = nullptr;
     static const char *stamp_path = getenv("CEL_SMALL_STAMPS");     // diagnostic: dump every block's phase stamps of each call
     unsigned long long *d_stamps = nullptr;
@@ -1652,68 +1666,102 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         for (int64_t s = 0; s < S; s++) live += chain_ids[s] >= 0;
         if (live < 1) live = 1;         // a launch needs a block; k_slice_live_jobs finds nothing to run
     }
-    int *h_flags = reinterpret_cast<int *>(c->pinned + MAX_BANDS + 2);
     int rc = CEL_OK;
-    // The chains advance on the device alone (propose -> records -> likelihoods -> consume), so rounds
-    // are queued SLICE_BATCH at a time and the flags read once per batch: the queue does not drain
-    // while the host takes its turn.  A round queued after the last chain has finished scores nothing
-    // (every job retires at its first instruction) and is not counted.
-    const int SLICE_BATCH = 4;                       // (6, 8 and 12 measure the same sweep: the batch boundary is not where the step's gaps are)
+    // The chains advance on the device alone (propose -> records -> likelihoods -> consume), so rounds are queued SLICE_BATCH
+    // at a time and the flags read once per batch -- and TWO batches are kept in flight: batch k + 1 is queued before the
+    // host waits for batch k's flags, so the queue does not drain while the host takes its turn (with one batch in flight
+    // a kernel trace shows the device idle for 50-100 us at every batch boundary; on an idle host the step measures the
+    // same either way, 12.6-13.0 ms -- the second batch is there for the hosts that wake up late).
+    // A round queued after the last chain has finished scores nothing (every job retires at its first instruction) and
+    // is not counted: the price is at most one batch of empty launches at the end.
+    const int SLICE_BATCH = 4;                       // (6, 8 and 12 measure the same sweep)
     const int ostr = (c->variant != 0) ? SLICE_SPLIT : 1;        // slots per job in d_ll: the recurrence kernels always fill all four
-    // the blocks of the coming batch: the full heaviest-first lists while (nearly) every chain runs, afterwards the running
-    // chains' blocks (k_slice_live_jobs, built behind the batch before: their counts came back with its flags)
-    int64_t live_dense = -1, live_nz = -1;                       // < 0: no live lists yet
+    // the blocks of a batch: the full heaviest-first lists while (nearly) every chain runs, afterwards the running chains'
+    // blocks (k_slice_live_jobs, built behind the batch before).  The host sizes a launch by the newest counts it has READ --
+    // those of the batch before the one whose lists the launch walks; chains only retire, so those are upper bounds (times
+    // PLL_PARTS where the lists in between began to deal every job), and the kernels stop at the device's own count.
+    int64_t live_dense = -1, live_nz = -1;                       // < 0: no live lists read yet
+    int *h_flags[2] = {reinterpret_cast<int *>(c->pinned + MAX_BANDS + 2), reinterpret_cast<int *>(c->pinned + MAX_BANDS + 8)};
+    if (!c->slice_ev[0]) {
+        HIP_TRY(hipEventCreateWithFlags(&c->slice_ev[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->slice_ev[1], hipEventDisableTiming));
+    }
+    int last_par[2] = {0, 0};                                    // parity of a batch's last round: which slot holds its running count
+    int deal_of[2] = {0, 0};                                     // whether a batch's live lists dealt every job
+    int deal_read = 0;                                           // ... of the batch whose counts live_dense / live_nz are
+    int qb = 0, rb = 0;                                          // batches queued / read
+    bool finished = false;
     for (;;) {
-        const int nb = (int)std::min<int64_t>(SLICE_BATCH, (int64_t)max_rounds - queued);
-        const bool use_live = live_dense >= 0 && (live_dense + live_nz) * 4 < (n_dense + n_nz) * 3;
-        const int64_t gd = use_live ? live_dense : n_dense, gn = !use_nz ? 0 : (use_live ? live_nz : n_nz);
-        for (int k = 0; k < nb; k++) {
-            // the first round's points; every later round's were named by the step kernel of the round before
-            if (queued == 0) hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags);
-            prop->gen = ++g_source_gen;
-            if ((rc = run_prep(im, prop, d_owner, 1))) return rc;      // the patch limits are fixed: no boxes
-            if (c->variant == 0) {
-                int pi = prof_slot(c, CEL_K_PATCH_LL);
-                LAUNCH_EV(k_patch_ll<int>, dim3((unsigned)(S * B)), dim3(256), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
-                          d_owner, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_nelec, im->H, im->W, 0, d_ll);
-            } else {
-                if (gd > 0) {
+        while (qb - rb < 2 && queued < max_rounds && !finished) {
+            const int nb = (int)std::min<int64_t>(SLICE_BATCH, (int64_t)max_rounds - queued);
+            const bool use_live = live_dense >= 0 && (live_dense + live_nz) * 4 < (n_dense + n_nz) * 3;
+            // the lists this batch walks are those of batch qb - 1; the counts in hand those of batch rb - 1 <= qb - 1
+            const int grow = (use_live && qb >= 1 && deal_of[(qb - 1) & 1] && !deal_read) ? SLICE_SPLIT : 1;
+            const int64_t cap_blocks = S * B * SLICE_SPLIT;
+            const int64_t gd = use_live ? std::min<int64_t>(live_dense * grow, cap_blocks) : n_dense;
+            const int64_t gn = !use_nz ? 0 : (use_live ? std::min<int64_t>(live_nz * grow, cap_blocks) : n_nz);
+            for (int k = 0; k < nb; k++) {
+                // the first round's points; every later round's were named by the step kernel of the round before
+                if (queued == 0) hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags);
+                prop->gen = ++g_source_gen;
+                if ((rc = run_prep(im, prop, d_owner, 1))) return rc;      // the patch limits are fixed: no boxes
+                if (c->variant == 0) {
                     int pi = prof_slot(c, CEL_K_PATCH_LL);
-                    LAUNCH_EV((k_patch_ll_hw<0, int>), dim3((unsigned)gd), dim3(64), st, EV0(c, pi), EV1(c, pi),
-                              im->d_bands, B, S, im->d_recs,
-                              d_owner, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll,
-                              (const int *)(use_live ? d_live : d_jobs), 1, (const int *)nullptr,
-                              (const int *)(use_nz ? im->d_nzmode : nullptr), 1, SLICE_SPLIT);
+                    LAUNCH_EV(k_patch_ll<int>, dim3((unsigned)(S * B)), dim3(256), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
+                              d_owner, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_nelec, im->H, im->W, 0, d_ll);
+                } else {
+                    if (gd > 0) {
+                        int pi = prof_slot(c, CEL_K_PATCH_LL);
+                        LAUNCH_EV((k_patch_ll_hw<0, int>), dim3((unsigned)gd), dim3(64), st, EV0(c, pi), EV1(c, pi),
+                                  im->d_bands, B, S, im->d_recs,
+                                  d_owner, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_nelec, im->H, im->W, im->d_snz, c->tail_T, d_ll,
+                                  (const int *)(use_live ? d_live : d_jobs), 1, (const int *)(use_live ? d_flags + 4 : nullptr),
+                                  (const int *)(use_nz ? im->d_nzmode : nullptr), 1, SLICE_SPLIT);
+                    }
+                    if (gn > 0) {
+                        int pi = prof_slot(c, CEL_K_PATCH_LL);
+                        LAUNCH_EV(k_patch_ll_nz, dim3((unsigned)gn), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
+                                  (const int *)d_owner, (const int4 *)im->d_sbox, (const int4 *)im->d_snz, (const int *)im->d_nzmode,
+                                  (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_ll,
+                                  (const int *)(use_live ? d_live_nz : d_jobs_nz), (const int *)(use_live ? d_flags + 5 : nullptr));
+                    }
                 }
-                if (gn > 0) {
-                    int pi = prof_slot(c, CEL_K_PATCH_LL);
-                    LAUNCH_EV(k_patch_ll_nz, dim3((unsigned)gn), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
-                              (const int *)d_owner, (const int4 *)im->d_sbox, (const int4 *)im->d_snz, (const int *)im->d_nzmode,
-                              (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_ll,
-                              (const int *)(use_live ? d_live_nz : d_jobs_nz), (const int *)nullptr);
-                }
+                hipLaunchKernelGGL(k_slice_step, dim3(g256), dim3(256), 0, st, ss, S, B, ostr, d_ll, sigma, d_flags, (int)queued, prop->d_radec, d_owner);
+                queued++;
             }
-            hipLaunchKernelGGL(k_slice_step, dim3(g256), dim3(256), 0, st, ss, S, B, ostr, d_ll, sigma, d_flags, (int)queued, prop->d_radec, d_owner);
-            queued++;
+            const int slot = qb & 1;
+            deal_of[slot] = 0;
+            if (c->variant != 0) {          // the running chains' blocks, for the next batch; few chains left: every job dealt
+                deal_of[slot] = (live * B <= SLICE_SPLIT_JOBS) ? 1 : 0;
+                HIP_TRY(hipMemsetAsync(d_flags + 4, 0, sizeof(int) * 2, st));
+                hipLaunchKernelGGL(k_slice_live_jobs, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, ss, S, B, d_live, d_flags + 4,
+                                   (const int *)(use_nz ? im->d_nzmode : nullptr), d_live_nz, d_flags + 5, (const int *)im->d_nnz,
+                                   (const int4 *)im->d_snz, deal_of[slot]);
+            }
+            HIP_TRY(hipMemcpyAsync(h_flags[slot], d_flags, sizeof(int) * 11, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(c->slice_ev[slot], st));
+            HIP_TRY(hipGetLastError());
+            last_par[slot] = (int)((queued - 1) & 1);
+            qb++;
         }
-        if (c->variant != 0) {          // the running chains' blocks, for the next batch; few chains left: every job dealt
-            HIP_TRY(hipMemsetAsync(d_flags + 4, 0, sizeof(int) * 2, st));
-            hipLaunchKernelGGL(k_slice_live_jobs, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, ss, S, B, d_live, d_flags + 4,
-                               (const int *)(use_nz ? im->d_nzmode : nullptr), d_live_nz, d_flags + 5, (const int *)im->d_nnz,
-                               (const int4 *)im->d_snz, (live * B <= SLICE_SPLIT_JOBS) ? 1 : 0);
-        }
-        HIP_TRY(hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 11, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(st));
-        const int running = h_flags[((queued - 1) & 1) ? 10 : 0], err = h_flags[1];      // the last round's slot
+        if (rb == qb) break;            // nothing in flight: max_rounds reached
+        const int slot = rb & 1;
+        HIP_TRY(hipEventSynchronize(c->slice_ev[slot]));
+        rb++;
+        const int *hf = h_flags[slot];
+        const int running = hf[last_par[slot] ? 10 : 0], err = hf[1];      // the batch's last round's slot
         live = running;
-        if (c->variant != 0) { live_dense = h_flags[4]; live_nz = h_flags[5]; }
-        if (err & 1) return fail(CEL_ERR_INVALID, "Slice sampler got a NaN");
-        if (err & 2) return fail(CEL_ERR_INVALID, "Slice sampler shrank to zero!");
-        evals = h_flags[2];
-        rounds = h_flags[3];
-        if (running == 0) break;
-        if (queued >= max_rounds) return fail(CEL_ERR_INVALID, "cel_slice_locations: %d rounds without every chain finishing", max_rounds);
+        if (c->variant != 0) { live_dense = hf[4]; live_nz = hf[5]; deal_read = deal_of[slot]; }
+        if (err & 3) {
+            (void)hipStreamSynchronize(st);                      // the batch still in flight works on this call's buffers
+            return fail(CEL_ERR_INVALID, (err & 1) ? "Slice sampler got a NaN" : "Slice sampler shrank to zero!");
+        }
+        evals = hf[2];
+        rounds = hf[3];
+        if (running == 0) finished = true;                       // whatever is still queued scores nothing
+        else if (queued >= max_rounds && rb == qb)
+            return fail(CEL_ERR_INVALID, "cel_slice_locations: %d rounds without every chain finishing", max_rounds);
+        if (finished) break;
     }
     // the new locations replace the catalogue's
     HIP_TRY(hipMemcpyAsync(src->d_radec, ss.x, sizeof(double) * 2 * S, hipMemcpyDeviceToDevice, st));

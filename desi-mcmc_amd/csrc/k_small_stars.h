@@ -51,6 +51,7 @@ struct SmallArgs {
     const double *consts;                     // per band SMALL_CONSTS doubles: what every block used to compute for itself (k_small_consts)
     unsigned long long *stamps;               // diagnostic (a -DSMALL_STAMPS build + CEL_SMALL_STAMPS): 6 wall-clock stamps (100 MHz) + XCC id per block, or nullptr
     int full_H, win_y0;
+    int perm_mul, perm_add;                   // block -> tile shuffle (see the kernel)
 };
 
 // Per-band constants of the star pass, formed ONCE per image set by k_small_consts with the device's own arithmetic (so a
@@ -260,7 +261,12 @@ k_small_stars(RenderArgs a, SmallArgs x) {
     const int per_band = a.ntx * a.nty;
     const int nblk_band = per_band * SMALL_NB;
     const int b = blockIdx.x / nblk_band;
-    const int q = blockIdx.x - b * nblk_band;           // this block among its band's
+    const int q0 = blockIdx.x - b * nblk_band;
+    // Which tile a block takes is shuffled per band (a multiplier coprime to the band's block count, an offset per band):
+    // blocks i, i + 256, i + 512 of a launch tend to share a CU, and the same tile of every band holds the same stars --
+    // unshuffled, a crowded tile's blocks sat on one CU in three bands at once and the launch ended 1.8 us later (25.2 against
+    // 23.4 us; tools/small_placement.py shows who shares a CU).
+    const int q = (int)(((long long)q0 * x.perm_mul + (long long)b * x.perm_add) % nblk_band);     // this block's tile among its band's
     const int t = q / SMALL_NB, p = q - t * SMALL_NB;
     const int ty = t / a.ntx, tx = t - ty * a.ntx;
     const int Y0 = ty * HW_TH;
@@ -442,7 +448,8 @@ k_small_stars(RenderArgs a, SmallArgs x) {
         unsigned long long *o = x.stamps + (int64_t)blockIdx.x * 8;
         for (int k = 0; k < 6; k++) o[k] = tstamp[k];
         o[6] = (unsigned long long)nh;
-        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) /* XCC_ID */;
+        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) /* XCC_ID */ |
+               ((unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4) /* HW_ID */ << 8);
     }
 #endif
 }
