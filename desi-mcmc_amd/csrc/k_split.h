@@ -94,12 +94,11 @@ __device__ inline double fast_rcp(double x) {
 // transcendental is evaluated (most draws of a split: a pixel in a source's tail).  Otherwise
 // (1 - r)^n comes from the table log / table exp of k_render.h (et: 64 doubles, lt: 128 doubles in
 // LDS): the exponent n log(1 - r) >= -42 carries an absolute error of ~n * 1e-16.
-__device__ inline long long binom_inversion(long long n, double r, Philox &g, const double *__restrict__ et,
-                                            const double *__restrict__ lt) {
+__device__ inline long long binom_inversion(long long n, double r, double U /* the first uniform */, Philox &g,
+                                            const double *__restrict__ et, const double *__restrict__ lt) {
     const double q = 1.0 - r;
     const double nd = (double)n;
     const double np = nd * r;
-    double U = philox_double(g);
     if (U <= 1.0 - np) return 0;
     const double qn = exp_tab64(nd * log_tab(q, lt) * EXP_SCALE, et);
     if (U <= qn) return 0;
@@ -183,14 +182,59 @@ __device__ inline long long binom_btpe(long long n, double r, Philox &g) {
 #ifndef BINV_MAX_NP
 #define BINV_MAX_NP 30.0
 #endif
-__device__ inline long long binomial_draw(long long n, double p, Philox &g, const double *__restrict__ et,
+// `a`: the inversion's first uniform is drawn from [a, 1) instead of [0, 1) -- the split's callers have already decided, on
+// the top 32 bits of that uniform, that it is not below a (split_first_word below); 0 everywhere else
+__device__ inline long long binomial_draw(long long n, double p, double a, Philox &g, const double *__restrict__ et,
                                           const double *__restrict__ lt) {
     if (n <= 0 || !(p > 0.0)) return 0;
     if (p >= 1.0) return n;
     const bool flip = p > 0.5;
     const double r = flip ? 1.0 - p : p;
-    long long y = (r * (double)n <= BINV_MAX_NP) ? binom_inversion(n, r, g, et, lt) : binom_btpe(n, r, g);
+    long long y;
+    if (r * (double)n <= BINV_MAX_NP) {
+        const double u = philox_double(g);
+        y = binom_inversion(n, r, a + u * (1.0 - a), g, et, lt);
+    } else {
+        y = binom_btpe(n, r, g);
+    }
     return flip ? n - y : y;
+}
+__device__ inline long long binomial_draw(long long n, double p, Philox &g, const double *__restrict__ et,
+                                          const double *__restrict__ lt) {
+    return binomial_draw(n, p, 0.0, g, et, lt);
+}
+
+// ---- the split's first decision on a shared 32-bit word --------------------------------------------------------------
+// Most of a split's binomials are 0 and are decided by the sampler's first test, U <= 1 - n p (a pixel in a source's tail):
+// that test needs no 53-bit uniform of its own.  Let V be the top 32 bits of U: if V + 1 <= floor((1 - n p) 2^32) =: tf the
+// test holds whatever the other bits are.  So ONE Philox block, keyed by (seed; band, column, the pixel's row with bits 1
+// and 2 cleared; source), serves the four pixels y, y + 2, y + 4, y + 6 of a column -- the four rows a lane of
+// k_photon_split_hw takes in consecutive steps -- word (y >> 1) & 3 each; a pixel that does not pass (V >= tf) goes to the
+// sampler proper with its own stream (seed; band, pixel; source), whose first uniform is drawn from [tf 2^-32, 1): the
+// law of U given V >= tf.  Together: P(first test holds) = tf 2^-32 + (1 - n p - tf 2^-32) = 1 - n p, exactly the
+// sampler's; a quarter of the Philox blocks (the first uniforms were 1.9 ms of the 6.9 ms kernel, tools/ablate_split.py).
+#define SPLIT_GROUP_BIT (1ull << 63)      // keys of the shared blocks: never a pixel's own stream (pixel indices stay below 2^63)
+__device__ inline double split_tf(long long n, double pr) {         // floor((1 - n p) 2^32): V < tf passes; <= 0: nobody does
+    return floor((1.0 - (double)n * pr) * 4294967296.0);
+}
+__device__ inline unsigned philox_word(const Philox &g, int w) {
+    return (w == 0) ? g.out[0] : (w == 1) ? g.out[1] : (w == 2) ? g.out[2] : g.out[3];
+}
+// the whole draw for one (pixel, source): what k_photon_split_hw does in two passes
+__device__ inline long long split_draw(long long n, double pr, unsigned long long seed, unsigned long long group_key, int word,
+                                       unsigned long long pixel_key, unsigned s, const double *__restrict__ et,
+                                       const double *__restrict__ lt) {
+    if (n <= 0 || !(pr > 0.0)) return 0;
+    double a = 0.0;
+    if (pr <= 0.5) {
+        const double tf = split_tf(n, pr);
+        Philox h = philox_init(seed, group_key | SPLIT_GROUP_BIT, s);
+        philox_block(h);
+        if ((double)philox_word(h, word) < tf) return 0;
+        a = fmax(tf, 0.0) * (1.0 / 4294967296.0);
+    }
+    Philox g = philox_init(seed, pixel_key, s);
+    return binomial_draw(n, pr, a, g, et, lt);
 }
 
 // ---- device-resident sample patches ------------------------------------------------------------
@@ -477,7 +521,6 @@ k_photon_split(SplitArgs a) {
     const BandDev *bd = a.bands + b;
     const double eps = bd->eps;
     const int64_t plane = (int64_t)b * a.H * a.W;
-    const int64_t key0 = (int64_t)b * a.full_H * a.W + (int64_t)a.win_y0 * a.W;   // full-frame pixel index of (x=0, y=0)
     const int cnt = a.tile_cnt[tile];
     const int64_t off = a.tile_off[tile];
     const SrcRec *recs = a.recs + (int64_t)b * a.S;
@@ -523,8 +566,10 @@ k_photon_split(SplitArgs a) {
                     double tot = rate[li];
                     long long z = 0;
                     if (n > 0) {
-                        Philox g = philox_init(a.seed, (unsigned long long)(key0 + (int64_t)y * a.W + xi), (unsigned)s);
-                        z = binomial_draw((long long)n, F * fast_rcp(tot), g, et, lt);   // curr_prob / sum_probs (:147)
+                        const int64_t yf = (int64_t)a.win_y0 + y;            // full-frame row
+                        const int64_t kb = (int64_t)b * a.full_H * a.W;
+                        z = split_draw((long long)n, F * fast_rcp(tot), a.seed, (unsigned long long)(kb + (yf & ~(int64_t)6) * a.W + xi),
+                                       (int)((yf >> 1) & 3), (unsigned long long)(kb + yf * a.W + xi), (unsigned)s, et, lt);   // curr_prob / sum_probs (:147)
                     }
                     left[li] = n - (int)z;
                     rate[li] = tot - F;                                   // sum_probs -= curr_prob (:152)
@@ -595,7 +640,8 @@ k_photon_split_hw(SplitArgs a) {
     const BandDev *bd = a.bands + b;
     const double eps = bd->eps;
     const int64_t plane = (int64_t)b * a.H * a.W;
-    const int64_t key0 = (int64_t)b * a.full_H * a.W + (int64_t)a.win_y0 * a.W;   // full-frame pixel index of (x=0, y=0)
+    const int64_t kband = (int64_t)b * a.full_H * a.W;                            // full-frame pixel index of the band's (0, 0)
+    const int64_t key0 = kband + (int64_t)a.win_y0 * a.W;                         // ... of this window's (x=0, y=0)
     unsigned covered = 0u;            // bit r: this lane's pixel of row pair r lies strictly inside some source's box
     et[lane] = exp2((double)lane * (1.0 / 64.0));
     // Every load unconditional (a pixel outside the frame reads the band's first pixel and drops the value): with a
@@ -672,9 +718,22 @@ k_photon_split_hw(SplitArgs a) {
         const int nx = rec.x1 - rec.x0;
         TS *patch0 = static_cast<TS *>(a.samp) + poff + (int64_t)(Y0 - rec.y0) * nx - rec.x0;   // + row * nx + x
         int nq = 0;
+        int64_t grp_have = -1;              // the row group (full-frame row, bits 1 and 2 cleared) whose block this lane holds
+        Philox hg;
+        hg.out[0] = hg.out[1] = hg.out[2] = hg.out[3] = 0u;
         for (int r = ra >> 1; 2 * r < rb; r++) {
             const int row = 2 * r + half;
             const int li = r * 64 + lane;
+            // the shared block of this lane's four consecutive rows: one per four steps, every lane at the same step
+            // (windows start on even rows), whether or not it has a pixel here
+            const int64_t yf = (int64_t)a.win_y0 + Y0 + row;
+            const int64_t grp = yf & ~(int64_t)6;
+            if (grp != grp_have && !(SPLIT_ABLATE(a) & 1)) {
+                hg = philox_init(a.seed, (unsigned long long)(kband + grp * a.W + (xi < a.W ? xi : 0)) | SPLIT_GROUP_BIT, (unsigned)s);
+                philox_block(hg);
+                grp_have = grp;
+            }
+            const unsigned vword = philox_word(hg, (int)((yf >> 1) & 3));
             bool slow = false;
             if (on && row >= ra && row < rb) {
                 const double F = one[li];
@@ -683,13 +742,7 @@ k_photon_split_hw(SplitArgs a) {
                 covered |= 1u << r;
                 if (n > 0 && !(SPLIT_ABLATE(a) & 1)) {
                     const double pr = F * fast_rcp(tot);                  // curr_prob / sum_probs (:147)
-                    if (pr > 0.0) {
-                        slow = true;
-                        if (pr <= 0.5) {                                  // binomial_draw's first test, on the same uniform
-                            Philox g = philox_init(a.seed, (unsigned long long)(key0 + (int64_t)(Y0 + row) * a.W + xi), (unsigned)s);
-                            slow = !(philox_double(g) <= 1.0 - (double)n * pr);
-                        }
-                    }
+                    if (pr > 0.0) slow = !(pr <= 0.5 && (double)vword < split_tf((long long)n, pr));     // the first test, on the shared word
                 }
                 if (!slow) {
                     one[li] = 0.0;                    // the scratch tile is clean again for the next source
@@ -711,7 +764,9 @@ k_photon_split_hw(SplitArgs a) {
                 const int n = (int)left[li];
                 const double tot = rate[li];
                 Philox g = philox_init(a.seed, (unsigned long long)(key0 + (int64_t)(Y0 + row) * a.W + xq), (unsigned)s);
-                const long long z = (SPLIT_ABLATE(a) & 2) ? 1 : binomial_draw((long long)n, F * fast_rcp(tot), g, et, lt);
+                const double pr = F * fast_rcp(tot);
+                const double afirst = (pr <= 0.5) ? fmax(split_tf((long long)n, pr), 0.0) * (1.0 / 4294967296.0) : 0.0;   // pass 1 saw V >= tf
+                const long long z = (SPLIT_ABLATE(a) & 2) ? 1 : binomial_draw((long long)n, pr, afirst, g, et, lt);
                 left[li] = (TL)(n - (int)z);
                 rate[li] = tot - F;
                 patch0[(int64_t)row * nx + xq] = (TS)z;
