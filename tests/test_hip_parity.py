@@ -944,6 +944,55 @@ def test_photon_split_conservation_moments_quirks(cel, ctx, orc):
                 r2 = ((z[ok] - mean[ok]) ** 2 / var[ok]).sum()
                 assert abs(r2 - ok.sum()) / np.sqrt(2.0 * ok.sum()) < 5.0, (b, s, r2 / ok.sum())
         assert tot == g["nelec"][b].sum()                                         # every photon lands exactly once
+    # The tail regime -- the draws the first test settles on a 32-bit word shared by four rows of a column (k_split.h,
+    # split_first_word): among the pixels with 1e-4 < n p < 0.3 the number holding a photon against its exact expectation
+    # sum 1 - (1 - p)^n, per band and over all bands (a word handed to the wrong row, or an interval of the sampler's first
+    # uniform that does not join up with the test, shows here long before it moves a source's total)
+    got_all = exp_all = var_all = 0.0
+    for b in range(5):
+        lam_strict = np.full((H, W), bands[b, 0])
+        Fs = []
+        for s in range(S):
+            p, yl, xl = orc.source_patch(ob[b], H, W, g["is_gal"][s], g["radec"][s], g["shape"][s])
+            if p is None:
+                Fs.append(None)
+                continue
+            f = p * counts[s, b]
+            f[0, :] = 0.0
+            f[:, 0] = 0.0
+            lam_strict[yl[0]:yl[1], xl[0]:xl[1]] += f
+            Fs.append((f, yl, xl))
+        # the conditional-binomial chain: source s at a pixel sees what the sources before it left -- in the tail regime
+        # those took next to nothing, so n = nelec and p = F_s / (total - the earlier sources' F) to first order in p
+        taken = np.zeros((H, W))
+        for s in range(S):
+            if Fs[s] is None:
+                continue
+            f, yl, xl = Fs[s]
+            sl = (slice(yl[0], yl[1]), slice(xl[0], xl[1]))
+            z = patches[b][s]
+            n = np.floor(g["nelec"][b][sl])
+            pr = f / (lam_strict[sl] - taken[sl])
+            taken[sl] += f
+            sel = (n * pr > 1e-4) & (n * pr < 0.3) & (f > 0)
+            # photons the earlier sources took at these pixels change n by a few parts in 10^3 at most here
+            q = 1.0 - (1.0 - pr[sel]) ** n[sel]
+            got_all += float((z[sel] > 0).sum()); exp_all += float(q.sum()); var_all += float((q * (1 - q)).sum())
+    assert exp_all > 300, exp_all
+    assert abs(got_all - exp_all) < 5.0 * np.sqrt(var_all) + 0.01 * exp_all, (got_all, exp_all, np.sqrt(var_all))
+    # the direct kernel (every pixel's whole draw in one go, split_draw) makes the same draws as the two-pass recurrence kernel,
+    # but for a pixel whose probability differs in the last bits between the two stamp evaluators
+    c3 = cel.Context(0)
+    c3.set_kernel("direct")
+    iset = cel.ImageSet(c3, bands, H, W, nelec=g["nelec"])
+    sset = cel.SourceSet(c3, S, 5).set(g["is_gal"], g["radec"], counts, g["shape"])
+    pd, bd_, nd = iset.photon_split(sset, seed=99)
+    differ = total = 0
+    for rb_, ra_ in zip(pd, patches):
+        for x_, y_ in zip(rb_, ra_):
+            if x_ is not None:
+                differ += int((x_ != y_).sum()); total += x_.size
+    assert differ <= 1e-4 * total, (differ, total)
 
 
 def test_photon_split_image_range_instantiations(cel, ctx):
