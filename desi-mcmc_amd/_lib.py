@@ -70,6 +70,7 @@ SYMBOLS = [
     ("cel_patch_loglik_multi", C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_int64, c_int32_p, c_int64_p, C.c_void_p,
                                           C.c_int, C.c_int, c_double_p]),
     ("cel_stamp_mass", C.c_int, [C.c_void_p, C.c_void_p, c_double_p]),
+    ("cel_stamp_mass_ready", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     ("cel_stamp_mass_begin", C.c_int, [C.c_void_p, C.c_void_p]),
     ("cel_stamp_mass_end", C.c_int, [C.c_void_p, c_double_p]),
     ("cel_slice_locations", C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_double, C.c_uint64, C.c_int, c_double_p,

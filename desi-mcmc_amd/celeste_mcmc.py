@@ -353,8 +353,13 @@ class ModelGibbs(object):
         # field's kernel is queued (stamp_mass_begin), the Gamma variates are drawn, then its values are collected.  (Fields
         # before the last are summed synchronously: two pending calls may not share a context.  Round 2 used a worker thread
         # for the overlap: its hand-over through the interpreter lock made the step vary between 2 and 4 ms.)
+        whole = {}                                  # fields whose masses come for the whole catalogue although this rank owns a part
+
         def field_sources(f):
             if mine is None:
+                return f.sset
+            if f.iset.stamp_mass_ready(f.sset):     # the replicated split has summed every source's stamps already: free, and
+                whole[id(f)] = True                 # every rank holds the numbers the single-rank chain holds
                 return f.sset
             from . import field as _field          # this rank's sources only; a (source, band) value does not depend on the batch
             if getattr(f, "sub", None) is None or f.sub.capacity < mine.size:
@@ -365,6 +370,9 @@ class ModelGibbs(object):
         def add_mass(psf_sums, f, m):
             if mine is None:
                 mass = m * f.has_patch
+            elif whole.get(id(f)):
+                mass = np.zeros((self.S, f.iset.B))
+                mass[mine] = m[mine] * f.has_patch[mine]
             else:
                 mass = np.zeros((self.S, f.iset.B))
                 mass[mine] = m * f.has_patch[mine]

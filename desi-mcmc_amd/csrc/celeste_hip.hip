@@ -126,7 +126,8 @@ struct cel_ctx {
     int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created
     bool tile_timing = false; // diagnostic: k_render stamps each tile's start/end wall clock
     double nz_bias = getenv("CEL_NZ_BIAS") ? atof(getenv("CEL_NZ_BIAS")) : 4.0;   // see k_nz_layout (the env var: experiments only)
-    int split_reuse = (getenv("CEL_SPLIT_REUSE") && atoi(getenv("CEL_SPLIT_REUSE")) == 0) ? 0 : 1;      // CEL_OPT_SPLIT_REUSE (the env var: the initial value, for A/B runs): the split's totals from a model image already on the device (k_border.h)
+    int split_reuse = getenv("CEL_SPLIT_REUSE") ? std::min(std::max(atoi(getenv("CEL_SPLIT_REUSE")), 0), 2) : 2;      // CEL_OPT_SPLIT_REUSE (the env var: the initial value, for A/B runs): 1 = the split's totals from a model image already on the device (k_border.h), 2 = ... and the stamp masses from the split's own sums
+    bool mass_reuse_of() const { return split_reuse >= 2; }
     int nz_force = 0;         // CEL_OPT_PHOTON_LISTS: 0 = per patch, whichever is estimated cheaper; 1 = every patch at its photons; 2 = never
     int debug = 0;            // CEL_OPT_DEBUG: timing-only ablation bits handed to the render kernel (results are wrong when set)
     int tile_layout = 1;      // 0: 64 x tile_rows tiles, one lane per column (k_render)
@@ -177,6 +178,10 @@ struct cel_images {
     // which sources the model image in d_lambda (full boxes, the current sky levels) and the tile lists belong to: what lets
     // the photon split take its totals from that image (k_border.h); 0 = not valid
     uint64_t lambda_gen = 0, lists_gen = 0;
+    unsigned long long *d_massfx = nullptr;   // the split's integer stamp-mass sums (k_split.h, k_border.h), per (source, band)
+    int64_t massfx_cap = 0;
+    uint64_t massfx_gen = 0;                  // ... hold the masses of the catalogue of this generation (0: of none)
+    int *d_mass_todo = nullptr;               // (source, band) jobs the mass kernel proper still has to do + their count behind them
     std::vector<int4> h_boxes;
     std::vector<int> h_status;
     int *d_tile_cnt = nullptr, *d_tile_nstar = nullptr, *d_tile_work = nullptr, *d_order = nullptr;
@@ -184,6 +189,7 @@ struct cel_images {
     int64_t cost_S = -1;          // number of sources that render had (-1: nothing measured yet)
     bool bin_two_level = false;   // a super-tile once held more than BIN_CH candidates: coarse lists in global memory from then on
     int64_t mass_pending = -1;       // doubles waiting in d_mass between cel_stamp_mass_begin and _end (-1: none)
+    int64_t mass_todo_S = -1;        // >= 0: that _begin took the short cut on a catalogue of so many sources; _end finishes its leftovers
     double *d_mass = nullptr;        // (a scratch slot of the context: not owned)
     long long *d_btot = nullptr;     // per-1024-entries totals of the patch / list layout scans
     bool nelec_u16 = false;          // every observed pixel in 0 ... 65 535: the split's 16-bit photons-left plane
@@ -497,7 +503,7 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         c->nz_force = (int)v;
         return CEL_OK;
     case CEL_OPT_SPLIT_REUSE:
-        if (v != 0.0 && v != 1.0) return fail(CEL_ERR_INVALID, "CEL_OPT_SPLIT_REUSE must be 0 or 1");
+        if (v != 0.0 && v != 1.0 && v != 2.0) return fail(CEL_ERR_INVALID, "CEL_OPT_SPLIT_REUSE must be 0, 1 or 2");
         c->split_reuse = (int)v;
         return CEL_OK;
     case CEL_OPT_STAR_TILES:
@@ -553,6 +559,8 @@ int cel_images_destroy(cel_images *im) {
     if (im->d_sgen) (void)hipFree(im->d_sgen);
     if (im->h_small) (void)hipHostFree(im->h_small);
     if (im->d_small_consts) (void)hipFree(im->d_small_consts);
+    if (im->d_massfx) (void)hipFree(im->d_massfx);
+    if (im->d_mass_todo) (void)hipFree(im->d_mass_todo);
     if (im->ev_step) (void)hipEventDestroy(im->ev_step);
     delete im;
     return CEL_OK;
@@ -682,6 +690,7 @@ int cel_images_set_window(cel_images *im, int y0, int full_H) {
     im->full_H = full_H;
     im->recs_gen = im->hbox_gen = 0;      // boxes are cut to the window
     im->lambda_gen = im->lists_gen = 0;
+    im->massfx_gen = 0;
     return CEL_OK;
 }
 
@@ -1500,6 +1509,13 @@ int cel_patch_loglik(cel_images *im, cel_sources *src, const int32_t *boxes, con
 // chain's trace render came last: the split slowed down by 1.35 ms for the 1.7 ms taken off the flux step and the sweep was
 // 0.9 ms LONGER than with the two kernels one behind the other; two VALU- and LDS-bound kernels have nothing to give each
 // other.  Removed again.)
+int cel_stamp_mass_ready(cel_images *im, cel_sources *src, int *ready) {
+    if (!im || !src || !ready) return fail(CEL_ERR_INVALID, "cel_stamp_mass_ready: null argument");
+    *ready = (src->ctx == im->ctx && src->B == im->B && im->ctx->mass_reuse_of() && src->gen != 0 && im->massfx_gen == src->gen &&
+              src->S * im->B <= im->massfx_cap) ? 1 : 0;
+    return CEL_OK;
+}
+
 int cel_stamp_mass_begin(cel_images *im, cel_sources *src) {
     if (!im || !src) return fail(CEL_ERR_INVALID, "cel_stamp_mass: null argument");
     if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
@@ -1508,15 +1524,32 @@ int cel_stamp_mass_begin(cel_images *im, cel_sources *src) {
     const int B = im->B;
     const int64_t S = src->S;
     im->mass_pending = -1;
+    im->mass_todo_S = -1;
     if (S == 0) { im->mass_pending = 0; return CEL_OK; }
-    int rc = run_prep(im, src);
+    int rc = CEL_OK;
+    const bool from_split = c->mass_reuse_of() && src->gen != 0 && im->massfx_gen == src->gen && S * B <= im->massfx_cap;
+    if (!from_split || im->recs_gen != src->gen) rc = run_prep(im, src);
     if (rc) return rc;
     double *d_out = nullptr;
     if ((rc = scratch_get(c, 2, sizeof(double) * S * B, (void **)&d_out))) return rc;
     int pi = prof_begin(c, CEL_K_MASS);
-    hipLaunchKernelGGL((k_patch_ll_hw<3, double>), dim3((unsigned)(S * B)), dim3(64), 0, c->stream, im->d_bands, B, S, im->d_recs,
-                       (const int *)nullptr, (const int4 *)nullptr, (const int64_t *)nullptr, (const double *)nullptr,
-                       (const double *)nullptr, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
+    if (from_split) {
+        // the photon split that has just run on this catalogue (with k_strict_totals before it) summed every unit stamp it
+        // evaluated: those sums are the masses; the mass kernel proper runs on the few jobs the short cut does not vouch for
+        int *d_ntodo = im->d_mass_todo + im->massfx_cap;
+        HIP_TRY(hipMemsetAsync(d_ntodo, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_mass_from_fx, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, c->stream, S * B, B,
+                           (const unsigned long long *)im->d_massfx, (const double *)src->d_counts, (const BandDev *)im->d_bands, d_out,
+                           im->d_mass_todo, d_ntodo);
+        // (how many: read in cel_stamp_mass_end, which launches the mass kernel on exactly those -- none at all in a field
+        // without very faint sources; a launch of S B blocks that find nothing to do cost 0.15 ms of the flux step)
+        HIP_TRY(hipMemcpyAsync(c->pinned + MAX_BANDS + 14, d_ntodo, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        im->mass_todo_S = S;
+    } else {
+        hipLaunchKernelGGL((k_patch_ll_hw<3, double>), dim3((unsigned)(S * B)), dim3(64), 0, c->stream, im->d_bands, B, S, im->d_recs,
+                           (const int *)nullptr, (const int4 *)nullptr, (const int64_t *)nullptr, (const double *)nullptr,
+                           (const double *)nullptr, im->H, im->W, (const int4 *)nullptr, c->tail_T, d_out);
+    }
     prof_end(c, pi);
     HIP_TRY(hipGetLastError());
     im->mass_pending = S * B;
@@ -1531,7 +1564,21 @@ int cel_stamp_mass_end(cel_images *im, double *mass) {
     HIP_TRY(hipSetDevice(c->device));
     const int64_t n = im->mass_pending;
     im->mass_pending = -1;
+    const int64_t S_todo = im->mass_todo_S;
+    im->mass_todo_S = -1;
     if (n == 0) return CEL_OK;
+    if (S_todo >= 0) {                  // the short cut's leftovers (cel_stamp_mass_begin)
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        int ntodo = 0;
+        memcpy(&ntodo, c->pinned + MAX_BANDS + 14, sizeof(int));
+        if (ntodo > 0) {
+            hipLaunchKernelGGL((k_patch_ll_hw<3, double>), dim3((unsigned)ntodo), dim3(64), 0, c->stream, im->d_bands, im->B, S_todo, im->d_recs,
+                               (const int *)nullptr, (const int4 *)nullptr, (const int64_t *)nullptr, (const double *)nullptr,
+                               (const double *)nullptr, im->H, im->W, (const int4 *)nullptr, c->tail_T, im->d_mass,
+                               (const int *)im->d_mass_todo);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     return copy_out(mass, im->d_mass, sizeof(double) * n, CEL_HOST, c->stream);
 }
 
@@ -1981,10 +2028,28 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
     // with the split's strict boxes (the model image of cel_images_get_lambda is left alone).
     // Direct form: a plain render (its kernel accumulates the totals itself).
     const bool hw = (c->variant != 0) && (im->TW == HW_TW);
+    bool use_massfx = false;
     int rc;
     if (hw) {
         if (!im->d_rate) HIP_TRY(hipMalloc((void **)&im->d_rate, sizeof(double) * (size_t)im->B * im->H * im->W));
+        im->massfx_gen = 0;
         if (c->split_reuse && src->gen != 0 && im->lambda_gen == src->gen && im->lists_gen == src->gen && im->recs_gen == src->gen) {
+            const int64_t nm = src->S * im->B;
+            if (resident && c->mass_reuse_of() && nm > 0) {
+                // both kernels of this path also sum every unit stamp they evaluate: together the stamps' masses (cel_stamp_mass)
+                if (nm > im->massfx_cap) {
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                    if (im->d_massfx) (void)hipFree(im->d_massfx);
+                    if (im->d_mass_todo) (void)hipFree(im->d_mass_todo);
+                    im->d_massfx = nullptr; im->d_mass_todo = nullptr; im->massfx_cap = 0;
+                    const int64_t cap = nm + nm / 4 + 64;
+                    HIP_TRY(hipMalloc((void **)&im->d_massfx, sizeof(unsigned long long) * cap));
+                    HIP_TRY(hipMalloc((void **)&im->d_mass_todo, sizeof(int) * (cap + 1)));
+                    im->massfx_cap = cap;
+                }
+                HIP_TRY(hipMemsetAsync(im->d_massfx, 0, sizeof(unsigned long long) * nm, c->stream));
+                use_massfx = true;
+            }
             // the model image, records and tile lists of exactly these sources are on the device (the chain's trace render
             // came last): the totals are that image minus every source's first box row and column (k_border.h)
             RenderArgs a;
@@ -1993,7 +2058,8 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
             a.lambda = im->d_lambda; a.S = src->S; a.capacity = im->lists_cap; a.B = im->B; a.H = im->H; a.W = im->W;
             a.ntx = im->ntx; a.nty = im->nty;
             int pi = prof_slot(c, CEL_K_TOTALS);
-            LAUNCH_EV(k_strict_totals, dim3((unsigned)(im->B * im->ntx * im->nty)), dim3(64), c->stream, EV0(c, pi), EV1(c, pi), a, im->d_rate);
+            LAUNCH_EV(k_strict_totals, dim3((unsigned)(im->B * im->ntx * im->nty)), dim3(64), c->stream, EV0(c, pi), EV1(c, pi), a, im->d_rate,
+                      use_massfx ? im->d_massfx : (unsigned long long *)nullptr);
             HIP_TRY(hipGetLastError());
             rc = CEL_OK;
         } else {
@@ -2088,6 +2154,7 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         a.order = (hw && tile_order_of(c, im)) ? im->d_order : nullptr;
         a.sums = fused_nz ? im->d_ssum : nullptr;
         a.nnz = lists ? im->d_nnz : nullptr;
+        a.massfx = (use_massfx && hw && resident) ? im->d_massfx : nullptr;
         a.debug = c->debug;
         if (hw && (rc = scratch_get(c, 2, sizeof(double) * 2 * (size_t)T, (void **)&a.partials))) return rc;
         int pi = prof_begin(c, CEL_K_SPLIT);
@@ -2120,6 +2187,7 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (noise) for (int b = 0; b < B; b++) noise[b] = c->pinned[b];
+    if (use_massfx && hw && resident) im->massfx_gen = src->gen;
     if (lists) {
         int64_t nn = 0;
         memcpy(&nn, c->pinned + MAX_BANDS + 2, sizeof(nn));

@@ -55,3 +55,5 @@ struct NzEntry { int xy, z; };
 
 #define PI_D 3.14159265358979323846
 
+// unit of the integer stamp-mass sums the photon split and k_strict_totals accumulate (cel_stamp_mass's short cut): 2^-60
+#define MASS_FX 1152921504606846976.0

@@ -18,7 +18,8 @@
 #include "k_render_hw.h"
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-k_strict_totals(RenderArgs a /* lambda: the full-box model image (in); lists / recs / tile_* of that render */, double *__restrict__ rate) {
+k_strict_totals(RenderArgs a /* lambda: the full-box model image (in); lists / recs / tile_* of that render */, double *__restrict__ rate,
+                unsigned long long *__restrict__ massfx /* per (source, band): += the unit stamp on these border pixels, 2^-60 units (k_split.h), or nullptr */) {
     __shared__ double acc[HW_TH * HW_TW];
     __shared__ double tA[K_GAL], tmx[K_GAL], tmy[K_GAL], tqa[K_GAL], tqb[K_GAL], tqc[K_GAL];
     __shared__ double et[64];
@@ -77,6 +78,7 @@ k_strict_totals(RenderArgs a /* lambda: the full-box model image (in); lists / r
             __syncthreads();
             if (Kk == 0) continue;
             any = true;
+            double bsum = 0.0;
             if (row_here) {             // row y0: the tile's 32 columns, the components dealt to the two half-waves
                 const double x = (double)(X0 + col), y = (double)rec.y0;
                 const bool on = (X0 + col >= rec.x0) && (X0 + col < rec.x1);
@@ -86,7 +88,7 @@ k_strict_totals(RenderArgs a /* lambda: the full-box model image (in); lists / r
                     const double q = tqa[k] * dx * dx + (2.0 * tqb[k] * dx + tqc[k] * dy) * dy;
                     v = fma(tA[k], exp_tab64(-0.5 * q, et), v);
                 }
-                if (on) lds_add(&acc[(rec.y0 - Y0) * HW_TW + col], v);
+                if (on) { lds_add(&acc[(rec.y0 - Y0) * HW_TW + col], v); bsum += v; }
             }
             if (col_here) {             // column x0 below the first row: the tile's 64 rows, one per lane
                 const int yi = Y0 + lane;
@@ -98,7 +100,12 @@ k_strict_totals(RenderArgs a /* lambda: the full-box model image (in); lists / r
                     const double q = tqa[k] * dx * dx + (2.0 * tqb[k] * dx + tqc[k] * dy) * dy;
                     v = fma(tA[k], exp_tab64(-0.5 * q, et), v);
                 }
-                if (on) lds_add(&acc[lane * HW_TW + (rec.x0 - X0)], v);
+                if (on) { lds_add(&acc[lane * HW_TW + (rec.x0 - X0)], v); bsum += v; }
+            }
+            if (massfx) {
+                bsum = wave_sum_lane63(bsum);
+                if (lane == 63 && bsum > 0.0 && rec.scale > 0.0)
+                    atomicAdd(massfx + ((int64_t)s * a.B + b), (unsigned long long)__double2ull_rn(bsum / rec.scale * MASS_FX));
             }
         }
         __syncthreads();

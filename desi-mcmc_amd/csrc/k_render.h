@@ -171,6 +171,25 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
+// The same sum by DPP moves (row shifts inside the rows of 16 lanes, then the two row broadcasts): VALU instructions instead
+// of twelve ds_bpermute round trips -- for sums taken once per (source, tile) pair, where a wave has nothing else in flight
+// to hide them behind.  The total arrives in LANE 63 only; a fixed tree: the same bits for the same inputs.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+    v += dpp_take<0x111, 0xf>(v);      // row_shr:1
+    v += dpp_take<0x112, 0xf>(v);      // row_shr:2
+    v += dpp_take<0x114, 0xf>(v);      // row_shr:4
+    v += dpp_take<0x118, 0xf>(v);      // row_shr:8: lane 15 of every row holds the row's sum
+    v += dpp_take<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v += dpp_take<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's
+    return v;
+}
+
 // Minimum of the positive-definite form a x^2 + 2 b x y + c y^2 over the rectangle
 // [x1,x2] x [y1,y2] (coordinates relative to the component mean).  0 when the mean is inside;
 // otherwise the minimum lies on the boundary: the smallest of the four 1-D constrained edge

@@ -496,6 +496,9 @@ struct SplitArgs {
     int *nnz;                   // k_photon_split_hw: pixels that received a photon, per (source, band), zeroed by the caller, or nullptr
     double *sums;               // k_photon_split_hw: photons per (source, band), index s*B + b, zeroed by the caller, or nullptr.
                                 // Integer-valued doubles: the atomic sums are exact, so their order does not matter
+    unsigned long long *massfx; // k_photon_split_hw: per (source, band), the unit stamp summed over the pixels the split walks
+                                // (strictly inside the box), in units of 2^-60 (MASS_FX): integer atomics, so the order of the
+                                // (source, half-tile) partials does not matter either; zeroed by the caller, or nullptr
 };
 
 template <typename TS>
@@ -713,7 +716,7 @@ k_photon_split_hw(SplitArgs a) {
         // queues the others (a ballot + prefix count per step); pass 2 runs the sampler on the queue,
         // 64 pixels per trip.  A pixel's draw takes the same numbers of its Philox stream either way.
         int zlo = INT_MAX, zhi = -1, xlo = INT_MAX, xhi = -1;   // where this lane's draws left photons
-        double zsum = 0.0;
+        double zsum = 0.0, fsum = 0.0;
         int zcnt = 0;
         const int nx = rec.x1 - rec.x0;
         TS *patch0 = static_cast<TS *>(a.samp) + poff + (int64_t)(Y0 - rec.y0) * nx - rec.x0;   // + row * nx + x
@@ -739,6 +742,7 @@ k_photon_split_hw(SplitArgs a) {
                 const double F = one[li];
                 const int n = (int)left[li];
                 const double tot = rate[li];
+                fsum += F;
                 covered |= 1u << r;
                 if (n > 0 && !(SPLIT_ABLATE(a) & 1)) {
                     const double pr = F * fast_rcp(tot);                  // curr_prob / sum_probs (:147)
@@ -776,6 +780,11 @@ k_photon_split_hw(SplitArgs a) {
                     zcnt += 1;
                 }
             }
+        }
+        if (a.massfx) {                  // this half-tile's share of the source's stamp mass (cel_stamp_mass's short cut)
+            fsum = wave_sum_lane63(fsum);
+            if (lane == 63 && fsum > 0.0 && rec.scale > 0.0)
+                atomicAdd(a.massfx + ((int64_t)s * a.B + b), (unsigned long long)__double2ull_rn(fsum * fast_rcp(rec.scale) * MASS_FX));   // 1 / scale to 4e-15
         }
         if (a.nz && __ballot(zhi >= 0)) {
             // the patch's photon rectangle (what the conditional likelihoods will evaluate): one

@@ -415,6 +415,13 @@ class ImageSet(object):
         L.check(L.lib().cel_stamp_mass(self._h, sources._h, L.dptr(out)))
         return out
 
+    def stamp_mass_ready(self, sources):
+        """True when stamp_mass(sources) would read the masses off the sums of the photon split that has just run on this
+        catalogue (CEL_OPT_SPLIT_REUSE = 2) instead of evaluating the stamps"""
+        r = C.c_int(0)
+        L.check(L.lib().cel_stamp_mass_ready(self._h, sources._h, C.byref(r)))
+        return bool(r.value)
+
     def stamp_mass_begin(self, sources):
         """queue stamp_mass and return: the device sums the stamps while the host does something else (no other call on
         this context before stamp_mass_end)"""

@@ -100,12 +100,18 @@ enum {
                                its own, no tile lists); 2 = k_render_stars at any size; 3 = rule 1 without the
                                one-launch path.  Tile layout 1 and the row-recurrence only.  The two kernels add a pixel's stars in different orders: values
                                agree to rounding (1e-15), and which one runs depends on the call's inputs only */
-    CEL_OPT_SPLIT_REUSE = 11,/* cel_photon_split's totals image (every pixel's rate under the split's strict boxes): 1 (default) =
-                               when the model image of exactly these sources and sky levels is on the device -- the chain's
-                               trace render came last -- it is formed from that image by subtracting the sources' first
-                               box row and column (k_strict_totals: 0.35 ms instead of a 1.3 ms render at configs[4]);
-                               0 = always rendered from scratch.  The two agree to ~1e-10 of a pixel's rate on those
-                               pixels (exactly elsewhere): equal in distribution, not photon for photon */
+    CEL_OPT_SPLIT_REUSE = 11,/* what a resident cel_photon_split takes from work already done.  1 = its totals image (every
+                               pixel's rate under the split's strict boxes): when the model image of exactly these sources and
+                               sky levels is on the device -- the chain's trace render came last -- it is formed from that image
+                               by subtracting the sources' first box row and column (k_strict_totals: 0.35 ms instead of a
+                               1.3 ms render at configs[4]).  The two agree to ~1e-10 of a pixel's rate on those pixels
+                               (exactly elsewhere): equal in distribution, not photon for photon.  2 (default) = that, and the
+                               two kernels also add up every unit stamp they evaluate, so that a cel_stamp_mass[_begin] of the
+                               same catalogue right after the split reads the masses off those sums instead of evaluating
+                               every stamp again (1.7 ms at configs[4]); sources fainter than a quarter of a sky pixel (counts <
+                               eps / 4) still go through the mass kernel.  The sums carry the split's drop rule: masses agree with
+                               the mass kernel's to 1e-11 eps / counts at most (measured; 1e-14 for a bright source).  0 = totals always rendered from scratch, masses
+                               always by the mass kernel */
     CEL_OPT_DEBUG = 8       /* diagnostics.  The shipped library accepts two result-preserving bits: 64 = the E-step
                                takes its per-source form, 128 = CEL_OPT_TILE_TIMING's third word carries the
                                row-waste counters of tools/row_waste.py.  The timing-only ABLATION bits (render:
@@ -288,14 +294,19 @@ int cel_patch_loglik_multi(cel_images *img, cel_sources *src, const int32_t *own
                            const int32_t *boxes, const int64_t *offsets, const double *data, int mem, int mode,
                            double *ll_out);
 
-/* Sum of every source's UNIT stamp over its own box, in every band: mass[s*B + b] -- what
- * Source.resample_fluxes multiplies by kappa/calib for the rate of its Gamma conditional
- * (CelestePy/sources.py:336-339) and celeste_em's sum_fs (celeste_em.py:89).  0 without a stamp.  Host output. */
 /* n standard Gamma(a[i]) variates, element i from its own counter-based streams keyed by (seed, i): the flux conditionals'
  * draws of Source.resample_fluxes (CelestePy/sources.py:341-345) for a whole catalogue (celeste_mcmc.gamma_by_stream is the
  * host form: the same streams and decisions, values equal to rounding).  Host arrays. */
 int cel_gamma_streams(cel_ctx *ctx, int64_t n, const double *a, uint64_t seed, double *out);
+/* Sum of every source's UNIT stamp over its own box, in every band: mass[s*B + b] -- what
+ * Source.resample_fluxes multiplies by kappa/calib for the rate of its Gamma conditional
+ * (CelestePy/sources.py:336-339) and celeste_em's sum_fs (celeste_em.py:89).  0 without a stamp.  Host output.
+ * Right after a resident cel_photon_split of the same catalogue that took its totals from the model image on the device
+ * (CEL_OPT_SPLIT_REUSE = 2) the values are read off the sums that split made (see the option); cel_stamp_mass_ready says
+ * whether this call would: a caller that could also ask for a part of the catalogue only (a rank of a dealt chain) then asks
+ * for the whole, which costs nothing and gives every rank the numbers the single-rank chain has. */
 int cel_stamp_mass(cel_images *img, cel_sources *src, double *mass);
+int cel_stamp_mass_ready(cel_images *img, cel_sources *src, int *ready);
 /* The same in two halves: _begin queues the kernel and returns, _end waits and copies the S*B values out -- so that the host
  * can draw its Gamma variates while the device sums the stamps (the flux step of a Gibbs sweep) without a second thread.
  * No other call on this context may come between the two (they share one of its scratch buffers). */

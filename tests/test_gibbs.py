@@ -1031,6 +1031,59 @@ def test_the_two_device_samplers_in_either_order(cel):
     assert x.shape == (400, 2) and st["evals"] >= 4 * 400
 
 
+
+def test_stamp_masses_read_off_the_split(cel, orc):
+    """CEL_OPT_SPLIT_REUSE = 2: the split that follows a trace render (k_strict_totals + k_photon_split_hw) adds up every unit
+    stamp it evaluates -- the boxes' first rows and columns in the one kernel, everything strictly inside in the other -- in
+    integer units of 2^-60, and a stamp_mass of the same catalogue right after reads the masses (sources.py:338-339: the unit
+    stamp summed over the source's box) off those sums.  Against the mass kernel: 1e-11 eps / counts (the sums carry the split's
+    drop rule); a source fainter than a quarter of a sky pixel or without counts in a band is not vouched for and takes the mass kernel
+    (the very same numbers); any change of the catalogue sends everything back to the mass kernel; against the oracle."""
+    from desi_mcmc_amd import _lib, synth
+    ctx = cel.default_context(0)
+    f = synth.SyntheticField(ctx, 300, 5, 320, 352, frac_gal=0.5, seed=23)
+    counts = f.src["counts"].copy()
+    eps = f.bands[:, 0]
+    faint = np.arange(0, 300, 7)
+    counts[np.arange(3, 300, 11)] = eps[None, :] * 0.3      # faint, and vouched for still
+    counts[faint] = eps[None, :] * 0.1                      # fainter than a quarter of a sky pixel: the mass kernel's
+    counts[5, 2] = 0.0                                      # no counts in one band: nothing to divide by
+    f.sources.set(f.src["type"], f.src["radec"], counts, f.src["shape"])
+    try:
+        ctx.set_option(_lib.CEL_OPT_SPLIT_REUSE, 1)
+        f.images.render(f.sources, loglik=True)
+        f.images.photon_split_resident(f.sources, seed=5)
+        exact = f.images.stamp_mass(f.sources)
+        ctx.set_option(_lib.CEL_OPT_SPLIT_REUSE, 2)
+        f.images.render(f.sources, loglik=True)
+        f.images.photon_split_resident(f.sources, seed=5)
+        quick = f.images.stamp_mass(f.sources)
+        assert exact.shape == quick.shape == (300, 5)
+        np.testing.assert_allclose(quick, exact, rtol=1e-10, atol=1e-13)      # 1e-11 eps / counts at most, counts >= eps / 4
+        bright = np.ones(300, bool); bright[faint] = False; bright[5] = False; bright[np.arange(3, 300, 11)] = False
+        np.testing.assert_allclose(quick[bright], exact[bright], rtol=1e-11)
+        assert np.any(quick[bright] != exact[bright])        # ... and it WAS the short cut (another order of summation)
+        assert np.array_equal(quick[faint], exact[faint])    # not vouched for: the mass kernel's own numbers
+        assert quick[5, 2] == exact[5, 2] and exact[5, 2] > 0.5
+        assert np.array_equal(f.images.stamp_mass(f.sources), quick)     # the sums stay valid while nothing changes
+        # a split that had to render its totals (the model image on the device is of another sky level) sums nothing: the mass kernel
+        f.images.set_epsilon(2, f.bands[2, 0] * 1.01)
+        f.images.photon_split_resident(f.sources, seed=6)
+        assert np.array_equal(f.images.stamp_mass(f.sources), exact)
+        # a changed catalogue after a short-cut split: the sums are of another generation
+        f.images.render(f.sources, loglik=True)
+        f.images.photon_split_resident(f.sources, seed=5)
+        f.sources.set(f.src["type"], f.src["radec"], counts, f.src["shape"])
+        assert np.array_equal(f.images.stamp_mass(f.sources), exact)
+    finally:
+        ctx.set_option(_lib.CEL_OPT_SPLIT_REUSE, 2)
+    # the oracle: unit stamps summed over their boxes
+    for s in (0, 1, 2, 7, 150, 151, 299):
+        for b in (0, 3):
+            p, yl, xl = orc.source_patch(f.images.band(b), f.H, f.W, f.src["type"][s], f.src["radec"][s], f.src["shape"][s])
+            want = 0.0 if p is None else p.sum()
+            assert abs(quick[s, b] - want) <= 1e-10 * max(want, 1e-3), (s, b, quick[s, b], want)
+
 def test_split_totals_from_the_trace_image(cel):
     """CEL_OPT_SPLIT_REUSE: when the model image of exactly these sources and sky levels is on the device (a chain's trace
     render came last), the photon split forms its totals image -- every pixel's rate under the strict-box rule of
@@ -1058,7 +1111,7 @@ def test_split_totals_from_the_trace_image(cel):
         ctx.set_option(_lib.CEL_OPT_SPLIT_REUSE, 0)
         f.images.render(f.sources, loglik=True)
         s_full, n_full, r_full = split(False)
-        ctx.set_option(_lib.CEL_OPT_SPLIT_REUSE, 1)
+        ctx.set_option(_lib.CEL_OPT_SPLIT_REUSE, 2)
         np.testing.assert_allclose(r_short, r_full, rtol=1e-9)
         same = r_short == r_full
         assert same.mean() > 0.5                                 # off the border pixels: the very same numbers
@@ -1067,7 +1120,7 @@ def test_split_totals_from_the_trace_image(cel):
         assert np.mean(s_short == s_full) > 0.999 and abs(s_short - s_full).sum() <= 8        # the same draws but for a rare flip
         split(True)                                              # the render of the totals left the model image alone: still valid
     finally:
-        ctx.set_option(_lib.CEL_OPT_SPLIT_REUSE, 1)
+        ctx.set_option(_lib.CEL_OPT_SPLIT_REUSE, 2)
         ctx.profile(False)
     f.images.render(f.sources, loglik=True)
     f.images.set_epsilon(2, f.bands[2, 0] * 1.01)                # a new sky level: the image on the device is stale
