@@ -211,6 +211,12 @@ struct cel_images {
     int4 *d_snz = nullptr;      // nonzero rectangles of the resident sample patches (k_patch_nzbox)
     double *d_ssum = nullptr;   // photons per (source, band) of the resident split, summed by the split kernel itself
     bool ssum_valid = false;
+    // host copies of the last resident split's sums and patch offsets (pinned), made INSIDE cel_photon_split before its last
+    // wait: cel_samples_fetch hands them over without touching the stream, on which the photon lists are still being compacted
+    double *h_ssum = nullptr;
+    int64_t *h_soff = nullptr;
+    int64_t hsum_cap = 0;
+    bool hsum_valid = false;
     // photon lists of the resident split (k_nz_layout / k_nz_compact): per patch the pixels that hold a photon
     int *d_nnz = nullptr, *d_nzmode = nullptr;
     int64_t *d_nzoff = nullptr;
@@ -560,6 +566,8 @@ int cel_images_destroy(cel_images *im) {
     if (im->h_small) (void)hipHostFree(im->h_small);
     if (im->d_small_consts) (void)hipFree(im->d_small_consts);
     if (im->d_massfx) (void)hipFree(im->d_massfx);
+    if (im->h_ssum) (void)hipHostFree(im->h_ssum);
+    if (im->h_soff) (void)hipHostFree(im->h_soff);
     if (im->d_mass_todo) (void)hipFree(im->d_mass_todo);
     if (im->ev_step) (void)hipEventDestroy(im->ev_step);
     delete im;
@@ -1729,6 +1737,12 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     // PLL_PARTS where the lists in between began to deal every job), and the kernels stop at the device's own count.
     int64_t live_dense = -1, live_nz = -1;                       // < 0: no live lists read yet
     int *h_flags[2] = {reinterpret_cast<int *>(c->pinned + MAX_BANDS + 2), reinterpret_cast<int *>(c->pinned + MAX_BANDS + 8)};
+    PrepArgs pa;                                                 // what run_prep(im, prop, d_owner, 1) hands k_prep
+    pa.bands = im->d_bands; pa.B = B; pa.H = im->full_H; pa.W = im->W; pa.win_y0 = im->win_y0; pa.win_h = im->H; pa.S = S;
+    pa.type = prop->d_type; pa.counts = prop->d_counts; pa.shape = prop->d_shape; pa.rsq_gal = rsq_galaxy();
+    pa.recs = im->d_recs; pa.boxes = im->d_boxes; pa.kind = im->d_kind; pa.status = im->d_status; pa.nobox = 1;
+    if ((rc = ensure_recs(im, S * B > 0 ? S * B : 1))) return rc;   // (before the pointers are taken)
+    pa.recs = im->d_recs; pa.boxes = im->d_boxes; pa.kind = im->d_kind; pa.status = im->d_status;
     if (!c->slice_ev[0]) {
         HIP_TRY(hipEventCreateWithFlags(&c->slice_ev[0], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->slice_ev[1], hipEventDisableTiming));
@@ -1751,7 +1765,8 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
                 // the first round's points; every later round's were named by the step kernel of the round before
                 if (queued == 0) hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags);
                 prop->gen = ++g_source_gen;
-                if ((rc = run_prep(im, prop, d_owner, 1))) return rc;      // the patch limits are fixed: no boxes
+                // the first round's records; every later round's were written by the step kernel that named its points
+                if (queued == 0 && (rc = run_prep(im, prop, d_owner, 1))) return rc;      // the patch limits are fixed: no boxes
                 if (c->variant == 0) {
                     int pi = prof_slot(c, CEL_K_PATCH_LL);
                     LAUNCH_EV(k_patch_ll<int>, dim3((unsigned)(S * B)), dim3(256), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
@@ -1773,7 +1788,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
                                   (const int *)(use_live ? d_live_nz : d_jobs_nz), (const int *)(use_live ? d_flags + 5 : nullptr));
                     }
                 }
-                hipLaunchKernelGGL(k_slice_step, dim3(g256), dim3(256), 0, st, ss, S, B, ostr, d_ll, sigma, d_flags, (int)queued, prop->d_radec, d_owner);
+                hipLaunchKernelGGL(k_slice_step, dim3((unsigned)((S + 63) / 64)), dim3(64 * B), 0, st, ss, S, B, ostr, d_ll, sigma, d_flags, (int)queued, prop->d_radec, d_owner, pa);
                 queued++;
             }
             const int slot = qb & 1;
@@ -2182,10 +2197,27 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
     }
     HIP_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
     if (lists) HIP_TRY(hipMemcpyAsync(c->pinned + MAX_BANDS + 2, im->d_nzoff + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (resident) im->hsum_valid = false;
+    if (fused_nz) {
+        // what a Gibbs sweep asks for next (the photons per source: the flux and sky steps; the patch areas) rides back now:
+        // cel_samples_fetch then needs no wait of its own, and the list compaction queued below runs under the host's work
+        if (n + 1 > im->hsum_cap) {
+            if (im->h_ssum) (void)hipHostFree(im->h_ssum);
+            if (im->h_soff) (void)hipHostFree(im->h_soff);
+            im->h_ssum = nullptr; im->h_soff = nullptr; im->hsum_cap = 0;
+            const int64_t cap = n + n / 4 + 64;
+            HIP_TRY(hipHostMalloc((void **)&im->h_ssum, sizeof(double) * cap, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void **)&im->h_soff, sizeof(int64_t) * cap, hipHostMallocDefault));
+            im->hsum_cap = cap;
+        }
+        HIP_TRY(hipMemcpyAsync(im->h_ssum, im->d_ssum, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(im->h_soff, im->d_soff, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, c->stream));
+    }
     if (!resident && mem != CEL_DEVICE && total > 0)
         HIP_TRY(hipMemcpyAsync(samp, d_samp, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (fused_nz) im->hsum_valid = true;
     if (noise) for (int b = 0; b < B; b++) noise[b] = c->pinned[b];
     if (use_massfx && hw && resident) im->massfx_gen = src->gen;
     if (lists) {
@@ -2221,6 +2253,11 @@ int cel_samples_fetch(cel_images *im, int32_t *boxes, int64_t *offsets, double *
     HIP_TRY(hipSetDevice(c->device));
     const int64_t n = im->samp_S * im->B;
     int rc = CEL_OK;
+    if (!boxes && !data && im->hsum_valid && n + 1 <= im->hsum_cap) {        // host copies made by the split itself: no wait
+        if (offsets) memcpy(offsets, im->h_soff, sizeof(int64_t) * (n + 1));
+        if (sums) memcpy(sums, im->h_ssum, sizeof(double) * n);
+        return CEL_OK;
+    }
     if (boxes) {
         std::vector<int4> hb((size_t)n);
         if ((rc = copy_out(hb.data(), im->d_sbox, sizeof(int4) * n, CEL_HOST, c->stream))) return rc;

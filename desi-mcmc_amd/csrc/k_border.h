@@ -55,18 +55,29 @@ k_strict_totals(RenderArgs a /* lambda: the full-box model image (in); lists / r
             const int K = (rec.type == 0) ? K_PSF : K_GAL;
             __syncthreads();            // the previous source's table has been read
             // The border lies where the source has faded to 1e-5 / 1e-3 of its mass: most of a galaxy's 42 components are
-            // nothing there.  A component is kept when it can exceed eps e^-40 somewhere on the box's first row or column
-            // (the form's minimum along the line y = y0, resp. x = x0: q_min = d^2 det / q_other): what is left out is below
-            // 42 e^-40 = 2e-16 of the sky level per pixel.  Kept components are compacted (ballot + prefix count).
+            // nothing there.  A component is kept when it can exceed eps e^-40 somewhere on the piece of the box's first row or
+            // column that lies on this tile: what is left out is below 42 e^-40 = 2e-16 of the sky level per pixel.  Kept
+            // components are compacted (ballot + prefix count).
             bool keep = false;
             Comp c;
             if (lane < K) {
                 c = make_comp_lc(lc, rec);
+                // ... on THIS tile's piece of the row / of the column: the form's minimum over the segment (a quadratic in one
+                // variable: the free minimiser clamped to the segment)
                 const double dy = (double)rec.y0 - c.my, dx = (double)rec.x0 - c.mx;
-                const double det = c.qa * c.qc - c.qb * c.qb;
-                const double qrow = dy * dy * det / c.qa, qcol = dx * dx * det / c.qc;
+                double qrow = INFINITY, qcol = INFINITY;
+                if (row_here) {
+                    const double lo = (double)max(rec.x0, X0) - c.mx, hi = (double)(min(rec.x1, X0 + HW_TW) - 1) - c.mx;
+                    const double t = fmin(fmax(-c.qb * dy / c.qa, lo), hi);
+                    qrow = c.qa * t * t + (2.0 * c.qb * t + c.qc * dy) * dy;
+                }
+                if (col_here) {
+                    const double lo = (double)max(rec.y0 + 1, Y0) - c.my, hi = (double)(min(rec.y1, Y0 + HW_TH) - 1) - c.my;
+                    const double t = fmin(fmax(-c.qb * dx / c.qc, lo), hi);
+                    qcol = c.qa * dx * dx + (2.0 * c.qb * dx + c.qc * t) * t;
+                }
                 const double lim = 2.0 * (40.0 + (double)__logf((float)fmax(fabs(c.A), 1e-300)) - log_eps);
-                keep = (fmin(qrow, qcol) <= lim) || !(lim == lim);
+                keep = (fmin(qrow, qcol) <= lim * (1.0 + 1e-6) + 1e-6) || !(lim == lim);
             }
             const unsigned long long km = __ballot(keep);
             const int Kk = __popcll(km);

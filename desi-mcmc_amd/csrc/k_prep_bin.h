@@ -76,29 +76,26 @@ __device__ __forceinline__ void prep_store(const SrcRec &r, int64_t i, SrcRec *_
     status[i] = r.type >= 0 ? 1 : (r.type == -3 ? -1 : 0);
 }
 
-__global__ void __launch_bounds__(256)
-k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int win_h, int64_t S,
-       const int *__restrict__ type, const double *__restrict__ radec,
-       const double *__restrict__ counts, const double *__restrict__ shape, double rsq_gal,
-       SrcRec *__restrict__ recs, int4 *__restrict__ boxes, int *__restrict__ kind, int *__restrict__ status,
-       unsigned long long *__restrict__ cursor /* the binning pass's 4 cursors / flags, zeroed here (a memset of
-                                                  its own cost 15 us of queue time per step), or nullptr */,
-       const int *__restrict__ live /* [S] or nullptr: a source with live[s] < 0 is skipped (a retired slice chain:
-                                       nothing reads its records this round) */,
-       int nobox = 0 /* 1: the records feed conditional likelihoods on FIXED patch limits (the slice samplers' rounds): a
-                        galaxy's own box -- the bounding radius over its 42 convolved components, most of this kernel's
-                        arithmetic -- is not needed and is set to the whole window */) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 4 && cursor) cursor[i] = 0ull;
-    if (i >= S * B) return;
-    int b = (int)(i / S);
-    int64_t s = i - (int64_t)b * S;
-    if (live && live[s] < 0) return;
+// the record of source s in band b (entry i = b * S + s of the tables): k_prep's whole arithmetic, also called by the slice
+// sampler's step kernel for the point it has just named (k_slice.h)
+struct PrepArgs {
+    const BandDev *bands;
+    int B, H, W, win_y0, win_h;
+    int64_t S;
+    const int *type;
+    const double *counts, *shape;
+    double rsq_gal;
+    SrcRec *recs; int4 *boxes; int *kind; int *status;      // recs == nullptr: nothing to do
+    int nobox;
+};
+__device__ __forceinline__ void prep_one(const BandDev *__restrict__ bands, int b, int64_t s, int64_t i, int B, int H, int W, int win_y0, int win_h,
+                                         const int *__restrict__ type, double ra, double dec, const double *__restrict__ counts,
+                                         const double *__restrict__ shape, double rsq_gal, SrcRec *__restrict__ recs,
+                                         int4 *__restrict__ boxes, int *__restrict__ kind, int *__restrict__ status, int nobox) {
     const BandDev &bd = bands[b];
     SrcRec r;
     memset(&r, 0, sizeof(r));
     int t = type[s];
-    double ra = radec[2 * s], dec = radec[2 * s + 1];
     // equa2pixel (fits_image.py:166-174)
     double cphi = cos(bd.phi[1] / 180.0 * PI_D);
     double px, py;
@@ -189,6 +186,27 @@ k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int w
     }
     prep_window(r, py, win_y0, win_h);
     prep_store(r, i, recs, boxes, kind, status);
+}
+
+__global__ void __launch_bounds__(256)
+k_prep(const BandDev *__restrict__ bands, int B, int H, int W, int win_y0, int win_h, int64_t S,
+       const int *__restrict__ type, const double *__restrict__ radec,
+       const double *__restrict__ counts, const double *__restrict__ shape, double rsq_gal,
+       SrcRec *__restrict__ recs, int4 *__restrict__ boxes, int *__restrict__ kind, int *__restrict__ status,
+       unsigned long long *__restrict__ cursor /* the binning pass's 4 cursors / flags, zeroed here (a memset of
+                                                  its own cost 15 us of queue time per step), or nullptr */,
+       const int *__restrict__ live /* [S] or nullptr: a source with live[s] < 0 is skipped (a retired slice chain:
+                                       nothing reads its records this round) */,
+       int nobox = 0 /* 1: the records feed conditional likelihoods on FIXED patch limits (the slice samplers' rounds): a
+                        galaxy's own box -- the bounding radius over its 42 convolved components, most of this kernel's
+                        arithmetic -- is not needed and is set to the whole window */) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4 && cursor) cursor[i] = 0ull;
+    if (i >= S * B) return;
+    int b = (int)(i / S);
+    int64_t s = i - (int64_t)b * S;
+    if (live && live[s] < 0) return;
+    prep_one(bands, b, s, i, B, H, W, win_y0, win_h, type, radec[2 * s], radec[2 * s + 1], counts, shape, rsq_gal, recs, boxes, kind, status, nobox);
 }
 
 // Gibbs resamples the sky level (models.py:156-160): one scalar, passed as a kernel argument so

@@ -155,12 +155,19 @@ k_slice_propose(SliceState st, int64_t S, double *__restrict__ prop_radec, int *
 // Consume round `round`'s log-likelihoods (per (chain, band), summed in band order as the host sums them) and name the
 // point every chain that is still running needs next: one kernel per round instead of a consume and a propose (a chain's
 // next point depends on its own state only).
-__global__ void __launch_bounds__(256)
+// Launch: 64 chains per block; with pa.recs, 64 * B threads -- the block's first wave runs the chains, then every thread
+// writes the record of one (chain, band) of the points just named.
+__global__ void __launch_bounds__(1024)
 k_slice_step(SliceState st, int64_t S, int B, int nparts /* blocks per (chain, band) job: their partial sums are added first, in order */,
              const double *__restrict__ ll_pb, double sigma, int *__restrict__ flags, int round,
-             double *__restrict__ prop_radec, int *__restrict__ owner) {
+             double *__restrict__ prop_radec, int *__restrict__ owner,
+             PrepArgs pa /* pa.recs != nullptr: the named point's records (k_prep's own arithmetic, prep_one) are written here too --
+                            the round's k_prep launch, 7 us of kernel and as much of queue, is gone */) {
 #pragma clang fp contract(off)
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double s_ra[64], s_dec[64];
+    __shared__ int s_own[64];
+    const bool chain_thread = threadIdx.x < 64;
+    const int64_t s = chain_thread ? (int64_t)blockIdx.x * 64 + threadIdx.x : S;        // (the other waves: no chain)
     int *const n_active = flags + ((round & 1) ? 10 : 0);
     int *const err = flags + 1;
     if (s == 0 && round > 0) {
@@ -218,7 +225,18 @@ k_slice_step(SliceState st, int64_t S, int B, int nparts /* blocks per (chain, b
     const unsigned long long m = __ballot(active), me = __ballot(scored);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_active, __popcll(m));
     if ((threadIdx.x & 63) == 0 && me) atomicAdd(err + 1, __popcll(me));         // evaluations so far (int: < 2^31 per call)
-    if (s < S) sl_propose_chain(st, s, prop_radec, owner);                       // the next round's point (a finished chain retires)
+    if (chain_thread) s_own[threadIdx.x] = -1;
+    if (s < S) {
+        sl_propose_chain(st, s, prop_radec, owner);                              // the next round's point (a finished chain retires)
+        s_ra[threadIdx.x] = prop_radec[2 * s]; s_dec[threadIdx.x] = prop_radec[2 * s + 1]; s_own[threadIdx.x] = owner[s];
+    }
+    if (!pa.recs) return;
+    __syncthreads();
+    const int ci = threadIdx.x / pa.B, b = threadIdx.x - ci * pa.B;             // one (chain, band) per thread
+    const int64_t sc = (int64_t)blockIdx.x * 64 + ci;
+    if (ci < 64 && sc < S && s_own[ci] >= 0)
+        prep_one(pa.bands, b, sc, (int64_t)b * pa.S + sc, pa.B, pa.H, pa.W, pa.win_y0, pa.win_h, pa.type, s_ra[ci], s_dec[ci], pa.counts, pa.shape,
+                 pa.rsq_gal, pa.recs, pa.boxes, pa.kind, pa.status, pa.nobox);
 }
 
 // the (chain, band) jobs of the chains that are still running, in no particular order (they all start at once:
