@@ -1547,7 +1547,7 @@ int cel_stamp_mass_begin(cel_images *im, cel_sources *src) {
         int *d_ntodo = im->d_mass_todo + im->massfx_cap;
         HIP_TRY(hipMemsetAsync(d_ntodo, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(k_mass_from_fx, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, c->stream, S * B, B,
-                           (const unsigned long long *)im->d_massfx, (const double *)src->d_counts, (const BandDev *)im->d_bands, d_out,
+                           (const unsigned long long *)im->d_massfx, (const double *)src->d_counts, (const int *)src->d_type, (const BandDev *)im->d_bands, d_out,
                            im->d_mass_todo, d_ntodo);
         // (how many: read in cel_stamp_mass_end, which launches the mass kernel on exactly those -- none at all in a field
         // without very faint sources; a launch of S B blocks that find nothing to do cost 0.15 ms of the flux step)

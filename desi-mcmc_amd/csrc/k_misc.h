@@ -20,12 +20,14 @@ k_scatter_rows(int64_t n, int B, const int *__restrict__ idx, const int *__restr
 // below eps e^-T on a half-tile is nothing beside the sky, but it is something of the stamp, the more the fainter the source.
 // Measured against the mass kernel (tools/dbg/mass_shortcut_error.py, 2 000 sources at one counts / eps ratio each): the
 // relative difference grows as eps / counts -- galaxies 1e-11 eps / counts at most (median 8e-13), stars 1.5e-13 -- so a
-// source is vouched for when counts >= eps / 4 (at most 5e-11 off); the others (and a source without counts) are listed for
-// the mass kernel proper.
-#define MASS_VOUCH 0.25
+// galaxy is vouched for when counts >= eps / 16 and a star when counts >= eps / 1024 (at most 1.6e-10 off either way; a chain's
+// faintest sources sit at a few hundredths of a sky pixel); the others (and a source without counts) are listed for the mass
+// kernel proper.
+#define MASS_VOUCH_GAL (1.0 / 16.0)
+#define MASS_VOUCH_STAR (1.0 / 1024.0)
 __global__ void __launch_bounds__(256)
 k_mass_from_fx(int64_t n, int B, const unsigned long long *__restrict__ massfx, const double *__restrict__ counts /* [S][B] */,
-               const BandDev *__restrict__ bands, double *__restrict__ mass, int *__restrict__ todo, int *__restrict__ ntodo) {
+               const int *__restrict__ type /* [S] */, const BandDev *__restrict__ bands, double *__restrict__ mass, int *__restrict__ todo, int *__restrict__ ntodo) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool need = false;
     if (i < n) {
@@ -34,7 +36,7 @@ k_mass_from_fx(int64_t n, int B, const unsigned long long *__restrict__ massfx, 
 #ifdef MASS_VOUCH_ALL      // tools/dbg/mass_shortcut_error.py: how far off the short cut is where it is NOT vouched for
         need = !(c > 0.0);
 #else
-        need = !(c >= MASS_VOUCH * eps) || !(eps > 0.0) || !(c < 1e300);
+        need = !(c >= ((type[i / B] == 0) ? MASS_VOUCH_STAR : MASS_VOUCH_GAL) * eps) || !(eps > 0.0) || !(c < 1e300);
 #endif
         mass[i] = (double)massfx[i] * (1.0 / MASS_FX);
     }

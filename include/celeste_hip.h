@@ -108,9 +108,10 @@ enum {
                                (exactly elsewhere): equal in distribution, not photon for photon.  2 (default) = that, and the
                                two kernels also add up every unit stamp they evaluate, so that a cel_stamp_mass[_begin] of the
                                same catalogue right after the split reads the masses off those sums instead of evaluating
-                               every stamp again (1.7 ms at configs[4]); sources fainter than a quarter of a sky pixel (counts <
-                               eps / 4) still go through the mass kernel.  The sums carry the split's drop rule: masses agree with
-                               the mass kernel's to 1e-11 eps / counts at most (measured; 1e-14 for a bright source).  0 = totals always rendered from scratch, masses
+                               every stamp again (1.7 ms at configs[4]); galaxies fainter than a sixteenth of a sky pixel (counts <
+                               eps / 16; stars: eps / 1024) still go through the mass kernel.  The sums carry the split's drop rule:
+                               masses agree with the mass kernel's to 1e-11 eps / counts at most for a galaxy, 1.5e-13 eps / counts for
+                               a star (measured; 1e-14 for a bright source): 1.6e-10 at the thresholds.  0 = totals always rendered from scratch, masses
                                always by the mass kernel */
     CEL_OPT_DEBUG = 8       /* diagnostics.  The shipped library accepts two result-preserving bits: 64 = the E-step
                                takes its per-source form, 128 = CEL_OPT_TILE_TIMING's third word carries the
