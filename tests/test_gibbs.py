@@ -1084,6 +1084,46 @@ def test_stamp_masses_read_off_the_split(cel, orc):
             want = 0.0 if p is None else p.sum()
             assert abs(quick[s, b] - want) <= 1e-10 * max(want, 1e-3), (s, b, quick[s, b], want)
 
+
+@pytest.mark.parametrize("y0,hw", [(37, 150), (64, 128), (91, 165)])
+def test_split_draws_do_not_depend_on_the_window(cel, y0, hw):
+    """A pixel's draws are keyed by its FULL-FRAME coordinates -- the first test's shared Philox word by (column, the row with
+    bits 1 and 2 cleared), the sampler's stream by the pixel -- so an image set that holds rows [y0, y0 + hw) of the frame
+    (cel_images_set_window: a rank's strip) splits its pixels exactly as the full frame's set does, wherever the window starts
+    (odd rows, rows that are no multiple of a tile: the lanes' four-row groups then straddle the kernel's steps)."""
+    from desi_mcmc_amd import synth
+    import desi_mcmc_amd as celmod
+    ctx = cel.default_context(0)
+    H, W, S, B = 256, 192, 220, 5
+    f = synth.SyntheticField(ctx, S, B, H, W, frac_gal=0.5, seed=31)
+    f.images.photon_split_resident(f.sources, seed=12)
+    bf, of, df = f.images.fetch_samples()
+    win = celmod.ImageSet(ctx, f.bands, hw, W, nelec=np.ascontiguousarray(f.nelec[:, y0:y0 + hw]))
+    win.set_window(y0, H)
+    win.photon_split_resident(f.sources, seed=12)
+    bw, ow, dw = win.fetch_samples()
+    compared = photons = 0
+    for s in range(S):
+        for b in range(B):
+            fy0, fy1, fx0, fx1 = bf[s, b]
+            wy0, wy1, wx0, wx1 = bw[s, b]
+            if fy1 <= fy0 or wy1 <= wy0:
+                continue
+            pf = df[of[s * B + b]:of[s * B + b + 1]].reshape(fy1 - fy0, fx1 - fx0)
+            pw = dw[ow[s * B + b]:ow[s * B + b + 1]].reshape(wy1 - wy0, wx1 - wx0)
+            assert (wx0, wx1) == (fx0, fx1)
+            # the window's box is the frame's cut to the window's rows (window-relative)
+            lo, hi = max(fy0, y0), min(fy1, y0 + hw)
+            assert (wy0 + y0, wy1 + y0) == (lo, hi)
+            # the box's first row takes no photons (celeste_sample_sources.pyx:50-51): where the window cuts a box its first
+            # row in the window is not the box's first row in the frame -- compare the rows strictly inside both
+            a = pf[lo - fy0 + 1:hi - fy0]
+            c = pw[1:]
+            assert np.array_equal(a, c), (s, b)
+            compared += a.size
+            photons += int(a.sum())
+    assert compared > 2e5 and photons > 1e4
+
 def test_split_totals_from_the_trace_image(cel):
     """CEL_OPT_SPLIT_REUSE: when the model image of exactly these sources and sky levels is on the device (a chain's trace
     render came last), the photon split forms its totals image -- every pixel's rate under the strict-box rule of
