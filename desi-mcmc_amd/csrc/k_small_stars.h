@@ -394,9 +394,18 @@ k_small_stars(RenderArgs a, SmallArgs x) {
 
     // ---- the block's stars into its waves' accumulators
     SMALL_STAMP(2);
+#ifdef SMALL_STAMPS
+    unsigned long long stage_ticks = 0;
+#endif
     for (int base = 0; base < nh; base += 64) {
         const int nb = min(64, nh - base);
+#ifdef SMALL_STAMPS
+        const unsigned long long ts0 = wall_clock64();
+#endif
         small_stage(a, x, ST, cpx, cpy, ccn, base, nb, tid, bdr, Xb, Y0);
+#ifdef SMALL_STAMPS
+        stage_ticks += wall_clock64() - ts0;
+#endif
         if (!(SMALL_ABL & 2)) small_walk<SMALL_CW>(ST, et, acc[wave], cum[wave], own[wave], nb, lane, Xa, Y0);
     }
 
@@ -447,7 +456,7 @@ k_small_stars(RenderArgs a, SmallArgs x) {
         tstamp[5] = wall_clock64();
         unsigned long long *o = x.stamps + (int64_t)blockIdx.x * 8;
         for (int k = 0; k < 6; k++) o[k] = tstamp[k];
-        o[6] = (unsigned long long)nh;
+        o[6] = (unsigned long long)nh | (stage_ticks << 32);
         o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) /* XCC_ID */ |
                ((unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4) /* HW_ID */ << 8);
     }

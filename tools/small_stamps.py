@@ -18,6 +18,8 @@ f = synth.SyntheticField.from_config(ctx, name)
 for _ in range(5):
     f.images.render(f.sources, loglik=True)
 st = np.fromfile(path, dtype=np.uint64).reshape(-1, 8).astype(np.int64)
+stage_us = (st[:, 6] >> 32) / 100.0
+st[:, 6] &= 0xffffffff
 t0 = st[:, 0].min()
 us = (st[:, :6] - t0) / 100.0
 print("blocks %d; kernel span %.2f us (first start -> last end)" % (len(st), us[:, 5].max()))
@@ -25,6 +27,7 @@ print("block start: median %.2f, p95 %.2f, max %.2f us" % (np.median(us[:, 0]), 
 d = np.diff(us, axis=1)
 for k, nm in enumerate(["loads+tables", "scan", "stage+walk", "epilogue", "records"]):
     print("%-14s mean %.2f  median %.2f  p95 %.2f  max %.2f us" % (nm, d[:, k].mean(), np.median(d[:, k]), np.percentile(d[:, k], 95), d[:, k].max()))
+print("  of stage+walk, the staging (barriers, boxes, sort): mean %.2f median %.2f p95 %.2f us" % (stage_us.mean(), np.median(stage_us), np.percentile(stage_us, 95)))
 dur = us[:, 5] - us[:, 0]
 print("block duration: mean %.2f median %.2f p95 %.2f max %.2f us; block end: median %.2f p95 %.2f max %.2f" %
       (dur.mean(), np.median(dur), np.percentile(dur, 95), dur.max(), np.median(us[:, 5]), np.percentile(us[:, 5], 95), us[:, 5].max()))
