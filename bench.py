@@ -536,7 +536,7 @@ def secondary_legs(args, env, field):
         S, B, H, W, fg = synth.CONFIGS[name]
         for _ in range(30):
             f.images.render(f.sources, loglik=True)
-        # the render kernel only (see run_render); a step of a few tens of microseconds (configs[1]: one 26 us launch) carries
+        # the render kernel only (see run_render); a step of a few tens of microseconds (configs[1]: one 23 us launch) carries
         # the event pair -- ~10 us of host time -- on every FOURTH launch: a sample of the timed region's launches
         ctx.profile(3 if name == "stars1k_512" else 2)
         torch.cuda.synchronize()
