@@ -17,13 +17,15 @@ CEL_HOST, CEL_DEVICE = 0, 1
 CEL_RENDER_LOGLIK, CEL_RENDER_NO_STORE = 1, 2
 CEL_OPT_KERNEL, CEL_OPT_TAIL_LOG, CEL_OPT_PROFILE, CEL_OPT_TILE_ORDER, CEL_OPT_TILE_ROWS = 1, 2, 3, 4, 5
 CEL_OPT_TILE_TIMING, CEL_OPT_TILE_LAYOUT, CEL_OPT_DEBUG, CEL_OPT_PHOTON_LISTS, CEL_OPT_STAR_TILES, CEL_OPT_SPLIT_REUSE = 6, 7, 8, 9, 10, 11
+CEL_OPT_TAIL_LOG_SOURCE = 12
 #: CEL_OPT_TAIL_LOG presets.  32 (the default): a skipped component is below eps * e^-32 on its tile, model pixels
 #: agree with the reference to ~1e-13, which is what the parity tests assert (1e-10).  20: the documented fast
 #: preset for callers that need only north_star's 1e-6 -- a skipped component is below eps * 2e-9, the sum of
 #: all skips on a pixel stays below ~1e-7 of lambda (tests/test_hip_parity.py::test_tail_log_fast_preset...).
 #: Round 4: the FIELD RENDER's default is 24 (a skipped component is below eps * 4e-11; the benchmark field's log-likelihood
 #: keeps all 16 digits and every pixel stays within 1e-10 of the oracle: tests/test_hip_parity.py::test_config3_full_vs_oracle),
-#: the per-source kernels keep 32.  TAIL_LOG_STRICT = 32 for both is what most parity tests run at (tests/conftest.py).
+#: the per-source kernels keep 32 (CEL_OPT_TAIL_LOG_SOURCE reads / sets theirs alone).  TAIL_LOG_STRICT = 32 for both: the
+#: strict variants of the parity tests (conftest.tail_log); the suite itself runs at these shipping defaults.
 TAIL_LOG_DEFAULT, TAIL_LOG_STRICT, TAIL_LOG_FAST = 24.0, 32.0, 20.0
 KERNELS = {"prep": 0, "bin": 1, "render": 2, "reduce": 3, "stamps": 4, "gmm": 5, "patch_ll": 6, "split": 7, "mass": 8, "estep": 9, "render_stars": 10, "small_stars": 11, "totals": 12}
 BAND_DOUBLES = 37

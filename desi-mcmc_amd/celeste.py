@@ -11,6 +11,7 @@ Divergences from the reference, all documented in DESIGN.md "Quirks":
   planck  stars given by temperature (`src.t`) need a hook: set `photons_expected_brightness`.
 """
 import collections
+import os
 import itertools
 import operator
 import sys
@@ -213,7 +214,7 @@ def _source_arrays(srcs, images, counts_fn=expected_photons):
             counts = (fl / calib[None, :]) * kappa[None, :]          # flux_dict convention (celeste.py:80-81,94)
         typ = (a == 1).astype(np.int32)
         return typ, u, counts, np.where((a == 1)[:, None], sh, 0.0)
-    if type(srcs) is list and len(srcs) >= _LIST_CACHE_MIN:
+    if type(srcs) is list and len(srcs) >= _LIST_CACHE_MIN and _LIST_CACHE_MODE[0] != "off":
         return _cached_list_arrays(srcs, images, counts_fn, bidx, calib, kappa)
     return _gather_plain(srcs, images, counts_fn, bidx, calib, kappa)
 
@@ -278,14 +279,37 @@ def _gather_plain(srcs, images, counts_fn, bidx, calib, kappa):
 # one C-level identity pass -- only the objects whose modification stamp moved (celeste_src.SrcParams.__setattr__) are read
 # again, and only their rows go to the device (cel_sources_set_rows).  A container changed IN PLACE without an attribute
 # assignment afterwards is not seen: celeste_src.touch(src) (the reference's own moves assign, mcmc_transitions.py:49-51).
+# The audit: every call that trusts the cache re-reads a rotating sixteenth of the list (at least 64 sources: ~0.15 ms of a
+# 10 000-source call) and compares it with the cached rows, so an in-place edit the stamps missed is found within 16 calls and
+# RAISES (the values returned since the edit were stale: silence would be worse than an exception).  list_cache("off") --
+# or CEL_LIST_CACHE=off in the environment -- gathers every list on every call, exactly as the reference re-reads every
+# source (celeste.py:203-219): 3.7 ms more per call at 10 000 sources.
 _LIST_CACHE_MIN = 64          # shorter lists are gathered every time (cheaper than the bookkeeping)
+_LIST_CACHE_MODE = [os.environ.get("CEL_LIST_CACHE", "stamps")]
+_AUDIT_PARTS = 16
+
+
+def list_cache(mode=None):
+    """how a plain LIST of SrcParams passed again and again is read: "stamps" (default) -- gathered once, afterwards only the
+    objects assigned to since (SrcParams.__setattr__ / celeste_src.touch) are re-read, with a rotating audit that raises
+    when it meets an in-place edit nobody stamped; "off" -- every source re-read on every call, as the reference does.
+    -> the mode in force (mode=None only asks)"""
+    if mode is not None:
+        if mode not in ("stamps", "off"):
+            raise ValueError("list_cache: 'stamps' or 'off'")
+        _LIST_CACHE_MODE[0] = mode
+        if mode == "off":
+            _LIST_CACHE.clear()
+            _ENTRY_OF.clear()
+    return _LIST_CACHE_MODE[0]
+
 _LIST_CACHE = collections.OrderedDict()   # (id(list), image ids, counts_fn) -> _ListEntry; a handful of lists
 _LIST_CACHE_MAX = 4
 _ENTRY_OF = {}                # id(typ array) -> entry: how _device_sources recognises cached arrays
 
 
 class _ListEntry(object):
-    __slots__ = ("srcs", "objs", "stamps", "clock", "imgkey", "typ", "radec", "counts", "shape", "version", "log")
+    __slots__ = ("srcs", "objs", "stamps", "clock", "imgkey", "typ", "radec", "counts", "shape", "version", "log", "audit")
 
     def rows_since(self, version):
         """rows changed after `version`, or None when the log no longer reaches back that far"""
@@ -326,6 +350,7 @@ def _cached_list_arrays(srcs, images, counts_fn, bidx, calib, kappa):
                     del ent.log[:-16]
                 ent.stamps, ent.clock = stamps, now
         if ent is not None:
+            _audit_rows(ent, srcs, images, counts_fn, bidx, calib, kappa)
             return ent.typ, ent.radec, ent.counts, ent.shape
     now = clock()
     stamps = _stamp_column(srcs, S)
@@ -338,13 +363,34 @@ def _cached_list_arrays(srcs, images, counts_fn, bidx, calib, kappa):
     ent = _ListEntry()
     ent.srcs, ent.objs, ent.stamps, ent.clock, ent.imgkey = srcs, list(srcs), stamps, now, imgkey
     ent.typ, ent.radec, ent.counts, ent.shape = arrs
-    ent.version, ent.log = 0, []
+    ent.version, ent.log, ent.audit = 0, [], 0
     _LIST_CACHE[key] = ent
     _ENTRY_OF[id(ent.typ)] = ent
     while len(_LIST_CACHE) > _LIST_CACHE_MAX:
         _, gone = _LIST_CACHE.popitem(last=False)
         _ENTRY_OF.pop(id(gone.typ), None)
     return arrs
+
+
+def _audit_rows(ent, srcs, images, counts_fn, bidx, calib, kappa):
+    """re-read the next sixteenth of the list and compare it with the cached rows: an object changed in place without an
+    assignment (src.u[0] = x, src.fluxes['r'] = f) makes the cache stale without moving its stamp"""
+    S = len(srcs)
+    n = min(S, max(64, -(-S // _AUDIT_PARTS)))
+    lo = ent.audit if ent.audit + n <= S else max(S - n, 0)
+    ent.audit = (lo + n) % S
+    t, r, c, sh = _gather_plain(srcs[lo:lo + n], images, counts_fn, bidx, calib, kappa)
+    ok = (np.array_equal(t, ent.typ[lo:lo + n]) and np.array_equal(r, ent.radec[lo:lo + n], equal_nan=True) and
+          np.array_equal(c, ent.counts[lo:lo + n], equal_nan=True) and np.array_equal(sh, ent.shape[lo:lo + n], equal_nan=True))
+    if not ok:
+        bad = lo + int(np.nonzero(np.any(r != ent.radec[lo:lo + n], axis=1) | np.any(c != ent.counts[lo:lo + n], axis=1) |
+                                  np.any(sh != ent.shape[lo:lo + n], axis=1) | (t != ent.typ[lo:lo + n]))[0][0])
+        _LIST_CACHE.clear()
+        _ENTRY_OF.clear()
+        raise RuntimeError("celeste: source %d of this list was changed IN PLACE (src.u[0] = x, src.fluxes['r'] = f) without an "
+                           "attribute assignment afterwards; the values returned since that edit did not see it.  Assign the "
+                           "attribute (src.u = u, as the reference's moves do), call celeste_src.touch(src), or switch the "
+                           "list cache off: celeste.list_cache('off') / CEL_LIST_CACHE=off" % bad)
 
 
 def _device_sources(iset, arrs):

@@ -117,8 +117,10 @@ struct cel_ctx {
     // component is below eps * 4e-11; the benchmark field's log-likelihood keeps all 16 digits, its kernel takes 13 % less
     // time than at 32), the per-source kernels against the source's own value (32: their outputs feed acceptance ratios
     // and are tested to 1e-11).  Setting the option sets both; CEL_TAIL_LOG in the environment is the initial value of both.
-    double tail_T = (getenv("CEL_TAIL_LOG") && atof(getenv("CEL_TAIL_LOG")) >= 0.0) ? atof(getenv("CEL_TAIL_LOG")) : 32.0;
-    double render_T = (getenv("CEL_TAIL_LOG") && atof(getenv("CEL_TAIL_LOG")) >= 0.0) ? atof(getenv("CEL_TAIL_LOG")) : 24.0;
+    // (the environment value is held to the option's own range, [0, 300]; anything else is ignored)
+    static bool env_tail_ok() { const char *e = getenv("CEL_TAIL_LOG"); return e && atof(e) >= 0.0 && atof(e) <= 300.0; }
+    double tail_T = env_tail_ok() ? atof(getenv("CEL_TAIL_LOG")) : 32.0;
+    double render_T = env_tail_ok() ? atof(getenv("CEL_TAIL_LOG")) : 24.0;
     int profile = 0;          // CEL_OPT_PROFILE: 0 off, 1 every kernel, 2 the evaluating kernels only
     int star_tiles = (getenv("CEL_STAR_TILES") && atoi(getenv("CEL_STAR_TILES")) >= 0 && atoi(getenv("CEL_STAR_TILES")) <= 3)
                          ? atoi(getenv("CEL_STAR_TILES")) : 1;       // CEL_OPT_STAR_TILES (the env var: the initial value, for test runs)
@@ -190,6 +192,9 @@ struct cel_images {
     bool bin_two_level = false;   // a super-tile once held more than BIN_CH candidates: coarse lists in global memory from then on
     int64_t mass_pending = -1;       // doubles waiting in d_mass between cel_stamp_mass_begin and _end (-1: none)
     int64_t mass_todo_S = -1;        // >= 0: that _begin took the short cut on a catalogue of so many sources; _end finishes its leftovers
+    uint64_t mass_gen = 0;           // ... of the catalogue of this generation, with the to-do list at mass_todo_ptr: what _end checks
+    const int *mass_todo_ptr = nullptr; //  before it launches on the leftovers (a call in between may have re-run k_prep for another
+                                     //     catalogue or re-allocated the split's buffers)
     double *d_mass = nullptr;        // (a scratch slot of the context: not owned)
     long long *d_btot = nullptr;     // per-1024-entries totals of the patch / list layout scans
     bool nelec_u16 = false;          // every observed pixel in 0 ... 65 535: the split's 16-bit photons-left plane
@@ -484,6 +489,11 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         c->tail_T = v;
         c->render_T = v;
         return CEL_OK;
+    case CEL_OPT_TAIL_LOG_SOURCE:
+        if (v != v) { c->tail_T = 32.0; return CEL_OK; }
+        if (!(v >= 0.0) || v > 300.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TAIL_LOG_SOURCE must be in [0, 300] (NaN: the default)");
+        c->tail_T = v;
+        return CEL_OK;
     case CEL_OPT_PROFILE:
         if (v != 0.0 && v != 1.0 && v != 2.0 && v != 3.0) return fail(CEL_ERR_INVALID, "CEL_OPT_PROFILE must be 0, 1, 2 or 3");
         if (v != 0.0 && !prof_alloc(c->prof)) return fail(CEL_ERR_HIP, "CEL_OPT_PROFILE: cannot create the timing events");
@@ -535,6 +545,7 @@ int cel_ctx_get_option(cel_ctx *c, int key, double *v) {
     switch (key) {
     case CEL_OPT_KERNEL: *v = c->variant; return CEL_OK;
     case CEL_OPT_TAIL_LOG: *v = c->render_T; return CEL_OK;
+    case CEL_OPT_TAIL_LOG_SOURCE: *v = c->tail_T; return CEL_OK;
     case CEL_OPT_PROFILE: *v = (double)c->profile; return CEL_OK;
     case CEL_OPT_TILE_ORDER: *v = (double)c->tile_order; return CEL_OK;
     case CEL_OPT_TILE_ROWS: *v = c->tile_rows; return CEL_OK;
@@ -812,6 +823,12 @@ int cel_sources_set_rows(cel_sources *s, int64_t n, const int32_t *idx, const in
     for (int64_t i = 0; i < n; i++)
         if (idx[i] < 0 || idx[i] >= s->S) return fail(CEL_ERR_INVALID, "cel_sources_set_rows: row %d outside the catalogue's %lld", idx[i], (long long)s->S);
     if (n == 0) return CEL_OK;
+    {   // a row named twice would be written by two threads of k_scatter_rows at once: the last writer is undefined
+        std::vector<int32_t> seen(idx, idx + n);
+        std::sort(seen.begin(), seen.end());
+        for (int64_t i = 1; i < n; i++)
+            if (seen[i] == seen[i - 1]) return fail(CEL_ERR_INVALID, "cel_sources_set_rows: row %d is named twice", seen[i]);
+    }
     cel_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
@@ -1553,6 +1570,7 @@ int cel_stamp_mass_begin(cel_images *im, cel_sources *src) {
         // without very faint sources; a launch of S B blocks that find nothing to do cost 0.15 ms of the flux step)
         HIP_TRY(hipMemcpyAsync(c->pinned + MAX_BANDS + 14, d_ntodo, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         im->mass_todo_S = S;
+        im->mass_gen = src->gen; im->mass_todo_ptr = im->d_mass_todo;
     } else {
         hipLaunchKernelGGL((k_patch_ll_hw<3, double>), dim3((unsigned)(S * B)), dim3(64), 0, c->stream, im->d_bands, B, S, im->d_recs,
                            (const int *)nullptr, (const int4 *)nullptr, (const int64_t *)nullptr, (const double *)nullptr,
@@ -1580,6 +1598,11 @@ int cel_stamp_mass_end(cel_images *im, double *mass) {
         int ntodo = 0;
         memcpy(&ntodo, c->pinned + MAX_BANDS + 14, sizeof(int));
         if (ntodo > 0) {
+            // Calls that came between _begin and _end (the header lists what may: cel_gamma_streams, cel_samples_fetch,
+            // cel_images_set_epsilon) leave the records and the to-do list alone.  Anything that re-ran k_prep for another
+            // catalogue, or a photon split that re-allocated its buffers, is caught here instead of scoring stale records:
+            if (im->mass_todo_ptr != im->d_mass_todo || im->recs_gen != im->mass_gen)
+                return fail(CEL_ERR_INVALID, "cel_stamp_mass_end: the source records or the photon split were rebuilt since cel_stamp_mass_begin");
             hipLaunchKernelGGL((k_patch_ll_hw<3, double>), dim3((unsigned)ntodo), dim3(64), 0, c->stream, im->d_bands, im->B, S_todo, im->d_recs,
                                (const int *)nullptr, (const int4 *)nullptr, (const int64_t *)nullptr, (const double *)nullptr,
                                (const double *)nullptr, im->H, im->W, (const int4 *)nullptr, c->tail_T, im->d_mass,
@@ -1736,7 +1759,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     // those of the batch before the one whose lists the launch walks; chains only retire, so those are upper bounds (times
     // PLL_PARTS where the lists in between began to deal every job), and the kernels stop at the device's own count.
     int64_t live_dense = -1, live_nz = -1;                       // < 0: no live lists read yet
-    int *h_flags[2] = {reinterpret_cast<int *>(c->pinned + MAX_BANDS + 2), reinterpret_cast<int *>(c->pinned + MAX_BANDS + 8)};
+    int *h_flag_slot[2] = {reinterpret_cast<int *>(c->pinned + MAX_BANDS + 2), reinterpret_cast<int *>(c->pinned + MAX_BANDS + 8)};
     PrepArgs pa;                                                 // what run_prep(im, prop, d_owner, 1) hands k_prep
     pa.bands = im->d_bands; pa.B = B; pa.H = im->full_H; pa.W = im->W; pa.win_y0 = im->win_y0; pa.win_h = im->H; pa.S = S;
     pa.type = prop->d_type; pa.counts = prop->d_counts; pa.shape = prop->d_shape; pa.rsq_gal = rsq_galaxy();
@@ -1800,7 +1823,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
                                    (const int *)(use_nz ? im->d_nzmode : nullptr), d_live_nz, d_flags + 5, (const int *)im->d_nnz,
                                    (const int4 *)im->d_snz, deal_of[slot]);
             }
-            HIP_TRY(hipMemcpyAsync(h_flags[slot], d_flags, sizeof(int) * 11, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_flag_slot[slot], d_flags, sizeof(int) * 11, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipEventRecord(c->slice_ev[slot], st));
             HIP_TRY(hipGetLastError());
             last_par[slot] = (int)((queued - 1) & 1);
@@ -1810,7 +1833,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         const int slot = rb & 1;
         HIP_TRY(hipEventSynchronize(c->slice_ev[slot]));
         rb++;
-        const int *hf = h_flags[slot];
+        const int *hf = h_flag_slot[slot];
         const int running = hf[last_par[slot] ? 10 : 0], err = hf[1];      // the batch's last round's slot
         live = running;
         if (c->variant != 0) { live_dense = hf[4]; live_nz = hf[5]; deal_read = deal_of[slot]; }
@@ -1837,12 +1860,12 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         HIP_TRY(hipMemsetAsync(d_bytes, 0, sizeof(unsigned long long), st));
         hipLaunchKernelGGL(k_slice_bytes, dim3(g256), dim3(256), 0, st, ss, S, B, (const int4 *)im->d_snz, d_bytes,
                            (const int *)(use_nz ? im->d_nzmode : nullptr), (const int64_t *)im->d_nzoff);
-        HIP_TRY(hipMemcpyAsync(h_flags + 6, d_bytes, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_flag_slot[0] + 6, d_bytes, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
     if (stats) {
         stats[0] = rounds; stats[1] = evals;
-        stats[2] = (int64_t)(*reinterpret_cast<unsigned long long *>(h_flags + 6));
+        stats[2] = (int64_t)(*reinterpret_cast<unsigned long long *>(h_flag_slot[0] + 6));
         stats[3] = queued;
     }
     return CEL_OK;

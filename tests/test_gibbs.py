@@ -1156,7 +1156,9 @@ def test_split_totals_from_the_trace_image(cel):
         same = r_short == r_full
         assert same.mean() > 0.5                                 # off the border pixels: the very same numbers
         lam = f.images.model_images()
-        assert np.all(r_full <= lam * (1 + 1e-12)) and np.any(r_full < lam * (1 - 1e-6))     # strict boxes: something was taken away
+        # strict boxes: something was taken away (the two renders drop their components on different rectangles: at the
+        # shipping threshold a total may exceed the full-box image by what the rule allows, a few e^-24 of the sky)
+        assert np.all(r_full <= lam * (1 + 1e-9)) and np.any(r_full < lam * (1 - 1e-6))
         assert np.mean(s_short == s_full) > 0.999 and abs(s_short - s_full).sum() <= 8        # the same draws but for a rare flip
         split(True)                                              # the render of the totals left the model image alone: still valid
     finally:
