@@ -617,6 +617,138 @@ def secondary_legs(args, env, field):
     return sec
 
 
+
+# ---- strong scaling, rank by rank on ONE GPU --------------------------------------------------------
+def measured_row_cost(ctx, _lib, images, sources, align):
+    """cost of every `align`-row band of the frame from the durations the render's tiles had in a whole-frame launch
+    (cel_debug_tile_timing): what dist.strip_edges evens out"""
+    from desi_mcmc_amd import dist
+    ctx.set_option(_lib.CEL_OPT_TILE_TIMING, 1)
+    try:
+        images.render(sources, loglik=True)
+        images.render(sources, loglik=True)
+        tt = images.tile_timing()
+    finally:
+        ctx.set_option(_lib.CEL_OPT_TILE_TIMING, 0)
+    dur = (tt[:, 1] - tt[:, 0]).astype(np.float64)
+    B, H, W = images.B, images.H, images.W
+    ntx, nty = (W + 31) // 32, (H + 63) // 64                   # the 32 x 64 layout's tiles, [band][tile row][tile column]
+    if dur.shape[0] != B * ntx * nty:
+        return None
+    return dist.strip_cost_from_tiles(dur, B, nty, ntx, 64, align)[: (H + align - 1) // align]
+
+
+def run_projection(args, env):
+    """--scaling strong --of N [--as-rank k] on ONE GPU, no process group: this process builds rank k's part of the N-rank job
+    exactly as that rank would -- its row strip (render workloads) or its window of the strip-partitioned / dealt chain
+    (gibbs10k) -- and times its FULL step (prep, binning, order, render, reduction; the whole sweep).  Without --as-rank every
+    rank is taken in turn.  The projected N-GPU step is the slowest rank's (the collectives, B doubles per step or 11 doubles
+    per source per sweep, are not in it); `projected_strong` states max, sum and the 1-rank time measured in the same process."""
+    torch, cel, dist, synth, _lib = env["torch"], env["cel"], env["dist"], env["synth"], env["_lib"]
+    ctx = env["ctx"]
+    N = args.of
+    ranks = [args.as_rank] if args.as_rank is not None else list(range(N))
+    if any(k < 0 or k >= N for k in ranks):
+        raise SystemExit("--as-rank must be in [0, --of)")
+    gibbs = args.workload == "gibbs10k"
+    base = "mixed10k_2048" if gibbs else args.workload
+    field = synth.SyntheticField.from_config(ctx, base, seed=42)
+    S, B, H, W, fg = synth.CONFIGS[base]
+    align = 64 if args.layout == 1 else dist.TILE_ROWS
+    steps, warm = args.steps, max(args.warmup, 3)
+
+    def timed(step, n, w):
+        for _ in range(w):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    row_cost = None
+    if args.strip_cut == "measured":
+        row_cost = measured_row_cost(ctx, _lib, field.images, field.sources, align)
+    edges = dist.strip_edges(H, N, row_cost, align=align)
+    out = {"workload": args.workload, "of": N, "ranks": ranks, "strip_cut": args.strip_cut if row_cost is not None else "equal",
+           "strip_edges": edges, "steps": steps}
+    per = []
+    if not gibbs:
+        one = timed(lambda: field.images.render(field.sources, loglik=True), steps, 100)
+        ll_full = field.images.render(field.sources, loglik=True)[0]
+        ll_sum = 0.0
+        for k in ranks:
+            y0, y1 = edges[k], edges[k + 1]
+            strip = cel.ImageSet(ctx, field.bands, y1 - y0, W, nelec=field.nelec[:, y0:y1])
+            strip.set_window(y0, H)
+            ms = timed(lambda: strip.render(field.sources, loglik=True), steps, warm + 20)
+            ctx.profile(1)
+            for _ in range(20):
+                ll_k = strip.render(field.sources, loglik=True)[0]
+            km = {"k_prep": ctx.profile_get("prep")[0], "k_bin": ctx.profile_get("bin")[0], "k_render": ctx.profile_render()[0],
+                  "k_reduce": ctx.profile_get("reduce")[0]}
+            ctx.profile(False)
+            ll_sum += ll_k
+            per.append({"rank": k, "rows": [y0, y1], "ms_per_step": ms, "kernels_ms": km, "n_tile_entries": strip.stats()["n_tile_entries"]})
+            strip.close()
+        out["one_rank_ms"] = one
+        if len(ranks) == N:
+            out["loglik_strips_sum"] = ll_sum
+            out["loglik_whole_frame"] = ll_full
+    else:
+        from desi_mcmc_amd import celeste_mcmc
+        slice_args = dict(step_out=False, sigma=args.slice_sigma)
+
+        def chain_ms(g, n):
+            def step():
+                g.sweep()
+                g.log_likelihood()
+            ms = timed(step, n, 3)
+            return ms
+        gf = celeste_mcmc.GibbsField(field.images, list(range(B)), field.bands[:, 2], field.bands[:, 1], H * W)
+        g1 = celeste_mcmc.ModelGibbs([gf], field.src["type"], field.src["radec"], field.flux5(), field.src["shape"], seed=1, slice_args=slice_args)
+        one = chain_ms(g1, steps)
+        out["one_rank_ms"] = one
+        out["split"] = args.split
+        boxes, status = field.images.source_boxes(field.sources)
+        eps0 = field.bands[:, 0].copy()
+        for k in ranks:
+            for b in range(B):
+                field.images.set_epsilon(b, eps0[b])
+            if args.split == "strips":
+                deal, gfk = celeste_mcmc.strip_gibbs_field(ctx, field.bands, field.nelec, field.src["pix"][:, 1], boxes, status, N, k,
+                                                           edges=edges, solo=True)
+            else:
+                deal = dist.SourceDeal(S, N, k, solo=True)
+                gfk = celeste_mcmc.GibbsField(field.images, list(range(B)), field.bands[:, 2], field.bands[:, 1], H * W)
+            g = celeste_mcmc.ModelGibbs([gfk], field.src["type"], field.src["radec"], field.flux5(), field.src["shape"], seed=1,
+                                        slice_args=slice_args, deal=deal)
+            for _ in range(2):
+                g.sweep()
+                g.log_likelihood()
+            for key in g.timing:
+                g.timing[key] = 0
+            ms = chain_ms(g, steps)
+            n = steps + 3
+            per.append({"rank": k, "ms_per_step": ms, "sources_owned": int(deal.mine.size),
+                        "window_rows": list(getattr(deal, "window", (0, H))),
+                        "sweep_ms": {"photon_split_and_sky": g.timing["split"] / n * 1e3, "flux": g.timing["flux"] / n * 1e3,
+                                     "location_slice": g.timing["location"] / n * 1e3}})
+            if args.split == "strips":
+                gfk.iset.close()
+                gfk.trace_iset.close()
+            del g, gfk, deal
+    t = [p["ms_per_step"] for p in per]
+    out["per_rank"] = per
+    out["projected_strong"] = {"max_ms": max(t), "sum_ms": sum(t), "mean_ms": sum(t) / len(t), "one_rank_ms": out["one_rank_ms"],
+                               "speedup_at_N": out["one_rank_ms"] / max(t), "efficiency": out["one_rank_ms"] / max(t) / N,
+                               "note": "one GPU, one rank of the %d-rank job at a time, no process group: the slowest rank's full step "
+                                       "against the 1-rank step of the same process; the collective (%s) is not in it"
+                                       % (N, "one all-gather of 11 doubles per source per sweep" if gibbs else "one all-reduce of %d doubles" % B)}
+    print(json.dumps(out))
+
+
 # ---- configs[3] stand-in: K fields dealt to ranks ----------------------------------------------------
 def run_fields(args, env):
     torch, cel, dist, synth = env["torch"], env["cel"], env["dist"], env["synth"]
@@ -909,6 +1041,13 @@ def main():
                     help="gibbs10k --scaling strong: every rank runs the whole photon split (the chain is the 1-GPU chain bit for "
                          "bit), or the split is partitioned by row strips like the sources (SURVEY 8e)")
     ap.add_argument("--shapes", action="store_true", help="gibbs10k: every sweep also resamples the galaxies' shapes")
+    ap.add_argument("--of", type=int, default=0,
+                    help="with --scaling strong on ONE GPU (no --gpus): play the ranks of an N-rank job one at a time, each "
+                         "building its strip / window exactly as in the N-rank job and timing its full step -> projected_strong")
+    ap.add_argument("--as-rank", type=int, default=None, help="with --of N: only this rank (default: all N in turn)")
+    ap.add_argument("--strip-cut", default="measured", choices=["measured", "equal"],
+                    help="--scaling strong: strip edges that even out the whole-frame render's measured tile durations "
+                         "(cel_debug_tile_timing; rank 0 measures, every rank cuts alike) or equal tile rows")
     ap.add_argument("--legs", default="all", choices=["all", "none"],
                     help="render workloads at N=1: 'all' (default) adds the untimed-by-the-contract extras after the timed region "
                          "(evaluated-Gaussian count, fast tail preset, source-upload step, Python-API call); 'none' runs the "
@@ -964,6 +1103,11 @@ def main():
         backend = {"nccl": "rccl (torch.distributed nccl)"}.get(td.get_backend(), td.get_backend())
     env = dict(torch=torch, cel=cel, dist=dist, synth=synth, _lib=_lib, rank=rank, world=world, local=local, ctx=ctx,
                backend=backend)
+    if args.of:
+        if world != 1 or args.scaling != "strong":
+            raise SystemExit("--of N plays the ranks of a strong-scaling job on ONE GPU: use it with --scaling strong and without --gpus")
+        run_projection(args, env)
+        return
     {"render": run_render, "fields": run_fields, "gibbs": run_gibbs}[kind](args, env)
     if world > 1:
         import torch.distributed as td

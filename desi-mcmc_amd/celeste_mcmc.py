@@ -135,7 +135,8 @@ class GibbsField(object):
         self.has_patch = None
 
 
-def strip_gibbs_field(ctx, bands, nelec, rows, boxes, status, world, rank, band_index=None, slack=48, device=None):
+def strip_gibbs_field(ctx, bands, nelec, rows, boxes, status, world, rank, band_index=None, slack=48, device=None, edges=None,
+                      solo=False):
     """This rank's part of ONE chain partitioned by row strips (dist.StripDeal).
         bands (B, 37) cel_band records, nelec (B, H, W) the whole frame's pixels (every rank can read them: only the window is
         uploaded), rows (S,) the sources' pixel rows, boxes (B, S, 4) / status (B, S) their boxes on the whole frame
@@ -145,12 +146,12 @@ def strip_gibbs_field(ctx, bands, nelec, rows, boxes, status, world, rank, band_
     from . import dist as _dist
     from . import field as _field
     B, H, W = nelec.shape
-    probe = _dist.StripDeal(rows, H, world, rank)
+    probe = _dist.StripDeal(rows, H, world, rank, edges=edges, solo=solo)       # (edges: dist.strip_edges, the same on every rank)
     mine = probe.mine
     has = status[:, mine] > 0
     reach = max(int(np.max(np.where(has, probe.strip[0] - boxes[:, mine, 0], 0), initial=0)),
                 int(np.max(np.where(has, boxes[:, mine, 1] - probe.strip[1], 0), initial=0)), 0)
-    deal = _dist.StripDeal(rows, H, world, rank, halo=reach + slack, device=device)
+    deal = _dist.StripDeal(rows, H, world, rank, halo=reach + slack, device=device, edges=edges, solo=solo)
     w0, w1 = deal.window
     win = _field.ImageSet(ctx, bands, w1 - w0, W, nelec=np.ascontiguousarray(nelec[:, w0:w1]))
     win.set_window(w0, H)

@@ -121,6 +121,8 @@ struct cel_ctx {
     static bool env_tail_ok() { const char *e = getenv("CEL_TAIL_LOG"); return e && atof(e) >= 0.0 && atof(e) <= 300.0; }
     double tail_T = env_tail_ok() ? atof(getenv("CEL_TAIL_LOG")) : 32.0;
     double render_T = env_tail_ok() ? atof(getenv("CEL_TAIL_LOG")) : 24.0;
+    int tile_parts = (getenv("CEL_TILE_PARTS") && (atoi(getenv("CEL_TILE_PARTS")) == 1 || atoi(getenv("CEL_TILE_PARTS")) == 2 || atoi(getenv("CEL_TILE_PARTS")) == 4))
+                         ? atoi(getenv("CEL_TILE_PARTS")) : 0;       // CEL_OPT_TILE_PARTS (the env var: the initial value, for A/B runs)
     int profile = 0;          // CEL_OPT_PROFILE: 0 off, 1 every kernel, 2 the evaluating kernels only
     int star_tiles = (getenv("CEL_STAR_TILES") && atoi(getenv("CEL_STAR_TILES")) >= 0 && atoi(getenv("CEL_STAR_TILES")) <= 3)
                          ? atoi(getenv("CEL_STAR_TILES")) : 1;       // CEL_OPT_STAR_TILES (the env var: the initial value, for test runs)
@@ -168,6 +170,9 @@ struct cel_images {
     double *d_nelec = nullptr, *d_lambda = nullptr, *d_partials = nullptr, *d_llband = nullptr;
     bool have_nelec = false;
     // per-render scratch, grown on demand
+    double *d_slabs = nullptr;       // k_render_hw<, PARTS>: PARTS accumulator slabs per render tile, allocated with the first such launch
+    int *d_part_cnt = nullptr;       // ... and the tiles' arrival counters
+    int slabs_parts = 0;
     SrcRec *d_recs = nullptr;
     int4 *d_boxes = nullptr;
     int *d_kind = nullptr;
@@ -267,8 +272,20 @@ struct cel_sources {
 
 // The launch order of the tiles matters only when there are more tiles than the chip runs at once (2048 waves of the
 // general kernel): below that every tile starts at once whatever the order, and a sort + its launch is all cost.
+// A frame of few tiles is rendered by several one-wave blocks per tile (k_render_hw<, PARTS>, k_render_hw.h): 4 while even
+// that many fit the chip's 2 048 wave slots at once (512 tiles), 2 up to 3 072 tiles (CEL_OPT_TILE_PARTS: 0 = this rule,
+// 1 / 2 / 4 = always that many).  Measured on one rank's strip of the benchmark field cut 8 ways (1 280 tiles): one wave per
+// tile 0.37 ms, two 0.21, four 0.25 -- every part pays ~10 us of tile set-up and slab traffic, and 5 120 blocks are 2.5
+// rounds of the chip.  The 32 x 64 layout's general kernel only; the star-tile kernels and the diagnostic instantiation
+// keep one wave per tile.
+static inline int tile_parts_of(const cel_ctx *c, const cel_images *im) {
+    if (im->TW != 32 || c->variant == 0) return 1;
+    if (c->tile_parts) return c->tile_parts;
+    const int64_t T = (int64_t)im->B * im->ntx * im->nty;
+    return T <= 512 ? 4 : (T <= 3072 ? 2 : 1);
+}
 static inline int tile_order_of(const cel_ctx *c, const cel_images *im) {
-    return ((int64_t)im->B * im->ntx * im->nty > 2048) ? c->tile_order : 0;
+    return ((int64_t)im->B * im->ntx * im->nty * tile_parts_of(c, im) > 2048) ? c->tile_order : 0;
 }
 
 static bool prof_alloc(Prof &p) {
@@ -494,6 +511,10 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         if (!(v >= 0.0) || v > 300.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TAIL_LOG_SOURCE must be in [0, 300] (NaN: the default)");
         c->tail_T = v;
         return CEL_OK;
+    case CEL_OPT_TILE_PARTS:
+        if (v != 0.0 && v != 1.0 && v != 2.0 && v != 4.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TILE_PARTS must be 0 (by the frame's size), 1, 2 or 4");
+        c->tile_parts = (int)v;
+        return CEL_OK;
     case CEL_OPT_PROFILE:
         if (v != 0.0 && v != 1.0 && v != 2.0 && v != 3.0) return fail(CEL_ERR_INVALID, "CEL_OPT_PROFILE must be 0, 1, 2 or 3");
         if (v != 0.0 && !prof_alloc(c->prof)) return fail(CEL_ERR_HIP, "CEL_OPT_PROFILE: cannot create the timing events");
@@ -546,6 +567,7 @@ int cel_ctx_get_option(cel_ctx *c, int key, double *v) {
     case CEL_OPT_KERNEL: *v = c->variant; return CEL_OK;
     case CEL_OPT_TAIL_LOG: *v = c->render_T; return CEL_OK;
     case CEL_OPT_TAIL_LOG_SOURCE: *v = c->tail_T; return CEL_OK;
+    case CEL_OPT_TILE_PARTS: *v = c->tile_parts; return CEL_OK;
     case CEL_OPT_PROFILE: *v = (double)c->profile; return CEL_OK;
     case CEL_OPT_TILE_ORDER: *v = (double)c->tile_order; return CEL_OK;
     case CEL_OPT_TILE_ROWS: *v = c->tile_rows; return CEL_OK;
@@ -567,7 +589,7 @@ int cel_images_destroy(cel_images *im) {
     void *ptrs[] = {im->d_bands, im->d_nelec, im->d_lambda, im->d_partials, im->d_llband, im->d_recs,
                     im->d_boxes, im->d_kind, im->d_status, im->d_tile_cnt, im->d_tile_nstar, im->d_tile_work, im->d_tile_cost, im->d_order, im->d_tile_off, im->d_lists, im->d_stats,
                     im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff, im->d_rate, im->d_snz, im->d_ssum,
-                    im->d_nnz, im->d_nzmode, im->d_nzoff, im->d_nzlist, im->d_btot};
+                    im->d_nnz, im->d_nzmode, im->d_nzoff, im->d_nzlist, im->d_btot, im->d_slabs, im->d_part_cnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (im->d_slice) (void)hipFree(im->d_slice);
@@ -1162,6 +1184,22 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         // general kernel has wave slots (STAR_TILES_MIN; measured break-even, tools/star_tiles_threshold.py); the
         // instantiation with counters / time stamps / ablations exists for the general kernel only
         const bool diag = a.timing || (c->debug & ~64);
+        const int parts = diag ? 1 : tile_parts_of(c, im);
+        a.slabs = nullptr; a.part_cnt = nullptr;
+        if (parts > 1) {
+            if (im->slabs_parts < parts) {
+                HIP_TRY(hipStreamSynchronize(st));
+                if (im->d_slabs) (void)hipFree(im->d_slabs);
+                im->d_slabs = nullptr; im->slabs_parts = 0;
+                HIP_TRY(hipMalloc((void **)&im->d_slabs, sizeof(double) * HW_TH * HW_TW * (size_t)T * parts));
+                if (!im->d_part_cnt) {
+                    HIP_TRY(hipMalloc((void **)&im->d_part_cnt, sizeof(int) * (size_t)T));
+                    HIP_TRY(hipMemsetAsync(im->d_part_cnt, 0, sizeof(int) * (size_t)T, st));
+                }
+                im->slabs_parts = parts;
+            }
+            a.slabs = im->d_slabs; a.part_cnt = im->d_part_cnt;
+        }
         const bool stars_only = im->TW == HW_TW && !diag && c->star_tiles && src->n_gal == 0 && im->star_one_segment &&
                                 c->variant != 0 && (c->star_tiles == 2 || T > STAR_TILES_MIN);    // (1 and 3: the rule; 3 = without the one-launch small path)
         pi = prof_slot(c, stars_only ? CEL_K_RENDER_STARS : CEL_K_RENDER);
@@ -1172,6 +1210,11 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
             // builds) ablations live in the second one
             if (diag) LAUNCH_EV(k_render_hw<true>, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
             else if (stars_only) LAUNCH_EV((k_render_stars<2, false>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
+            else if (parts > 1) {
+                const unsigned grid = (unsigned)(((T + 7) / 8) * 8 * parts);
+                if (parts == 4) LAUNCH_EV((k_render_hw<false, 4>), dim3(grid), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
+                else LAUNCH_EV((k_render_hw<false, 2>), dim3(grid), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
+            }
             else LAUNCH_EV(k_render_hw<false>, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
         }
         else if (im->TH == 64)

@@ -418,6 +418,8 @@ struct RenderArgs {
     int flags;        // CEL_RENDER_*
     int variant;      // 0 direct, 1 recurrence
     double tail_T;    // drop threshold (0 = never)
+    double *slabs;    // k_render_hw<, PARTS > 1>: PARTS accumulator tiles per render tile (16 KB each), and
+    int *part_cnt;    //   the tiles' arrival counters (zero between launches)
 };
 
 template <int TH>

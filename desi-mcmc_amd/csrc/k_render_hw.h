@@ -174,7 +174,8 @@ __device__ __forceinline__ bool star_setup(StarTab &ST, const BandDev *__restric
 // columns [Xa, Xa + CW) into an accumulator of CW doubles per row (the whole tile: Xa = X0, CW = HW_TW); a caller
 // that walks the same batch again (another part of the columns) puts a barrier between the walks.
 __device__ __forceinline__ void star_stage(const RenderArgs &a, StarTab &ST, const SrcRec *__restrict__ recs, int64_t off, int base, int nb,
-                                           int lane, int X0, int Y0, int strict) {
+                                           int lane, int X0, int Y0, int strict, int lfirst = 0, int lstride = 1 /* the batch's star j is
+                                           entry lfirst + lstride * (base + j) of the tile's list: one PART of a tile's stars (k_render_hw<, PARTS>) */) {
     __syncthreads();                   // the previous batch has been read
     // One lane per star loads it; the batch is then SORTED by the number of rows the star has on this tile
     // (descending; ties by list position).  The rank of a star is a count over the batch (<= 64 LDS
@@ -184,7 +185,7 @@ __device__ __forceinline__ void star_stage(const RenderArgs &a, StarTab &ST, con
     int4 bx4 = make_int4(0, 0, 0, 0);
     int nrows = -1;
     if (lane < nb) {
-        const SrcRec *rp = recs + a.lists[off + base + lane];
+        const SrcRec *rp = recs + a.lists[off + lfirst + (int64_t)lstride * (base + lane)];
         pp = *reinterpret_cast<const double2 *>(&rp->px);
         sc = rp->scale;
         bx4 = *reinterpret_cast<const int4 *>(&rp->x0);
@@ -319,10 +320,10 @@ __device__ __forceinline__ void star_walk(const RenderArgs &a, StarTab &ST, cons
 template <bool DIAG>
 __device__ __forceinline__ void star_pass(const RenderArgs &a, StarTab &ST, const double *__restrict__ et, double *__restrict__ acc,
                                           const SrcRec *__restrict__ recs, int64_t off, int nstar, int lane, int X0, int Y0,
-                                          int strict, unsigned &dbg_halfrows, unsigned &dbg_pairs) {
+                                          int strict, unsigned &dbg_halfrows, unsigned &dbg_pairs, int lfirst = 0, int lstride = 1) {
     for (int base = 0; base < nstar; base += 64) {
         const int nb = min(64, nstar - base);
-        star_stage(a, ST, recs, off, base, nb, lane, X0, Y0, strict);
+        star_stage(a, ST, recs, off, base, nb, lane, X0, Y0, strict, lfirst, lstride);
         if (DIAG && a.timing) { dbg_pairs += (unsigned)nb; }
         star_walk<DIAG, HW_TW>(a, ST, et, acc, nb, lane, X0, Y0, strict, dbg_halfrows);
     }
@@ -454,7 +455,18 @@ static_assert(sizeof(CompTab) >= 128 * sizeof(double), "log table must fit the c
 // CEL_OPT_TILE_TIMING and, in a -DCEL_ABLATE build only, the timing-only ablation switches of CEL_OPT_DEBUG:
 // the host launches it only when one of them is asked for, so the hottest loop of the library carries no
 // diagnostic branch, scalar register or counter (round 2: 8 flag tests inside per-source / per-batch code).
-template <bool DIAG>
+//
+// PARTS > 1 (round 5): a FRAME OF FEW TILES -- one rank's strip of an 8-way cut is 1 280 tiles for 2 048 wave slots, a real
+// 51 x 51 field is five -- finishes when its heaviest tile does, a single wave walking ~40 sources (0.35-0.43 ms for a
+// strip whose share of the work is 0.14 ms).  Here PARTS one-wave blocks share a tile: part p takes the stars and the
+// galaxies p, p + PARTS, ... of the tile's list (by list position: the dealing depends on the data only), accumulates
+// them in its own LDS tile and stores that as a 16 KB slab; the block that draws the last ticket of the tile's counter
+// adds the slabs IN PART ORDER -- whoever it is -- and runs the epilogue.  The hand-off is the in-launch split-K reduction
+// of the CDNA guide (plain slab stores, vmcnt drain, agent-scope release, relaxed agent fetch_add; the last arriver: agent
+// acquire, plain loads): correct wherever a tile's parts run.  A tile's parts sit on ONE XCD (block id -> XCD is round
+// robin: ids that agree mod 8 share an L2), where the slabs are read at twice the cross-XCD rate.  Values agree with the
+// one-wave form to rounding (a pixel's terms are added part by part), and are the same bits in every run.
+template <bool DIAG, int PARTS = 1>
 __global__ void __launch_bounds__(64)
 k_render_hw(RenderArgs a) {
     __shared__ double acc[HW_TH * HW_TW];
@@ -465,7 +477,14 @@ k_render_hw(RenderArgs a) {
     unsigned long long *const timing = DIAG ? a.timing : nullptr;
     const int dbg = DIAG ? CEL_ABLATE_BITS(a.flags) : 0;
     const unsigned long long t_start = (timing || a.cost) ? wall_clock64() : 0ull;
-    const int tile = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    int tpos = blockIdx.x, part = 0;
+    if (PARTS > 1) {                   // ids b, b + 8, ..., b + 8 (PARTS - 1) -- one XCD -- are the parts of one tile
+        const int q = blockIdx.x >> 3;
+        tpos = (q / PARTS) * 8 + (blockIdx.x & 7);
+        part = q % PARTS;
+        if (tpos >= a.B * a.ntx * a.nty) return;
+    }
+    const int tile = a.order ? a.order[tpos] : tpos;
     const int per_band = a.ntx * a.nty;
     const int b = tile / per_band;
     const int t = tile - b * per_band;
@@ -477,7 +496,10 @@ k_render_hw(RenderArgs a) {
 
     const int cnt = a.tile_cnt[tile];
     if (dbg & 8) return;             // ablation: launch + header load only
-    if (cnt == 0 && !timing) { hw_empty_tile(a, bd, tile, b, X0, Y0, lane, t_start); return; }
+    if (cnt == 0 && !timing) {
+        if (part == 0) hw_empty_tile(a, bd, tile, b, X0, Y0, lane, t_start);
+        return;
+    }
 
     et[lane] = exp2((double)lane * (1.0 / 64.0));
 #pragma unroll
@@ -503,25 +525,29 @@ k_render_hw(RenderArgs a) {
         __syncthreads();                       // et[] is written
         if (!star_setup(ST, bd, et, lane)) nstar = 0;   // a very sharp PSF component: general path (segments, direct fallback)
     }
+    const int nstar_all = nstar;               // the rest of the list begins behind ALL of the tile's stars
+    if (PARTS > 1) nstar = (nstar > part) ? (nstar - part + PARTS - 1) / PARTS : 0;       // this part's stars: entries part, part + PARTS, ...
     // (Requesting a star-only tile's nelec BEFORE the star pass, so that the loads land under the
     // arithmetic, was tried here -- before and after the first batch's record loads: a wave's loads
     // return in order -- and in a persistent, software-pipelined star kernel: slower in every form,
     // 0.179 / 0.180 / 0.205 against 0.171 ms on the dense star field -- DESIGN.md 5.)
     if (nstar > 0)
-        star_pass<DIAG>(a, *reinterpret_cast<StarTab *>(&T), et, acc, recs, off, nstar, lane, X0, Y0, strict, dbg_halfrows, dbg_pairs);
+        star_pass<DIAG>(a, *reinterpret_cast<StarTab *>(&T), et, acc, recs, off, nstar, lane, X0, Y0, strict, dbg_halfrows, dbg_pairs,
+                        PARTS > 1 ? part : 0, PARTS);
 
     const LaneConst lc = lane_consts(lane, bd);
     // the rest of the tile's list (everything when there was no star pass), 64 indices per coalesced
     // load; the next source's record is in flight while the current one is evaluated
-    const int64_t off2 = off + nstar;
-    const int nent = (dbg & 32) ? 0 : nent_all - nstar;
-    int idx64 = (lane < nent) ? a.lists[off2 + lane] : 0;
+    const int64_t off2 = off + nstar_all + (PARTS > 1 ? part : 0);
+    int nent = (dbg & 32) ? 0 : nent_all - nstar_all;
+    if (PARTS > 1) nent = (nent > part) ? (nent - part + PARTS - 1) / PARTS : 0;          // entries part, part + PARTS, ... of the rest
+    int idx64 = (lane < nent) ? a.lists[off2 + (int64_t)PARTS * lane] : 0;
     int recw_next = (nent > 0) ? rec_fetch(recs, __builtin_amdgcn_readlane(idx64, 0), lane) : 0;
 
     for (int e = 0; e < nent; e++) {
         const int recw = recw_next;
         if (e + 1 < nent) {
-            if (((e + 1) & 63) == 0) idx64 = (e + 1 + lane < nent) ? a.lists[off2 + e + 1 + lane] : 0;
+            if (((e + 1) & 63) == 0) idx64 = (e + 1 + lane < nent) ? a.lists[off2 + (int64_t)PARTS * (e + 1 + lane)] : 0;
             recw_next = rec_fetch(recs, __builtin_amdgcn_readlane(idx64, (e + 1) & 63), lane);
         }
         const RecU rec = rec_unpack(recw);
@@ -632,8 +658,40 @@ k_render_hw(RenderArgs a) {
         }
     }
 
+    if (PARTS > 1) {
+        // the tile's parts meet: this part's accumulator goes out as a slab; the last of the tile's parts to arrive adds all of
+        // them up in part order
+        __syncthreads();
+        double *slab = a.slabs + ((size_t)tile * PARTS + part) * (HW_TH * HW_TW);
+#pragma unroll
+        for (int r = 0; r < HW_TH / 2; r++) slab[r * 64 + lane] = acc[r * 64 + lane];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int ticket = 0;
+        if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ticket = __hip_atomic_fetch_add(&a.part_cnt[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != PARTS - 1) return;
+        if (lane == 0) {
+            __hip_atomic_store(&a.part_cnt[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch (zeroed when allocated)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        const double *s0 = a.slabs + (size_t)tile * PARTS * (HW_TH * HW_TW);
+#pragma unroll 4
+        for (int r = 0; r < HW_TH / 2; r++) {
+            double v = s0[r * 64 + lane];
+#pragma unroll
+            for (int p = 1; p < PARTS; p++) v += s0[(size_t)p * (HW_TH * HW_TW) + r * 64 + lane];
+            acc[r * 64 + lane] = v;
+        }
+    }
     hw_epilogue<false, DIAG>(a, acc, reinterpret_cast<double *>(&T), bd, tile, b, xi, Y0, lane, nullptr);
-    if (a.cost && lane == 0) a.cost[tile] = (int)min(wall_clock64() - t_start, 0x3fffffffull) + 1;
+    if (a.cost && lane == 0) a.cost[tile] = (int)min((wall_clock64() - t_start) * (unsigned long long)PARTS, 0x3fffffffull) + 1;
     if (timing && lane == 0) {
         timing[3 * (size_t)blockIdx.x + 0] = t_start;
         timing[3 * (size_t)blockIdx.x + 1] = wall_clock64();

@@ -28,6 +28,42 @@ def strip_rows(H, world, rank, align=TILE_ROWS):
     return min(lo * align, H), min(hi * align, H)
 
 
+def strip_edges(H, world, row_cost=None, align=TILE_ROWS):
+    """The world + 1 row edges of the strips: equal tile rows (strip_rows) without `row_cost`; with it -- the cost of every
+    `align`-row band of the frame, e.g. strip_cost_from_tiles() of a whole-frame render's measured tile durations -- the
+    cut that evens out the strips' summed cost (each strip at least one band).  Edges are multiples of `align`, the last
+    one H.  Every rank must cut from the SAME numbers (measure on one rank and broadcast, or use an estimate that does not
+    depend on the rank)."""
+    if row_cost is None:
+        return [strip_rows(H, world, r, align)[0] for r in range(world)] + [H]
+    cost = np.asarray(row_cost, dtype=np.float64)
+    nb = (H + align - 1) // align
+    if cost.shape != (nb,):
+        raise ValueError("row_cost must hold one value per %d-row band of the frame (%d)" % (align, nb))
+    if world > nb:
+        raise ValueError("%d strips for %d bands of %d rows" % (world, nb, align))
+    cum = np.concatenate([[0.0], np.cumsum(np.maximum(cost, 0.0) + 1e-12 * max(float(cost.max()), 1.0))])
+    edges = [0]
+    for r in range(1, world):
+        k = int(np.searchsorted(cum, cum[-1] * r / world))
+        # the nearer of the two band edges around the ideal cut, leaving every strip a band
+        if k > 0 and abs(cum[k - 1] - cum[-1] * r / world) <= abs(cum[min(k, nb)] - cum[-1] * r / world):
+            k -= 1
+        k = min(max(k, edges[-1] + 1), nb - (world - r))
+        edges.append(k)
+    edges.append(nb)
+    return [min(e * align, H) for e in edges]
+
+
+def strip_cost_from_tiles(tile_cost, B, nty, ntx, tile_rows, align=TILE_ROWS):
+    """per-`align`-row cost of the frame from per-tile costs laid out [band][tile row][tile column] (the render's
+    measured tile durations, ImageSet.tile_timing, or the binning pass's estimates): a tile row's cost spread over the
+    bands of `align` rows it covers"""
+    c = np.asarray(tile_cost, dtype=np.float64).reshape(B, nty, ntx).sum(axis=(0, 2))
+    per = max(tile_rows // align, 1)
+    return np.repeat(c / per, per)
+
+
 def field_shard(n_fields, world, rank):
     """Indices of the fields rank owns (round-robin: equal counts when world divides n_fields)."""
     return list(range(rank, n_fields, world))
@@ -45,8 +81,12 @@ class SourceDeal(object):
 
     kind = "replicated"
 
-    def __init__(self, S, world=1, rank=0, device=None, owner=None):
+    def __init__(self, S, world=1, rank=0, device=None, owner=None, solo=False):
         self.S, self.world, self.rank = int(S), int(world), int(rank)
+        # solo: this process plays rank `rank` of `world` WITHOUT a process group (bench.py --as-rank k --of N: one rank's step
+        # timed on one GPU).  The exchanges return this rank's own contribution in every rank's place -- the numbers of the
+        # other ranks' sources then go stale, which the timing of this rank's work does not depend on.
+        self.solo = bool(solo)
         if not 0 <= self.rank < self.world:
             raise ValueError("rank %d outside a world of %d" % (rank, world))
         self.device = device
@@ -73,6 +113,8 @@ class SourceDeal(object):
         import torch
         import torch.distributed as dist
         send = np.ascontiguousarray(send, dtype=np.float64)
+        if self.solo:
+            return np.broadcast_to(send, (self.world,) + send.shape).copy()
         if dist.get_backend() != "nccl":
             t = torch.from_numpy(send)
             recv = torch.empty((self.world * t.shape[0], t.shape[1]), dtype=t.dtype)      # rank-major concatenation
@@ -99,8 +141,8 @@ class SourceDeal(object):
         arr = np.ascontiguousarray(arr, dtype=np.float64)
         if arr.ndim != 2 or arr.shape[0] != self.S:
             raise ValueError("merge takes an (S, k) array")
-        if self.world == 1:
-            return arr.copy()
+        if self.world == 1 or self.solo:
+            return arr.copy()                 # (solo: the other ranks' rows stay as they are)
         send = np.zeros((self.per_rank, arr.shape[1]))
         send[:self.mine.size] = arr[self.mine]
         got = self._gather(send)
@@ -137,16 +179,21 @@ class StripDeal(SourceDeal):
 
     kind = "strips"
 
-    def __init__(self, rows, H, world=1, rank=0, halo=0, device=None):
+    def __init__(self, rows, H, world=1, rank=0, halo=0, device=None, edges=None, solo=False):
         rows = np.asarray(rows, dtype=np.float64)
         if int(world) > -(-int(H) // TILE_ROWS):
             raise ValueError("StripDeal: %d ranks for a frame of %d rows = %d tile rows: a rank would own no rows"
                              % (world, H, -(-int(H) // TILE_ROWS)))
-        edges = np.array([strip_rows(H, world, r)[1] for r in range(world)])
-        owner = np.minimum(np.searchsorted(edges, np.clip(np.floor(rows), 0, H - 1), side="right"), world - 1)
-        SourceDeal.__init__(self, rows.shape[0], world, rank, device=device, owner=owner)
+        # edges: the world + 1 strip edges (strip_edges: equal tile rows, or evened out by a measured cost); the same on every rank
+        edges = strip_edges(H, world) if edges is None else [int(e) for e in edges]
+        if len(edges) != world + 1 or edges[0] != 0 or edges[-1] != int(H) or any(b <= a for a, b in zip(edges, edges[1:])):
+            raise ValueError("StripDeal: edges must be %d increasing rows from 0 to %d" % (world + 1, H))
+        ends = np.array(edges[1:])
+        owner = np.minimum(np.searchsorted(ends, np.clip(np.floor(rows), 0, H - 1), side="right"), world - 1)
+        SourceDeal.__init__(self, rows.shape[0], world, rank, device=device, owner=owner, solo=solo)
         self.H = int(H)
-        self.strip = strip_rows(H, world, rank)
+        self.edges = edges
+        self.strip = (edges[rank], edges[rank + 1])
         halo = int(-(-int(halo) // TILE_ROWS) * TILE_ROWS)               # whole tiles
         self.window = (max(0, self.strip[0] - halo), min(self.H, self.strip[1] + halo))
 

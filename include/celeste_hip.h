@@ -73,6 +73,12 @@ enum {
                               (the per-source kernels': CEL_OPT_TAIL_LOG_SOURCE).  CEL_TAIL_LOG in the
                               environment, when inside [0, 300], is the initial value of both       */
     CEL_OPT_TAIL_LOG_SOURCE = 12, /* the per-source kernels' threshold alone (set / get; NaN: its default, 32) */
+    CEL_OPT_TILE_PARTS = 13, /* how many one-wave blocks share a render tile of the general 32 x 64 kernel.  0 (default) = by
+                               the frame's size: 4 for at most 512 tiles, 2 for at most 3 072, else 1 -- a frame of few tiles
+                               (one rank's row strip of a field cut 8 ways, a 51 x 51 real field) finishes when its heaviest
+                               tile does; with PARTS blocks per tile each takes every PARTS-th source of the tile's list and the
+                               last to finish adds their accumulators in part order.  1 / 2 / 4 = always that many.  Values
+                               agree to rounding between settings and are reproducible bit for bit under each */
     CEL_OPT_PROFILE = 3,   /* 1 = bracket every kernel launch with HIP events; 2 = the evaluating kernels only (render,
                               conditional likelihoods, split, mass, E-step: not the prep / binning / reduction launches
                               around a render -- an event pair costs the host ~10 us per launch); 3 = as 2 on a SAMPLE of

@@ -234,7 +234,7 @@ def test_field_render_accepts_profile_route_sources(cel, orc, imgs):
             p, yl, xl = orc.galaxy_prof_psf_image(B[b], 51, 51, profs[n], Rs[n], radec[n])
             if p is not None:
                 want[yl[0]:yl[1], xl[0]:xl[1]] += counts[n, b] * p
-        np.testing.assert_allclose(lam[b], want, rtol=1e-10)
+        np.testing.assert_allclose(lam[b], want, rtol=1e-9)        # (the shipping drop threshold of the field render: T = 24)
         np.testing.assert_allclose(llb[b], orc.poisson_loglike(rec["nelec"][b], want), rtol=1e-11)
 
 

@@ -3,9 +3,10 @@
 Tolerances.  north_star: 1e-6 relative for fp64 model pixels and log-lik.  The tests assert
 tighter bounds that the design guarantees:
   RT_STAMP 1e-10  unit-flux stamps (direct evaluator) against goldens / oracle
-  RT_LAM   1e-10  model pixels lambda (both evaluators) -- holds at the library's SHIPPING drop threshold (T = 24 for the
-                  field render: a dropped component is < eps*e^-24 = 3.8e-11 eps on its tile) on every field of this file but
-                  the crowded ones, which assert RT_LAM_DEFAULT = 1e-9 at the default and RT_LAM under tail_log(ctx, "strict")
+  RT_LAM   1e-9   model pixels lambda at the library's SHIPPING drop threshold (T = 24 for the field render: a dropped
+                  component is < eps*e^-24 = 3.8e-11 eps on its tile; a pixel under a dozen galaxies' tails collects a few e-10)
+  RT_LAM_STRICT 1e-10  the same under tail_log(ctx, "strict") (T = 32), with the direct evaluator, and wherever nothing is
+                  dropped: star-only fields (the star passes keep all three components)
   RT_LL    1e-11  log-likelihoods
 The suite runs at the shipping defaults (tests/conftest.py sets no threshold); one strict variant per kernel family:
 test_mixed_field_vs_oracle[recurrence-1-strict] and test_config3_full_vs_oracle (k_render_hw),
@@ -20,8 +21,9 @@ from conftest import load_golden, tail_log, unpack_ragged
 
 pytestmark = pytest.mark.gpu
 
-RT_STAMP, RT_LAM, RT_LL = 1e-10, 1e-10, 1e-11
-RT_LAM_DEFAULT = 1e-9        # crowded / full-size fields at the shipping threshold (T = 24)
+RT_STAMP, RT_LAM, RT_LL = 1e-10, 1e-9, 1e-11
+RT_LAM_STRICT = 1e-10
+RT_LAM_DEFAULT = RT_LAM
 BANDS = ["u", "g", "r", "i", "z"]
 
 
@@ -170,7 +172,7 @@ def test_mini_field_golden(cel, ctx, kernel, tail):
         sset = cel.SourceSet(ctx, 12, 5).set(g["is_gal"], g["radec"], counts, g["shape"])
         ll, llb = iset.render(sset, loglik=True)
         lam = iset.model_images()
-        rt = RT_LAM if tail != 25.0 else 1e-8
+        rt = 1e-8 if tail == 25.0 else (RT_LAM if tail == "default" else RT_LAM_STRICT)
         np.testing.assert_allclose(lam, g["lam"], rtol=rt)
         np.testing.assert_allclose(llb, g["ll_band"], rtol=RT_LL)
         np.testing.assert_allclose(ll, g["ll"], rtol=RT_LL)
@@ -199,7 +201,7 @@ def test_reference_api_on_mini_field(cel, stamp_images):
     idx = g["star_idx"]
     stars = [cel.SrcParams(u=g["radec"][s], a=0, fluxes=dict(zip(BANDS, g["flux"][s]))) for s in idx]
     for b in (0, 3):
-        np.testing.assert_allclose(celeste.gen_model_image(stars, imgs[b]), g["star_lam"][b], rtol=RT_LAM)
+        np.testing.assert_allclose(celeste.gen_model_image(stars, imgs[b]), g["star_lam"][b], rtol=RT_LAM_STRICT)
     np.testing.assert_allclose(celeste.celeste_likelihood_multi_image(stars, imgs), g["star_ll"], rtol=RT_LL)
     # mixed list through the extended gen_model_image (Q3)
     srcs = [cel.SrcParams(u=g["radec"][s], a=int(g["is_gal"][s]), fluxes=g["flux"][s], theta=g["shape"][s, 0],
@@ -217,12 +219,16 @@ def test_reference_api_on_mini_field(cel, stamp_images):
     # responsibilities sum to one (celeste.py:222-234)
     layers = celeste.gen_src_prob_layers(srcs, imgs[2])
     assert layers.shape == (13, H, W)
-    np.testing.assert_allclose(layers.sum(axis=0), 1.0, rtol=1e-12)
+    # (the layers are stamps at the per-source threshold, their denominator the model image at the field render's: 1e-9 at the
+    # shipping defaults, 1e-12 when both run at T = 32)
+    np.testing.assert_allclose(layers.sum(axis=0), 1.0, rtol=1e-9)
+    with tail_log(cel.default_context(0), "strict"):
+        np.testing.assert_allclose(celeste.gen_src_prob_layers(srcs, imgs[2]).sum(axis=0), 1.0, rtol=1e-12)
     # epsilon is updatable without re-upload (models.py:156-160)
     old = imgs[1].epsilon
     imgs[1].epsilon = old * 1.5
     lam = celeste.gen_model_image(srcs, imgs[1])
-    np.testing.assert_allclose(lam, g["lam"][1] + 0.5 * old, rtol=1e-12)
+    np.testing.assert_allclose(lam, g["lam"][1] + 0.5 * old, rtol=RT_LAM)        # (what is dropped is measured against the sky level)
     imgs[1].epsilon = old
 
 
@@ -237,7 +243,7 @@ def test_config1_real_stamps(cel, stamp_images):
     np.testing.assert_allclose(celeste.celeste_likelihood_multi_image(srcs, imgs), g["ll"], rtol=RT_LL)
     star = cel.SrcParams(u=g["one_u"], a=0, fluxes=dict(zip(BANDS, g["one_flux"])))
     np.testing.assert_allclose(celeste.gen_src_image(star, imgs[2]), g["one_patch"], rtol=RT_STAMP)
-    np.testing.assert_allclose(celeste.gen_model_image([star], imgs[2]), g["one_lam"], rtol=RT_LAM)
+    np.testing.assert_allclose(celeste.gen_model_image([star], imgs[2]), g["one_lam"], rtol=RT_LAM_STRICT)
     np.testing.assert_allclose(celeste.celeste_likelihood([star], imgs[2]), g["one_ll"], rtol=RT_LL)
 
 
@@ -273,9 +279,9 @@ def test_every_real_field_through_the_reference_api(cel):
             np.testing.assert_allclose(im.logdets, f["rec"]["logdets"][b], rtol=1e-12)
             lam = celeste.gen_model_image(srcs, im)
             if f["lam"] is not None:
-                np.testing.assert_allclose(lam, f["lam"][b], rtol=RT_LAM, err_msg=f["name"])
+                np.testing.assert_allclose(lam, f["lam"][b], rtol=RT_LAM_STRICT, err_msg=f["name"])
             else:
-                np.testing.assert_allclose(lam[::4, ::4], f["lam_sub"][b], rtol=RT_LAM, err_msg=f["name"])
+                np.testing.assert_allclose(lam[::4, ::4], f["lam_sub"][b], rtol=RT_LAM_STRICT, err_msg=f["name"])
             np.testing.assert_allclose(celeste.celeste_likelihood(srcs, im), f["ll_band"][b], rtol=RT_LL, err_msg=f["name"])
             for s, q in enumerate(srcs):
                 patch, yl, xl = celeste.gen_point_source_psf_image(q.u, im)
@@ -308,7 +314,7 @@ def test_small_star_path_scans_a_catalogue_of_thousands(cel, ctx, orc):
     ctx.profile(False)
     lam = f.images.model_images()
     o_lam, o_ll, o_st = orc.render_field(oracle_bands(f), f.H, f.W, f.src["type"], f.src["radec"], f.src["counts"], f.src["shape"], f.nelec)
-    np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM)
+    np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM_STRICT)
     np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
     st = f.images.stats()
     assert st["n_srcpix"] == o_st["n_srcpix"]
@@ -379,7 +385,7 @@ def test_config2_stars_512_vs_oracle(cel, ctx, orc, kernel):
         lam = f.images.model_images()
         o_lam, o_ll, o_st = orc.render_field(oracle_bands(f), f.H, f.W, f.src["type"], f.src["radec"],
                                              f.src["counts"], f.src["shape"], f.nelec)
-        np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM)
+        np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM_STRICT)
         np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
         st = f.images.stats()
         assert st["n_srcpix"] == o_st["n_srcpix"] and st["n_gauss"] == o_st["n_gauss"]
@@ -404,7 +410,7 @@ def test_mixed_field_vs_oracle(cel, ctx, orc, kernel, layout, tail):
         lam = f.images.model_images()
         o_lam, o_ll, o_st = orc.render_field(oracle_bands(f), f.H, f.W, f.src["type"], f.src["radec"],
                                              f.src["counts"], f.src["shape"], f.nelec)
-        np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM)
+        np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM_STRICT if (tail == "strict" or kernel == "direct") else RT_LAM)
         np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
         assert f.images.stats()["n_srcpix"] == o_st["n_srcpix"]
     finally:
@@ -515,8 +521,8 @@ def test_full_size_properties(cel, ctx, big_field):
         lam3 = f.images.model_images()
     finally:
         ctx.set_kernel("recurrence")
-    np.testing.assert_allclose(lam1, lam3, rtol=1e-11)
-    np.testing.assert_allclose(llb1, llb3, rtol=1e-12)
+    np.testing.assert_allclose(lam1, lam3, rtol=RT_LAM)             # (the recurrence form at the shipping threshold; the direct form drops nothing)
+    np.testing.assert_allclose(llb1, llb3, rtol=1e-11)
     # (4) linearity in the source set: (lam(A) - eps) + (lam(B) - eps) == lam(A u B) - eps
     half = f.S // 2
     eps = f.bands[:, 0][:, None, None]
@@ -571,7 +577,7 @@ def test_star_field_full_size_star_tile_kernel(cel, ctx, orc):
         np.testing.assert_allclose(llb0, llb1, rtol=1e-13)
         o_lam, o_ll, o_st = orc.render_field(oracle_bands(f), f.H, f.W, f.src["type"], f.src["radec"],
                                              f.src["counts"], f.src["shape"], f.nelec)
-        np.testing.assert_allclose(lam1, o_lam, rtol=RT_LAM)
+        np.testing.assert_allclose(lam1, o_lam, rtol=RT_LAM_STRICT)
         np.testing.assert_allclose(llb1, o_ll, rtol=RT_LL)
         assert f.images.stats()["n_srcpix"] == o_st["n_srcpix"]
     finally:
@@ -614,7 +620,7 @@ def test_config3_full_vs_oracle(cel, ctx, orc, big_field):
         ll, llb = f.images.render(f.sources, loglik=True)
         lam = f.images.model_images()
     for b in range(f.B):
-        np.testing.assert_allclose(lam[b], o_lam[b], rtol=RT_LAM)
+        np.testing.assert_allclose(lam[b], o_lam[b], rtol=RT_LAM_STRICT)
     np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
     np.testing.assert_allclose(ll, o_ll.sum(), rtol=RT_LL)
     del lam
@@ -671,17 +677,28 @@ def test_full_size_gibbs_kernels_properties(cel, ctx, big_field):
     np.testing.assert_allclose(iso_r, iso_d, rtol=RT_LL)
     np.testing.assert_allclose(xt, xt_d, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(mass, mass_d, rtol=1e-10)
-    np.testing.assert_allclose(nz, nz_d, rtol=1e-12)
+    np.testing.assert_allclose(nz, nz_d, rtol=1e-10)                # (the sky term is nelec * eps / lambda summed: lambda at the render's threshold)
 
 
-@pytest.mark.parametrize("world,frac_gal", [(2, 0.5), (3, 0.5), (3, 0.0)])
-def test_row_strips_tile_the_frame(cel, ctx, world, frac_gal):
+@pytest.mark.parametrize("world,frac_gal,tail", [(2, 0.5, "default"), (2, 0.5, "strict"), (3, 0.5, "default"), (3, 0.0, "default")])
+def test_row_strips_tile_the_frame(cel, ctx, world, frac_gal, tail):
     """strong-scaling partition on ONE gpu: strips rendered through cel_images_set_window must
     reproduce the whole frame's model pixels, and their ll partials must add up.  frac_gal = 0: a star-only catalogue on a
     small frame -- frame and strips take the one-launch path (k_small_stars), whose blocks apply the window themselves"""
     from desi_mcmc_amd import dist, synth
     H, W = 200, 300
     f = synth.SyntheticField(ctx, 300, 2, H, W, frac_gal=frac_gal, seed=11)
+    if tail == "strict":
+        with tail_log(ctx, "strict"):
+            _row_strips_body(cel, ctx, f, H, W, world, frac_gal, 1e-12)
+    else:
+        # strips whose first row is no multiple of the 64-row tile cut the frame into other tiles: the drop rule (a component
+        # below eps * e^-24 on ITS tile) then skips other components -- 1e-9 at the shipping threshold, rounding at T = 32
+        _row_strips_body(cel, ctx, f, H, W, world, frac_gal, 1e-12 if frac_gal == 0.0 else RT_LAM)
+
+
+def _row_strips_body(cel, ctx, f, H, W, world, frac_gal, rt):
+    from desi_mcmc_amd import dist
     ctx.profile(True)
     ll, llb = f.images.render(f.sources, loglik=True)
     assert ctx.profile_get("small_stars")[1] == (1 if frac_gal == 0.0 else 0)
@@ -696,11 +713,64 @@ def test_row_strips_tile_the_frame(cel, ctx, world, frac_gal):
         strip.set_window(y0, H)
         _, p = strip.render(f.sources, loglik=True)
         # same pixels, same tiles, same source order; only the row origin of the fp arithmetic moves
-        np.testing.assert_allclose(strip.model_images(), lam[:, y0:y1], rtol=1e-12)
+        np.testing.assert_allclose(strip.model_images(), lam[:, y0:y1], rtol=rt)
         parts += p
-    np.testing.assert_allclose(parts, llb, rtol=1e-13)
+    np.testing.assert_allclose(parts, llb, rtol=1e-13 if rt <= 1e-12 else 1e-11)
     with pytest.raises(ValueError):
         cel.ImageSet(ctx, f.bands, 64, W).set_window(150, H)       # window does not fit the frame
+
+
+@pytest.mark.parametrize("frac_gal", [0.6, 0.05])
+def test_tile_parts_agree_and_each_is_reproducible(cel, ctx, orc, frac_gal):
+    """CEL_OPT_TILE_PARTS: a frame of few tiles is rendered by 2 or 4 one-wave blocks per tile (k_render_hw<, PARTS>: every
+    PARTS-th entry of the tile's list each, accumulator slabs added in part order by the last block to arrive).  Against the
+    oracle at the strict threshold; 1, 2 and 4 parts agree to rounding; each is the same bits run after run (50 launches:
+    whoever arrives last adds the slabs in the same order); a row window, a ragged frame, crowded tiles (more stars than one
+    batch of 64, more sources than one index window), tiles without any source; the model image alone (no log-likelihood)."""
+    from desi_mcmc_amd import synth
+    L = cel._lib
+    H, W, B, S = 333, 500, 3, 2600
+    bands = synth.make_bands(H, W, B)
+    src = synth.make_sources(S, H, W, bands, frac_gal=frac_gal, seed=21)
+    src["radec"][:400] = synth.pixel2equa(bands[0], np.column_stack([np.random.RandomState(1).uniform(40, 90, 400),
+                                                                    np.random.RandomState(2).uniform(100, 160, 400)]))    # a crowded corner
+    nelec = np.random.RandomState(3).poisson(900.0, size=(B, H, W)).astype(float)
+    got = {}
+    try:
+        for parts in (1, 2, 4):
+            ctx.set_option(L.CEL_OPT_TILE_PARTS, parts)
+            assert ctx.get_option(L.CEL_OPT_TILE_PARTS) == parts
+            with tail_log(ctx, "strict"):
+                iset = cel.ImageSet(ctx, bands, H, W, nelec=nelec)
+                sset = cel.SourceSet(ctx, S, B).set(src["type"], src["radec"], src["counts"], src["shape"])
+                ll, llb = iset.render(sset, loglik=True)
+                lam = iset.model_images()
+                for _ in range(50):
+                    ll2, llb2 = iset.render(sset, loglik=True)
+                    assert np.array_equal(llb, llb2)
+                assert np.array_equal(lam, iset.model_images())
+                iset.render(sset, loglik=False)                      # gen_model_image alone
+                assert np.array_equal(lam, iset.model_images())
+                win = cel.ImageSet(ctx, bands, 128, W, nelec=nelec[:, 64:192])
+                win.set_window(64, H)
+                _, llw = win.render(sset, loglik=True)
+                got[parts] = (lam, llb, win.model_images(), llw)
+        with pytest.raises(ValueError):
+            ctx.set_option(L.CEL_OPT_TILE_PARTS, 3)
+    finally:
+        ctx.set_option(L.CEL_OPT_TILE_PARTS, 0)
+    ob = bands.copy()
+    ob[:, 36] = [iset.band(b)[36] for b in range(B)]
+    o_lam, o_ll, _ = orc.render_field(ob, H, W, src["type"], src["radec"], src["counts"], src["shape"], nelec)
+    for parts in (1, 2, 4):
+        lam, llb, wlam, llw = got[parts]
+        np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM_STRICT)
+        np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
+        np.testing.assert_allclose(lam, got[1][0], rtol=1e-13)
+        np.testing.assert_allclose(wlam, got[1][2], rtol=1e-13)
+        np.testing.assert_allclose(wlam, lam[:, 64:192], rtol=1e-12)     # (64-row aligned: the same tiles, the same drops)
+        np.testing.assert_allclose(llw, got[1][3], rtol=1e-13)
+    assert not np.array_equal(got[4][0], got[1][0])                 # the parts do change the order of the additions
 
 
 def test_estep_statistics_and_model_classes(cel, orc):
@@ -728,7 +798,7 @@ def test_estep_statistics_and_model_classes(cel, orc):
     oxt, oms, onz = orc.estep_stats(ob, H, W, g["is_gal"], g["radec"], counts, g["shape"], g["nelec"])
     np.testing.assert_allclose(X, oxt, rtol=1e-10)
     np.testing.assert_allclose(F, np.minimum(1.0, oms), rtol=1e-10)
-    np.testing.assert_allclose(X.sum(axis=0) + Z, g["nelec"].sum(axis=(1, 2)), rtol=1e-12)
+    np.testing.assert_allclose(X.sum(axis=0) + Z, g["nelec"].sum(axis=(1, 2)), rtol=1e-10)      # (stamps at T = 32 over a model image at T = 24)
     # model classes: render_model_image / img_log_likelihood / log_likelihood
     m = models.Celeste()
     m.initialize_sources(init_src_params=srcs)
@@ -741,7 +811,8 @@ def test_estep_statistics_and_model_classes(cel, orc):
     wo = m.render_model_image(imgs[2], exclude=m.srcs[3])
     p, yl, xl = m.srcs[3].compute_model_patch(imgs[2])
     diff = full - wo
-    np.testing.assert_allclose(diff[int(yl[0]):int(yl[1]), int(xl[0]):int(xl[1])], p, rtol=1e-9, atol=1e-9)
+    # (a difference of two field renders: each within RT_LAM of ITS pixels' values)
+    np.testing.assert_allclose(diff[int(yl[0]):int(yl[1]), int(xl[0]):int(xl[1])], p, rtol=1e-9, atol=2 * RT_LAM * float(full.max()))
     # caller-imposed limits crop to the box (models.py:99-100)
     sub = m.render_model_image(imgs[2], xlim=(10, 60), ylim=(5, 50))
     assert sub.shape == (45, 50)
@@ -800,9 +871,9 @@ def test_crowded_field_exercises_list_chunking_and_regrowth(cel, ctx, orc, tail)
             o_lam, o_ll, o_st = orc.render_field(ob, H, W, src["type"], src["radec"], src["counts"], src["shape"], nelec)
             assert st["n_srcpix"] == o_st["n_srcpix"]
             lam1, llb1 = lam, llb
-        np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM if tail == "strict" else RT_LAM_DEFAULT)
+        np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM_STRICT if tail == "strict" else RT_LAM)
         np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
-    np.testing.assert_allclose(lam, lam1, rtol=1e-11 if tail == "strict" else RT_LAM_DEFAULT)
+    np.testing.assert_allclose(lam, lam1, rtol=1e-11 if tail == "strict" else RT_LAM)
 
 
 def test_abi_error_paths(cel, ctx):
@@ -1286,14 +1357,21 @@ def test_fuzz_random_fields_vs_oracle(cel, ctx, orc, seed):
     finally:
         ctx.set_option(cel._lib.CEL_OPT_TILE_LAYOUT, 1)
     sset = cel.SourceSet(ctx, S, B).set(typ, radec, counts, shape)
-    ll, llb = iset.render(sset, loglik=True)
+    # the arithmetic at the extremes, so at the STRICT threshold (the same fields at the shipping one:
+    # test_fuzz_random_fields_vs_oracle_default_threshold, at what the rule guarantees)
+    ctx.set_tail_log("strict")
+    try:
+        ll, llb = iset.render(sset, loglik=True)
+        lam_got = iset.model_images()
+        xt, ms, nz = iset.estep_stats(sset)
+    finally:
+        ctx.set_tail_log("default")
     ob = bands.copy()
     ob[:, 36] = [iset.band(b)[36] for b in range(B)]
     o_lam, o_ll, o_st = orc.render_field(ob, H, W, typ, radec, counts, shape, nelec)
-    np.testing.assert_allclose(iset.model_images(), o_lam, rtol=RT_LAM)
+    np.testing.assert_allclose(lam_got, o_lam, rtol=RT_LAM_STRICT)
     np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
     assert iset.stats()["n_srcpix"] == o_st["n_srcpix"]
-    xt, ms, nz = iset.estep_stats(sset)
     oxt, oms, onz = orc.estep_stats(ob, H, W, typ, radec, counts, shape, nelec)
     np.testing.assert_allclose(xt, oxt, rtol=1e-10, atol=1e-9)
     np.testing.assert_allclose(ms, oms, rtol=1e-10, atol=1e-13)
@@ -1623,7 +1701,7 @@ def test_fuzz_star_fields_vs_oracle(cel, ctx, orc, seed):
     iset.set_nelec(nelec)
     ll, llb = iset.render(ss, loglik=True)
     o_lam, o_ll, o_st = orc.render_field(ob, H, W, typ, radec, counts, np.zeros((S, 4)), nelec)
-    np.testing.assert_allclose(iset.model_images(), o_lam, rtol=RT_LAM)
+    np.testing.assert_allclose(iset.model_images(), o_lam, rtol=RT_LAM_STRICT)
     np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
     assert iset.stats()["n_srcpix"] == o_st["n_srcpix"]
     # the split conserves every photon on the same (stars-first) lists
@@ -1693,7 +1771,7 @@ def test_star_tile_kernel_vs_oracle_and_general_kernel(cel, ctx, orc, seed):
         fell_back = (ns5, ng5) == (1, 1)
         assert (ns5, ng5) == ((0, 1) if seed in (3, 4) else (1, 0)) or (fell_back and S >= 256)
         o_lam, o_ll, o_st = orc.render_field(ob, H, W, typ, radec, counts, np.zeros((S, 4)), nelec)
-        np.testing.assert_allclose(lam5, o_lam, rtol=RT_LAM)
+        np.testing.assert_allclose(lam5, o_lam, rtol=RT_LAM_STRICT)
         np.testing.assert_allclose(llb5, o_ll, rtol=RT_LL)
         np.testing.assert_allclose(lam5, lam0, rtol=1e-13)
         np.testing.assert_allclose(llb5, llb0, rtol=1e-13)
@@ -1717,7 +1795,7 @@ def test_star_tile_kernel_vs_oracle_and_general_kernel(cel, ctx, orc, seed):
         ll2, llb2, ns2, ng2 = run(2)
         lam2 = iset.model_images()
         assert (ns2, ng2) == ((0, 1) if seed in (3, 4) else (1, 0))      # 3, 4: exponents beyond the one-segment bound
-        np.testing.assert_allclose(lam2, o_lam, rtol=RT_LAM)
+        np.testing.assert_allclose(lam2, o_lam, rtol=RT_LAM_STRICT)
         np.testing.assert_allclose(llb2, o_ll, rtol=RT_LL)
         np.testing.assert_allclose(lam2, lam0, rtol=1e-13)
         np.testing.assert_allclose(llb2, llb0, rtol=1e-13)
