@@ -275,6 +275,117 @@ def cpu_baseline(field, nsample, orc):
     return out
 
 
+
+# ---- sustained runs: seconds, not milliseconds ------------------------------------------------------
+class SmiSampler(object):
+    """clock and power of the GPU sampled in a thread while a long leg runs: sysfs where readable (pp_dpm_sclk's starred
+    level, hwmon power1_average / power1_input), `rocm-smi -c -P --json` otherwise; a box that offers neither yields []"""
+
+    def __init__(self, device=0, period=0.5):
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self._t0 = time.perf_counter()
+        self._dev = self._find_sysfs(device)
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _find_sysfs(device):
+        """the sysfs directory of HIP device `device`: by its PCI address (a box shows every card of the host under
+        /sys/class/drm, the process sees one of them as device 0)"""
+        try:
+            import torch
+            p = torch.cuda.get_device_properties(device)
+            bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+            d = os.path.join("/sys/bus/pci/devices", bdf)
+            return d if os.path.exists(os.path.join(d, "pp_dpm_sclk")) else None
+        except Exception:
+            return None
+
+    def _read_sysfs(self):
+        import glob
+        out = {}
+        try:
+            for line in open(os.path.join(self._dev, "pp_dpm_sclk")):
+                if "*" in line:
+                    out["sclk_mhz"] = float(line.split(":")[1].strip().split("M")[0])
+            for name in ("power1_average", "power1_input"):
+                hw = glob.glob(os.path.join(self._dev, "hwmon", "hwmon*", name))
+                if hw:
+                    out["power_w"] = float(open(hw[0]).read()) / 1e6
+                    break
+        except Exception:
+            return None
+        return out or None
+
+    @staticmethod
+    def _read_smi():
+        import subprocess
+        try:
+            r = subprocess.run(["rocm-smi", "-c", "-P", "--json"], capture_output=True, text=True, timeout=5)
+            d = json.loads(r.stdout)
+            card = d[sorted(d)[0]]
+            out = {}
+            for k, v in card.items():
+                kl = k.lower()
+                if "sclk" in kl and "mhz" in str(v).lower():
+                    out["sclk_mhz"] = float(str(v).lower().replace("(", "").split("mhz")[0])
+                if "power" in kl and "socket" in kl or "average graphics package power" in kl:
+                    try:
+                        out["power_w"] = float(v)
+                    except ValueError:
+                        pass
+            return out or None
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            smp = self._read_sysfs() if self._dev else None
+            if smp is None:
+                smp = self._read_smi()
+            if smp:
+                smp["source"] = "sysfs " + os.path.basename(self._dev) if self._dev else "rocm-smi (first card listed)"
+                smp["t_s"] = round(time.perf_counter() - self._t0, 3)
+                self.samples.append(smp)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._th.join(timeout=10)
+
+
+def sustained_leg(torch, step, seconds=None, steps=None, bucket_s=0.5, sync_every=1):
+    """back-to-back steps for `seconds` of wall time (or exactly `steps`), ms per step in buckets of bucket_s, SMI samples
+    beside them: what the clocks do over a run longer than the contract's 20 steps"""
+    buckets, n_tot = [], 0
+    with SmiSampler() as smi:
+        torch.cuda.synchronize()
+        t_start = t_b = time.perf_counter()
+        n_b = 0
+        while True:
+            step()
+            n_b += 1
+            n_tot += 1
+            now = time.perf_counter()
+            done = (steps is not None and n_tot >= steps) or (seconds is not None and now - t_start >= seconds)
+            if now - t_b >= bucket_s or done:
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                buckets.append({"t_s": round(now - t_start, 3), "steps": n_b, "ms_per_step": (now - t_b) / n_b * 1e3})
+                t_b, n_b = now, 0
+            if done:
+                break
+        total = time.perf_counter() - t_start
+    ms = [b["ms_per_step"] for b in buckets]
+    return {"wall_s": total, "steps": n_tot, "ms_per_step": total / n_tot * 1e3, "bucket_s": bucket_s,
+            "ms_per_step_first_bucket": ms[0], "ms_per_step_last_bucket": ms[-1], "ms_per_step_min_bucket": min(ms), "ms_per_step_max_bucket": max(ms),
+            "buckets": buckets, "smi": smi.samples,
+            "smi_note": "sclk / socket power sampled every 0.5 s in a thread (sysfs, else rocm-smi); [] when the box exposes neither"}
+
 # ---- render workloads (configs[1], configs[2] and the star-only fields) ---------------------------------
 def run_render(args, env):
     torch, cel, dist, synth, _lib = env["torch"], env["cel"], env["dist"], env["synth"], env["_lib"]
@@ -375,8 +486,10 @@ def run_render(args, env):
                      "traffic_source": pmc["source"] if pmc else pmc_note,
                      "kernel": render_kernel, "kernel_ms": t_render, "launches": n_render,
                      "algorithmic_bytes_per_launch": alg_bytes},
-        "work": {"n_srcpix_per_step": n_srcpix_all, "n_gauss_per_step": n_gauss_all,
-                 "gauss_evals_per_s": n_gauss_all * args.steps / dt_max,
+        # gauss_evals_per_s is put on the EVALUATED count below (extra_render_legs counts it); until then, and for the other
+        # workloads, the nominal K x box-area count carries its own name
+        "work": {"n_srcpix_per_step": n_srcpix_all, "n_gauss_per_step_nominal": n_gauss_all,
+                 "gauss_evals_per_s_nominal": n_gauss_all * args.steps / dt_max,
                  "n_tile_entries": stats["n_tile_entries"]},
         "kernels_ms": {"k_prep": t_prep, "k_bin": t_bin, "k_render": t_render, "k_reduce": t_red},
         "loglik": float(np.sum(last["llb"])),
@@ -396,8 +509,20 @@ def run_render(args, env):
     out["fp64_valu"] = fp
     if world == 1 and not strong and args.legs == "all":
         extra_render_legs(args, env, field, out)
+        ev = out["work"].get("n_gauss_evaluated_per_step")
+        if ev:
+            # the honest rate: Gaussian-pixels the kernel really walks per second (the nominal count divides work the drop rule
+            # never does by the same time)
+            out["work"]["gauss_evals_per_s"] = ev * args.steps / dt_max
+            out["work"]["evaluated_fraction_of_nominal"] = ev / n_gauss_all
+            out["fp64_valu"]["equivalent_tflops_35flop_per_evaluated_gauss"] = FLOP_PER_GAUSS * ev / (t_render * 1e-3) / 1e12 if t_render > 0 else 0.0
         if args.workload == "mixed10k_2048":
             out["secondary"] = secondary_legs(args, env, field)
+            if args.sustained > 0:
+                # the same step for seconds instead of the contract's K steps (24 ms at K = 20): never the headline
+                ctx.profile(False)
+                out["sustained"] = {"mixed10k_2048": sustained_leg(torch, lambda: field.images.render(field.sources, loglik=True), seconds=args.sustained)}
+                out["sustained"]["gibbs10k_200"] = out["secondary"].pop("gibbs10k_200_sustained", None)
     if world == 1 and args.cpu_sample > 0:
         from oracle import oracle as orc      # cpu_baseline leg only
         out["cpu_baseline"] = cpu_baseline(field, min(args.cpu_sample, S), orc)
@@ -584,6 +709,14 @@ def secondary_legs(args, env, field):
         if args.cpu_sample > 0:
             from oracle import oracle as orc      # cpu_baseline leg only
             sec["gibbs10k"]["cpu_baseline"] = gibbs_cpu_baseline(field, g, gf, orc, n_sources=32)
+        if args.sustained > 0:
+            # BASELINE configs[4] as quoted: 200 sweeps of the same chain, sustained (every sweep + its trace render)
+            def sweep_step():
+                g.sweep()
+                g.log_likelihood()
+            sus = sustained_leg(torch, sweep_step, steps=200)
+            sus["samples_per_s"] = float(g.active.sum()) * sus["steps"] / sus["wall_s"]
+            sec["gibbs10k_200_sustained"] = sus
     finally:
         for b in range(B):                      # the sweeps redrew the sky levels: the headline field gets its own back
             field.images.set_epsilon(b, eps0[b])
@@ -825,7 +958,7 @@ def run_fields(args, env):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": "k_render", "kernel_ms": t_render, "launches": n_render,
                      "algorithmic_bytes_per_launch": alg_bytes},
-        "work": {"n_srcpix_per_step": srcpix_all, "n_gauss_per_step": gauss_all},
+        "work": {"n_srcpix_per_step": srcpix_all, "n_gauss_per_step_nominal": gauss_all},
         "loglik": float(np.sum(last["llb"])),
         "cpu_baseline": _fields_cpu_baseline(args, fields[0], S) if (world == 1 and args.cpu_sample > 0) else None}))
 
@@ -1053,6 +1186,9 @@ def main():
                          "(evaluated-Gaussian count, fast tail preset, source-upload step, Python-API call); 'none' runs the "
                          "timed region only -- what the committed rocprofv3 summaries profile, so that their per-kernel "
                          "averages are those of the timed launches")
+    ap.add_argument("--sustained", type=float, default=5.0,
+                    help="default run at N = 1: seconds of back-to-back mixed10k_2048 steps after the timed region (ms per step in "
+                         "0.5-s buckets + SMI clock / power samples), and 200 Gibbs sweeps likewise -> `sustained`; 0 = skip")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
     args = ap.parse_args()
 

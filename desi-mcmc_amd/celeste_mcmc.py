@@ -187,7 +187,7 @@ class ModelGibbs(object):
     BANDS = ['u', 'g', 'r', 'i', 'z']
 
     def __init__(self, fields, typ, u, fluxes, shape, seed=0, flux_a_0=5., flux_b_0=.005, slice_args=None, engine="auto",
-                 deal=None, shape_args=None, shape_logprior=None, phi_period=180.):
+                 deal=None, shape_args=None, shape_logprior=None, phi_period=180., shape_mass="reference"):
         self.fields = list(fields)
         self.typ = np.ascontiguousarray(typ, dtype=np.int32)
         self.S = self.typ.shape[0]
@@ -211,6 +211,16 @@ class ModelGibbs(object):
         self.shape_args = dict(step_out=True, doubling_step=True, compwise=False, numdir=4)
         self.shape_args.update(shape_args or {})
         self.phi_period = float(phi_period)
+        # The conditional likelihood the shape step scores (Source.log_likelihood(shape=), sources.py:134-183) charges a source
+        # its FULL expected photons, band_flux * sum(psf weights), whatever the shape ("model_outside ... should be small",
+        # :166-170) -- but the photons it is given were split on the source's box, and how much of a proposal's stamp lies on
+        # its box depends on the shape: for an extended de Vaucouleurs-dominated galaxy at high signal to noise the constant
+        # term leaves sigma 10-20 % low (tests/test_calibration.py: the calibration test that found it; DESIGN Q20).
+        # "reference" keeps the reference's term; "exact" charges counts * (the proposal's unit stamp summed over its own box,
+        # cel_stamp_mass) -- the Gibbs conditional of the model the renderer draws from.  ("exact" runs the host engine.)
+        if shape_mass not in ("reference", "exact"):
+            raise ValueError("shape_mass must be 'reference' or 'exact'")
+        self.shape_mass = shape_mass
         self._default_shape_prior = shape_logprior is None
         if shape_logprior is None:
             from .celeste_galaxy_conditionals import galaxy_shape_prior_constrained
@@ -309,6 +319,14 @@ class ModelGibbs(object):
     def resample_photons(self):
         import time
         t0 = time.perf_counter()
+        self._split_photons()
+        self._resample_sky()
+        self.timing["split"] += time.perf_counter() - t0
+        return self.noise_sums
+
+    def _split_photons(self):
+        """the photon split of every field at the chain's current state (celeste_sample_sources.pyx:61-156): sample patches on the
+        device, photons per (source, image), the sky photons per image"""
         self.noise_sums = []
         any_patch = np.zeros(self.S, dtype=bool)
         for k, f in enumerate(self.fields):
@@ -324,7 +342,12 @@ class ModelGibbs(object):
             f.has_patch = f.iset.sample_box_areas() > 0
             any_patch |= f.has_patch.any(axis=1)
             self.noise_sums.append(noise)
-            # resample the noise parameter of every image (models.py:155-160)
+        self.active = any_patch
+
+    def _resample_sky(self):
+        """the noise parameter of every image from its Gamma conditional given the sky photons of the current split
+        (models.py:155-160)"""
+        for f, noise in zip(self.fields, self.noise_sums):
             a_n = f.a_0 + noise
             b_n = f.b_0 + f.npix
             f.epsilon = self.rng.gamma(a_n, 1. / b_n)
@@ -334,9 +357,6 @@ class ModelGibbs(object):
                     f.trace_iset.set_epsilon(b, f.epsilon[b])
                 if getattr(f, "images", None) is not None:
                     f.images[b].epsilon = float(f.epsilon[b])
-        self.active = any_patch
-        self.timing["split"] += time.perf_counter() - t0
-        return self.noise_sums
 
     # -- Source.resample_fluxes: sources.py:321-349 --------------------------------------------------
     def resample_fluxes(self):
@@ -438,8 +458,14 @@ class ModelGibbs(object):
             if f.prop is None or f.prop.capacity < sel.shape[0]:
                 f.prop = _field.SourceSet(f.iset.ctx, max(2 * self.S, sel.shape[0], 16), f.iset.B)
             cts = getattr(f, "_counts", None)
-            f.prop.set(self.typ[sel], self.u[sel], self.counts(f, idx=sel) if cts is None else cts[sel], TH[ok])
+            pc = self.counts(f, idx=sel) if cts is None else cts[sel]
+            f.prop.set(self.typ[sel], self.u[sel], pc, TH[ok])
             ll += f.iset.patch_loglik_resident(f.prop, owner)
+            if self.shape_mass == "exact":
+                # -counts * (stamp mass on the proposal's own box) in place of -counts * sum(psf weights), where the source has a patch
+                wsum = np.array([f.iset.band(b)[3:6].sum() for b in range(f.iset.B)])
+                mass = f.iset.stamp_mass(f.prop)
+                ll -= (pc * (mass - wsum[None, :]) * f.has_patch[sel]).sum(axis=1)
         out[ok] += ll
         return out
 
@@ -491,7 +517,8 @@ class ModelGibbs(object):
         those of slice_sample_skew's family: no stepping out or doubling, component-wise or random directions"""
         a = self.shape_args
         ok = (len(self.fields) == 1 and self._default_shape_prior and (not a.get("step_out", True) or a.get("doubling_step", True))
-              and set(a) <= {"step_out", "doubling_step", "compwise", "numdir", "sigma", "max_steps_out"})
+              and set(a) <= {"step_out", "doubling_step", "compwise", "numdir", "sigma", "max_steps_out"}
+              and a.get("accept", "reference") == "reference" and self.shape_mass == "reference")
         if self.engine == "device" and not ok:
             raise ValueError("the device shape sampler runs one field, the built-in log-prior, stepping out by doubling or none")
         return ok and self.engine != "host"
@@ -550,6 +577,25 @@ class ModelGibbs(object):
         if shapes:
             self.resample_shapes()
         self.merge_ranks()
+        self.sweeps += 1
+
+    def sweep_reversed(self, shapes=False):
+        """The sweep's blocks in REVERSE order -- (shapes,) locations, fluxes, sky levels, photons -- on the augmented state (sources, sky
+        levels, the current photon split): the time reversal of sweep().  Every block is reversible with respect to its
+        conditional (Gibbs draws; slice updates whose axis order is shuffled per call), so a chain run backwards from a state
+        is a chain run with this.  It needs a photon split of the current state to start from (_split_photons()).  Used by the
+        calibration test (tests/test_calibration.py) to put the true parameters at a random position of a stationary chain;
+        a single rank."""
+        if self.deal is not None and self.deal.world > 1:
+            raise ValueError("sweep_reversed runs a single-rank chain")
+        if not self.noise_sums:
+            raise ValueError("sweep_reversed needs a photon split of the current state: call _split_photons() first")
+        if shapes:
+            self.resample_shapes()
+        self.resample_locations()
+        self.resample_fluxes()
+        self._resample_sky()
+        self._split_photons()
         self.sweeps += 1
 
     def merge_ranks(self):

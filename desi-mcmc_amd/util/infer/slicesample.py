@@ -89,7 +89,7 @@ _P_LEVEL, _P_OUT_DOUBLE, _P_OUT_LEFT, _P_OUT_RIGHT, _P_SHRINK, _P_ACCEPT, _P_DON
 
 def slicesample_lockstep(init_x, logprob_batch, sigma=1.0, step_out=True, max_steps_out=1000, compwise=True,
                          numdir=2, doubling_step=True, upper_bound=np.inf, lower_bound=-np.inf, seed=0,
-                         chain_ids=None, stats=None, rng=None):
+                         chain_ids=None, stats=None, rng=None, accept="reference"):
     """One slicesample() update of S chains at once.
 
     init_x          (S, D) current states
@@ -98,6 +98,8 @@ def slicesample_lockstep(init_x, logprob_batch, sigma=1.0, step_out=True, max_st
                     interval while stepping out).
     other arguments as slicesample (slicesample.py:110-118); seed / chain_ids name the random streams
     stats           optional dict: receives 'rounds', 'evals', 'max_steps_in'
+    accept          "reference" (default: `acceptable` as the reference writes it) or "neal" (the doubling procedure's
+                    acceptance test with Neal's sticky flag: see _accept_advance)
     rng             optional replacement of the per-chain streams (`uniform(idx)`, `normal(idx)`): how the
                     tests hand the engine the very draws the reference made (tests/golden/slicesample.npz)
     -> (new_x (S, D), new_llh (S,))"""
@@ -133,6 +135,7 @@ def slicesample_lockstep(init_x, logprob_batch, sigma=1.0, step_out=True, max_st
     u_out = np.zeros(S, dtype=np.int64)
     start_lower, start_upper = np.zeros(S), np.zeros(S)
     new_z, acc_L, acc_U = np.zeros(S), np.zeros(S), np.zeros(S)
+    sticky = np.zeros(S, dtype=bool) if accept == "neal" else None
     steps_in = np.zeros(S, dtype=np.int64)
     max_in = 0
 
@@ -246,7 +249,7 @@ def slicesample_lockstep(init_x, logprob_batch, sigma=1.0, step_out=True, max_st
                 acc_L[t] = start_lower[t]
                 acc_U[t] = start_upper[t]
                 phase[t] = _P_ACCEPT
-                _accept_advance(t, new_z, llh_s, acc_L, acc_U, sigma, phase, None, None)
+                _accept_advance(t, new_z, llh_s, acc_L, acc_U, sigma, phase, None, None, sticky)
             r = c[~inside]
             if r.size:
                 if np.any(new_z[r] == 0.0):
@@ -257,7 +260,7 @@ def slicesample_lockstep(init_x, logprob_batch, sigma=1.0, step_out=True, max_st
         m = p2 == _P_ACCEPT                                # the halving test of `acceptable`
         c = double[m]
         if c.size:
-            _accept_advance(c, new_z, llh_s, acc_L, acc_U, sigma, phase, va[m], vb[m])
+            _accept_advance(c, new_z, llh_s, acc_L, acc_U, sigma, phase, va[m], vb[m], sticky)
             rej = c[phase[c] == _P_SHRINK]
             if rej.size:                                   # not acceptable: shrink as a rejection (:180-183)
                 neg = new_z[rej] < 0
@@ -286,12 +289,19 @@ def slicesample_lockstep(init_x, logprob_batch, sigma=1.0, step_out=True, max_st
     return X, new_llh
 
 
-def _accept_advance(c, new_z, llh_s, acc_L, acc_U, sigma, phase, vL, vU):
+def _accept_advance(c, new_z, llh_s, acc_L, acc_U, sigma, phase, vL, vU, sticky=None):
     """`acceptable` (slicesample.py:119-131) for the chains c, resumed with the values vL, vU of
     logprob at the interval ends the previous halving asked for (None: first entry).  Chains leave
     with phase _P_DONE (acceptable), _P_SHRINK (not acceptable) or stay in _P_ACCEPT with the next
-    pair of ends to evaluate in acc_L / acc_U."""
+    pair of ends to evaluate in acc_L / acc_U.
+    sticky (a bool array over all chains, or None): Neal's test (2003, fig. 6) keeps its flag D once a halving has parted the
+    new point from the start point and checks the ends at EVERY halving from then on; the reference recomputes `splits` per
+    halving (:124) and checks only where the new point lies in the upper half again -- it accepts points Neal's test
+    rejects, and its doubling updates do not leave the target exactly invariant (DESIGN Q20; the calibration test shows it).
+    The default reproduces the reference; accept="neal" in the sampler's options passes the array."""
     todo = c
+    if vL is None and sticky is not None:
+        sticky[c] = False
     if vL is not None:
         # the halving that asked for these values had `splits` true: reject when both ends are below the level
         bad = (llh_s[c] >= vU) & (llh_s[c] >= vL)
@@ -311,6 +321,9 @@ def _accept_advance(c, new_z, llh_s, acc_L, acc_U, sigma, phase, vL, vU):
         acc_L[todo[~lo]] = middle[~lo]
         # chains whose halving split off the start point need logprob at both new ends: they wait
         # for the next round; the others halve again at once
+        if sticky is not None:
+            sticky[todo] |= splits
+            splits = sticky[todo]
         todo = todo[~splits]
 
 
