@@ -790,15 +790,21 @@ def run_projection(args, env):
     align = 64 if args.layout == 1 else dist.TILE_ROWS
     steps, warm = args.steps, max(args.warmup, 3)
 
-    def timed(step, n, w):
+    def timed(step, n, w, chunks=5):
+        """ms per step: the MEDIAN of `chunks` back-to-back chunks of n / chunks steps (a chunk that meets a one-off stall
+        of the host or the box does not decide the rank's number)"""
         for _ in range(w):
             step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            step()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n * 1e3
+        per = max(n // chunks, 1)
+        out = []
+        for _ in range(chunks):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(per):
+                step()
+            torch.cuda.synchronize()
+            out.append((time.perf_counter() - t0) / per * 1e3)
+        return float(np.median(out))
 
     row_cost = None
     if args.strip_cut == "measured":

@@ -186,8 +186,16 @@ k_estep_tiles(EstepArgs a) {
     const int xi = X0 + col;
     const BandDev *bd = a.bands + b;
     const double eps = bd->eps;
-    // the tile's nelec / lambda, once
+    // the tile's nelec / lambda, once: 32 quotients per lane in registers across the whole source loop -- 64 VGPRs beside the
+    // ~200 of hw_build / hw_walk: 14 of them spill (60 B of scratch per lane, re-read once per source).  -DESTEP_W_LDS keeps
+    // the quotients in a second 16 KB LDS tile instead: no scratch, and four waves per CU instead of eight (tools/ab_scratch.sh)
+#ifdef ESTEP_W_LDS
+    __shared__ double wl[HW_TH * HW_TW];
+#define ESTEP_W(r) wl[(r) * 64 + lane]
+#else
     double w[HW_TH / 2];
+#define ESTEP_W(r) w[r]
+#endif
     double noise = 0.0;
     {
         const int64_t base = (int64_t)b * a.H * a.W + (int64_t)(Y0 + half) * a.W + xi;
@@ -200,7 +208,7 @@ k_estep_tiles(EstepArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < HW_TH / 2; r++) {
-            w[r] = ne[r] / la[r];
+            ESTEP_W(r) = ne[r] / la[r];
             noise += ne[r] * eps / la[r];
         }
     }
@@ -240,7 +248,7 @@ k_estep_tiles(EstepArgs a) {
             if (2 * r + 1 >= ra && 2 * r < rb) {            // (wave-uniform) the row pair meets the box
                 const double u = acc[r * 64 + lane];        // 0 outside the box's rows and columns
                 acc[r * 64 + lane] = 0.0;                   // clean for the next source
-                xt = fma(u, w[r], xt);
+                xt = fma(u, ESTEP_W(r), xt);
                 ms += u;
             }
         }

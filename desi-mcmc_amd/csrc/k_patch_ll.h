@@ -174,8 +174,15 @@ __device__ __forceinline__ double nz_trip(const NzEntry *__restrict__ L, int n, 
 }
 
 #define PLL_PARTS 4
+// MODE 3 (the stamp-mass kernel) at three waves per SIMD keeps 168 VGPRs and 24 B of scratch (5 spilled registers, re-read
+// once per chunk); -DPLL_MASS_TWO_WAVES gives it 256 registers, no scratch and two waves: the A/B of tools/ab_scratch.sh
+#ifdef PLL_MASS_TWO_WAVES
+#define PLL_MASS_WAVES 2
+#else
+#define PLL_MASS_WAVES 3
+#endif
 template <int MODE, typename TZ = double>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ? 3 : 2, MODE == 3 ? 3 : 2)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 3 ? PLL_MASS_WAVES : 2, MODE == 3 ? PLL_MASS_WAVES : 2)))
 k_patch_ll_hw(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__restrict__ recs,
               const int *__restrict__ owner, const int4 *__restrict__ pbox, const int64_t *__restrict__ offsets,
               const TZ *__restrict__ data, const double *__restrict__ nelec, int H, int W,

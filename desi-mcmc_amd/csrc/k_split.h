@@ -674,7 +674,11 @@ k_photon_split_hw(SplitArgs a) {
     const SrcRec *recs = a.recs + (int64_t)b * a.S;
     const int dropmode = (a.tail_T > 0.0 && eps > 0.0) ? HW_DROP_SKY : HW_DROP_NONE;
     const double log_sky = (eps > 0.0) ? (double)__logf((float)eps) : 0.0;
-#ifndef SPLIT_LC_PER_SOURCE
+    // The band's lane constants (28 VGPRs) are read again per source instead of living in registers across the walk: 253
+    // VGPRs and NO scratch (round 4: 256 + 20 B, round 5: + 28 B with them held).  Measured on the benchmark field, three
+    // repeats each way (tools/ab_scratch.sh, profiles/r05_ab_scratch.txt): 6.50-6.52 ms held, 6.52-6.53 ms re-read --
+    // equal; -DSPLIT_LC_IN_REGISTERS builds the other form.
+#ifdef SPLIT_LC_IN_REGISTERS
     const LaneConst lc = lane_consts(lane, bd);
 #endif
     const int nent = (Y0 < a.H) ? (int)min((int64_t)cnt, a.capacity > off ? a.capacity - off : (int64_t)0) : 0;
@@ -701,8 +705,8 @@ k_photon_split_hw(SplitArgs a) {
         if (ra >= rb || xa > xb) continue;          // touches the tile's other half only (wave-uniform)
         const bool on = (xi >= xa) && (xi <= xb);
         bool direct;
-#ifdef SPLIT_LC_PER_SOURCE
-        asm volatile("" ::: "memory");      // the band's lane constants are read again per source instead of living in 28 VGPRs across the walk
+#ifndef SPLIT_LC_IN_REGISTERS
+        asm volatile("" ::: "memory");      // (keeps the compiler from hoisting the loads out of the loop again)
         const LaneConst lc = lane_consts(lane, bd);
 #endif
         const int Kk = hw_build(T, lc, rec, lane, dropmode, a.tail_T, log_sky, Y0, xa, xb, ra, rb, direct, nullptr, et);
