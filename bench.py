@@ -876,7 +876,8 @@ def run_projection(args, env):
                                      "location_slice": g.timing["location"] / n * 1e3}})
             if args.split == "strips":
                 gfk.iset.close()
-                gfk.trace_iset.close()
+                if gfk.trace_iset is not None:
+                    gfk.trace_iset.close()
             del g, gfk, deal
     t = [p["ms_per_step"] for p in per]
     out["per_rank"] = per

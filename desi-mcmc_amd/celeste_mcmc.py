@@ -136,29 +136,41 @@ class GibbsField(object):
 
 
 def strip_gibbs_field(ctx, bands, nelec, rows, boxes, status, world, rank, band_index=None, slack=48, device=None, edges=None,
-                      solo=False):
+                      solo=False, window_trace=True):
     """This rank's part of ONE chain partitioned by row strips (dist.StripDeal).
         bands (B, 37) cel_band records, nelec (B, H, W) the whole frame's pixels (every rank can read them: only the window is
         uploaded), rows (S,) the sources' pixel rows, boxes (B, S, 4) / status (B, S) their boxes on the whole frame
         (ImageSet.source_boxes): the halo is as tall as this rank's sources' boxes reach beyond its strip, plus `slack` rows
         for the few pixels they move per sweep.
-    -> (StripDeal, GibbsField over the window with the strip as its trace image set)"""
+        window_trace (round 5): the chain's log-likelihood trace is rendered on the WINDOW image set, whose log-likelihood adds
+        the strip's tile rows only (cel_images_set_noise_rows: the rows this rank owns) -- so the model image the next photon
+        split needs is already on the device (its totals come from k_strict_totals instead of a render, the flux step's stamp
+        masses from the split's own sums): what the single-rank chain does.  Needs strip edges and halo on 64-row tiles (the
+        default layout's); otherwise, and with window_trace=False, a second image set of the strip alone renders the trace.
+    -> (StripDeal, GibbsField over the window [with the strip as its trace image set])"""
     from . import dist as _dist
     from . import field as _field
     B, H, W = nelec.shape
-    probe = _dist.StripDeal(rows, H, world, rank, edges=edges, solo=solo)       # (edges: dist.strip_edges, the same on every rank)
+    align = 64 if window_trace else _dist.TILE_ROWS
+    if edges is not None and any(int(e) % 64 for e in list(edges)[:-1]):
+        align, window_trace = _dist.TILE_ROWS, False
+    if edges is None and int(world) > -(-H // 64):
+        align, window_trace = _dist.TILE_ROWS, False
+    probe = _dist.StripDeal(rows, H, world, rank, edges=edges, solo=solo, align=align)       # (edges: dist.strip_edges, the same on every rank)
     mine = probe.mine
     has = status[:, mine] > 0
     reach = max(int(np.max(np.where(has, probe.strip[0] - boxes[:, mine, 0], 0), initial=0)),
                 int(np.max(np.where(has, boxes[:, mine, 1] - probe.strip[1], 0), initial=0)), 0)
-    deal = _dist.StripDeal(rows, H, world, rank, halo=reach + slack, device=device, edges=edges, solo=solo)
+    deal = _dist.StripDeal(rows, H, world, rank, halo=reach + slack, device=device, edges=probe.edges, solo=solo, align=align)
     w0, w1 = deal.window
     win = _field.ImageSet(ctx, bands, w1 - w0, W, nelec=np.ascontiguousarray(nelec[:, w0:w1]))
     win.set_window(w0, H)
     win.set_noise_rows(*deal.noise_rows())
     y0, y1 = deal.strip
-    strip = _field.ImageSet(ctx, bands, max(y1 - y0, 1), W, nelec=np.ascontiguousarray(nelec[:, y0:max(y1, y0 + 1)]))
-    strip.set_window(y0, H)
+    strip = None
+    if not window_trace:
+        strip = _field.ImageSet(ctx, bands, max(y1 - y0, 1), W, nelec=np.ascontiguousarray(nelec[:, y0:max(y1, y0 + 1)]))
+        strip.set_window(y0, H)
     bands = np.asarray(bands)
     gf = GibbsField(win, list(range(B)) if band_index is None else band_index, bands[:, 2], bands[:, 1], H * W, trace_iset=strip)
     return deal, gf
@@ -571,12 +583,18 @@ class ModelGibbs(object):
         """CelesteBase.resample_model: every field's photons, then every source (fluxes, location) -- and, with
         shapes=True, the galaxies' shapes as sample_galaxy_params does (celeste_mcmc.py:166-243;
         Source.resample_shape is a stub in the reference, sources.py:321-325, so it is off by default)"""
+        solo = self.deal is not None and getattr(self.deal, "solo", False) and self.deal.world > 1
+        if solo:        # one rank of an N-rank chain played alone (bench.py --as-rank): the other ranks' rows keep their values
+            before = (self.u.copy(), self.fluxes.copy(), self.shape.copy())
         self.resample_photons()
         self.resample_fluxes()
         self.resample_locations()
         if shapes:
             self.resample_shapes()
         self.merge_ranks()
+        if solo:
+            other = ~self.deal.mask
+            self.u[other], self.fluxes[other], self.shape[other] = before[0][other], before[1][other], before[2][other]
         self.sweeps += 1
 
     def sweep_reversed(self, shapes=False):
@@ -614,7 +632,11 @@ class ModelGibbs(object):
         tot = 0.0
         strips = self.deal is not None and self.deal.kind == "strips"
         for f in self.fields:
-            if strips:          # this rank's strip of every image; the strips' sums added over the ranks
+            if strips and f.trace_iset is None:
+                # the window image set adds its own rows' terms only (strip_gibbs_field, window_trace): one render gives this
+                # rank's share of the trace AND the model image the next split and flux step start from
+                ll, _ = f.iset.render(self._sources(f), loglik=True)
+            elif strips:        # this rank's strip of every image; the strips' sums added over the ranks
                 from . import field as _field
                 if getattr(f, "trace_sset", None) is None or f.trace_sset.capacity < self.S:
                     f.trace_sset = _field.SourceSet(f.trace_iset.ctx, max(self.S, 1), f.trace_iset.B)

@@ -1096,9 +1096,19 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
     // (the photon split, the E-step), an image of its own or the diagnostics
     const bool keep_lists = (flags & CEL_RENDER_KEEP_LISTS) != 0;
     flags &= ~CEL_RENDER_KEEP_LISTS;
+    // the rows this image set OWNS (cel_images_set_noise_rows; default: all): the log-likelihood adds their tiles only
+    const bool own_rows = im->noise_y0 > 0 || im->noise_y1 < im->H;
+    int own_ty0 = 0, own_ty1 = im->nty;
+    if (own_rows && (flags & CEL_RENDER_LOGLIK)) {
+        if (im->noise_y0 % im->TH != 0 || (im->noise_y1 % im->TH != 0 && im->noise_y1 < im->H))
+            return fail(CEL_ERR_INVALID, "the owned rows [%d, %d) must begin and end on render-tile rows (%d) for a log-likelihood",
+                        im->noise_y0, im->noise_y1, im->TH);
+        own_ty0 = im->noise_y0 / im->TH;
+        own_ty1 = std::min(im->nty, (im->noise_y1 + im->TH - 1) / im->TH);
+    }
     if (S > 0 && S <= SMALL_MAX_S && T <= STAR_TILES_MIN && im->TW == HW_TW && c->variant != 0 && c->star_tiles == 1 &&
         !c->tile_timing && !(c->debug & ~64) && src->n_gal == 0 && im->star_one_segment && !im->small_off && !lambda_out &&
-        !keep_lists && !(flags & CEL_RENDER_STRICT)) {
+        !keep_lists && !(flags & CEL_RENDER_STRICT) && !own_rows) {
         bool done = false;
         if ((rc = render_small_stars(im, src, flags, &done))) return rc;
         if (done) {
@@ -1223,7 +1233,8 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
             LAUNCH_EV((k_render<32>), dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
         if (flags & CEL_RENDER_LOGLIK) {
             pi = prof_slot(c, CEL_K_REDUCE);
-            LAUNCH_EV(k_reduce, dim3(im->B), dim3(256), st, EV0(c, pi), EV1(c, pi), (const double *)im->d_partials, im->ntx * im->nty, im->d_llband);
+            LAUNCH_EV(k_reduce, dim3(im->B), dim3(256), st, EV0(c, pi), EV1(c, pi), (const double *)im->d_partials, im->ntx * im->nty, im->d_llband,
+                      im->ntx, own_ty0, own_ty1);
             im->llband_on_host = false;
         }
         // the per-band sums, the total list length and the overflow flags ride back in ONE copy
@@ -2249,7 +2260,8 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         else if (resident) hipLaunchKernelGGL(k_photon_split<int>, dim3(T), dim3(64), 0, c->stream, a);
         else hipLaunchKernelGGL(k_photon_split<double>, dim3(T), dim3(64), 0, c->stream, a);
         prof_end(c, pi);
-        hipLaunchKernelGGL(k_reduce, dim3(B), dim3(256), 0, c->stream, a.partials, (hw ? 2 : 1) * im->ntx * im->nty, im->d_llband);
+        hipLaunchKernelGGL(k_reduce, dim3(B), dim3(256), 0, c->stream, a.partials, (hw ? 2 : 1) * im->ntx * im->nty, im->d_llband,
+                           (hw ? 2 : 1) * im->ntx * im->nty, 0, 1);
         if (resident && n > 0 && !fused_nz)   // where each patch's photons are: the conditional likelihoods evaluate only there
             hipLaunchKernelGGL(k_patch_nzbox<int>, dim3((unsigned)n), dim3(64), 0, c->stream, im->d_sbox, im->d_soff, (const int *)im->d_samp, im->d_snz);
     }
@@ -2418,7 +2430,7 @@ int cel_estep_stats(cel_images *im, cel_sources *src, double *xtilde, double *ma
     if (!tiles)      // the tile walk has left the sky term's per-tile sums in d_partials
         hipLaunchKernelGGL(k_estep_noise, dim3(B * nblk), dim3(256), 0, c->stream, im->d_bands, (int64_t)im->H * im->W, nblk,
                            im->d_nelec, im->d_lambda, im->d_partials);
-    hipLaunchKernelGGL(k_reduce, dim3(B), dim3(256), 0, c->stream, im->d_partials, nblk, im->d_llband);
+    hipLaunchKernelGGL(k_reduce, dim3(B), dim3(256), 0, c->stream, im->d_partials, nblk, im->d_llband, nblk, 0, 1);
     ES_TRY(hipMemcpyAsync(c->pinned, im->d_llband, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
     ES_TRY(hipGetLastError());
     ES_TRY(hipStreamSynchronize(c->stream));

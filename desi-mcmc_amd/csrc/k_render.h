@@ -573,12 +573,15 @@ k_render(RenderArgs a) {
     }
 }
 
-// fixed-order reduction of the per-tile partials: one block per band
+// fixed-order reduction of the per-tile partials: one block per band.  Only the tiles of tile rows [ty0, ty1) count (row
+// width ntx; the whole band: ntx = per_band, rows [0, 1)): a rank's image set that holds a halo around the rows it OWNS
+// (cel_images_set_noise_rows) adds its own rows' terms only -- the same terms, in the same order, as an image set of those rows
 __global__ void __launch_bounds__(256)
-k_reduce(const double *__restrict__ partials, int per_band, double *__restrict__ ll_band) {
+k_reduce(const double *__restrict__ partials, int per_band, double *__restrict__ ll_band, int ntx, int ty0, int ty1) {
     __shared__ double sm[256];
     int b = blockIdx.x;
-    const double *p = partials + (int64_t)b * per_band;
+    const double *p = partials + (int64_t)b * per_band + (int64_t)ty0 * ntx;
+    per_band = min(per_band, ty1 * ntx) - ty0 * ntx;
     double s = 0.0, c = 0.0;   // Kahan per thread, fixed stride
     for (int i = threadIdx.x; i < per_band; i += 256) {
         double y = p[i] - c;

@@ -179,13 +179,17 @@ class StripDeal(SourceDeal):
 
     kind = "strips"
 
-    def __init__(self, rows, H, world=1, rank=0, halo=0, device=None, edges=None, solo=False):
+    def __init__(self, rows, H, world=1, rank=0, halo=0, device=None, edges=None, solo=False, align=TILE_ROWS):
         rows = np.asarray(rows, dtype=np.float64)
         if int(world) > -(-int(H) // TILE_ROWS):
             raise ValueError("StripDeal: %d ranks for a frame of %d rows = %d tile rows: a rank would own no rows"
                              % (world, H, -(-int(H) // TILE_ROWS)))
         # edges: the world + 1 strip edges (strip_edges: equal tile rows, or evened out by a measured cost); the same on every rank
-        edges = strip_edges(H, world) if edges is None else [int(e) for e in edges]
+        # align: strip edges (when not given) and the halo are multiples of it; 64 -- the default layout's tile height -- lets a
+        # rank add its strip's log-likelihood from a render of its whole window (celeste_mcmc.strip_gibbs_field)
+        if edges is None:
+            edges = strip_edges(H, world, align=align if int(world) <= -(-int(H) // align) else TILE_ROWS)
+        edges = [int(e) for e in edges]
         if len(edges) != world + 1 or edges[0] != 0 or edges[-1] != int(H) or any(b <= a for a, b in zip(edges, edges[1:])):
             raise ValueError("StripDeal: edges must be %d increasing rows from 0 to %d" % (world + 1, H))
         ends = np.array(edges[1:])
@@ -194,7 +198,7 @@ class StripDeal(SourceDeal):
         self.H = int(H)
         self.edges = edges
         self.strip = (edges[rank], edges[rank + 1])
-        halo = int(-(-int(halo) // TILE_ROWS) * TILE_ROWS)               # whole tiles
+        halo = int(-(-int(halo) // align) * align)                       # whole tiles
         self.window = (max(0, self.strip[0] - halo), min(self.H, self.strip[1] + halo))
 
     def noise_rows(self):

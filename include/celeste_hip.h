@@ -195,8 +195,9 @@ int cel_images_set_epsilon(cel_images *img, int band, double eps);
  * the full frame (celeste.py:130-140) and then cut to the window, so the strips tile the frame's
  * model image exactly.  WCS (rho) stays that of the full frame. */
 int cel_images_set_window(cel_images *img, int y0, int full_H);
-/* Rows [y0, y1) of THIS image set (window-relative) whose left-over photons cel_photon_split's noise sums count; default:
- * every row.  One Gibbs chain partitioned over GPUs by row strips ("the photon split ... uses the same spatial
+/* The rows [y0, y1) of THIS image set (window-relative) that it OWNS; default: every row.  cel_photon_split's noise sums count
+ * the left-over photons of these rows only, and cel_render_field's log-likelihood adds the Poisson terms of these rows only
+ * (they must then begin and end on render-tile rows, 64 in the default layout; the model image is rendered on every row).  One Gibbs chain partitioned over GPUs by row strips ("the photon split ... uses the same spatial
  * partition"): a rank's image set holds its strip plus a halo as tall as its own sources' boxes reach, so that their sample
  * patches are complete; the sky photons of the halo rows belong to the neighbours' sums (Field.resample_photons,
  * CelestePy/models.py:155-160, needs the frame's total: the ranks all-reduce their strips' sums). */

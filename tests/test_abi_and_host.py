@@ -191,6 +191,47 @@ def test_strip_partition_covers_frame_once(built):
 
 
 # ---- host-side containers added in round 2 (no device call) ------------------------------------------
+def test_strip_edges_even_out_a_measured_cost_and_solo_deals(built):
+    """dist.strip_edges: without a cost the equal-tile-row cut of strip_rows; with the per-band cost of a whole-frame render
+    (strip_cost_from_tiles of the measured tile durations) the aligned cut that evens the strips' summed cost, every strip at
+    least one band; StripDeal takes the edges (the same on every rank) and a 64-row alignment for the window trace; a solo
+    deal (bench.py --as-rank k --of N: one rank played without a process group) sums to N times its own part and leaves the
+    other ranks' rows alone."""
+    from desi_mcmc_amd import dist
+    for H, world, align in ((2048, 8, 32), (2048, 8, 64), (1000, 3, 32), (333, 4, 64), (96, 3, 32)):
+        e = dist.strip_edges(H, world, align=align)
+        assert e[0] == 0 and e[-1] == H and len(e) == world + 1 and all(b > a for a, b in zip(e, e[1:]))
+        assert all(x % align == 0 for x in e[:-1])
+        if align == 32:
+            assert e == [dist.strip_rows(H, world, r)[0] for r in range(world)] + [H]
+    cost = np.ones(64)
+    cost[:16] = 3.0                                           # the frame's top quarter three times as expensive
+    e = dist.strip_edges(2048, 8, cost)
+    per = [cost[a // 32:b // 32].sum() for a, b in zip(e, e[1:])]
+    assert e == [0, 128, 256, 384, 512, 896, 1280, 1664, 2048] and max(per) == min(per) == 12.0
+    lumpy = np.array([100.0, 1, 1, 1, 1, 1, 1, 1])
+    e = dist.strip_edges(256, 4, lumpy)                       # one band holds nearly everything: still a band per strip
+    assert e[0] == 0 and e[-1] == 256 and all(b - a >= 32 for a, b in zip(e, e[1:]))
+    with pytest.raises(ValueError):
+        dist.strip_edges(256, 4, np.ones(7))
+    with pytest.raises(ValueError):
+        dist.strip_edges(64, 3, np.ones(2))
+    tc = np.arange(2 * 4 * 3, dtype=float).reshape(2, 4, 3)   # B = 2, nty = 4 (64-row tiles), ntx = 3
+    rc = dist.strip_cost_from_tiles(tc.ravel(), 2, 4, 3, 64, 32)
+    assert rc.shape == (8,) and np.allclose(rc[::2], tc.sum(axis=(0, 2)) / 2) and np.allclose(rc[::2], rc[1::2])
+    rows = np.random.RandomState(0).uniform(0, 2048, 500)
+    d = dist.StripDeal(rows, 2048, 8, 3, halo=100, edges=[0, 128, 256, 384, 512, 896, 1280, 1664, 2048], solo=True, align=64)
+    assert d.strip == (384, 512) and d.window == (256, 640) and d.noise_rows() == (128, 256) and d.solo
+    assert np.array_equal(d.mine, np.nonzero((rows >= 384) & (rows < 512))[0])
+    assert np.array_equal(d.rank_sum([1.0, 2.5]), [8.0, 20.0])
+    arr = np.arange(500 * 3, dtype=float).reshape(500, 3)
+    assert np.array_equal(d.merge(arr), arr)
+    with pytest.raises(ValueError):
+        dist.StripDeal(rows, 2048, 8, 3, edges=[0, 128, 256])
+    d64 = dist.StripDeal(rows, 2048, 8, 0, halo=70)           # default alignment 32: the halo is whole 32-row tiles
+    assert d64.window == (0, 256 + 96)
+
+
 def test_src_catalog_reads_as_a_sequence_of_srcparams(built):
     cel = built
     ps = [cel.SrcParams(u=np.array([10.0 + i, 20.0 - i]), a=(i % 2), fluxes=np.arange(5.0) + i, theta=.3, sigma=1. + i,

@@ -720,6 +720,36 @@ def _row_strips_body(cel, ctx, f, H, W, world, frac_gal, rt):
         cel.ImageSet(ctx, f.bands, 64, W).set_window(150, H)       # window does not fit the frame
 
 
+def test_owned_rows_restrict_the_log_likelihood(cel, ctx):
+    """cel_images_set_noise_rows: an image set that holds a halo around the rows it OWNS (a rank's window of the
+    strip-partitioned chain) renders the model image on every row and adds the Poisson terms of its own rows only -- the
+    log-likelihood of an image set of exactly those rows; rows that do not begin and end on render tiles are refused."""
+    from desi_mcmc_amd import synth
+    f = synth.SyntheticField(ctx, 500, 3, 448, 300, frac_gal=0.5, seed=12)
+    ll, llb = f.images.render(f.sources, loglik=True)
+    lam = f.images.model_images()
+    win = cel.ImageSet(ctx, f.bands, 320, f.W, nelec=f.nelec[:, 64:384])
+    win.set_window(64, f.H)
+    win.set_noise_rows(64, 256)                                  # frame rows [128, 320)
+    _, llw = win.render(f.sources, loglik=True)
+    np.testing.assert_allclose(win.model_images(), lam[:, 64:384], rtol=1e-12)
+    strip = cel.ImageSet(ctx, f.bands, 192, f.W, nelec=f.nelec[:, 128:320])
+    strip.set_window(128, f.H)
+    _, lls = strip.render(f.sources, loglik=True)
+    np.testing.assert_allclose(llw, lls, rtol=1e-13)
+    want = np.array([np.sum(f.nelec[b, 128:320] * np.log(lam[b, 128:320]) - lam[b, 128:320]) for b in range(3)])
+    np.testing.assert_allclose(llw, want, rtol=1e-12)
+    win.set_noise_rows(0, 320)                                   # everything again
+    np.testing.assert_allclose(win.render(f.sources, loglik=True)[1],
+                               [np.sum(f.nelec[b, 64:384] * np.log(lam[b, 64:384]) - lam[b, 64:384]) for b in range(3)], rtol=1e-12)
+    win.set_noise_rows(32, 256)
+    with pytest.raises(ValueError):
+        win.render(f.sources, loglik=True)
+    win.render(f.sources, loglik=False)                          # (the model image alone does not care)
+    win.set_noise_rows(64, 320)                                  # up to the set's last row: fine whatever its height
+    win.render(f.sources, loglik=True)
+
+
 @pytest.mark.parametrize("frac_gal", [0.6, 0.05])
 def test_tile_parts_agree_and_each_is_reproducible(cel, ctx, orc, frac_gal):
     """CEL_OPT_TILE_PARTS: a frame of few tiles is rendered by 2 or 4 one-wave blocks per tile (k_render_hw<, PARTS>: every
