@@ -720,6 +720,24 @@ def secondary_legs(args, env, field):
     finally:
         for b in range(B):                      # the sweeps redrew the sky levels: the headline field gets its own back
             field.images.set_epsilon(b, eps0[b])
+    # The strong-scaling jobs at N = 8, every rank played on this one GPU (run_projection): the field cut into row strips, and
+    # ONE Gibbs chain partitioned by strips.  No multi-GPU node has been available to any round; this is what stands in.
+    if args.projection:
+        import copy
+        pa = copy.copy(args)
+        pa.of, pa.as_rank, pa.workload, pa.steps, pa.warmup, pa.strip_cut = 8, None, "mixed10k_2048", 60, 10, "measured"
+        pr = run_projection(pa, env, field=field, emit=False)
+        pg = copy.copy(pa)
+        pg.workload, pg.steps, pg.split = "gibbs10k", 5, "strips"
+        eps1 = field.images.eps.copy()
+        pgo = run_projection(pg, env, field=field, emit=False)
+        for b in range(B):
+            field.images.set_epsilon(b, eps1[b])
+        sec["projected_strong_N8"] = {
+            "mixed10k_2048_row_strips": dict(pr["projected_strong"], per_rank_ms=[round(p["ms_per_step"], 4) for p in pr["per_rank"]],
+                                             kernels_ms_rank0=pr["per_rank"][0]["kernels_ms"], strip_edges=pr["strip_edges"]),
+            "gibbs10k_strip_chain": dict(pgo["projected_strong"], per_rank_ms=[round(p["ms_per_step"], 3) for p in pgo["per_rank"]],
+                                         sweep_ms_rank3=pgo["per_rank"][3]["sweep_ms"], window_rows_rank3=pgo["per_rank"][3]["window_rows"])}
     # BASELINE configs[3]'s stand-in (the Stripe-82 set is absent from the reference tree): 8 fields of the configs[2]
     # population as ONE field set on this GPU, 3 timed steps (what `bench.py --workload fields8_2048` reports on more)
     K, steps = 8, 3
@@ -771,7 +789,7 @@ def measured_row_cost(ctx, _lib, images, sources, align):
     return dist.strip_cost_from_tiles(dur, B, nty, ntx, 64, align)[: (H + align - 1) // align]
 
 
-def run_projection(args, env):
+def run_projection(args, env, field=None, emit=True):
     """--scaling strong --of N [--as-rank k] on ONE GPU, no process group: this process builds rank k's part of the N-rank job
     exactly as that rank would -- its row strip (render workloads) or its window of the strip-partitioned / dealt chain
     (gibbs10k) -- and times its FULL step (prep, binning, order, render, reduction; the whole sweep).  Without --as-rank every
@@ -785,7 +803,8 @@ def run_projection(args, env):
         raise SystemExit("--as-rank must be in [0, --of)")
     gibbs = args.workload == "gibbs10k"
     base = "mixed10k_2048" if gibbs else args.workload
-    field = synth.SyntheticField.from_config(ctx, base, seed=42)
+    if field is None:
+        field = synth.SyntheticField.from_config(ctx, base, seed=42)
     S, B, H, W, fg = synth.CONFIGS[base]
     align = 64 if args.layout == 1 else dist.TILE_ROWS
     steps, warm = args.steps, max(args.warmup, 3)
@@ -839,10 +858,13 @@ def run_projection(args, env):
         from desi_mcmc_amd import celeste_mcmc
         slice_args = dict(step_out=False, sigma=args.slice_sigma)
 
+        ran = [0]
+
         def chain_ms(g, n):
             def step():
                 g.sweep()
                 g.log_likelihood()
+                ran[0] += 1
             ms = timed(step, n, 3)
             return ms
         gf = celeste_mcmc.GibbsField(field.images, list(range(B)), field.bands[:, 2], field.bands[:, 1], H * W)
@@ -868,8 +890,9 @@ def run_projection(args, env):
                 g.log_likelihood()
             for key in g.timing:
                 g.timing[key] = 0
+            ran[0] = 0
             ms = chain_ms(g, steps)
-            n = steps + 3
+            n = max(ran[0], 1)
             per.append({"rank": k, "ms_per_step": ms, "sources_owned": int(deal.mine.size),
                         "window_rows": list(getattr(deal, "window", (0, H))),
                         "sweep_ms": {"photon_split_and_sky": g.timing["split"] / n * 1e3, "flux": g.timing["flux"] / n * 1e3,
@@ -886,7 +909,9 @@ def run_projection(args, env):
                                "note": "one GPU, one rank of the %d-rank job at a time, no process group: the slowest rank's full step "
                                        "against the 1-rank step of the same process; the collective (%s) is not in it"
                                        % (N, "one all-gather of 11 doubles per source per sweep" if gibbs else "one all-reduce of %d doubles" % B)}
-    print(json.dumps(out))
+    if emit:
+        print(json.dumps(out))
+    return out
 
 
 # ---- configs[3] stand-in: K fields dealt to ranks ----------------------------------------------------
@@ -1196,6 +1221,9 @@ def main():
     ap.add_argument("--sustained", type=float, default=5.0,
                     help="default run at N = 1: seconds of back-to-back mixed10k_2048 steps after the timed region (ms per step in "
                          "0.5-s buckets + SMI clock / power samples), and 200 Gibbs sweeps likewise -> `sustained`; 0 = skip")
+    ap.add_argument("--no-projection", dest="projection", action="store_false",
+                    help="default run at N = 1: skip `secondary.projected_strong_N8` (the ranks of the 8-GPU strong-scaling jobs played "
+                         "one at a time on this GPU: ~10 s)")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
     args = ap.parse_args()
 
