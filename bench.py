@@ -396,9 +396,14 @@ def run_render(args, env):
     field = synth.SyntheticField.from_config(ctx, args.workload, seed=42 + (0 if strong else 1000 * rank))
     full_stats = None
     if strong:
-        y0, y1 = dist.strip_rows(field.H, world, rank)
         field.images.render(field.sources, loglik=False)
         full_stats = field.images.stats()                  # the whole field's work: what every step of the job does
+        # strip edges: every rank holds the whole field at this point; the cut that evens out the whole-frame render's measured
+        # tile durations is taken from rank 0's measurement (dist.agree_on_edges) -- or equal tile rows (--strip-cut equal)
+        align = 64 if args.layout == 1 else dist.TILE_ROWS
+        row_cost = measured_row_cost(ctx, _lib, field.images, field.sources, align) if args.strip_cut == "measured" else None
+        edges = dist.agree_on_edges(dist.strip_edges(field.H, world, row_cost, align=align if world <= -(-field.H // align) else dist.TILE_ROWS))
+        y0, y1 = edges[rank], edges[rank + 1]
         strip = cel.ImageSet(ctx, field.bands, max(y1 - y0, 1), field.W, nelec=field.nelec[:, y0:max(y1, y0 + 1)])
         strip.set_window(y0, field.H)
         field.images = strip

@@ -64,6 +64,20 @@ def strip_cost_from_tiles(tile_cost, B, nty, ntx, tile_rows, align=TILE_ROWS):
     return np.repeat(c / per, per)
 
 
+def agree_on_edges(edges, src=0):
+    """every rank gets rank `src`'s strip edges (a measured cost differs from rank to rank; the cut must not): one broadcast of
+    world + 1 integers.  No process group: the edges as they are."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [int(e) for e in edges]
+    t = torch.tensor([int(e) for e in edges], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda(torch.cuda.current_device())
+    dist.broadcast(t, src=src)
+    return [int(e) for e in t.cpu().tolist()]
+
+
 def field_shard(n_fields, world, rank):
     """Indices of the fields rank owns (round-robin: equal counts when world divides n_fields)."""
     return list(range(rank, n_fields, world))

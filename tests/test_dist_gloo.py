@@ -36,6 +36,17 @@ def _worker(rank, world, port, mode, out_dir):
     if mode == "strips":
         y0, y1 = dist.strip_rows(H, world, rank)
         part = np.array([orc.poisson_loglike(g["nelec"][b, y0:y1], lam[b, y0:y1]) for b in range(5)])
+    elif mode == "strips_measured":
+        # strip edges from a MEASURED per-band cost: every rank measures something else (here: a cost that depends on the
+        # rank), the cut is rank 0's (dist.agree_on_edges) -- the strips still tile the frame exactly once
+        nb = -(-H // 32)
+        cost = np.ones(nb) + (rank + 1) * np.arange(nb)[::-1]
+        mine_edges = dist.strip_edges(H, world, cost)
+        edges = dist.agree_on_edges(mine_edges)
+        assert edges == dist.strip_edges(H, world, np.ones(nb) + np.arange(nb)[::-1]) and len(edges) == world + 1
+        assert mine_edges == dist.strip_edges(H, world, cost)               # (a rank's own measurement: possibly another cut)
+        y0, y1 = edges[rank], edges[rank + 1]
+        part = np.array([orc.poisson_loglike(g["nelec"][b, y0:y1], lam[b, y0:y1]) for b in range(5)])
     else:  # fields: 8 fields dealt to the ranks as bench.py --workload fields8_2048 deals them
         # (field k = the same sky observed with +k electrons per pixel)
         mine = dist.field_shard(8, world, rank)
@@ -232,7 +243,7 @@ def test_strip_deal_world3_gloo(tmp_path):
     np.testing.assert_allclose(state, np.repeat(want, 3, axis=1).reshape(len(owner), 3), rtol=1e-15)
 
 
-@pytest.mark.parametrize("mode", ["strips", "fields"])
+@pytest.mark.parametrize("mode", ["strips", "strips_measured", "fields"])
 def test_world2_gloo_loglik_allreduce(tmp_path, mode):
     import torch.multiprocessing as mp
     world = 2
@@ -240,7 +251,7 @@ def test_world2_gloo_loglik_allreduce(tmp_path, mode):
     mp.spawn(_worker, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
     res = [np.load(os.path.join(str(tmp_path), "%s_%d.npy" % (mode, r))) for r in range(world)]
     g = load_golden("mini_field.npz")
-    if mode == "strips":
+    if mode.startswith("strips"):
         expect = g["ll_band"]
     else:
         from oracle import oracle as orc
