@@ -275,8 +275,8 @@ struct cel_sources {
 // A frame of few tiles is rendered by several one-wave blocks per tile (k_render_hw<, PARTS>, k_render_hw.h): 4 while even
 // that many fit the chip's 2 048 wave slots at once (512 tiles), 2 up to 3 072 tiles (CEL_OPT_TILE_PARTS: 0 = this rule,
 // 1 / 2 / 4 = always that many).  Measured on one rank's strip of the benchmark field cut 8 ways (1 280 tiles): one wave per
-// tile 0.37 ms, two 0.21, four 0.25 -- every part pays ~10 us of tile set-up and slab traffic, and 5 120 blocks are 2.5
-// rounds of the chip.  The 32 x 64 layout's general kernel only; the star-tile kernels and the diagnostic instantiation
+// tile 0.37 ms, two 0.21, four 0.25-0.29 -- every part pays its tile set-up and slab traffic, and 5 120 blocks are 2.5
+// rounds of the chip.  (A tile whose list is short uses fewer of its parts: one per HW_PART_ENTRIES entries.)  The 32 x 64 layout's general kernel only; the star-tile kernels and the diagnostic instantiation
 // keep one wave per tile.
 static inline int tile_parts_of(const cel_ctx *c, const cel_images *im) {
     if (im->TW != 32 || c->variant == 0) return 1;

@@ -24,6 +24,9 @@
 #define HW_TW 32
 #define HW_TH 64
 #define HW_PAD 12   // zero components behind the compacted table: a half's group may read past the end
+#ifndef HW_PART_ENTRIES
+#define HW_PART_ENTRIES 12   // k_render_hw<, PARTS>: list entries per working part of a tile
+#endif
 
 // largest value of the convex form a x^2 + 2 b x y + c y^2 on a rectangle: at one of the corners
 __host__ __device__ inline double quad_max_rect_hw(double a, double b, double c, double x1, double x2, double y1, double y2) {
@@ -500,6 +503,11 @@ k_render_hw(RenderArgs a) {
         if (part == 0) hw_empty_tile(a, bd, tile, b, X0, Y0, lane, t_start);
         return;
     }
+    // how many of the tile's PARTS blocks work: one per HW_PART_ENTRIES list entries (a tile of a few sources is not worth a
+    // slab hand-off; the heaviest tiles, which decide when a launch of few tiles ends, get all of them).  A function of the
+    // tile's list length only: every block of the tile computes the same number, the others leave at once.
+    const int peff = (PARTS > 1) ? min(PARTS, max(1, (cnt + HW_PART_ENTRIES - 1) / HW_PART_ENTRIES)) : 1;
+    if (PARTS > 1 && part >= peff) return;
 
     et[lane] = exp2((double)lane * (1.0 / 64.0));
 #pragma unroll
@@ -526,28 +534,28 @@ k_render_hw(RenderArgs a) {
         if (!star_setup(ST, bd, et, lane)) nstar = 0;   // a very sharp PSF component: general path (segments, direct fallback)
     }
     const int nstar_all = nstar;               // the rest of the list begins behind ALL of the tile's stars
-    if (PARTS > 1) nstar = (nstar > part) ? (nstar - part + PARTS - 1) / PARTS : 0;       // this part's stars: entries part, part + PARTS, ...
+    if (PARTS > 1) nstar = (nstar > part) ? (nstar - part + peff - 1) / peff : 0;         // this part's stars: entries part, part + peff, ...
     // (Requesting a star-only tile's nelec BEFORE the star pass, so that the loads land under the
     // arithmetic, was tried here -- before and after the first batch's record loads: a wave's loads
     // return in order -- and in a persistent, software-pipelined star kernel: slower in every form,
     // 0.179 / 0.180 / 0.205 against 0.171 ms on the dense star field -- DESIGN.md 5.)
     if (nstar > 0)
         star_pass<DIAG>(a, *reinterpret_cast<StarTab *>(&T), et, acc, recs, off, nstar, lane, X0, Y0, strict, dbg_halfrows, dbg_pairs,
-                        PARTS > 1 ? part : 0, PARTS);
+                        PARTS > 1 ? part : 0, peff);
 
     const LaneConst lc = lane_consts(lane, bd);
     // the rest of the tile's list (everything when there was no star pass), 64 indices per coalesced
     // load; the next source's record is in flight while the current one is evaluated
     const int64_t off2 = off + nstar_all + (PARTS > 1 ? part : 0);
     int nent = (dbg & 32) ? 0 : nent_all - nstar_all;
-    if (PARTS > 1) nent = (nent > part) ? (nent - part + PARTS - 1) / PARTS : 0;          // entries part, part + PARTS, ... of the rest
-    int idx64 = (lane < nent) ? a.lists[off2 + (int64_t)PARTS * lane] : 0;
+    if (PARTS > 1) nent = (nent > part) ? (nent - part + peff - 1) / peff : 0;            // entries part, part + peff, ... of the rest
+    int idx64 = (lane < nent) ? a.lists[off2 + (int64_t)peff * lane] : 0;
     int recw_next = (nent > 0) ? rec_fetch(recs, __builtin_amdgcn_readlane(idx64, 0), lane) : 0;
 
     for (int e = 0; e < nent; e++) {
         const int recw = recw_next;
         if (e + 1 < nent) {
-            if (((e + 1) & 63) == 0) idx64 = (e + 1 + lane < nent) ? a.lists[off2 + (int64_t)PARTS * (e + 1 + lane)] : 0;
+            if (((e + 1) & 63) == 0) idx64 = (e + 1 + lane < nent) ? a.lists[off2 + (int64_t)peff * (e + 1 + lane)] : 0;
             recw_next = rec_fetch(recs, __builtin_amdgcn_readlane(idx64, (e + 1) & 63), lane);
         }
         const RecU rec = rec_unpack(recw);
@@ -658,7 +666,7 @@ k_render_hw(RenderArgs a) {
         }
     }
 
-    if (PARTS > 1) {
+    if (PARTS > 1 && peff > 1) {
         // the tile's parts meet: this part's accumulator goes out as a slab; the last of the tile's parts to arrive adds all of
         // them up in part order
         __syncthreads();
@@ -674,7 +682,7 @@ k_render_hw(RenderArgs a) {
             ticket = __hip_atomic_fetch_add(&a.part_cnt[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         ticket = __builtin_amdgcn_readfirstlane(ticket);
-        if (ticket != PARTS - 1) return;
+        if (ticket != peff - 1) return;
         if (lane == 0) {
             __hip_atomic_store(&a.part_cnt[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch (zeroed when allocated)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -685,13 +693,12 @@ k_render_hw(RenderArgs a) {
 #pragma unroll 4
         for (int r = 0; r < HW_TH / 2; r++) {
             double v = s0[r * 64 + lane];
-#pragma unroll
-            for (int p = 1; p < PARTS; p++) v += s0[(size_t)p * (HW_TH * HW_TW) + r * 64 + lane];
+            for (int p = 1; p < peff; p++) v += s0[(size_t)p * (HW_TH * HW_TW) + r * 64 + lane];
             acc[r * 64 + lane] = v;
         }
     }
     hw_epilogue<false, DIAG>(a, acc, reinterpret_cast<double *>(&T), bd, tile, b, xi, Y0, lane, nullptr);
-    if (a.cost && lane == 0) a.cost[tile] = (int)min((wall_clock64() - t_start) * (unsigned long long)PARTS, 0x3fffffffull) + 1;
+    if (a.cost && lane == 0) a.cost[tile] = (int)min((wall_clock64() - t_start) * (unsigned long long)peff, 0x3fffffffull) + 1;
     if (timing && lane == 0) {
         timing[3 * (size_t)blockIdx.x + 0] = t_start;
         timing[3 * (size_t)blockIdx.x + 1] = wall_clock64();
