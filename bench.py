@@ -586,6 +586,25 @@ def extra_render_legs(args, env, field, out):
         field.images.render(field.sources, loglik=True)
     torch.cuda.synchronize()
     out["ms_per_step_with_source_upload"] = (time.perf_counter() - t0) / n * 1e3
+    # ONE source changed between evaluations (the reference's single-source moves, util/infer/mcmc_transitions.py:37-152): its
+    # row goes up (cel_sources_set_rows) and the render is INCREMENTAL -- only the tiles its old and new boxes touch are
+    # rendered again, bit for bit the full render's pixels and log-likelihood (CEL_OPT_INCREMENTAL; prep and binning in full)
+    field.sources.set(src["type"], src["radec"], src["counts"], src["shape"])
+    field.images.render(field.sources, loglik=True)
+    rs1 = np.random.RandomState(11)
+    pick = rs1.choice(field.S, n, replace=False).astype(np.int32)
+    dirty = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n):
+        row = pick[k:k + 1]
+        field.sources.set_rows(row, src["type"][row], src["radec"][row] + 1e-5, src["counts"][row] * 1.01, src["shape"][row])
+        ll_inc, _ = field.images.render(field.sources, loglik=True)
+    torch.cuda.synchronize()
+    out["ms_per_step_one_source_changed"] = (time.perf_counter() - t0) / n * 1e3
+    out["one_source_changed_tiles_rendered"] = field.images.last_render_dirty_tiles()
+    field.sources.set(src["type"], src["radec"], src["counts"], src["shape"])           # (back to the benchmark's catalogue)
+    field.images.render(field.sources, loglik=True)
     # the drop-in Python API north_star names: celeste_likelihood_multi_image(srcs, imgs)
     from desi_mcmc_amd import celeste
     imgs = synth.fits_images(field)

@@ -121,6 +121,7 @@ struct cel_ctx {
     static bool env_tail_ok() { const char *e = getenv("CEL_TAIL_LOG"); return e && atof(e) >= 0.0 && atof(e) <= 300.0; }
     double tail_T = env_tail_ok() ? atof(getenv("CEL_TAIL_LOG")) : 32.0;
     double render_T = env_tail_ok() ? atof(getenv("CEL_TAIL_LOG")) : 24.0;
+    int incremental = (getenv("CEL_INCREMENTAL") && atoi(getenv("CEL_INCREMENTAL")) == 0) ? 0 : 1;       // CEL_OPT_INCREMENTAL
     int tile_parts = (getenv("CEL_TILE_PARTS") && (atoi(getenv("CEL_TILE_PARTS")) == 1 || atoi(getenv("CEL_TILE_PARTS")) == 2 || atoi(getenv("CEL_TILE_PARTS")) == 4))
                          ? atoi(getenv("CEL_TILE_PARTS")) : 0;       // CEL_OPT_TILE_PARTS (the env var: the initial value, for A/B runs)
     int profile = 0;          // CEL_OPT_PROFILE: 0 off, 1 every kernel, 2 the evaluating kernels only
@@ -248,6 +249,10 @@ struct cel_images {
     cel_sources *sgen_prop = nullptr;
     int64_t last_S = 0;
     double last_entries = 0;
+    uint64_t partials_gen = 0;       // the per-tile Poisson partials in d_partials are those of this catalogue generation's render (0: not)
+    uint64_t lambda_uid = 0;         // the catalogue OBJECT whose generation lambda_gen is (the incremental render compares row stamps of the same object only)
+    int *d_dirty = nullptr;          // per tile: touched by a changed source's box (the incremental render)
+    int64_t last_dirty = -1;         // tiles the last render rendered incrementally (-1: it rendered every tile)
     // the one-launch path of a small star field (k_small_stars.h): per-block partials + per-band arrival counters
     double *d_small = nullptr, *h_small = nullptr;      // one buffer: pinned host memory and its device address
     double *d_small_consts = nullptr;
@@ -264,6 +269,9 @@ struct cel_sources {
     int64_t cap = 0, S = 0;
     int B = 0;
     uint64_t gen = 0;              // changes with every cel_sources_set (process-wide counter)
+    uint64_t uid = 0;              // which catalogue object this is (process-wide, never reused: a generation alone does not say whose it is)
+    uint64_t full_gen = 0;         // ... the generation of the last change of the WHOLE catalogue (cel_sources_set, a sampler's update)
+    std::vector<uint64_t> row_gen; // per row: the generation of its last change by cel_sources_set_rows (empty: none since full_gen)
     int64_t n_gal = -1;            // entries that are not stars (type != 0); -1 = unknown (types set from device memory)
     int *d_type = nullptr;
     double *d_radec = nullptr, *d_counts = nullptr, *d_shape = nullptr;
@@ -511,6 +519,10 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         if (!(v >= 0.0) || v > 300.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TAIL_LOG_SOURCE must be in [0, 300] (NaN: the default)");
         c->tail_T = v;
         return CEL_OK;
+    case CEL_OPT_INCREMENTAL:
+        if (v != 0.0 && v != 1.0) return fail(CEL_ERR_INVALID, "CEL_OPT_INCREMENTAL must be 0 or 1");
+        c->incremental = (int)v;
+        return CEL_OK;
     case CEL_OPT_TILE_PARTS:
         if (v != 0.0 && v != 1.0 && v != 2.0 && v != 4.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TILE_PARTS must be 0 (by the frame's size), 1, 2 or 4");
         c->tile_parts = (int)v;
@@ -568,6 +580,7 @@ int cel_ctx_get_option(cel_ctx *c, int key, double *v) {
     case CEL_OPT_TAIL_LOG: *v = c->render_T; return CEL_OK;
     case CEL_OPT_TAIL_LOG_SOURCE: *v = c->tail_T; return CEL_OK;
     case CEL_OPT_TILE_PARTS: *v = c->tile_parts; return CEL_OK;
+    case CEL_OPT_INCREMENTAL: *v = c->incremental; return CEL_OK;
     case CEL_OPT_PROFILE: *v = (double)c->profile; return CEL_OK;
     case CEL_OPT_TILE_ORDER: *v = (double)c->tile_order; return CEL_OK;
     case CEL_OPT_TILE_ROWS: *v = c->tile_rows; return CEL_OK;
@@ -589,7 +602,7 @@ int cel_images_destroy(cel_images *im) {
     void *ptrs[] = {im->d_bands, im->d_nelec, im->d_lambda, im->d_partials, im->d_llband, im->d_recs,
                     im->d_boxes, im->d_kind, im->d_status, im->d_tile_cnt, im->d_tile_nstar, im->d_tile_work, im->d_tile_cost, im->d_order, im->d_tile_off, im->d_lists, im->d_stats,
                     im->d_sup_cnt, im->d_sup_off, im->d_clist, im->d_timing, im->d_samp, im->d_sbox, im->d_soff, im->d_rate, im->d_snz, im->d_ssum,
-                    im->d_nnz, im->d_nzmode, im->d_nzoff, im->d_nzlist, im->d_btot, im->d_slabs, im->d_part_cnt};
+                    im->d_nnz, im->d_nzmode, im->d_nzoff, im->d_nzlist, im->d_btot, im->d_slabs, im->d_part_cnt, im->d_dirty};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (im->d_slice) (void)hipFree(im->d_slice);
@@ -797,6 +810,7 @@ int cel_sources_create(cel_ctx *c, int64_t capacity, int B, cel_sources **out) {
     cel_sources *s = new (std::nothrow) cel_sources();
     if (!s) return fail(CEL_ERR_NOMEM, "out of host memory");
     s->ctx = c; s->cap = capacity; s->B = B;
+    s->uid = ++g_source_gen;
     hipError_t e;
     if ((e = hipMalloc((void **)&s->d_type, sizeof(int) * capacity)) != hipSuccess ||
         (e = hipMalloc((void **)&s->d_radec, sizeof(double) * 2 * capacity)) != hipSuccess ||
@@ -824,7 +838,8 @@ int cel_sources_set(cel_sources *s, int64_t S, const int32_t *type, const double
         if (mem != CEL_DEVICE) HIP_TRY(hipStreamSynchronize(st));   // pageable sources must stay valid: one sync for the four
     }
     s->S = S;
-    s->gen = ++g_source_gen;
+    s->gen = s->full_gen = ++g_source_gen;
+    s->row_gen.clear();
     s->n_gal = -1;
     s->h_type.clear();
     if (mem != CEL_DEVICE) {
@@ -883,6 +898,10 @@ int cel_sources_set_rows(cel_sources *s, int64_t n, const int32_t *idx, const in
         s->n_gal = -1;
     }
     s->gen = ++g_source_gen;
+    // which rows changed since when: a render whose image set still holds the model image of an earlier generation of THIS
+    // catalogue renders only the tiles these rows' boxes touch (render_impl: the incremental path)
+    if ((int64_t)s->row_gen.size() != s->S) s->row_gen.assign((size_t)s->S, 0);
+    for (int64_t i = 0; i < n; i++) s->row_gen[idx[i]] = s->gen;
     return CEL_OK;
 }
 
@@ -1123,10 +1142,48 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
             return CEL_OK;
         }
     }
+    // The INCREMENTAL render (round 5).  The reference's single-source moves (util/infer/mcmc_transitions.py:37-152) evaluate the
+    // whole field's likelihood after changing ONE source.  When this image set still holds the model image, records, lists and
+    // per-tile Poisson partials of an earlier generation of THIS catalogue and only a few rows changed since
+    // (cel_sources_set_rows stamps them), only the tiles that the changed sources' boxes touch -- the boxes they had and the
+    // boxes they have now -- are rendered again, each from its complete list: the same arithmetic in the same order as the full
+    // render, so pixels, partials and log-likelihoods are the full render's bit for bit; every other tile's pixels and partial
+    // are still valid.  Source preparation and binning run in full (66 us at configs[2]); a render with nothing changed, or
+    // after a whole-catalogue upload, is a full render -- nothing is ever answered from a cache.
+    const bool diag_r = c->tile_timing || (c->debug & ~64);
+    const bool stars_only_r = im->TW == HW_TW && !diag_r && c->star_tiles && src->n_gal == 0 && im->star_one_segment &&
+                              c->variant != 0 && (c->star_tiles == 2 || T > STAR_TILES_MIN);
+    DeltaRows delta;
+    delta.n = 0;
+    bool incr = c->incremental && !lambda_out && !(flags & (CEL_RENDER_NO_STORE | CEL_RENDER_STRICT)) && im->TW == HW_TW &&
+                c->variant != 0 && !diag_r && !stars_only_r && tile_parts_of(c, im) == 1 && S > 0 && S == im->last_S &&
+                im->lambda_gen != 0 && im->lambda_uid == src->uid && im->lambda_gen != src->gen && im->lambda_gen >= src->full_gen &&
+                im->lists_gen == im->lambda_gen && im->recs_gen == im->lambda_gen && (int64_t)src->row_gen.size() == S &&
+                (!(flags & CEL_RENDER_LOGLIK) || im->partials_gen == im->lambda_gen);
+    if (incr) {
+        for (int64_t s = 0; s < S && incr; s++)
+            if (src->row_gen[(size_t)s] > im->lambda_gen) {
+                if (delta.n == DELTA_MAX) incr = false;
+                else delta.idx[delta.n++] = (int)s;
+            }
+        if (delta.n == 0) incr = false;
+    }
+    if (incr) {
+        if (!im->d_dirty) HIP_TRY(hipMalloc((void **)&im->d_dirty, sizeof(int) * (size_t)T));
+        HIP_TRY(hipMemsetAsync(im->d_dirty, 0, sizeof(int) * (size_t)T, st));
+        // the tiles the changed sources' OLD boxes touch (before k_prep rewrites the boxes) ...
+        hipLaunchKernelGGL(k_mark_dirty, dim3((unsigned)((delta.n * im->B + 255) / 256)), dim3(256), 0, st, delta, (const int4 *)im->d_boxes, S, im->B,
+                           im->ntx, im->nty, im->TW, im->TH, im->d_dirty);
+    }
+    if (flags & CEL_RENDER_LOGLIK) im->partials_gen = 0;
     im->lists_gen = 0;
     if (!lambda_out && !(flags & CEL_RENDER_NO_STORE)) im->lambda_gen = 0;
     rc = run_prep(im, src);
     if (rc) return rc;
+    if (incr)       // ... and the tiles their new boxes touch
+        hipLaunchKernelGGL(k_mark_dirty, dim3((unsigned)((delta.n * im->B + 255) / 256)), dim3(256), 0, st, delta, (const int4 *)im->d_boxes, S, im->B,
+                           im->ntx, im->nty, im->TW, im->TH, im->d_dirty);
+    im->last_dirty = -1;
     if (im->lists_cap == 0) {
         // first guess: every (band, source) touches ~6 tiles; grown on overflow below
         rc = ensure_lists(im, (S * im->B) * 6 + 1024);
@@ -1185,6 +1242,7 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         a.S = S; a.capacity = im->lists_cap; a.B = im->B; a.H = im->H; a.W = im->W; a.ntx = im->ntx; a.nty = im->nty;
         a.flags = flags | (c->debug << 8); a.variant = c->variant; a.tail_T = c->render_T; a.order = tile_order ? im->d_order : nullptr;
         a.timing = nullptr;
+        a.dirty = incr ? im->d_dirty : nullptr;
         a.cost = (im->TW == HW_TW || im->TW == QW_TW) ? im->d_tile_cost : nullptr;
         if (c->tile_timing) {
             if (!im->d_timing) HIP_TRY(hipMalloc((void **)&im->d_timing, sizeof(unsigned long long) * 3 * T));
@@ -1263,7 +1321,12 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         if (fine_ok && coarse_ok) {
             im->cost_S = a.cost ? S : -1; im->order_S = post_order ? S : -1;
             im->lists_gen = src->gen;
-            if (!lambda_out && !(flags & (CEL_RENDER_NO_STORE | CEL_RENDER_STRICT)) && im->TW == HW_TW && c->variant != 0) im->lambda_gen = src->gen;
+            if (!lambda_out && !(flags & (CEL_RENDER_NO_STORE | CEL_RENDER_STRICT)) && im->TW == HW_TW && c->variant != 0) {
+                im->lambda_gen = src->gen;
+                im->lambda_uid = src->uid;
+                if (flags & CEL_RENDER_LOGLIK) im->partials_gen = src->gen;
+            }
+            if (incr) im->last_dirty = -2;          // (counted on request: cel_debug_last_render)
             break;
         }
         im->cost_S = -1;
@@ -1291,6 +1354,21 @@ int cel_debug_split_rates(cel_images *im, double *out) {
     if (!im->d_rate) return fail(CEL_ERR_INVALID, "no totals image: cel_photon_split on the recurrence kernels has not run");
     HIP_TRY(hipSetDevice(im->ctx->device));
     return copy_out(out, im->d_rate, sizeof(double) * (size_t)im->B * im->H * im->W, CEL_HOST, im->ctx->stream);
+}
+
+int cel_debug_last_render(cel_images *im, int64_t *dirty_tiles) {
+    if (!im || !dirty_tiles) return fail(CEL_ERR_INVALID, "cel_debug_last_render: null argument");
+    *dirty_tiles = -1;
+    if (im->last_dirty == -1 || !im->d_dirty) return CEL_OK;
+    HIP_TRY(hipSetDevice(im->ctx->device));
+    const int T = im->B * im->ntx * im->nty;
+    std::vector<int> h((size_t)T);
+    int rc = copy_out(h.data(), im->d_dirty, sizeof(int) * (size_t)T, CEL_HOST, im->ctx->stream);
+    if (rc) return rc;
+    int64_t n = 0;
+    for (int v : h) n += (v != 0);
+    *dirty_tiles = n;
+    return CEL_OK;
 }
 
 int cel_debug_tile_timing(cel_images *im, uint64_t *out, int64_t *n_tiles) {
@@ -1841,7 +1919,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
             for (int k = 0; k < nb; k++) {
                 // the first round's points; every later round's were named by the step kernel of the round before
                 if (queued == 0) hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags);
-                prop->gen = ++g_source_gen;
+                prop->gen = prop->full_gen = ++g_source_gen;
                 // the first round's records; every later round's were written by the step kernel that named its points
                 if (queued == 0 && (rc = run_prep(im, prop, d_owner, 1))) return rc;      // the patch limits are fixed: no boxes
                 if (c->variant == 0) {
@@ -1904,7 +1982,8 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     }
     // the new locations replace the catalogue's
     HIP_TRY(hipMemcpyAsync(src->d_radec, ss.x, sizeof(double) * 2 * S, hipMemcpyDeviceToDevice, st));
-    src->gen = ++g_source_gen;
+    src->gen = src->full_gen = ++g_source_gen;
+    src->row_gen.clear();
     if (radec_out) HIP_TRY(hipMemcpyAsync(radec_out, ss.x, sizeof(double) * 2 * S, hipMemcpyDeviceToHost, st));
     if (llh_out) HIP_TRY(hipMemcpyAsync(llh_out, ss.new_llh, sizeof(double) * S, hipMemcpyDeviceToHost, st));
     unsigned long long *d_bytes = reinterpret_cast<unsigned long long *>(((uintptr_t)(d_flags + 6) + 7) & ~(uintptr_t)7);
@@ -2035,7 +2114,7 @@ int cel_slice_sample(cel_images *im, cel_sources *src, int param, const int32_t 
         for (int k = 0; k < nb; k++) {
             hipLaunchKernelGGL(k_sg_propose, dim3(g256), dim3(256), 0, st, g, rs, S, param ? prop->d_shape : prop->d_radec, d_owner, d_flags,
                                queued == 0 ? 1 : 0);
-            prop->gen = ++g_source_gen;
+            prop->gen = prop->full_gen = ++g_source_gen;
             if ((rc = run_prep(im, prop, d_owner, 1))) return rc;      // the patch limits are fixed: no boxes
             if (c->variant == 0) {
                 int pi = prof_slot(c, CEL_K_PATCH_LL);
@@ -2079,7 +2158,7 @@ int cel_slice_sample(cel_images *im, cel_sources *src, int param, const int32_t 
     }
     // the new states replace the catalogue's
     HIP_TRY(hipMemcpyAsync(param ? src->d_shape : src->d_radec, g.x, sizeof(double) * D * S, hipMemcpyDeviceToDevice, st));
-    src->gen = ++g_source_gen;
+    src->gen = src->full_gen = ++g_source_gen; src->row_gen.clear();
     if (x_out) HIP_TRY(hipMemcpyAsync(x_out, g.x, sizeof(double) * D * S, hipMemcpyDeviceToHost, st));
     if (llh_out) HIP_TRY(hipMemcpyAsync(llh_out, g.new_llh, sizeof(double) * S, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -2122,6 +2201,7 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
     const bool hw = (c->variant != 0) && (im->TW == HW_TW);
     bool use_massfx = false;
     int rc;
+    if (!hw) im->partials_gen = 0;              // (the direct form keeps its noise partials in the render's buffer)
     if (hw) {
         if (!im->d_rate) HIP_TRY(hipMalloc((void **)&im->d_rate, sizeof(double) * (size_t)im->B * im->H * im->W));
         im->massfx_gen = 0;
@@ -2387,6 +2467,7 @@ int cel_estep_stats(cel_images *im, cel_sources *src, double *xtilde, double *ma
     const int B = im->B;
     const int64_t S = src->S;
     const int nblk = im->ntx * im->nty;                 // d_partials holds B * nblk doubles
+    im->partials_gen = 0;                               // ... of this call's sky term from here on
     double *d_x = nullptr, *d_m = nullptr, *d_part = nullptr;
     // recurrence evaluator on the 32 x 64 layout: the tile-walking form (the render above left the
     // lists and boxes of exactly these sources on the device); CEL_OPT_DEBUG bit 64 keeps the per-source form

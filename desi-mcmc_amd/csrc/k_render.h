@@ -420,7 +420,25 @@ struct RenderArgs {
     double tail_T;    // drop threshold (0 = never)
     double *slabs;    // k_render_hw<, PARTS > 1>: PARTS accumulator tiles per render tile (16 KB each), and
     int *part_cnt;    //   the tiles' arrival counters (zero between launches)
+    const int *dirty; // k_render_hw<false, 1>: per tile, != 0: render it; 0: its pixels and its partial are still those of the last
+                      //   render (no changed source's box touches it); nullptr: every tile
 };
+
+// The tiles a box touches are marked dirty (32-column x 64-row tiles).  One thread per (changed row, band); called once with the
+// boxes the changed sources HAD (before k_prep rewrites them) and once with those they have now.
+#define DELTA_MAX 64
+struct DeltaRows { int n; int idx[DELTA_MAX]; };
+__global__ void __launch_bounds__(256)
+k_mark_dirty(DeltaRows d, const int4 *__restrict__ boxes /* [B][S]: x0, x1, y0, y1 */, int64_t S, int B, int ntx, int nty, int TW, int TH,
+             int *__restrict__ dirty) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n * B) return;
+    const int r = i / B, b = i - r * B;
+    const int4 q = boxes[(int64_t)b * S + d.idx[r]];
+    if (q.y <= q.x || q.w <= q.z) return;
+    for (int ty = q.z / TH; ty <= (q.w - 1) / TH && ty < nty; ty++)
+        for (int tx = q.x / TW; tx <= (q.y - 1) / TW && tx < ntx; tx++) dirty[(b * nty + ty) * ntx + tx] = 1;
+}
 
 template <int TH>
 __global__ void __launch_bounds__(64)

@@ -488,6 +488,7 @@ k_render_hw(RenderArgs a) {
         if (tpos >= a.B * a.ntx * a.nty) return;
     }
     const int tile = a.order ? a.order[tpos] : tpos;
+    if (PARTS == 1 && !DIAG && a.dirty && !a.dirty[tile]) return;      // an incremental render: this tile did not change
     const int per_band = a.ntx * a.nty;
     const int b = tile / per_band;
     const int t = tile - b * per_band;

@@ -271,6 +271,13 @@ class ImageSet(object):
         L.check(L.lib().cel_debug_tile_timing(self._h, buf.ctypes.data, C.byref(n)))
         return buf
 
+    def last_render_dirty_tiles(self):
+        """-1 when the last render of this set rendered every tile; otherwise the number of tiles its incremental render
+        (CEL_OPT_INCREMENTAL: only the tiles the changed rows' boxes touch) rendered -- diagnostic (cel_debug_last_render)"""
+        n = C.c_int64(0)
+        L.check(L.lib().cel_debug_last_render(self._h, C.byref(n)))
+        return n.value
+
     def source_boxes(self, sources):
         """(boxes[B,S,4] = y0,y1,x0,x1, status[B,S]) for every band."""
         S = sources.S

@@ -73,6 +73,13 @@ enum {
                               (the per-source kernels': CEL_OPT_TAIL_LOG_SOURCE).  CEL_TAIL_LOG in the
                               environment, when inside [0, 300], is the initial value of both       */
     CEL_OPT_TAIL_LOG_SOURCE = 12, /* the per-source kernels' threshold alone (set / get; NaN: its default, 32) */
+    CEL_OPT_INCREMENTAL = 14, /* 1 (default): a cel_render_field whose image set still holds the model image, tile lists and Poisson
+                               partials of an earlier state of the SAME catalogue, from which at most 64 rows were changed by
+                               cel_sources_set_rows since, renders only the tiles those rows' old and new boxes touch -- each
+                               from its complete source list, so every pixel and the log-likelihood are the full render's bit
+                               for bit (source preparation and binning still run in full).  The reference's single-source moves
+                               (util/infer/mcmc_transitions.py:37-152) evaluate the whole likelihood after changing one source.
+                               A render after cel_sources_set, or with nothing changed, renders every tile.  0 = always every tile */
     CEL_OPT_TILE_PARTS = 13, /* how many one-wave blocks share a render tile of the general 32 x 64 kernel.  0 (default) = by
                                the frame's size: 4 for at most 512 tiles, 2 for at most 3 072, else 1 -- a frame of few tiles
                                (one rank's row strip of a field cut 8 ways, a 51 x 51 real field) finishes when its heaviest
@@ -256,6 +263,11 @@ int cel_field_stats(cel_images *img, double *n_srcpix, double *n_gauss, double *
  * strict boxes), B*H*W doubles to host memory: what the tests compare between the two ways of forming it (CEL_OPT_SPLIT_REUSE) */
 int cel_debug_split_rates(cel_images *img, double *out);
 int cel_debug_tile_timing(cel_images *img, uint64_t *out, int64_t *n_tiles);
+/* diagnostic: how the last cel_render_field of this image set rendered -- *dirty_tiles = -1: every tile; >= 0: incrementally
+ * (CEL_OPT_INCREMENTAL), that many tiles: those touched by the boxes of the rows cel_sources_set_rows changed since the
+ * image set's previous render of the same catalogue.  What the tests use to know which path ran; replaces nothing in the
+ * reference (its gen_model_image re-renders every source on every call, CelestePy/celeste.py:203-219). */
+int cel_debug_last_render(cel_images *img, int64_t *dirty_tiles);
 
 /* ---- stamps --------------------------------------------------------------------------- */
 /* gen_point_source_psf_image (celeste.py:114-176) / gen_galaxy_psf_image

@@ -720,6 +720,105 @@ def _row_strips_body(cel, ctx, f, H, W, world, frac_gal, rt):
         cel.ImageSet(ctx, f.bands, 64, W).set_window(150, H)       # window does not fit the frame
 
 
+def test_incremental_render_is_the_full_render_bit_for_bit(cel, ctx, big_field):
+    """CEL_OPT_INCREMENTAL: after cel_sources_set_rows changed a few rows of the catalogue an image set already holds the model
+    image of, cel_render_field renders only the tiles the changed sources' old and new boxes touch.  Every such tile is
+    rendered from its complete list, so model pixels, per-band log-likelihoods and work counters equal a full render of the
+    same catalogue BIT FOR BIT -- a source moved within its tile, across tiles, off the frame and back, a flux change, a
+    star <-> galaxy change, a galaxy grown to a box of hundreds of pixels, many rows at once; more than 64 changed rows, a
+    whole-catalogue upload, a new sky level, another catalogue in between, a render without the log-likelihood before one
+    with it, and the option switched off all fall back to rendering every tile; a render with NOTHING changed renders every
+    tile too (nothing is answered from a cache).  On the BASELINE-size field (10 240 tiles) and on a small frame."""
+    from desi_mcmc_amd import synth
+    L = cel._lib
+    small = synth.SyntheticField(ctx, 700, 3, 400, 300, frac_gal=0.5, seed=19)
+    for f, force_parts in ((big_field, 0), (small, 1)):
+        ctx.set_option(L.CEL_OPT_TILE_PARTS, force_parts)           # (a frame of few tiles takes the several-waves-per-tile kernel: every tile)
+        try:
+            S, B = f.S, f.B
+            cur = {k: np.array(f.src[k], copy=True) for k in ("type", "radec", "counts", "shape")}
+            sset = cel.SourceSet(ctx, S, B).set(cur["type"], cur["radec"], cur["counts"], cur["shape"])
+            ref_set = cel.SourceSet(ctx, S, B)
+            ref_img = cel.ImageSet(ctx, f.bands, f.H, f.W, nelec=f.nelec)
+            img = cel.ImageSet(ctx, f.bands, f.H, f.W, nelec=f.nelec)
+            rs = np.random.RandomState(3)
+
+            def check(rows, expect_incremental, loglik=True):
+                rows = np.asarray(rows, dtype=np.int32)
+                if rows.size:
+                    sset.set_rows(rows, cur["type"][rows], cur["radec"][rows], cur["counts"][rows], cur["shape"][rows])
+                out = img.render(sset, loglik=loglik)
+                dirty = img.last_render_dirty_tiles()
+                assert (dirty >= 0) == expect_incremental, (dirty, expect_incremental, rows[:8])
+                want = ref_img.render(ref_set.set(cur["type"], cur["radec"], cur["counts"], cur["shape"]), loglik=True)
+                assert ref_img.last_render_dirty_tiles() == -1
+                assert np.array_equal(img.model_images(), ref_img.model_images())
+                if loglik:
+                    assert np.array_equal(out[1], want[1]) and out[0] == want[0]
+                    assert img.stats() == ref_img.stats()
+                return dirty
+            check([], False)                                         # the first render: every tile
+            check([], False)                                         # nothing changed: every tile again, not a cached answer
+            s0 = int(np.nonzero(cur["type"] == 1)[0][5])
+            cur["radec"][s0] += [2e-5, -1e-5]                        # a galaxy moved by a fraction of a pixel
+            d1 = check([s0], True)
+            assert 0 < d1 < 0.2 * B * ((f.W + 31) // 32) * ((f.H + 63) // 64)
+            cur["radec"][s0] = synth.pixel2equa(f.bands[0], np.array([[f.W * 0.2, f.H * 0.8]]))[0]     # across the frame: old and new tiles
+            check([s0], True)
+            s1 = int(np.nonzero(cur["type"] == 0)[0][7])
+            cur["counts"][s1] *= 3.0                                 # a star's flux
+            cur["type"][s1] = 1                                      # ... and it turns into a galaxy
+            cur["shape"][s1] = [0.4, 1.3, 30.0, 0.6]
+            check([s1], True)
+            cur["radec"][s1] = synth.pixel2equa(f.bands[0], np.array([[-400.0, -300.0]]))[0]            # off the frame: an empty box now
+            check([s1], True)
+            cur["radec"][s1] = synth.pixel2equa(f.bands[0], np.array([[f.W / 2.0, f.H / 2.0]]))[0]      # and back
+            cur["shape"][s1] = [0.1, 4.0, 120.0, 0.9]                # a 4-arcsec galaxy: a box hundreds of pixels wide
+            check([s1], True)
+            many = rs.choice(S, 40, replace=False)
+            cur["radec"][many] += rs.normal(0, 3e-5, (40, 2))
+            cur["counts"][many] *= np.exp(rs.normal(0, 0.2, (40, B)))
+            check(many, True)
+            some = rs.choice(S, 30, replace=False)                   # two batches before one render: 60 rows in all
+            cur["counts"][some] *= 1.1
+            sset.set_rows(some.astype(np.int32), cur["type"][some], cur["radec"][some], cur["counts"][some], cur["shape"][some])
+            more = np.setdiff1d(rs.choice(S, 40, replace=False), some)[:30]
+            cur["counts"][more] *= 0.9
+            check(more, True)
+            lots = rs.choice(S, 100, replace=False)                  # more rows than the path takes: every tile
+            cur["counts"][lots] *= 1.05
+            check(lots, False)
+            cur["counts"][s0] *= 1.01
+            check([s0], True)
+            cur["counts"][s0] *= 1.01                                # the whole catalogue uploaded: every tile
+            sset.set(cur["type"], cur["radec"], cur["counts"], cur["shape"])
+            check([], False)
+            cur["counts"][s0] *= 1.01
+            img.set_epsilon(0, f.bands[0, 0] * 1.001)                # a new sky level: the image on the device is stale
+            ref_img.set_epsilon(0, f.bands[0, 0] * 1.001)
+            check([s0], False)
+            cur["counts"][s0] *= 1.01                                # a render WITHOUT the log-likelihood does not refresh the partials ...
+            check([s0], True, loglik=False)
+            cur["counts"][s0] *= 1.01                                # ... so the next one with it renders every tile
+            check([s0], False)
+            cur["counts"][s0] *= 1.01                                # another catalogue rendered in between: every tile
+            img.render(ref_set, loglik=True)
+            check([s0], False)
+            cur["counts"][s0] *= 1.01
+            ctx.set_option(L.CEL_OPT_INCREMENTAL, 0)
+            try:
+                check([s0], False)
+            finally:
+                ctx.set_option(L.CEL_OPT_INCREMENTAL, 1)
+            cur["counts"][s0] *= 1.01
+            check([s0], True)
+            img.set_epsilon(0, f.bands[0, 0])
+        finally:
+            ctx.set_option(L.CEL_OPT_TILE_PARTS, 0)
+    with pytest.raises(ValueError):
+        ctx.set_option(L.CEL_OPT_INCREMENTAL, 2)
+
+
 def test_owned_rows_restrict_the_log_likelihood(cel, ctx):
     """cel_images_set_noise_rows: an image set that holds a halo around the rows it OWNS (a rank's window of the
     strip-partitioned chain) renders the model image on every row and adds the Poisson terms of its own rows only -- the
