@@ -309,7 +309,7 @@ _ENTRY_OF = {}                # id(typ array) -> entry: how _device_sources reco
 
 
 class _ListEntry(object):
-    __slots__ = ("srcs", "objs", "stamps", "clock", "imgkey", "typ", "radec", "counts", "shape", "version", "log", "audit")
+    __slots__ = ("srcs", "objs", "stamps", "clock", "imgkey", "typ", "radec", "counts", "shape", "version", "log", "audit", "index")
 
     def rows_since(self, version):
         """rows changed after `version`, or None when the log no longer reaches back that far"""
@@ -328,7 +328,7 @@ def _stamp_column(srcs, S):
 
 
 def _cached_list_arrays(srcs, images, counts_fn, bidx, calib, kappa):
-    from .celeste_src import clock
+    from .celeste_src import clock, stamped_since
     S = len(srcs)
     key = (id(srcs), tuple(map(id, images)), counts_fn)
     imgkey = (tuple(bidx), tuple(calib.tolist()), tuple(kappa.tolist()))
@@ -337,8 +337,16 @@ def _cached_list_arrays(srcs, images, counts_fn, bidx, calib, kappa):
         _LIST_CACHE.move_to_end(key)
         now = clock()
         if now != ent.clock:                   # some SrcParams somewhere was assigned to since the last look
-            stamps = _stamp_column(srcs, S)
-            rows = np.nonzero(stamps != ent.stamps)[0]
+            ids = stamped_since(ent.clock)     # which: from the assignment log's tail, or -- the log too short -- from every stamp
+            if ids is not None and len(ids) <= 64 and ent.index is not None:
+                rows = np.array(sorted({ent.index[i] for i in ids if i in ent.index}), dtype=np.int64)
+                stamps = ent.stamps
+                if rows.size:
+                    stamps = ent.stamps.copy()
+                    stamps[rows] = [srcs[i]._stamp for i in rows]
+            else:
+                stamps = _stamp_column(srcs, S)
+                rows = np.nonzero(stamps != ent.stamps)[0]
             if rows.size > max(S // 8, 16):
                 ent = None                      # most of the list moved: gather it whole
             else:
@@ -364,6 +372,9 @@ def _cached_list_arrays(srcs, images, counts_fn, bidx, calib, kappa):
     ent.srcs, ent.objs, ent.stamps, ent.clock, ent.imgkey = srcs, list(srcs), stamps, now, imgkey
     ent.typ, ent.radec, ent.counts, ent.shape = arrs
     ent.version, ent.log, ent.audit = 0, [], 0
+    ent.index = {i: k for k, i in enumerate(map(id, srcs))}          # id(object) -> row (the entry keeps the objects alive: ids stay theirs)
+    if len(ent.index) != S:
+        ent.index = None                                             # an object listed twice: the stamps decide
     _LIST_CACHE[key] = ent
     _ENTRY_OF[id(ent.typ)] = ent
     while len(_LIST_CACHE) > _LIST_CACHE_MAX:

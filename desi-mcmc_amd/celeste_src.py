@@ -28,6 +28,11 @@ def nanomaggies2mags(nanos):
 # of a list after changing ONE source (util/infer/mcmc_transitions.py:37-152, celeste_mcmc.py:130).
 _CLOCK = [0]
 _set = object.__setattr__
+# ... and a bounded log of (stamp, id(object)) of the latest assignments: a cached list of 10 000 sources finds the one object
+# that was assigned to since its last look by reading the log's tail instead of every object's stamp (celeste._cached_list_arrays;
+# when the log no longer reaches back to that look, it reads the stamps)
+import collections as _collections
+_LOG = _collections.deque(maxlen=8192)
 
 
 def clock():
@@ -40,6 +45,22 @@ def touch(src):
     after their in-place edits (mcmc_transitions.py:49-51) -- stamps by itself."""
     _CLOCK[0] += 1
     _set(src, "_stamp", _CLOCK[0])
+    _LOG.append((_CLOCK[0], id(src)))
+
+
+def stamped_since(clock0, limit=64):
+    """ids of the objects assigned to after the clock read `clock0` (at most limit + 1 of them: the caller then reads the
+    stamps instead), or None when the log does not reach back that far"""
+    if _CLOCK[0] - clock0 > limit:                 # (every assignment ticks the clock once)
+        return None
+    if not _LOG or _LOG[0][0] > clock0 + 1:
+        return None if _CLOCK[0] != clock0 else []
+    out = []
+    for stamp, oid in reversed(_LOG):
+        if stamp <= clock0:
+            break
+        out.append(oid)
+    return out
 
 
 class SrcParams(object):
@@ -57,6 +78,7 @@ class SrcParams(object):
         _set(self, name, value)
         _CLOCK[0] += 1
         _set(self, "_stamp", _CLOCK[0])
+        _LOG.append((_CLOCK[0], id(self)))
 
     def __eq__(self, other):
         return isinstance(other, SrcParams) and np.array_equal(self.u, other.u) and self.b == other.b

@@ -393,6 +393,15 @@ def test_list_of_srcparams_is_gathered_once_and_then_row_by_changed_row(built):
     assert check()[0].shape[0] == S + 1
     del ps[10]
     assert check()[0].shape[0] == S
+    ps[20] = ps[21]                                                     # one object listed twice: both rows follow it
+    check()
+    ps[21].sigma = 3.25
+    got = check()
+    assert got[3][20, 1] == got[3][21, 1] == 3.25 or ps[21].a != 1
+    for k in range(9000):                                               # more assignments than the log holds: the stamps decide
+        ps[30].rho = 0.5 + 1e-6 * k
+    ps[31].rho = 0.25
+    check()
     short = ps[:10]                                                     # short lists are not cached
     celeste._source_arrays(short, ims)
     assert all(e.srcs is not short for e in celeste._LIST_CACHE.values())
