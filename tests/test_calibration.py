@@ -123,9 +123,11 @@ def run_replicate(cel, ctx, rep, engine, chain_seed, J, ncell=12, shapes=False, 
 
 
 def pooled_ranks(cel, ctx, engine, ncell, shapes=False, shape_args=None, shape_mass="reference"):
+    import os
+    reps = (K_DRAWS + 1) * max(1, int(os.environ.get("CEL_SBC_ROUNDS", "1")))       # every position J equally often (CEL_SBC_ROUNDS=8: 64 replicates)
     parts = zip(*[run_replicate(cel, ctx, rep, engine, chain_seed=rep, J=rep % (K_DRAWS + 1), ncell=ncell, shapes=shapes, shape_args=shape_args,
                                 shape_mass=shape_mass)
-                  for rep in range(K_DRAWS + 1)])
+                  for rep in range(reps)])
     return tuple(np.concatenate(p) for p in parts)
 
 
