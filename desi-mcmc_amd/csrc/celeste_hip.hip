@@ -251,6 +251,8 @@ struct cel_images {
     double last_entries = 0;
     uint64_t partials_gen = 0;       // the per-tile Poisson partials in d_partials are those of this catalogue generation's render (0: not)
     uint64_t lambda_uid = 0;         // the catalogue OBJECT whose generation lambda_gen is (the incremental render compares row stamps of the same object only)
+    double lambda_T = -1.0;          // ... and the drop threshold that image was rendered at
+    int lambda_parts = 0;            // ... with so many blocks per tile
     int *d_dirty = nullptr;          // per tile: touched by a changed source's box (the incremental render)
     int64_t last_dirty = -1;         // tiles the last render rendered incrementally (-1: it rendered every tile)
     // the one-launch path of a small star field (k_small_stars.h): per-block partials + per-band arrival counters
@@ -705,6 +707,7 @@ int cel_images_set_nelec(cel_images *im, const double *nelec, int mem) {
     int rc = copy_in(im->d_nelec, nelec, sizeof(double) * (size_t)im->B * im->H * im->W, mem, im->ctx->stream);
     if (rc != CEL_OK) return rc;
     im->have_nelec = true;
+    im->partials_gen = 0;                 // the tiles' Poisson partials were formed against the old pixels (the incremental render keeps none of them)
     // the image's range: 0 ... 65 535 everywhere lets the photon split keep its photons-left plane in 16 bits (k_split.h)
     im->nelec_u16 = false;
     {
@@ -1157,7 +1160,8 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
     delta.n = 0;
     bool incr = c->incremental && !lambda_out && !(flags & (CEL_RENDER_NO_STORE | CEL_RENDER_STRICT)) && im->TW == HW_TW &&
                 c->variant != 0 && !diag_r && !stars_only_r && tile_parts_of(c, im) == 1 && S > 0 && S == im->last_S &&
-                im->lambda_gen != 0 && im->lambda_uid == src->uid && im->lambda_gen != src->gen && im->lambda_gen >= src->full_gen &&
+                im->lambda_gen != 0 && im->lambda_uid == src->uid && im->lambda_T == c->render_T && im->lambda_parts == 1 && im->lambda_gen != src->gen &&
+                im->lambda_gen >= src->full_gen &&
                 im->lists_gen == im->lambda_gen && im->recs_gen == im->lambda_gen && (int64_t)src->row_gen.size() == S &&
                 (!(flags & CEL_RENDER_LOGLIK) || im->partials_gen == im->lambda_gen);
     if (incr) {
@@ -1184,6 +1188,7 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         hipLaunchKernelGGL(k_mark_dirty, dim3((unsigned)((delta.n * im->B + 255) / 256)), dim3(256), 0, st, delta, (const int4 *)im->d_boxes, S, im->B,
                            im->ntx, im->nty, im->TW, im->TH, im->d_dirty);
     im->last_dirty = -1;
+    int parts_used = 1;
     if (im->lists_cap == 0) {
         // first guess: every (band, source) touches ~6 tiles; grown on overflow below
         rc = ensure_lists(im, (S * im->B) * 6 + 1024);
@@ -1253,6 +1258,7 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         // instantiation with counters / time stamps / ablations exists for the general kernel only
         const bool diag = a.timing || (c->debug & ~64);
         const int parts = diag ? 1 : tile_parts_of(c, im);
+        parts_used = (im->TW == HW_TW && !diag) ? parts : 1;
         a.slabs = nullptr; a.part_cnt = nullptr;
         if (parts > 1) {
             if (im->slabs_parts < parts) {
@@ -1324,6 +1330,8 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
             if (!lambda_out && !(flags & (CEL_RENDER_NO_STORE | CEL_RENDER_STRICT)) && im->TW == HW_TW && c->variant != 0) {
                 im->lambda_gen = src->gen;
                 im->lambda_uid = src->uid;
+                im->lambda_T = c->render_T;
+                im->lambda_parts = parts_used;
                 if (flags & CEL_RENDER_LOGLIK) im->partials_gen = src->gen;
             }
             if (incr) im->last_dirty = -2;          // (counted on request: cel_debug_last_render)

@@ -804,6 +804,16 @@ def test_incremental_render_is_the_full_render_bit_for_bit(cel, ctx, big_field):
             cur["counts"][s0] *= 1.01                                # another catalogue rendered in between: every tile
             img.render(ref_set, loglik=True)
             check([s0], False)
+            cur["counts"][s0] *= 1.01                                # new observed pixels: the kept tiles' Poisson partials are stale
+            img.set_nelec(f.nelec)
+            check([s0], False)
+            cur["counts"][s0] *= 1.01                                # another drop threshold: the kept tiles were rendered at the old one
+            with tail_log(ctx, "strict"):
+                check([s0], False)
+                cur["counts"][s0] *= 1.01
+                check([s0], True)
+            cur["counts"][s0] *= 1.01
+            check([s0], False)
             cur["counts"][s0] *= 1.01
             ctx.set_option(L.CEL_OPT_INCREMENTAL, 0)
             try:
