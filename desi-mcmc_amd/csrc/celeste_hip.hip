@@ -1276,6 +1276,7 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         }
         const bool stars_only = im->TW == HW_TW && !diag && c->star_tiles && src->n_gal == 0 && im->star_one_segment &&
                                 c->variant != 0 && (c->star_tiles == 2 || T > STAR_TILES_MIN);    // (1 and 3: the rule; 3 = without the one-launch small path)
+        if (stars_only) parts_used = 0;         // (the star-tile kernel adds a pixel's stars in another order: not the general kernel's bits)
         pi = prof_slot(c, stars_only ? CEL_K_RENDER_STARS : CEL_K_RENDER);
         if (im->TW == QW_TW)
             LAUNCH_EV(k_render_qw, dim3(T), dim3(64), st, EV0(c, pi), EV1(c, pi), a);
