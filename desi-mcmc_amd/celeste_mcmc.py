@@ -199,7 +199,7 @@ class ModelGibbs(object):
     BANDS = ['u', 'g', 'r', 'i', 'z']
 
     def __init__(self, fields, typ, u, fluxes, shape, seed=0, flux_a_0=5., flux_b_0=.005, slice_args=None, engine="auto",
-                 deal=None, shape_args=None, shape_logprior=None, phi_period=180., shape_mass="reference"):
+                 deal=None, shape_args=None, shape_logprior=None, phi_period=180., shape_mass="reference", conditional="reference"):
         self.fields = list(fields)
         self.typ = np.ascontiguousarray(typ, dtype=np.int32)
         self.S = self.typ.shape[0]
@@ -233,6 +233,14 @@ class ModelGibbs(object):
         if shape_mass not in ("reference", "exact"):
             raise ValueError("shape_mass must be 'reference' or 'exact'")
         self.shape_mass = shape_mass
+        # conditional="exact": the location AND the shape step score the Gibbs conditional of the model the renderer draws from --
+        # the proposal's stamp summed over ITS OWN box as the mass term, and no photon of the source outside that box (the model
+        # puts none there: such a proposal has probability zero).  Host engine.
+        if conditional not in ("reference", "exact"):
+            raise ValueError("conditional must be 'reference' or 'exact'")
+        self.conditional = conditional
+        if conditional == "exact":
+            self.shape_mass = "exact"
         self._default_shape_prior = shape_logprior is None
         if shape_logprior is None:
             from .celeste_galaxy_conditionals import galaxy_shape_prior_constrained
@@ -341,9 +349,21 @@ class ModelGibbs(object):
         device, photons per (source, image), the sky photons per image"""
         self.noise_sums = []
         any_patch = np.zeros(self.S, dtype=bool)
+        from . import _lib
         for k, f in enumerate(self.fields):
             seed = self.step_seed("split", k)
-            noise = f.iset.photon_split_resident(self._sources(f), seed)
+            if self.conditional == "exact":
+                # the split of the model the renderer draws from: a source takes part on its whole box (the reference's rule
+                # leaves every box's first row and column out, celeste_sample_sources.pyx:50-51)
+                ctx = f.iset.ctx
+                was = ctx.get_option(_lib.CEL_OPT_SPLIT_FULL_BOX)
+                ctx.set_option(_lib.CEL_OPT_SPLIT_FULL_BOX, 1)
+                try:
+                    noise = f.iset.photon_split_resident(self._sources(f), seed)
+                finally:
+                    ctx.set_option(_lib.CEL_OPT_SPLIT_FULL_BOX, was)
+            else:
+                noise = f.iset.photon_split_resident(self._sources(f), seed)
             if self.deal is not None and self.deal.kind == "strips":
                 # this rank split its window and counted its strip's sky photons: the frame's sum over the ranks; and its own
                 # sources' boxes have to lie inside the window (their patches must be complete)
@@ -353,6 +373,8 @@ class ModelGibbs(object):
             f.sums = f.iset.sample_sums()                              # photons per (source, image)
             f.has_patch = f.iset.sample_box_areas() > 0
             any_patch |= f.has_patch.any(axis=1)
+            if self.conditional == "exact":
+                f.photon_rects = f.iset.photon_rects()                 # where each source's photons lie: what its box must cover
             self.noise_sums.append(noise)
         self.active = any_patch
 
@@ -447,9 +469,28 @@ class ModelGibbs(object):
             if f.prop is None or f.prop.capacity < P:
                 f.prop = _field.SourceSet(f.iset.ctx, max(2 * self.S, P, 16), f.iset.B)
             cts = getattr(f, "_counts", None)            # (S, B), fixed while the locations are sampled
-            f.prop.set(typ, U, self.counts(f, idx=idx) if cts is None else cts[idx], shape)
+            pc = self.counts(f, idx=idx) if cts is None else cts[idx]
+            f.prop.set(typ, U, pc, shape)
             ll += f.iset.patch_loglik_resident(f.prop, owner)
+            if self.conditional == "exact":
+                ll += self._exact_terms(f, idx, pc)
         return ll
+
+    def _exact_terms(self, f, sel, pc):
+        """what turns Source.log_likelihood's value for the proposals in f.prop (chains `sel`, expected photons `pc`) into the
+        exact conditional: -counts * (the proposal's stamp mass on its own box) in place of -counts * sum(psf weights) where
+        the source has a patch, and -inf where a photon of the source lies outside the proposal's box"""
+        wsum = np.array([f.iset.band(b)[3:6].sum() for b in range(f.iset.B)])
+        mass = f.iset.stamp_mass(f.prop)
+        out = -(pc * (mass - wsum[None, :]) * f.has_patch[sel]).sum(axis=1)
+        rects = getattr(f, "photon_rects", None)
+        if rects is not None:
+            bx, st = f.iset.source_boxes(f.prop)                       # (B, P, 4) = y0, y1, x0, x1
+            bx, st, r = bx.transpose(1, 0, 2), st.T, rects[sel]
+            held = r[..., 1] > r[..., 0]                               # the (source, band) pairs that hold a photon at all
+            inside = (st > 0) & (bx[..., 0] <= r[..., 0]) & (bx[..., 1] >= r[..., 1]) & (bx[..., 2] <= r[..., 2]) & (bx[..., 3] >= r[..., 3])
+            out = np.where((held & ~inside).any(axis=1), -np.inf, out)
+        return out
 
     # -- the galaxies' shapes: celeste_mcmc.py:209-243 (skew_likelihood, slice_sample_skew) ---------------------------
     def shape_logprob(self, idx, TH):
@@ -474,10 +515,7 @@ class ModelGibbs(object):
             f.prop.set(self.typ[sel], self.u[sel], pc, TH[ok])
             ll += f.iset.patch_loglik_resident(f.prop, owner)
             if self.shape_mass == "exact":
-                # -counts * (stamp mass on the proposal's own box) in place of -counts * sum(psf weights), where the source has a patch
-                wsum = np.array([f.iset.band(b)[3:6].sum() for b in range(f.iset.B)])
-                mass = f.iset.stamp_mass(f.prop)
-                ll -= (pc * (mass - wsum[None, :]) * f.has_patch[sel]).sum(axis=1)
+                ll += self._exact_terms(f, sel, pc)
         out[ok] += ll
         return out
 
@@ -530,7 +568,7 @@ class ModelGibbs(object):
         a = self.shape_args
         ok = (len(self.fields) == 1 and self._default_shape_prior and (not a.get("step_out", True) or a.get("doubling_step", True))
               and set(a) <= {"step_out", "doubling_step", "compwise", "numdir", "sigma", "max_steps_out"}
-              and a.get("accept", "reference") == "reference" and self.shape_mass == "reference")
+              and a.get("accept", "reference") == "reference" and self.shape_mass == "reference" and self.conditional == "reference")
         if self.engine == "device" and not ok:
             raise ValueError("the device shape sampler runs one field, the built-in log-prior, stepping out by doubling or none")
         return ok and self.engine != "host"
@@ -538,7 +576,7 @@ class ModelGibbs(object):
     def _device_engine_applies(self):
         a = self.slice_args
         return (len(self.fields) == 1 and not a.get("step_out", True) and a.get("compwise", True)
-                and set(a) <= {"step_out", "compwise", "sigma"})
+                and set(a) <= {"step_out", "compwise", "sigma"} and self.conditional == "reference")
 
     def resample_locations(self):
         import time

@@ -121,6 +121,7 @@ struct cel_ctx {
     static bool env_tail_ok() { const char *e = getenv("CEL_TAIL_LOG"); return e && atof(e) >= 0.0 && atof(e) <= 300.0; }
     double tail_T = env_tail_ok() ? atof(getenv("CEL_TAIL_LOG")) : 32.0;
     double render_T = env_tail_ok() ? atof(getenv("CEL_TAIL_LOG")) : 24.0;
+    int split_full = 0;         // CEL_OPT_SPLIT_FULL_BOX
     int incremental = (getenv("CEL_INCREMENTAL") && atoi(getenv("CEL_INCREMENTAL")) == 0) ? 0 : 1;       // CEL_OPT_INCREMENTAL
     int tile_parts = (getenv("CEL_TILE_PARTS") && (atoi(getenv("CEL_TILE_PARTS")) == 1 || atoi(getenv("CEL_TILE_PARTS")) == 2 || atoi(getenv("CEL_TILE_PARTS")) == 4))
                          ? atoi(getenv("CEL_TILE_PARTS")) : 0;       // CEL_OPT_TILE_PARTS (the env var: the initial value, for A/B runs)
@@ -235,6 +236,7 @@ struct cel_images {
     int64_t nzlist_cap = 0;
     bool nz_valid = false;
     double *d_rate = nullptr;   // per-pixel total rates of the photon split (strict boxes), B*H*W, on first use
+    bool rate_in_lambda = false;    // the last split read its totals from the model image itself (CEL_OPT_SPLIT_FULL_BOX with a current image)
     int64_t samp_cap = 0;
     int4 *d_sbox = nullptr;
     int64_t *d_soff = nullptr;
@@ -525,6 +527,10 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         if (v != 0.0 && v != 1.0) return fail(CEL_ERR_INVALID, "CEL_OPT_INCREMENTAL must be 0 or 1");
         c->incremental = (int)v;
         return CEL_OK;
+    case CEL_OPT_SPLIT_FULL_BOX:
+        if (v != 0.0 && v != 1.0) return fail(CEL_ERR_INVALID, "CEL_OPT_SPLIT_FULL_BOX must be 0 or 1");
+        c->split_full = (int)v;
+        return CEL_OK;
     case CEL_OPT_TILE_PARTS:
         if (v != 0.0 && v != 1.0 && v != 2.0 && v != 4.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TILE_PARTS must be 0 (by the frame's size), 1, 2 or 4");
         c->tile_parts = (int)v;
@@ -583,6 +589,7 @@ int cel_ctx_get_option(cel_ctx *c, int key, double *v) {
     case CEL_OPT_TAIL_LOG_SOURCE: *v = c->tail_T; return CEL_OK;
     case CEL_OPT_TILE_PARTS: *v = c->tile_parts; return CEL_OK;
     case CEL_OPT_INCREMENTAL: *v = c->incremental; return CEL_OK;
+    case CEL_OPT_SPLIT_FULL_BOX: *v = c->split_full; return CEL_OK;
     case CEL_OPT_PROFILE: *v = (double)c->profile; return CEL_OK;
     case CEL_OPT_TILE_ORDER: *v = (double)c->tile_order; return CEL_OK;
     case CEL_OPT_TILE_ROWS: *v = c->tile_rows; return CEL_OK;
@@ -1362,7 +1369,7 @@ int cel_debug_split_rates(cel_images *im, double *out) {
     if (!im || !out) return fail(CEL_ERR_INVALID, "cel_debug_split_rates: null argument");
     if (!im->d_rate) return fail(CEL_ERR_INVALID, "no totals image: cel_photon_split on the recurrence kernels has not run");
     HIP_TRY(hipSetDevice(im->ctx->device));
-    return copy_out(out, im->d_rate, sizeof(double) * (size_t)im->B * im->H * im->W, CEL_HOST, im->ctx->stream);
+    return copy_out(out, im->rate_in_lambda ? im->d_lambda : im->d_rate, sizeof(double) * (size_t)im->B * im->H * im->W, CEL_HOST, im->ctx->stream);
 }
 
 int cel_debug_last_render(cel_images *im, int64_t *dirty_tiles) {
@@ -2209,12 +2216,19 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
     // Direct form: a plain render (its kernel accumulates the totals itself).
     const bool hw = (c->variant != 0) && (im->TW == HW_TW);
     bool use_massfx = false;
+    const double *full_rate = nullptr;
     int rc;
     if (!hw) im->partials_gen = 0;              // (the direct form keeps its noise partials in the render's buffer)
     if (hw) {
         if (!im->d_rate) HIP_TRY(hipMalloc((void **)&im->d_rate, sizeof(double) * (size_t)im->B * im->H * im->W));
         im->massfx_gen = 0;
-        if (c->split_reuse && src->gen != 0 && im->lambda_gen == src->gen && im->lists_gen == src->gen && im->recs_gen == src->gen) {
+        const bool current = src->gen != 0 && im->lambda_gen == src->gen && im->lists_gen == src->gen && im->recs_gen == src->gen;
+        if (c->split_full) {
+            // CEL_OPT_SPLIT_FULL_BOX: a source takes part on its WHOLE box, so the totals are the model image itself -- the one
+            // on the device when it is these sources', a render into the totals image otherwise
+            if (c->split_reuse && current) { full_rate = im->d_lambda; rc = CEL_OK; }
+            else rc = render_impl(im, src, 0, nullptr, nullptr, im->d_rate);
+        } else if (c->split_reuse && current) {
             const int64_t nm = src->S * im->B;
             if (resident && c->mass_reuse_of() && nm > 0) {
                 // both kernels of this path also sum every unit stamp they evaluate: together the stamps' masses (cel_stamp_mass)
@@ -2331,7 +2345,9 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         a.ntx = im->ntx; a.nty = im->nty; a.TW = im->TW; a.TH = im->TH; a.seed = seed;
         a.win_y0 = im->win_y0; a.full_H = im->full_H;
         a.noise_y0 = im->noise_y0; a.noise_y1 = im->noise_y1;
-        a.rate_img = im->d_rate; a.tail_T = c->tail_T; a.nz = fused_nz ? im->d_snz : nullptr;
+        a.rate_img = full_rate ? full_rate : im->d_rate; a.tail_T = c->tail_T; a.nz = fused_nz ? im->d_snz : nullptr;
+        a.strict = c->split_full ? 0 : 1;
+        im->rate_in_lambda = full_rate != nullptr;
         a.order = (hw && tile_order_of(c, im)) ? im->d_order : nullptr;
         a.sums = fused_nz ? im->d_ssum : nullptr;
         a.nnz = lists ? im->d_nnz : nullptr;
@@ -2447,6 +2463,24 @@ int cel_samples_fetch(cel_images *im, int32_t *boxes, int64_t *offsets, double *
             hipLaunchKernelGGL(k_patch_sums<int>, dim3((unsigned)n), dim3(256), 0, c->stream, im->d_soff, (const int *)im->d_samp, d_sums);
             if ((rc = copy_out(sums, d_sums, sizeof(double) * n, CEL_HOST, c->stream))) return rc;
         }
+    }
+    return CEL_OK;
+}
+
+int cel_samples_photon_rects(cel_images *im, int32_t *rects) {
+    if (!im || !rects) return fail(CEL_ERR_INVALID, "cel_samples_photon_rects: null argument");
+    if (im->samp_S <= 0 || !im->d_snz)
+        return fail(CEL_ERR_INVALID, "no resident photon split: call cel_photon_split with offsets = NULL first");
+    cel_ctx *c = im->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t n = im->samp_S * im->B;
+    std::vector<int4> hb((size_t)n);
+    int rc = copy_out(hb.data(), im->d_snz, sizeof(int4) * n, CEL_HOST, c->stream);
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; i++) {
+        const bool held = hb[i].y > hb[i].x && hb[i].w > hb[i].z;         // (the kernels mark an empty patch in two ways)
+        rects[4 * i] = held ? hb[i].z : 0; rects[4 * i + 1] = held ? hb[i].w : 0;
+        rects[4 * i + 2] = held ? hb[i].x : 0; rects[4 * i + 3] = held ? hb[i].y : 0;
     }
     return CEL_OK;
 }

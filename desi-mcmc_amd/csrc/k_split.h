@@ -493,6 +493,8 @@ struct SplitArgs {
     int noise_y0, noise_y1;     // rows [noise_y0, noise_y1) of the window whose sky photons the noise sums count (a rank of a
                                 // strip-partitioned chain splits a halo beyond its strip and counts its strip only)
     int debug;                  // CEL_OPT_DEBUG bits (timing-only ablations; results are wrong when set)
+    int strict;                 // 1: a source takes part strictly inside its box on the low side (the reference, :50-51); 0: on its
+                                // whole box (CEL_OPT_SPLIT_FULL_BOX: the split of the model the renderer draws from)
     int *nnz;                   // k_photon_split_hw: pixels that received a photon, per (source, band), zeroed by the caller, or nullptr
     double *sums;               // k_photon_split_hw: photons per (source, band), index s*B + b, zeroed by the caller, or nullptr.
                                 // Integer-valued doubles: the atomic sums are exact, so their order does not matter
@@ -555,10 +557,10 @@ k_photon_split(SplitArgs a) {
             __syncthreads();
             const int nx = bx1 - bx0;
             TS *patch = static_cast<TS *>(a.samp) + a.offsets[(int64_t)s * a.B + b];    // source-major, like cel_patch_loglik_multi
-            const bool colin = (xi > bx0) && (xi < bx1);                 // strict on the low side (:50)
+            const bool colin = (xi >= bx0 + a.strict) && (xi < bx1);     // strict on the low side (:50)
             for (int i = 0; i < niter; i++) {
                 const int y = Y0 + i * rstep + rsub;
-                if (!(colin && y > by0 && y < by1)) continue;
+                if (!(colin && y >= by0 + a.strict && y < by1)) continue;
                 const double F = counts * eval_direct(T, 0, K, (double)xi, (double)y, 1.0);
                 const int li = i * 64 + lane;
                 if (pass == 0) {
@@ -699,7 +701,7 @@ k_photon_split_hw(SplitArgs a) {
         }
         const RecU rec = rec_unpack(recw);
         // strictly inside the box on the low side (celeste_sample_sources.pyx:50-51)
-        const int sx0 = rec.x0 + 1, sy0 = rec.y0 + 1;
+        const int sx0 = rec.x0 + a.strict, sy0 = rec.y0 + a.strict;
         const int ra = max(sy0, Y0) - Y0, rb = min(rec.y1, Y0 + SP_TH) - Y0;
         const int xa = max(sx0, X0), xb = min(rec.x1, X0 + HW_TW) - 1;
         if (ra >= rb || xa > xb) continue;          // touches the tile's other half only (wave-uniform)

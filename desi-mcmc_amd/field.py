@@ -415,6 +415,15 @@ class ImageSet(object):
                                           data.ctypes.data, None))
         return boxes, offs, data[:tot.value]
 
+    def photon_rects(self):
+        """(S, B, 4) = y0, y1, x0, x1: the smallest rectangle of each (source, band) patch of the resident split that holds
+        all of its photons; zeros for a patch without a photon"""
+        S, tot = C.c_int64(0), C.c_int64(0)
+        L.check(L.lib().cel_samples_info(self._h, C.byref(S), C.byref(tot)))
+        rects = np.zeros((S.value, self.B, 4), dtype=np.int32)
+        L.check(L.lib().cel_samples_photon_rects(self._h, rects.ctypes.data_as(L.c_int32_p)))
+        return rects
+
     def stamp_mass(self, sources):
         """sum of every source's unit stamp over its own box -> (S, B)  (sources.py:336-339)"""
         out = np.zeros((sources.S, self.B))

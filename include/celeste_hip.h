@@ -80,6 +80,13 @@ enum {
                                for bit (source preparation and binning still run in full).  The reference's single-source moves
                                (util/infer/mcmc_transitions.py:37-152) evaluate the whole likelihood after changing one source.
                                A render after cel_sources_set, or with nothing changed, renders every tile.  0 = always every tile */
+    CEL_OPT_SPLIT_FULL_BOX = 15, /* 0 (default): the photon split gives a source photons only STRICTLY inside its box on the low side, as
+                               the reference does (celeste_sample_sources.pyx:50-51: the first row and column of every sample patch
+                               stay 0) -- although the renderer adds the source on its whole box (celeste.py:217-219).  1 = on the
+                               whole box: the split of the model the renderer draws from, which the exact conditionals of
+                               ModelGibbs(conditional="exact") need (DESIGN Q20: with the reference's rule a big galaxy's first box
+                               row and column -- up to 10^-4 of its photons -- are modelled but never attributed).  The stamp-mass
+                               short cut of CEL_OPT_SPLIT_REUSE = 2 is not taken then */
     CEL_OPT_TILE_PARTS = 13, /* how many one-wave blocks share a render tile of the general 32 x 64 kernel.  0 (default) = by
                                the frame's size: 4 for at most 512 tiles, 2 for at most 3 072, else 1 -- a frame of few tiles
                                (one rank's row strip of a field cut 8 ways, a 51 x 51 real field) finishes when its heaviest
@@ -404,6 +411,12 @@ int cel_samples_info(cel_images *img, int64_t *S, int64_t *total);
  *   sums S*B = photons attributed to source s in band b (the flux Gibbs step's statistic,
  *   sources.py:327-345), reduced on the device */
 int cel_samples_fetch(cel_images *img, int32_t *boxes, int64_t *offsets, double *data, double *sums);
+/* where the resident split put each source's photons: rects S*B*4 (y0,y1,x0,x1 at s*B+b), the smallest rectangle of the
+ * patch of (s, b) that holds every pixel with a photon, all zeros when the patch holds none.  A proposal for source s has
+ * a non-zero conditional probability only if its own box covers that rectangle: the model draws a source's photons on its
+ * box and nowhere else (celeste.py:217-219 adds the patch at its limits; sources.py:134-183 scores the fixed data patch
+ * whatever the proposal's limits -- ModelGibbs(conditional="exact") applies the rule, DESIGN Q20). */
+int cel_samples_photon_rects(cel_images *img, int32_t *rects);
 /* diagnostic: N independent Binomial(n, p) variates from the split's sampler (stream i = draw i) */
 int cel_debug_binomial(cel_ctx *ctx, int64_t n, double p, uint64_t seed, int64_t N, int64_t *out);
 

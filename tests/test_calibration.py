@@ -40,6 +40,7 @@ K_DRAWS, THIN = 7, 3
 FLUX_A, FLUX_B = 3.0, 0.1
 EPS_A, EPS_B = 400.0, 2.0
 CELL = 64
+MOVE_CHECK = True          # (tools/dbg/sbc_exact.py switches blocks of the sweep off)
 
 
 def chi2_pvalue(ranks, K):
@@ -81,7 +82,7 @@ def make_scene(cel, ctx, rep, NCELL=12, shapes=False):
     return dict(bands=bands, iset=iset, typ=typ, radec=radec, flux=flux, shape=shape, H=H, W=W, B=B, S=S, pix=pix)
 
 
-def run_replicate(cel, ctx, rep, engine, chain_seed, J, ncell=12, shapes=False, shape_args=None, shape_mass="reference"):
+def run_replicate(cel, ctx, rep, engine, chain_seed, J, ncell=12, shapes=False, shape_args=None, shape_mass="reference", conditional="reference"):
     """theta* at position J of a stationary stretch of K + 1 states -> its ranks: (S, 2) for the location, (S, 5) for the fluxes"""
     from desi_mcmc_amd import celeste_mcmc
     sc = make_scene(cel, ctx, rep, ncell, shapes)
@@ -91,7 +92,7 @@ def run_replicate(cel, ctx, rep, engine, chain_seed, J, ncell=12, shapes=False, 
         for b in range(sc["B"]):
             sc["iset"].set_epsilon(b, sc["bands"][b, 0])                 # (the forward chain moved the sky levels)
         return celeste_mcmc.ModelGibbs([gf], sc["typ"], sc["radec"], sc["flux"], sc["shape"], seed=chain_seed, flux_a_0=FLUX_A,
-                                       flux_b_0=FLUX_B, engine=engine, shape_args=shape_args, shape_mass=shape_mass)
+                                       flux_b_0=FLUX_B, engine=engine, shape_args=shape_args, shape_mass=shape_mass, conditional=conditional)
     du, df, ds = [], [], []
     g = chain()                                                          # forward: the production sweep + its trace render
     for k in range((K_DRAWS - J) * THIN):
@@ -102,7 +103,7 @@ def run_replicate(cel, ctx, rep, engine, chain_seed, J, ncell=12, shapes=False, 
             du.append(g.u.copy())
             df.append(g.fluxes.copy())
             ds.append(g.shape.copy())
-    if K_DRAWS - J > 0:
+    if K_DRAWS - J > 0 and MOVE_CHECK:
         assert (np.abs(du[-1] - sc["radec"]).max(axis=1) > 0).mean() > 0.99     # the chains do move
     g = chain()                                                          # backward: from (theta*, a split at theta*)
     g.seed = chain_seed + 7919                                           # (its own streams)
@@ -122,11 +123,11 @@ def run_replicate(cel, ctx, rep, engine, chain_seed, J, ncell=12, shapes=False, 
     return ranks
 
 
-def pooled_ranks(cel, ctx, engine, ncell, shapes=False, shape_args=None, shape_mass="reference"):
+def pooled_ranks(cel, ctx, engine, ncell, shapes=False, shape_args=None, shape_mass="reference", conditional="reference"):
     import os
     reps = (K_DRAWS + 1) * max(1, int(os.environ.get("CEL_SBC_ROUNDS", "1")))       # every position J equally often (CEL_SBC_ROUNDS=8: 64 replicates)
     parts = zip(*[run_replicate(cel, ctx, rep, engine, chain_seed=rep, J=rep % (K_DRAWS + 1), ncell=ncell, shapes=shapes, shape_args=shape_args,
-                                shape_mass=shape_mass)
+                                shape_mass=shape_mass, conditional=conditional)
                   for rep in range(reps)])
     return tuple(np.concatenate(p) for p in parts)
 
@@ -140,14 +141,18 @@ def shape_rank_table(ru, rf, rs_):
 
 
 def test_sweep_with_the_shape_step_leaves_the_posterior_invariant():
-    """sweep(shapes=True) with shape_mass="exact": the galaxies' (theta, sigma, phi, rho) by slice sampling along random
-    directions with stepping out by doubling, under the shape step's own prior, every proposal charged counts * (its unit stamp
-    summed over its own box) -- ranks of all four, with the locations and fluxes again"""
+    """sweep(shapes=True) with conditional="exact": the galaxies' (theta, sigma, phi, rho) by slice sampling along random
+    directions with stepping out by doubling, under the shape step's own prior -- the photons split on whole boxes
+    (CEL_OPT_SPLIT_FULL_BOX), and in the location AND the shape step every proposal charged counts * (its unit stamp summed over
+    its own box) and refused when a photon of the source lies outside that box: the Gibbs conditionals of the model the
+    renderer draws from.  Ranks of all four, with the locations and fluxes again.  (CEL_SBC_ROUNDS=24, 192 replicates, 8 829
+    galaxies: p = 0.91 / 0.02 / 0.42 / 0.33 / 0.22 / 0.38, profiles/r05_calibration_exact_192_replicates.txt; with the mass term
+    alone -- shape_mass="exact" -- sigma and rho fail at 192 replicates, p = 0.001 / 0.01: DESIGN Q20.)"""
     import desi_mcmc_amd as cel
     ctx = cel.default_context(0)
-    ru, rf, rs_ = pooled_ranks(cel, ctx, "host", 8, shapes=True, shape_mass="exact")
+    ru, rf, rs_ = pooled_ranks(cel, ctx, "host", 8, shapes=True, conditional="exact")
     out = shape_rank_table(ru, rf, rs_)
-    print("SBC ranks with the shape step, exact mass term (%d sources, %d galaxies): %s" % (ru.shape[0], rs_.shape[0], out))
+    print("SBC ranks with the shape step, exact conditionals (%d sources, %d galaxies): %s" % (ru.shape[0], rs_.shape[0], out))
     for name, (stat, p, counts) in out.items():
         assert p > 1e-3 / 6, (name, stat, p, counts)
 
@@ -160,7 +165,7 @@ def test_the_reference_conditional_leaves_sigma_low():
     10^3 for an extended de Vaucouleurs-dominated galaxy, which at 10^5 photons is tens of nats per posterior standard
     deviation.  The chain's sigma sits 5-20 % low for a tenth of the galaxies: the top rank (theta* above every draw) holds
     twice its share.  theta, phi, rho, the locations and the fluxes stay calibrated.  The device engine runs this conditional
-    (the default, parity with the reference); shape_mass="exact" (above) is the corrected step."""
+    (the default, parity with the reference); conditional="exact" (above) is the corrected sweep."""
     import desi_mcmc_amd as cel
     ctx = cel.default_context(0)
     ru, rf, rs_ = pooled_ranks(cel, ctx, "device", 8, shapes=True)
@@ -211,3 +216,156 @@ def test_a_broken_sweep_fails_the_calibration(monkeypatch):
     p_flux = chi2_pvalue(rf, K_DRAWS)[1]
     print("streams re-used by every sweep: p(location) = %.3g, p(flux) = %.3g" % (p_loc, p_flux))
     assert min(p_loc, p_flux) < 1e-8
+
+
+def _one_big_galaxy(cel, ctx, rho=0.5):
+    """an extended de Vaucouleurs-dominated galaxy (sigma 3.5", axis ratio rho, 1.2e5 photons) with a star on its wing and a
+    galaxy 40 px away, on a 256 x 256 frame with data drawn from the model"""
+    from desi_mcmc_amd import synth
+    rs = np.random.RandomState(11)
+    H = W = 256
+    bands = synth.make_bands(H, W, 5)
+    bands[:, 0] = 200.0
+    typ = np.array([1, 0, 1], np.int32)
+    pix = np.array([[128.3, 127.6], [140.2, 131.0], [168.0, 120.0]])
+    shape = np.array([[0.1, 3.5, 100., rho], [0, 0, 0, 0], [0.5, 1.0, 20., 0.5]])
+    flux = np.array([[40.] * 5, [30.] * 5, [25.] * 5])
+    radec = synth.pixel2equa(bands[0], pix)
+    counts = flux / bands[None, :, 2] * bands[None, :, 1]
+    iset = cel.ImageSet(ctx, bands, H, W)
+    iset.render(cel.SourceSet(ctx, 3, 5).set(typ, radec, counts, shape), loglik=False)
+    lam = iset.model_images()
+    nelec = rs.poisson(lam).astype(np.float64)
+    iset.set_nelec(nelec)
+    return dict(iset=iset, bands=bands, typ=typ, radec=radec, shape=shape, flux=flux, counts=counts, lam=lam, nelec=nelec, H=H, W=W)
+
+
+@pytest.mark.parametrize("conditional", ["exact", "reference"])
+def test_split_then_sigma_leaves_the_observed_data_posterior_invariant(conditional):
+    """The sharpest form of the calibration question, free of any sampler: on a grid of values of ONE galaxy's sigma (everything
+    else at the truth), pi_k is the observed-data posterior (the rendered log-likelihood) and P[k, k'] the probability that a
+    photon split at sigma_k followed by a draw of sigma from the shape step's conditional on the grid lands on sigma_k'
+    (Rao-Blackwellised over M splits).  A Gibbs sweep whose conditionals are the model's has pi P = pi -- whatever its mixing;
+    the test compares the two in total variation and in the mean.
+    conditional="exact" (the proposal's stamp mass on ITS box, no photon outside that box, the split on WHOLE boxes:
+    CEL_OPT_SPLIT_FULL_BOX) passes to the Monte-Carlo error.  The reference's three rules together (sources.py:166-170 the
+    constant mass term; sources.py:134-183 the fixed data patch scored whatever the proposal's box;
+    celeste_sample_sources.pyx:50-51 no photons in a box's first row and column) do not: for this galaxy, whose box the
+    reference's bounding radius cuts where each edge row still holds two photons, probability flows towards smaller sigma
+    across every change of the integer box (DESIGN Q20)."""
+    import desi_mcmc_amd as cel
+    from desi_mcmc_amd import celeste_mcmc
+    ctx = cel.default_context(0)
+    sc = _one_big_galaxy(cel, ctx)
+    iset, typ, radec, counts, shape = sc["iset"], sc["typ"], sc["radec"], sc["counts"], sc["shape"]
+    G, M = 9, 300
+    grid = shape[0, 1] * np.linspace(0.98, 1.02, G)
+    ll = np.array([iset.render(cel.SourceSet(ctx, 3, 5).set(typ, radec, counts, np.vstack([[0.1, s_, 100., 0.5], shape[1:]])), loglik=True)[0]
+                   for s_ in grid])
+    pi = np.exp(ll - ll.max())
+    pi /= pi.sum()
+    gf = celeste_mcmc.GibbsField(iset, list(range(5)), sc["bands"][:, 2], sc["bands"][:, 1], sc["H"] * sc["W"], a_0=EPS_A, b_0=EPS_B)
+    g = celeste_mcmc.ModelGibbs([gf], typ, radec, sc["flux"], shape, seed=5, flux_a_0=FLUX_A, flux_b_0=FLUX_B, engine="host",
+                                shape_logprior=lambda TH: np.zeros(TH.shape[0]), conditional=conditional)
+    P, V = np.zeros((G, G)), np.zeros((G, G))
+    TH = np.tile(shape[0], (G, 1))
+    TH[:, 1] = grid
+    idx = np.zeros(G, dtype=np.int64)
+    for k in range(G):
+        for m in range(M):
+            g.shape[0, 1] = grid[k]
+            g._split_photons()
+            for f in g.fields:
+                f._counts = g.counts(f)
+            lp = g.shape_logprob(idx, TH)
+            for f in g.fields:
+                f._counts = None
+            g.sweeps += 1
+            p = np.exp(lp - lp.max())
+            p /= p.sum()
+            P[k] += p
+            V[k] += p * p
+        P[k] /= M
+        V[k] = np.maximum(V[k] / M - P[k] ** 2, 0) / M
+    out = pi @ P
+    se = np.sqrt((pi[:, None] ** 2 * V).sum(axis=0))
+    tv = 0.5 * np.abs(out - pi).sum()                                 # total variation between pi P and pi
+    tv_noise = 0.5 * np.sqrt(2 / np.pi) * se.sum()                    # ... expected from the Monte-Carlo error alone
+    shift = ((out - pi) * grid).sum() / np.sqrt((pi * (grid - (pi * grid).sum()) ** 2).sum())
+    print("conditional=%s: pi %s\n    pi P %s\n    |pi P - pi| = %.4f (Monte-Carlo error %.4f); one sweep moves the mean by %+.4f posterior sd" % (
+        conditional, np.round(pi, 4).tolist(), np.round(out, 4).tolist(), tv, tv_noise, shift))
+    if conditional == "exact":
+        assert tv < 0.004 + 3 * tv_noise and abs(shift) < 0.01, (tv, tv_noise, shift)
+    else:
+        assert tv > 0.03 and shift < -0.02, (tv, tv_noise, shift)
+
+
+def test_full_box_split_reaches_the_first_row_and_column():
+    """CEL_OPT_SPLIT_FULL_BOX.  0 (the reference, celeste_sample_sources.pyx:50-51): the first row and column of every sample patch
+    stay empty; 1: a source takes part on its whole box -- its photons there match their expectation nelec * rate / lambda, every
+    pixel's photons are conserved, pixels strictly inside draw the same numbers either way, and cel_samples_photon_rects is the
+    patches' own rectangle."""
+    import desi_mcmc_amd as cel
+    L = cel._lib
+    ctx = cel.default_context(0)
+    sc = _one_big_galaxy(cel, ctx)
+    iset = sc["iset"]
+    sset = cel.SourceSet(ctx, 3, 5).set(sc["typ"], sc["radec"], sc["counts"], sc["shape"])
+    assert ctx.get_option(L.CEL_OPT_SPLIT_FULL_BOX) == 0
+    with pytest.raises(Exception):
+        ctx.set_option(L.CEL_OPT_SPLIT_FULL_BOX, 2)
+    NS = 120
+    acc = {}
+    try:
+        for full in (0, 1):
+            ctx.set_option(L.CEL_OPT_SPLIT_FULL_BOX, full)
+            assert ctx.get_option(L.CEL_OPT_SPLIT_FULL_BOX) == full
+            for k in range(NS):
+                noise = iset.photon_split_resident(sset, 4000 + k)
+                boxes, offs, data = iset.fetch_samples()
+                if k == 0:
+                    acc[full] = np.zeros_like(data)
+                    first = data.copy()
+                    rects = iset.photon_rects()
+                    for s in range(3):
+                        for b in range(5):
+                            y0, y1, x0, x1 = boxes[s, b]
+                            p = data[offs[s * 5 + b]:offs[s * 5 + b + 1]].reshape(y1 - y0, x1 - x0)
+                            ys, xs = np.nonzero(p)
+                            assert rects[s, b].tolist() == [y0 + ys.min(), y0 + ys.max() + 1, x0 + xs.min(), x0 + xs.max() + 1]
+                    assert data.sum() + noise.sum() == sc["nelec"].sum()                     # conservation
+                acc[full] += data
+            acc[full] /= NS
+            if full == 0:
+                first0 = first
+            else:                                                                            # strictly inside: the same draws
+                for s in range(3):
+                    for b in range(5):
+                        y0, y1, x0, x1 = boxes[s, b]
+                        a0 = first0[offs[s * 5 + b]:offs[s * 5 + b + 1]].reshape(y1 - y0, x1 - x0)
+                        a1 = first[offs[s * 5 + b]:offs[s * 5 + b + 1]].reshape(y1 - y0, x1 - x0)
+                        # (a pixel in ANOTHER source's first row or column has a different total, hence other draws: compare where
+                        # no box edge passes)
+                        edge = np.zeros((sc["H"], sc["W"]), dtype=bool)
+                        for t in range(3):
+                            ty0, ty1, tx0, tx1 = boxes[t, b]
+                            edge[ty0, tx0:tx1] = True
+                            edge[ty0:ty1, tx0] = True
+                        m = ~edge[y0:y1, x0:x1]
+                        assert np.array_equal(a0[m], a1[m])
+    finally:
+        ctx.set_option(L.CEL_OPT_SPLIT_FULL_BOX, 0)
+    for b in range(5):
+        st, bx = iset.stamps(sset, b, scaled=True)
+        y0, y1, x0, x1 = boxes[0, b]
+        want = sc["nelec"][b, y0:y1, x0:x1] * st[0] / sc["lam"][b, y0:y1, x0:x1]
+        for full in (0, 1):
+            got = acc[full][offs[b]:offs[b + 1]].reshape(y1 - y0, x1 - x0)
+            edge_got = got[0].sum() + got[1:, 0].sum()
+            edge_want = want[0].sum() + want[1:, 0].sum()
+            if full == 0:
+                assert edge_got == 0.0
+            else:
+                assert abs(edge_got - edge_want) < 5 * np.sqrt(edge_want / NS) + 1e-9, (b, edge_got, edge_want)
+            inner_got, inner_want = got[1:, 1:].sum(), want[1:, 1:].sum()
+            assert abs(inner_got - inner_want) < 5 * np.sqrt(inner_want / NS), (b, full, inner_got, inner_want)
