@@ -228,14 +228,20 @@ class ModelGibbs(object):
         # :166-170) -- but the photons it is given were split on the source's box, and how much of a proposal's stamp lies on
         # its box depends on the shape: for an extended de Vaucouleurs-dominated galaxy at high signal to noise the constant
         # term leaves sigma 10-20 % low (tests/test_calibration.py: the calibration test that found it; DESIGN Q20).
-        # "reference" keeps the reference's term; "exact" charges counts * (the proposal's unit stamp summed over its own box,
-        # cel_stamp_mass) -- the Gibbs conditional of the model the renderer draws from.  ("exact" runs the host engine.)
+        # shape_mass="reference" keeps the reference's term; "exact" charges counts * (the proposal's unit stamp summed over its
+        # own box, cel_stamp_mass) in the shape step (host engine).  That is one of three corrections: conditional="exact"
+        # below makes all of them.
         if shape_mass not in ("reference", "exact"):
             raise ValueError("shape_mass must be 'reference' or 'exact'")
         self.shape_mass = shape_mass
-        # conditional="exact": the location AND the shape step score the Gibbs conditional of the model the renderer draws from --
-        # the proposal's stamp summed over ITS OWN box as the mass term, and no photon of the source outside that box (the model
-        # puts none there: such a proposal has probability zero).  Host engine.
+        # conditional="exact": every block of the sweep samples the Gibbs conditional of the model the RENDERER draws from -- a
+        # source's photons lie on its own box and nowhere else (celeste.py:217-219).  Three departures from the reference:
+        # the photons are split on whole boxes (CEL_OPT_SPLIT_FULL_BOX; celeste_sample_sources.pyx:50-51 leaves a box's first
+        # row and column out); the location AND the shape step charge counts * (the proposal's stamp mass on ITS box); and a
+        # proposal whose box does not cover every photon of the source has probability zero (the reference scores the fixed
+        # data patch whatever the proposal's box, sources.py:134-183).  Calibrated at 192 replicates and pi P = pi on a sigma
+        # grid (tests/test_calibration.py, DESIGN Q20).  Host engine; a change of the integer box needs the ring between the two
+        # boxes free of the source's photons, so big galaxies mix more slowly across box sizes than under the reference's rules.
         if conditional not in ("reference", "exact"):
             raise ValueError("conditional must be 'reference' or 'exact'")
         self.conditional = conditional

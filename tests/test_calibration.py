@@ -30,6 +30,10 @@ Priors (the sampler's own conjugate ones, with hyper-parameters that put the sce
                     theta, rho ~ U(0, 1), phi ~ U(0, 180), sigma with density sigma^-4 exp(-sigma^-2), i.e. sigma^-2 ~ Gamma(3/2)
                     -- test_sweep_with_the_shape_step_..., sweep(shapes=True)
 Deliberately broken sweeps -- the stamp masses off by 3 %, every sweep re-using the streams of the first -- must FAIL it.
+
+With the shape step the test found three rules of the reference's sweep that are not the model's conditionals (DESIGN Q20);
+ModelGibbs(conditional="exact") makes the three corrections and passes -- test_sweep_with_the_shape_step_..., and, free of any
+sampler, test_split_then_sigma_leaves_the_observed_data_posterior_invariant (pi P = pi on a grid of sigma).
 """
 import numpy as np
 import pytest
