@@ -268,6 +268,8 @@ class ModelGibbs(object):
         self.deal = deal
         if deal is not None and deal.S != self.S:
             raise ValueError("the deal is over %d sources, the catalogue has %d" % (deal.S, self.S))
+        if deal is not None and getattr(deal, "kind", "") == "strips" and self.conditional == "exact":
+            raise ValueError("conditional='exact' runs on whole frames (a replicated deal or one rank): its box tests are not window-relative")
         self.noise_sums = None
         self.active = np.ones(self.S, dtype=bool)
         # the flux conditionals' Gamma variates: on the device (cel_gamma_streams) or, host_gamma=True, by the numpy form of
