@@ -1466,7 +1466,9 @@ def test_patch_loglik_adversarial_patches_vs_oracle(cel, ctx, orc, kernel, tail)
         ctx.set_tail_log("default")
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CEL_FUZZ_SEEDS", "10"))))
+# (CEL_FUZZ_SEEDS / CEL_FUZZ_FIRST: a longer run -- profiles/r05_fuzz_run.txt)
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CEL_FUZZ_FIRST", "0")),
+                                       int(__import__("os").environ.get("CEL_FUZZ_FIRST", "0")) + int(__import__("os").environ.get("CEL_FUZZ_SEEDS", "10"))))
 def test_fuzz_random_fields_vs_oracle(cel, ctx, orc, seed):
     """Seeded random small fields at the extremes the synthetic benchmark population never visits:
     frames of any size, sharp and broad PSFs, sky levels over six decades, galaxy scales from
@@ -1509,7 +1511,10 @@ def test_fuzz_random_fields_vs_oracle(cel, ctx, orc, seed):
     ob[:, 36] = [iset.band(b)[36] for b in range(B)]
     o_lam, o_ll, o_st = orc.render_field(ob, H, W, typ, radec, counts, shape, nelec)
     np.testing.assert_allclose(lam_got, o_lam, rtol=RT_LAM_STRICT)
-    np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
+    # a band's log-likelihood is a sum of terms of both signs: the tolerance is relative to the sum of their magnitudes
+    # (seed 2635 of a 3 000-seed run: a band whose terms cancel to 1e-3 of their size, 3e-11 of the result off)
+    scale = (np.abs(nelec * np.log(o_lam)) + o_lam).sum(axis=(1, 2))
+    assert np.all(np.abs(llb - o_ll) <= RT_LL * scale), (llb, o_ll, scale)
     assert iset.stats()["n_srcpix"] == o_st["n_srcpix"]
     oxt, oms, onz = orc.estep_stats(ob, H, W, typ, radec, counts, shape, nelec)
     np.testing.assert_allclose(xt, oxt, rtol=1e-10, atol=1e-9)
@@ -1528,7 +1533,20 @@ def test_fuzz_random_fields_vs_oracle(cel, ctx, orc, seed):
             want = sum(orc.patch_loglik(ob[b], H, W, typ[s], radec[s], shape[s], counts[s, b], bxs[b],
                                         np.ascontiguousarray(data[b]), 1 if isolated else 0)
                        for b in range(B) if data[b] is not None)
-            np.testing.assert_allclose(got, want, rtol=RT_LL, atol=1e-9, err_msg="seed %d src %d iso %s" % (seed, s, isolated))
+            # relative to the size of the terms, not of their sum (seed 5282 of a long run: terms of 1e2 that add up to 90
+            # with 3.5e-8 between the two sums): the photon term's magnitudes and the mass from the oracle; on the observed
+            # image an upper bound of |y log(lambda)| + lambda
+            scale = 0.0
+            for b in range(B):
+                if data[b] is None:
+                    continue
+                if not isolated:
+                    t = orc.patch_loglik_terms(ob[b], H, W, typ[s], radec[s], shape[s], counts[s, b], bxs[b], np.ascontiguousarray(data[b]))
+                    scale += t[1] + t[2]
+                else:
+                    eps_b = ob[b, 0]
+                    scale += (data[b].sum() * max(abs(np.log(eps_b)), abs(np.log(eps_b + counts[s, b]))) + eps_b * data[b].size + counts[s, b])
+            assert abs(got - want) <= RT_LL * max(scale, abs(want)) + 1e-9, "seed %d src %d iso %s: %r %r (scale %g)" % (seed, s, isolated, got, want, scale)
 
 
 @pytest.mark.parametrize("seed", range(10))
