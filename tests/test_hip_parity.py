@@ -1466,9 +1466,15 @@ def test_patch_loglik_adversarial_patches_vs_oracle(cel, ctx, orc, kernel, tail)
         ctx.set_tail_log("default")
 
 
-# (CEL_FUZZ_SEEDS / CEL_FUZZ_FIRST: a longer run -- profiles/r05_fuzz_run.txt)
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CEL_FUZZ_FIRST", "0")),
-                                       int(__import__("os").environ.get("CEL_FUZZ_FIRST", "0")) + int(__import__("os").environ.get("CEL_FUZZ_SEEDS", "10"))))
+def _fuzz_seeds(default):
+    """the seeds of a fuzz test: `default` of them in the suite; CEL_FUZZ_SEEDS / CEL_FUZZ_FIRST ask for a longer run
+    (profiles/r05_fuzz_run.txt)"""
+    import os
+    first = int(os.environ.get("CEL_FUZZ_FIRST", "0"))
+    return range(first, first + int(os.environ.get("CEL_FUZZ_SEEDS", str(default))))
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds(10))
 def test_fuzz_random_fields_vs_oracle(cel, ctx, orc, seed):
     """Seeded random small fields at the extremes the synthetic benchmark population never visits:
     frames of any size, sharp and broad PSFs, sky levels over six decades, galaxy scales from
@@ -1827,7 +1833,7 @@ def test_image_set_cache_lru_budget_and_superset_reuse(cel, stamp_images):
     np.testing.assert_allclose(ll, sum(np.sum(i.nelec * np.log(i.epsilon) - i.epsilon) for i in imgs), rtol=1e-13)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _fuzz_seeds(6))
 def test_fuzz_star_fields_vs_oracle(cel, ctx, orc, seed):
     """random STAR-ONLY fields through the batched star pass: odd frame sizes, crowded tiles (more than
     one 64-star batch), stars on and off every edge, a PSF so sharp that the one-segment path must
@@ -2123,7 +2129,7 @@ print("rccl one-rank ok")
     assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", _fuzz_seeds(8))
 def test_fuzz_patch_loglik_vs_oracle(cel, ctx, orc, seed):
     """random sources, random patch rectangles around and beside them, SPARSE photon patches (most pixels hold
     no photon, some rows and whole chunks none: the conditional form skips their logs and crops to the photon
@@ -2163,4 +2169,13 @@ def test_fuzz_patch_loglik_vs_oracle(cel, ctx, orc, seed):
             for s in range(P):
                 want = sum(orc.patch_loglik(ob[b], H, W, typ[s], radec[s], shape[s], counts[s, b], boxes[b], data[b],
                                             1 if isolated else 0) for b in range(B))
-                np.testing.assert_allclose(got[s], want, rtol=RT_LL, err_msg="seed %d case %d src %d iso %s" % (seed, case, s, isolated))
+                tol = RT_LL * abs(want)
+                if not isolated:
+                    # every source is scored on every rectangle: one 200 px from its photons has a unit stamp in the SUBNORMAL range
+                    # there, where whether a pixel counts at all (m > 0) depends on the order of the arithmetic -- in the
+                    # reference's own evaluators too.  The oracle prices that range (patch_loglik_terms' fourth number; seeds
+                    # 101, 144, 904, 1285 of a 1 500-seed run: up to two photons' worth, 1 466 nats of -4.8e6); elsewhere the
+                    # tolerance is relative to the photon term's magnitudes
+                    t = np.array([orc.patch_loglik_terms(ob[b], H, W, typ[s], radec[s], shape[s], counts[s, b], boxes[b], data[b]) for b in range(B)])
+                    tol = RT_LL * t[:, 1].sum() + 8 * np.finfo(float).eps * t[:, 2].sum() + t[:, 3].sum()
+                assert abs(got[s] - want) <= tol, "seed %d case %d src %d iso %s: %r against %r (tolerance %g)" % (seed, case, s, isolated, got[s], want, tol)
