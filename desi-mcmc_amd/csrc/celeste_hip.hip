@@ -251,6 +251,7 @@ struct cel_images {
     cel_sources *sgen_prop = nullptr;
     int64_t last_S = 0;
     double last_entries = 0;
+    bool nelec_shared = false;       // cel_images_device_ptrs handed the observed pixels' device pointer out
     uint64_t partials_gen = 0;       // the per-tile Poisson partials in d_partials are those of this catalogue generation's render (0: not)
     uint64_t lambda_uid = 0;         // the catalogue OBJECT whose generation lambda_gen is (the incremental render compares row stamps of the same object only)
     double lambda_T = -1.0;          // ... and the drop threshold that image was rendered at
@@ -740,6 +741,7 @@ int cel_images_set_epsilon(cel_images *im, int band, double eps) {
     HIP_TRY(hipSetDevice(im->ctx->device));
     im->hb[band].eps = eps;
     im->lambda_gen = 0;                   // the model image on the device was rendered with the old sky level
+    im->partials_gen = 0;                 // ... and the tiles' Poisson partials against it
     // stream-ordered, no host synchronisation (Gibbs calls this per band per sweep)
     hipLaunchKernelGGL(k_set_eps, dim3(1), dim3(1), 0, im->ctx->stream, im->d_bands, band, eps);
     HIP_TRY(hipGetLastError());
@@ -780,7 +782,9 @@ int cel_images_get_lambda(cel_images *im, double *out, int mem) {
 
 int cel_images_device_ptrs(cel_images *im, void **nelec, void **lambda) {
     if (!im) return fail(CEL_ERR_INVALID, "null images");
-    if (nelec) { *nelec = im->d_nelec; im->nelec_u16 = false; }     // the caller may write it: no assumption about its range any more
+    if (nelec) {        // the caller may write it, at any time: no assumption about its range any more, no Poisson partials kept
+        *nelec = im->d_nelec; im->nelec_u16 = false; im->nelec_shared = true; im->partials_gen = 0;
+    }
     if (lambda) *lambda = im->d_lambda;
     return CEL_OK;
 }
@@ -1170,7 +1174,7 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
                 im->lambda_gen != 0 && im->lambda_uid == src->uid && im->lambda_T == c->render_T && im->lambda_parts == 1 && im->lambda_gen != src->gen &&
                 im->lambda_gen >= src->full_gen &&
                 im->lists_gen == im->lambda_gen && im->recs_gen == im->lambda_gen && (int64_t)src->row_gen.size() == S &&
-                (!(flags & CEL_RENDER_LOGLIK) || im->partials_gen == im->lambda_gen);
+                (!(flags & CEL_RENDER_LOGLIK) || (im->partials_gen == im->lambda_gen && !im->nelec_shared));
     if (incr) {
         for (int64_t s = 0; s < S && incr; s++)
             if (src->row_gen[(size_t)s] > im->lambda_gen) {
@@ -1340,7 +1344,9 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
                 im->lambda_uid = src->uid;
                 im->lambda_T = c->render_T;
                 im->lambda_parts = parts_used;
-                if (flags & CEL_RENDER_LOGLIK) im->partials_gen = src->gen;
+                // (a render WITHOUT the log-likelihood vouches for no partials: those in the buffer may be of another sky
+                // level or drop threshold although the catalogue's generation is the same -- found by tools/dbg/incremental_stress.py)
+                im->partials_gen = (flags & CEL_RENDER_LOGLIK) ? src->gen : 0;
             }
             if (incr) im->last_dirty = -2;          // (counted on request: cel_debug_last_render)
             break;

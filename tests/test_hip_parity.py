@@ -823,6 +823,23 @@ def test_incremental_render_is_the_full_render_bit_for_bit(cel, ctx, big_field):
             cur["counts"][s0] *= 1.01
             check([s0], True)
             img.set_epsilon(0, f.bands[0, 0])
+            ref_img.set_epsilon(0, f.bands[0, 0])
+            # (found by tools/dbg/incremental_stress.py) a new sky level, then a render WITHOUT the log-likelihood while the
+            # catalogue's generation has not moved, then an edit: the partials in the buffer are the old sky level's
+            check([], False)
+            img.set_epsilon(B - 1, f.bands[B - 1, 0] * 1.002)
+            ref_img.set_epsilon(B - 1, f.bands[B - 1, 0] * 1.002)
+            check([], False, loglik=False)
+            cur["counts"][s0] *= 1.01
+            check([s0], False)
+            cur["counts"][s0] *= 1.01
+            check([s0], True)
+            with tail_log(ctx, "strict"):                            # the same with the drop threshold
+                check([], False, loglik=False)
+                cur["counts"][s0] *= 1.01
+                check([s0], False)
+            img.set_epsilon(B - 1, f.bands[B - 1, 0])
+            ref_img.set_epsilon(B - 1, f.bands[B - 1, 0])
         finally:
             ctx.set_option(L.CEL_OPT_TILE_PARTS, 0)
     with pytest.raises(ValueError):
