@@ -1,0 +1,41 @@
+"""Random OPERATION SEQUENCES against state the library keeps between calls (tools/dbg/*_stress.py, short runs; the long ones are
+in profiles/r05_stress_runs.txt).  The scripted tests visit the transitions somebody thought of; round 5's incremental render
+trusted stale Poisson partials after `new sky level -> render without the log-likelihood -> edit`, which only a random walk
+over the calls found.  Each script compares, after every step that returns numbers, with a second object that is told the same
+things and takes no short cut: bit for bit for the renders and the list cache, to the short cuts' documented bounds for the
+split's re-use paths."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(script, *args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg", script)] + [str(a) for a in args], capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-2500:]
+    assert r.returncode == 0 and "\nok: " in "\n" + r.stdout, tail
+    return r.stdout
+
+
+@pytest.mark.parametrize("seed", [11, 3])       # (11: the sequence that found the stale partials)
+def test_incremental_render_under_random_call_sequences(seed):
+    out = run("incremental_stress.py", 5000, seed)
+    ok = [ln for ln in out.splitlines() if ln.startswith("ok: ")][0]
+    assert "'incremental': 0," not in ok, ok               # the dirty-tile path was taken
+
+
+def test_incremental_render_under_random_call_sequences_full_size():
+    run("incremental_stress.py", 600, 5, "big")
+
+
+def test_list_cache_under_random_caller_behaviour():
+    out = run("list_cache_stress.py", 2500, 4, "big")
+    assert " 0 of dirty tiles only" not in out          # the row uploads did reach the dirty-tile render
+
+
+def test_split_and_mass_short_cuts_under_random_call_sequences():
+    run("reuse_stress.py", 2500, 2)
