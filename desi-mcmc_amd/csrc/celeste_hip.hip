@@ -121,6 +121,7 @@ struct cel_ctx {
     static bool env_tail_ok() { const char *e = getenv("CEL_TAIL_LOG"); return e && atof(e) >= 0.0 && atof(e) <= 300.0; }
     double tail_T = env_tail_ok() ? atof(getenv("CEL_TAIL_LOG")) : 32.0;
     double render_T = env_tail_ok() ? atof(getenv("CEL_TAIL_LOG")) : 24.0;
+    int live = 0;               // image sets and source sets of this context that have not been destroyed (cel_ctx_destroy refuses)
     int split_full = 0;         // CEL_OPT_SPLIT_FULL_BOX
     int incremental = (getenv("CEL_INCREMENTAL") && atoi(getenv("CEL_INCREMENTAL")) == 0) ? 0 : 1;       // CEL_OPT_INCREMENTAL
     int tile_parts = (getenv("CEL_TILE_PARTS") && (atoi(getenv("CEL_TILE_PARTS")) == 1 || atoi(getenv("CEL_TILE_PARTS")) == 2 || atoi(getenv("CEL_TILE_PARTS")) == 4))
@@ -251,6 +252,7 @@ struct cel_images {
     cel_sources *sgen_prop = nullptr;
     int64_t last_S = 0;
     double last_entries = 0;
+    bool counted = false;            // in ctx->live
     bool nelec_shared = false;       // cel_images_device_ptrs handed the observed pixels' device pointer out
     uint64_t partials_gen = 0;       // the per-tile Poisson partials in d_partials are those of this catalogue generation's render (0: not)
     uint64_t lambda_uid = 0;         // the catalogue OBJECT whose generation lambda_gen is (the incremental render compares row stamps of the same object only)
@@ -271,6 +273,7 @@ static std::atomic<uint64_t> g_source_gen{0};
 
 struct cel_sources {
     cel_ctx *ctx = nullptr;
+    bool counted = false;          // in ctx->live
     int64_t cap = 0, S = 0;
     int B = 0;
     uint64_t gen = 0;              // changes with every cel_sources_set (process-wide counter)
@@ -472,6 +475,8 @@ int cel_ctx_create(int device, void *stream, cel_ctx **out) {
 
 int cel_ctx_destroy(cel_ctx *c) {
     if (!c) return CEL_OK;
+    if (c->live > 0)        // their destructors synchronise this context's stream: destroy them first
+        return fail(CEL_ERR_INVALID, "cel_ctx_destroy: %d image / source sets of this context are still alive", c->live);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->prof.ev)
@@ -626,6 +631,7 @@ int cel_images_destroy(cel_images *im) {
     if (im->h_soff) (void)hipHostFree(im->h_soff);
     if (im->d_mass_todo) (void)hipFree(im->d_mass_todo);
     if (im->ev_step) (void)hipEventDestroy(im->ev_step);
+    if (im->counted) im->ctx->live--;
     delete im;
     return CEL_OK;
 }
@@ -702,6 +708,8 @@ int cel_images_create(cel_ctx *c, int B, int H, int W, const cel_band *bands, ce
     IM_TRY(hipMalloc((void **)&im->d_stats, sizeof(double) * 2));
     IM_TRY(hipMemsetAsync(im->d_lambda, 0, sizeof(double) * npix, c->stream));
 #undef IM_TRY
+    im->counted = true;
+    c->live++;
     *out = im;
     return CEL_OK;
 bad:
@@ -812,6 +820,7 @@ int cel_sources_destroy(cel_sources *s) {
     void *ptrs[] = {s->d_type, s->d_radec, s->d_counts, s->d_shape};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->counted) s->ctx->live--;
     delete s;
     return CEL_OK;
 }
@@ -833,6 +842,8 @@ int cel_sources_create(cel_ctx *c, int64_t capacity, int B, cel_sources **out) {
         cel_sources_destroy(s);
         return fail(CEL_ERR_NOMEM, "hipMalloc(sources): %s", hipGetErrorString(e));
     }
+    s->counted = true;
+    s->ctx->live++;
     *out = s;
     return CEL_OK;
 }

@@ -34,6 +34,13 @@ def pack_bands(rec):
     return np.stack([pack_band(*[np.asarray(rec[k])[b] for k in BAND_KEYS]) for b in range(B)])
 
 
+def _destroy_child(destroy, handle, ctx):
+    """finalizer of an object that lives on a Context: `ctx` rides along so that the Context cannot be collected -- and
+    cel_ctx_destroy run -- before this has (objects in one reference cycle are finalized in no particular order, and a child's
+    destructor synchronises its context's stream)"""
+    destroy(handle)
+
+
 class Context(object):
     """One HIP device + stream.  `stream` is a raw hipStream_t (int), e.g.
     torch.cuda.current_stream().cuda_stream; None lets the library create its own."""
@@ -136,7 +143,7 @@ class SourceSet(object):
         self.ctx, self.B, self.capacity = ctx, int(B), int(capacity)
         self._h = C.c_void_p()
         L.check(L.lib().cel_sources_create(ctx._h, int(capacity), int(B), C.byref(self._h)))
-        self._finalizer = weakref.finalize(self, L.lib().cel_sources_destroy, self._h)
+        self._finalizer = weakref.finalize(self, _destroy_child, L.lib().cel_sources_destroy, self._h, ctx)
         self.S = 0
 
     def set(self, typ, radec, counts, shape=None):
@@ -175,7 +182,7 @@ class ImageSet(object):
         self.ctx, self.B, self.H, self.W = ctx, bands.shape[0], int(H), int(W)
         self._h = C.c_void_p()
         L.check(L.lib().cel_images_create(ctx._h, self.B, self.H, self.W, L.dptr(bands), C.byref(self._h)))
-        self._finalizer = weakref.finalize(self, L.lib().cel_images_destroy, self._h)
+        self._finalizer = weakref.finalize(self, _destroy_child, L.lib().cel_images_destroy, self._h, ctx)
         self._srcs = None
         self.eps = bands[:, 0].copy()          # host mirror of the sky levels on the device
         if nelec is not None:

@@ -188,6 +188,8 @@ int cel_device_count(int *n);
 
 /* device: HIP ordinal.  stream: a hipStream_t to enqueue on (NULL = the library creates one). */
 int cel_ctx_create(int device, void *stream, cel_ctx **out);
+/* fails with CEL_ERR_INVALID (and destroys nothing) while image sets or source sets created on the context are alive: their own
+ * destructors use the context's stream */
 int cel_ctx_destroy(cel_ctx *ctx);
 int cel_ctx_set_stream(cel_ctx *ctx, void *stream);
 int cel_ctx_synchronize(cel_ctx *ctx);

@@ -23,7 +23,7 @@ def run(script, *args):
 
 @pytest.mark.parametrize("seed", [11, 3])       # (11: the sequence that found the stale partials)
 def test_incremental_render_under_random_call_sequences(seed):
-    out = run("incremental_stress.py", 5000, seed)
+    out = run("incremental_stress.py", 4500 if seed == 11 else 2000, seed)
     ok = [ln for ln in out.splitlines() if ln.startswith("ok: ")][0]
     assert "'incremental': 0," not in ok, ok               # the dirty-tile path was taken
 
@@ -39,3 +39,24 @@ def test_list_cache_under_random_caller_behaviour():
 
 def test_split_and_mass_short_cuts_under_random_call_sequences():
     run("reuse_stress.py", 2500, 2)
+
+
+def test_objects_created_and_collected_in_any_order_leave_no_device_memory():
+    """contexts, image sets, source sets and whole Gibbs chains created, used and dropped 40 times: the device's free memory comes
+    back, and objects of one reference cycle may be finalized in any order (a Context finalized before its image sets used to take
+    the process down inside the next HIP call: a child's finalizer now keeps its Context alive, and cel_ctx_destroy refuses while
+    children live)"""
+    run("leak_check.py", 40)
+
+
+def test_ctx_destroy_refuses_while_children_live():
+    import ctypes as C
+    from desi_mcmc_amd import _lib
+    L = _lib.lib()
+    ctx = C.c_void_p()
+    _lib.check(L.cel_ctx_create(0, None, C.byref(ctx)))
+    src = C.c_void_p()
+    _lib.check(L.cel_sources_create(ctx, 8, 2, C.byref(src)))
+    assert L.cel_ctx_destroy(ctx) == _lib.CEL_ERR_INVALID and b"still alive" in L.cel_last_error()
+    _lib.check(L.cel_sources_destroy(src))
+    _lib.check(L.cel_ctx_destroy(ctx))
