@@ -19,6 +19,8 @@
  *   - device memory for images, sources, bins and partial sums is owned by the library;
  *   - work is enqueued on the context's HIP stream; calls that return values to the host
  *     synchronise that stream, the *_async forms do not;
+ *   - threads: a context and the objects created on it belong to one host thread at a time; different contexts may be
+ *     driven from different threads at once (tools/dbg/two_threads.py: results equal to the threads run alone);
  *   - there is NO CPU fallback: without a HIP device cel_ctx_create fails with
  *     CEL_ERR_NO_DEVICE.
  */

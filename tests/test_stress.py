@@ -60,3 +60,9 @@ def test_ctx_destroy_refuses_while_children_live():
     assert L.cel_ctx_destroy(ctx) == _lib.CEL_ERR_INVALID and b"still alive" in L.cel_last_error()
     _lib.check(L.cel_sources_destroy(src))
     _lib.check(L.cel_ctx_destroy(ctx))
+
+
+def test_host_threads_with_a_context_each():
+    """three host threads, a context each, on one GPU (renders, splits, masses, location steps on edited catalogues): every number
+    equals what the thread computes alone -- the contract include/celeste_hip.h states"""
+    run("two_threads.py", 3, 25)
