@@ -66,3 +66,9 @@ def test_host_threads_with_a_context_each():
     """three host threads, a context each, on one GPU (renders, splits, masses, location steps on edited catalogues): every number
     equals what the thread computes alone -- the contract include/celeste_hip.h states"""
     run("two_threads.py", 3, 25)
+
+
+def test_device_and_host_engines_on_random_edge_scenes():
+    """120 random small scenes (one source, stars only, galaxies only, sources on and beyond the border, sky over three decades):
+    two sweeps with the shape step on each engine, every chain equal bit for bit (3 200 scenes: profiles/r05_stress_runs.txt)"""
+    run("engines_fuzz.py", 120, 0)
