@@ -72,3 +72,9 @@ def test_device_and_host_engines_on_random_edge_scenes():
     """120 random small scenes (one source, stars only, galaxies only, sources on and beyond the border, sky over three decades):
     two sweeps with the shape step on each engine, every chain equal bit for bit (3 200 scenes: profiles/r05_stress_runs.txt)"""
     run("engines_fuzz.py", 120, 0)
+
+
+def test_random_row_strip_partitions_add_up_to_the_frame():
+    """150 random frames cut into 2-8 random tile-aligned row strips (cel_images_set_window), random tile parts, default and strict
+    thresholds: strips' model images and summed log-likelihoods against the whole frame's, to what the drop rule allows"""
+    run("strips_fuzz.py", 150, 0)
