@@ -1460,6 +1460,7 @@ int cel_render_stamps(cel_images *im, cel_sources *src, int band, int scaled, co
     HIP_TRY(hipSetDevice(c->device));
     int64_t S = src->S;
     if (S == 0) return CEL_OK;
+    if (offsets[0] != 0) return fail(CEL_ERR_INVALID, "cel_render_stamps: offsets[0] must be 0");
     std::vector<int32_t> hb((size_t)S * 4), hs((size_t)S);
     int rc = cel_stamp_boxes(im, src, band, hb.data(), hs.data());
     if (rc) return rc;
@@ -1567,6 +1568,7 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
     const int B = im->B;
     const int64_t P = src->S, nb = NB * B;
     if (P == 0) return CEL_OK;
+    if (!resident && offsets[0] != 0) return fail(CEL_ERR_INVALID, "cel_patch_loglik: offsets[0] must be 0");
     std::vector<int4> hbox((size_t)(resident ? 0 : nb));
     for (int64_t i = 0; i < (resident ? 0 : nb); i++) {
         int y0 = boxes[4 * i], y1 = boxes[4 * i + 1], x0 = boxes[4 * i + 2], x1 = boxes[4 * i + 3];
@@ -2334,6 +2336,19 @@ int cel_photon_split(cel_images *im, cel_sources *src, uint64_t seed, const int6
         im->samp_S = S;
         im->samp_total = total;
     } else {
+        // the caller's layout against the sources' own boxes (cel_source_boxes): a patch too small for its box would be
+        // written past its end
+        if (offsets[0] != 0) return fail(CEL_ERR_INVALID, "cel_photon_split: offsets[0] must be 0");
+        if ((rc = host_boxes(im, src))) return rc;
+        for (int64_t sidx = 0; sidx < S; sidx++)
+            for (int b = 0; b < B; b++) {
+                const int4 bx = im->h_boxes[(size_t)((int64_t)b * S + sidx)];
+                const int64_t area = (im->h_status[(size_t)((int64_t)b * S + sidx)] > 0) ? (int64_t)(bx.y - bx.x) * (bx.w - bx.z) : 0;
+                const int64_t i = sidx * B + b;
+                if (offsets[i + 1] - offsets[i] != area)
+                    return fail(CEL_ERR_INVALID, "cel_photon_split: offsets give source %lld band %d %lld values, its box has %lld pixels (cel_source_boxes)",
+                                (long long)sidx, b, (long long)(offsets[i + 1] - offsets[i]), (long long)area);
+            }
         total = offsets[n];
         if ((rc = scratch_get(c, 1, sizeof(int64_t) * (n + 1), (void **)&d_off))) return rc;
         HIP_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, c->stream));

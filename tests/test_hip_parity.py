@@ -1064,6 +1064,32 @@ def test_abi_error_paths(cel, ctx):
     with pytest.raises(ValueError):
         iset.patch_loglik(sset, np.array([[0, 10, 0, 10], [0, 0, 0, 0]]), [np.zeros((9, 10)), None])
     iset.set_nelec(np.ones((2, 64, 64)))
+    # a caller's patch layout is checked before anything is written through it (raw ABI: the Python wrappers build it themselves)
+    import ctypes as C
+    Lb = _lib.lib()
+    star = cel.SourceSet(ctx, 4, 2).set(np.zeros(1, np.int32), synth.pixel2equa(bands[0], np.array([[30.0, 30.0]])), np.full((1, 2), 100.0), np.zeros((1, 4)))
+    bx, st = iset.source_boxes(star)
+    area = [int((bx[b, 0, 1] - bx[b, 0, 0]) * (bx[b, 0, 3] - bx[b, 0, 2])) for b in range(2)]
+    buf = np.zeros(sum(area) + 8)
+    noise = np.zeros(2)
+    good = np.array([0, area[0], area[0] + area[1]], dtype=np.int64)
+    assert Lb.cel_photon_split(iset._h, star._h, C.c_uint64(1), good.ctypes.data_as(_lib.c_int64_p), buf.ctypes.data, _lib.CEL_HOST, _lib.dptr(noise)) == 0
+    for wrong in (good + 4, np.array([0, area[0] - 1, area[0] + area[1] - 1]), np.array([0, area[0], area[0] + area[1] - 3])):
+        w = np.ascontiguousarray(wrong, dtype=np.int64)
+        assert Lb.cel_photon_split(iset._h, star._h, C.c_uint64(1), w.ctypes.data_as(_lib.c_int64_p), buf.ctypes.data, _lib.CEL_HOST,
+                                   _lib.dptr(noise)) == _lib.CEL_ERR_INVALID
+    boxes = np.array([0, 4, 0, 4, 0, 0, 0, 0], dtype=np.int32)
+    data = np.zeros(32)
+    ll = np.zeros(1)
+    for offs, want in ((np.array([0, 16, 16]), 0), (np.array([3, 19, 19]), _lib.CEL_ERR_INVALID), (np.array([0, 15, 15]), _lib.CEL_ERR_INVALID)):
+        o = np.ascontiguousarray(offs, dtype=np.int64)
+        assert Lb.cel_patch_loglik(iset._h, star._h, boxes.ctypes.data_as(_lib.c_int32_p), o.ctypes.data_as(_lib.c_int64_p), _lib.dptr(data), _lib.CEL_HOST, 0,
+                                   _lib.dptr(ll)) == want, offs
+    sb = np.array([0, 4, 0, 4], dtype=np.int32)
+    out = np.zeros(32)
+    for offs, want in ((np.array([0, 16]), 0), (np.array([2, 18]), _lib.CEL_ERR_INVALID), (np.array([0, 12]), _lib.CEL_ERR_INVALID)):
+        o = np.ascontiguousarray(offs, dtype=np.int64)
+        assert Lb.cel_render_stamps(iset._h, star._h, 0, 0, sb.ctypes.data_as(_lib.c_int32_p), o.ctypes.data_as(_lib.c_int64_p), _lib.dptr(out), _lib.CEL_HOST) == want, offs
     with pytest.raises(ValueError, match="outside"):
         iset.patch_loglik(sset, np.array([[0, 70, 0, 10], [0, 0, 0, 0]]), [np.zeros((70, 10)), None])
     # NaN source parameters contribute nothing instead of poisoning the field
