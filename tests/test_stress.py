@@ -21,9 +21,9 @@ def run(script, *args):
     return r.stdout
 
 
-@pytest.mark.parametrize("seed", [11, 3])       # (11: the sequence that found the stale partials)
+@pytest.mark.parametrize("seed", [3, 4])         # (seed 11 at step 4 219 found the stale partials: a scripted case of test_hip_parity now)
 def test_incremental_render_under_random_call_sequences(seed):
-    out = run("incremental_stress.py", 4500 if seed == 11 else 2000, seed)
+    out = run("incremental_stress.py", 1500, seed)
     ok = [ln for ln in out.splitlines() if ln.startswith("ok: ")][0]
     assert "'incremental': 0," not in ok, ok               # the dirty-tile path was taken
 
