@@ -459,16 +459,19 @@ int cel_ctx_create(int device, void *stream, cel_ctx **out) {
     for (int i = 0; i < 8; i++) sd += H_DEV_AMP[i];
     for (int i = 0; i < 6; i++) { amp[i] = H_EXP_AMP[i] / se; var[i] = H_EXP_VAR[i]; }
     for (int i = 0; i < 8; i++) { amp[6 + i] = H_DEV_AMP[i] / sd; var[6 + i] = H_DEV_VAR[i]; }
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_prof_amp), amp, sizeof(amp)));
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_prof_var), var, sizeof(var)));
     double ic[64], lc[64];
     for (int j = 0; j < 64; j++) {
         long double cj = 1.0L + ((long double)j + 0.5L) / 64.0L;
         ic[j] = (double)(1.0L / cj);
         lc[j] = (double)(-logl((long double)ic[j]));
     }
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_log_ic), ic, sizeof(ic)));
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_log_lc), lc, sizeof(lc)));
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_prof_amp), amp, sizeof(amp))) != hipSuccess ||
+        (e = hipMemcpyToSymbol(HIP_SYMBOL(c_prof_var), var, sizeof(var))) != hipSuccess ||
+        (e = hipMemcpyToSymbol(HIP_SYMBOL(c_log_ic), ic, sizeof(ic))) != hipSuccess ||
+        (e = hipMemcpyToSymbol(HIP_SYMBOL(c_log_lc), lc, sizeof(lc))) != hipSuccess) {
+        (void)cel_ctx_destroy(c);           // (the stream and the pinned block go with it)
+        return fail(CEL_ERR_HIP, "hipMemcpyToSymbol: %s", hipGetErrorString(e));
+    }
     *out = c;
     return CEL_OK;
 }
