@@ -1598,7 +1598,7 @@ def test_fuzz_random_fields_vs_oracle(cel, ctx, orc, seed):
             assert abs(got - want) <= RT_LL * max(scale, abs(want)) + 1e-9, "seed %d src %d iso %s: %r %r (scale %g)" % (seed, s, isolated, got, want, scale)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", _fuzz_seeds(10))
 def test_fuzz_random_fields_vs_oracle_default_threshold(cel, ctx, orc, seed):
     """The same random extreme fields rendered at the library's DEFAULT drop threshold (T = 24).  What the rule guarantees:
     a skipped component adds less than eps * e^-T on its tile, so |d lambda| / lambda <= n * e^-T with n the components
@@ -1632,7 +1632,9 @@ def test_fuzz_random_fields_vs_oracle_default_threshold(cel, ctx, orc, seed):
     err = float(np.max(np.abs(lam / o_lam - 1.0)))
     assert err <= 42 * S * np.exp(-24.0) + 1e-12, (err, S)          # the rule's guarantee
     assert err < 1e-9, err                                           # what these fields show
-    np.testing.assert_allclose(llb, o_ll, rtol=1e-9)
+    # (relative to the terms' magnitudes: 5 of 4 000 seeds hold a band whose terms cancel to a tenth of their size)
+    scale = (np.abs(nelec * np.log(o_lam)) + o_lam).sum(axis=(1, 2))
+    assert np.all(np.abs(llb - o_ll) <= 1e-9 * scale), (llb, o_ll, scale)
 
 
 def test_integration_md_ctypes_binding(cel, orc):
