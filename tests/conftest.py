@@ -81,3 +81,11 @@ def real_fields(dirs=None):
         if dirs is None or f["dir"] in dirs:
             out.append(f)
     return g, out
+
+
+def fuzz_seeds(default):
+    """the seeds of a fuzz test: `default` of them in the suite; CEL_FUZZ_SEEDS / CEL_FUZZ_FIRST ask for a longer run
+    (profiles/r05_fuzz_run.txt)"""
+    import os
+    first = int(os.environ.get("CEL_FUZZ_FIRST", "0"))
+    return range(first, first + int(os.environ.get("CEL_FUZZ_SEEDS", str(default))))

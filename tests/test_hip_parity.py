@@ -17,7 +17,7 @@ Boxes (integer work) are compared bit-exact.
 import numpy as np
 import pytest
 
-from conftest import load_golden, tail_log, unpack_ragged
+from conftest import fuzz_seeds as _fuzz_seeds, load_golden, tail_log, unpack_ragged
 
 pytestmark = pytest.mark.gpu
 
@@ -1509,12 +1509,6 @@ def test_patch_loglik_adversarial_patches_vs_oracle(cel, ctx, orc, kernel, tail)
         ctx.set_tail_log("default")
 
 
-def _fuzz_seeds(default):
-    """the seeds of a fuzz test: `default` of them in the suite; CEL_FUZZ_SEEDS / CEL_FUZZ_FIRST ask for a longer run
-    (profiles/r05_fuzz_run.txt)"""
-    import os
-    first = int(os.environ.get("CEL_FUZZ_FIRST", "0"))
-    return range(first, first + int(os.environ.get("CEL_FUZZ_SEEDS", str(default))))
 
 
 @pytest.mark.parametrize("seed", _fuzz_seeds(10))
