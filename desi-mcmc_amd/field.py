@@ -220,9 +220,13 @@ class ImageSet(object):
         L.check(L.lib().cel_images_get_band(self._h, int(b), L.dptr(out)))
         return out
 
-    def device_ptrs(self):
+    def device_ptrs(self, nelec=True):
+        """(device address of the observed pixels, of the model images).  Asking for the observed pixels' address tells the
+        library that the caller may write them at any time: it stops assuming their range and keeps no Poisson partials
+        between renders (the dirty-tile render of a log-likelihood is off for this set); nelec=False asks for the model
+        images' address alone -> (None, address)"""
         a, b = C.c_void_p(), C.c_void_p()
-        L.check(L.lib().cel_images_device_ptrs(self._h, C.byref(a), C.byref(b)))
+        L.check(L.lib().cel_images_device_ptrs(self._h, C.byref(a) if nelec else None, C.byref(b)))
         return a.value, b.value
 
     def loglik_device_ptr(self):

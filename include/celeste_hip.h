@@ -225,7 +225,8 @@ int cel_images_get_band(cel_images *img, int band, cel_band *out);
 int cel_images_get_lambda(cel_images *img, double *out, int mem);
 /* raw device pointers of the library-owned B*H*W buffers (for zero-copy consumers).  Asking for `nelec` tells the library that
  * the caller may write the observed image in place: it stops assuming the range cel_images_set_nelec found (the photon split's
- * 16-bit photons-left plane) until the next cel_images_set_nelec */
+ * 16-bit photons-left plane) until the next cel_images_set_nelec, and from then on keeps no per-tile Poisson sums between
+ * renders (CEL_OPT_INCREMENTAL renders every tile when a log-likelihood is asked for).  nelec = NULL asks for neither */
 int cel_images_device_ptrs(cel_images *img, void **nelec, void **lambda);
 /* device pointer of the B per-band log-likelihoods of the LAST render with CEL_RENDER_LOGLIK (doubles, valid until the next
  * render, photon split or E-step call on this image set -- they reduce into the same buffer; the stream has been synchronised
