@@ -508,3 +508,22 @@ def test_step_seeds_are_unrelated_for_every_chain_seed():
             st = ChainStreams(celeste_mcmc.step_seed(seed, step, 0), np.arange(50))
             first[step] = st.uniform(np.arange(50))
         assert not np.any(first["flux"] == first["location"]) and not np.any(first["shape"] == first["location"])
+
+
+def test_python_constants_are_the_headers(built):
+    """every enumerator of include/celeste_hip.h that desi_mcmc_amd._lib names has the header's value (options are added by
+    hand on both sides), and every option of the header is named"""
+    import re
+    from desi_mcmc_amd import _lib
+    text = open(os.path.join(ROOT, "include", "celeste_hip.h")).read()
+    enums = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"\b(CEL_[A-Z0-9_]+)\s*=\s*(-?\d+)\s*[,/}\n]", text))
+    assert len(enums) > 30
+    named = [n for n in dir(_lib) if n.startswith("CEL_") and isinstance(getattr(_lib, n), int)]
+    assert len(named) > 20
+    for n in named:
+        assert n in enums and getattr(_lib, n) == enums[n], (n, getattr(_lib, n), enums.get(n))
+    for n, v in enums.items():
+        if n.startswith("CEL_OPT_") or n.startswith("CEL_ERR_") or n.startswith("CEL_RENDER_"):
+            assert getattr(_lib, n, None) == v, (n, v)
+    opts = sorted(v for n, v in enums.items() if n.startswith("CEL_OPT_"))
+    assert opts == list(range(1, len(opts) + 1)), opts            # no key used twice, none skipped
