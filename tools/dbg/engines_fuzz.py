@@ -27,13 +27,19 @@ for seed in range(first, first + N):
     iset = cel.ImageSet(ctx, bands, H, W)
     iset.render(cel.SourceSet(ctx, S, 5).set(typ, radec, counts, shape), loglik=False)
     iset.set_nelec(rs.poisson(iset.model_images()).astype(np.float64))
+    # the samplers' options the device engines take: the shape step along the axes or along 1-4 random directions, stepping
+    # out by doubling or not at all, any interval; the location step's interval
+    shape_args = dict(compwise=bool(rs.randint(2)), numdir=int(rs.randint(1, 5)), sigma=float(rs.choice([1.0, 0.3, 0.05])))
+    if rs.rand() < 0.4:
+        shape_args["step_out"] = False
+    slice_args = None if rs.rand() < 0.5 else dict(sigma=float(rs.choice([1e-3, 3e-4, 5e-3])))
     out = {}
     err = {}
     for engine in ("device", "host"):
         for b in range(5):
             iset.set_epsilon(b, bands[b, 0])
         gf = celeste_mcmc.GibbsField(iset, list(range(5)), bands[:, 2], bands[:, 1], H * W)
-        g = celeste_mcmc.ModelGibbs([gf], typ, radec, flux, shape, seed=seed, engine=engine)
+        g = celeste_mcmc.ModelGibbs([gf], typ, radec, flux, shape, seed=seed, engine=engine, shape_args=shape_args, slice_args=slice_args)
         tr = []
         try:
             for k in range(2):
