@@ -373,3 +373,69 @@ def test_full_box_split_reaches_the_first_row_and_column():
                 assert abs(edge_got - edge_want) < 5 * np.sqrt(edge_want / NS) + 1e-9, (b, edge_got, edge_want)
             inner_got, inner_want = got[1:, 1:].sum(), want[1:, 1:].sum()
             assert abs(inner_got - inner_want) < 5 * np.sqrt(inner_want / NS), (b, full, inner_got, inner_want)
+
+
+def test_two_exposures_of_the_same_sources():
+    """CelesteBase holds a LIST of fields (models.py:60-83: several exposures of the same sky); every source's flux and location
+    conditionals add over them.  The same calibration test with two image sets -- all five bands, and a second exposure of g, r,
+    i with other sky levels, calibrations and seeing -- sharing one catalogue (the host engine: the device engines run one field):
+    a field counted twice, or left out of a conditional, fails it by orders of magnitude (asserted with the second field's masses
+    dropped from the flux step)."""
+    import desi_mcmc_amd as cel
+    from desi_mcmc_amd import celeste_mcmc, synth
+    ctx = cel.default_context(0)
+
+    def ranks(break_it=False):
+        allu, allf = [], []
+        for rep in range(K_DRAWS + 1):
+            sc = make_scene(cel, ctx, rep + 500, 5)
+            rs = np.random.RandomState(77 + rep)
+            b2 = sc["bands"][[1, 2, 3]].copy()
+            b2[:, 0] = rs.gamma(EPS_A, 1.0 / EPS_B, 3)                 # another night: sky,
+            b2[:, 2] *= rs.uniform(0.7, 1.4, 3)                        # calibration,
+            b2[:, 12:24] *= 1.3                                        # seeing
+            counts2 = sc["flux"][:, [1, 2, 3]] / b2[None, :, 2] * b2[None, :, 1]
+            i2 = cel.ImageSet(ctx, b2, sc["H"], sc["W"])
+            i2.render(cel.SourceSet(ctx, sc["S"], 3).set(sc["typ"], sc["radec"], counts2, sc["shape"]), loglik=False)
+            i2.set_nelec(rs.poisson(i2.model_images()).astype(np.float64))
+            J = rep % (K_DRAWS + 1)
+
+            def chain(seed):
+                for b in range(5):
+                    sc["iset"].set_epsilon(b, sc["bands"][b, 0])
+                for b in range(3):
+                    i2.set_epsilon(b, b2[b, 0])
+                g1 = celeste_mcmc.GibbsField(sc["iset"], [0, 1, 2, 3, 4], sc["bands"][:, 2], sc["bands"][:, 1], sc["H"] * sc["W"], a_0=EPS_A, b_0=EPS_B)
+                g2 = celeste_mcmc.GibbsField(i2, [1, 2, 3], b2[:, 2], b2[:, 1], sc["H"] * sc["W"], a_0=EPS_A, b_0=EPS_B)
+                g = celeste_mcmc.ModelGibbs([g1, g2], sc["typ"], sc["radec"], sc["flux"], sc["shape"], seed=seed, flux_a_0=FLUX_A, flux_b_0=FLUX_B)
+                if break_it:
+                    real = g2.iset.stamp_mass_end
+                    g2.iset.stamp_mass_end = lambda: real() * 0.0
+                return g
+            du, df = [], []
+            g = chain(rep)
+            for k in range((K_DRAWS - J) * THIN):
+                g.sweep()
+                if k % THIN == THIN - 1:
+                    du.append(g.u.copy()); df.append(g.fluxes.copy())
+            g = chain(rep + 7919)
+            g._split_photons()
+            for k in range(J * THIN):
+                g.sweep_reversed()
+                if k % THIN == THIN - 1:
+                    du.append(g.u.copy()); df.append(g.fluxes.copy())
+            allu.append((np.array(du) < sc["radec"][None]).sum(axis=0))
+            allf.append((np.array(df) < sc["flux"][None]).sum(axis=0))
+        return np.concatenate(allu), np.concatenate(allf)
+    ru, rf = ranks()
+    out = {}
+    for name, r in (("location", ru), ("flux g r i (both exposures)", rf[:, 1:4]), ("flux u z (one)", rf[:, [0, 4]])):
+        stat, p, counts = chi2_pvalue(r, K_DRAWS)
+        out[name] = (round(stat, 2), p, counts.astype(int).tolist())
+    print("SBC ranks, two fields (%d sources): %s" % (ru.shape[0], out))
+    for name, (stat, p, counts) in out.items():
+        assert p > 1e-3 / 3, (name, stat, p, counts)
+    ru, rf = ranks(break_it=True)
+    p_bad = chi2_pvalue(rf[:, 1:4], K_DRAWS)[1]
+    print("second field's masses dropped from the flux step: p(flux g r i) = %.3g" % p_bad)
+    assert p_bad < 1e-8
