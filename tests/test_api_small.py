@@ -79,3 +79,44 @@ def test_reference_named_stamp_and_photon_entry_points():
     assert s0.flux_samples.shape == (1, 5) and s0.shape_samples.shape == (1, 4) and s0.location_samples.shape == (1, 2)
     s0.clear_sample_images()
     assert s0.sample_image_list == []
+
+
+@pytest.mark.gpu
+def test_caller_stream_and_device_resident_pixels():
+    """cel_ctx_set_stream with a torch stream and cel_images_set_nelec(mem = CEL_DEVICE) with a torch tensor's address (the
+    zero-copy interop INTEGRATION.md describes): the numbers of the library's own stream and a host upload.  In a process of
+    its own that imports torch FIRST, as bench.py does: torch ships a HIP runtime, and whichever is loaded first serves both."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    code = '''
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+torch.cuda.init()
+import desi_mcmc_amd as cel
+from desi_mcmc_amd import synth
+ctx = cel.Context(0)
+f = synth.SyntheticField(ctx, 200, 3, 192, 224, frac_gal=0.5, seed=4)
+ll0, llb0 = f.images.render(f.sources, loglik=True)
+lam0 = f.images.model_images()
+st = torch.cuda.Stream()
+ctx.set_stream(st.cuda_stream)
+t = torch.from_numpy(f.nelec).to("cuda")
+torch.cuda.synchronize()
+f.images.set_nelec_device(t.data_ptr())
+ll1, llb1 = f.images.render(f.sources, loglik=True)
+assert ll1 == ll0 and np.array_equal(llb1, llb0) and np.array_equal(f.images.model_images(), lam0)
+t2 = t * 1.0
+t2[0, 5, 7] += 3.0
+torch.cuda.synchronize()
+f.images.set_nelec_device(t2.data_ptr())
+_, llb2 = f.images.render(f.sources, loglik=True)
+assert llb2[0] != llb0[0] and np.array_equal(llb2[1:], llb0[1:])
+np.testing.assert_allclose(llb2[0] - llb0[0], 3.0 * np.log(lam0[0, 5, 7]), rtol=1e-9)
+ctx.set_stream(None)
+f.images.set_nelec(f.nelec)
+assert f.images.render(f.sources, loglik=True)[0] == ll0
+print("interop ok")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "interop ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
