@@ -38,6 +38,16 @@ if blocks:
     M.log_likelihood = lambda self: 0.0
     tc.MOVE_CHECK = "loc" in on
 ctx = cel.default_context(0)
+_real = tc.run_replicate
+
+
+def _progress(cel_, ctx_, rep, *a, **k):          # (a line every few replicates: a silent GPU job is taken for hung)
+    if rep % 8 == 0:
+        print("replicate %d" % rep, flush=True)
+    return _real(cel_, ctx_, rep, *a, **k)
+
+
+tc.run_replicate = _progress
 kw = dict(shape_mass="exact") if "mass_only" in sys.argv else dict(conditional="exact")
 if "reference" in sys.argv: kw = {}
 ru, rf, rs_ = tc.pooled_ranks(cel, ctx, "host", 8, shapes=True, shape_args=args or None, **kw)
