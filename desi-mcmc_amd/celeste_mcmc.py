@@ -488,7 +488,9 @@ class ModelGibbs(object):
         """what turns Source.log_likelihood's value for the proposals in f.prop (chains `sel`, expected photons `pc`) into the
         exact conditional: -counts * (the proposal's stamp mass on its own box) in place of -counts * sum(psf weights) where
         the source has a patch, and -inf where a photon of the source lies outside the proposal's box"""
-        wsum = np.array([f.iset.band(b)[3:6].sum() for b in range(f.iset.B)])
+        wsum = getattr(f, "_wsum", None)
+        if wsum is None:                                               # (the PSF weights of an image set do not change)
+            wsum = f._wsum = np.array([f.iset.band(b)[3:6].sum() for b in range(f.iset.B)])
         mass = f.iset.stamp_mass(f.prop)
         out = -(pc * (mass - wsum[None, :]) * f.has_patch[sel]).sum(axis=1)
         rects = getattr(f, "photon_rects", None)
