@@ -109,11 +109,26 @@ def load_gibbs_pmc():
     if not ks:
         return {"stale": "%s holds no likelihood launches" % GIBBS_PMC_PROFILE}
     rounds = max(prof["kernels"][k]["FETCH_SIZE"]["launches"] for k in ks)       # every round launches the photon-list kernel
-    tot = 0.0
+    tot = valu = 0.0
     for k in ks:
         c = prof["kernels"][k]
         tot += (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0 * c["FETCH_SIZE"]["launches"]
-    return {"traffic": tot / rounds, "source": GIBBS_PMC_PROFILE, "kernels": ks}
+        valu += c["SQ_INSTS_VALU"]["mean"] * c["SQ_INSTS_VALU"]["launches"] if "SQ_INSTS_VALU" in c else 0.0
+    split = [k for k in prof["kernels"] if "k_photon_split_hw" in k]
+    split_valu = prof["kernels"][split[0]].get("SQ_INSTS_VALU", {}).get("mean") if split else None
+    return {"traffic": tot / rounds, "valu_insts": valu / rounds, "split_valu_insts": split_valu, "source": GIBBS_PMC_PROFILE, "kernels": ks}
+
+
+def _issue_binding(valu_insts, kernel_ms, source, split_valu=None, split_ms=None):
+    """roofline.binding of a launch from its counted VALU wave-instructions: executed lane-instructions per second against the
+    data-sheet fp64 issue rate (the roof the Gaussian evaluators are on; bench.py keeps `bound: "hbm"` as the contract's)"""
+    ok = bool(valu_insts) and kernel_ms and kernel_ms > 0
+    out = {"bound": "fp64_valu_issue", "achieved": valu_insts * 64.0 / (kernel_ms * 1e-3) if ok else None, "peak": FP64_LANE_OPS_PEAK,
+           "unit": "fp64 VALU lane-instructions/s", "frac": valu_insts * 64.0 / (kernel_ms * 1e-3) / FP64_LANE_OPS_PEAK if ok else None,
+           "pmc_source": source}
+    if split_valu and split_ms and split_ms > 0:
+        out["k_photon_split_hw_frac"] = split_valu * 64.0 / (split_ms * 1e-3) / FP64_LANE_OPS_PEAK
+    return out
 
 
 CPU_THREADS_MAX = 16         # the GPU box's CPU share for one GPU
@@ -238,7 +253,7 @@ def cpu_baseline(field, nsample, orc):
     (celeste.py:203-219) -- for 100 sources in one band, which is what makes the reference O(S H W)."""
     bands = field.bands.copy()
     for b in range(field.B):
-        bands[b, 36] = field.images.band(b)[36]
+        bands[b, 36] = orc.checked_radius(bands[b], field.images.band(b)[36])
     nthr = max(1, min(orc.max_threads(), host_threads()))
 
     def timed(ns, threads):
@@ -512,6 +527,11 @@ def run_render(args, env):
     else:
         fp.update({"achieved": None, "frac": None})
     out["fp64_valu"] = fp
+    # the contract's `bound` stays "hbm"; the roof that binds rides INSIDE `roofline` so that the driver's record keeps it
+    # ("report against the binding roof").  useful_frac is filled in below once the evaluated count is known.
+    out["roofline"]["binding"] = {"bound": "fp64_valu_issue", "achieved": fp["achieved"], "peak": FP64_LANE_OPS_PEAK,
+                                  "unit": fp["unit"], "frac": fp["frac"], "useful_frac": None,
+                                  "valu_busy_frac": fp.get("valu_busy_frac_pmc"), "pmc_source": fp.get("pmc_source") or pmc_note}
     if world == 1 and not strong and args.legs == "all":
         extra_render_legs(args, env, field, out)
         ev = out["work"].get("n_gauss_evaluated_per_step")
@@ -521,6 +541,9 @@ def run_render(args, env):
             out["work"]["gauss_evals_per_s"] = ev * args.steps / dt_max
             out["work"]["evaluated_fraction_of_nominal"] = ev / n_gauss_all
             out["fp64_valu"]["equivalent_tflops_35flop_per_evaluated_gauss"] = FLOP_PER_GAUSS * ev / (t_render * 1e-3) / 1e12 if t_render > 0 else 0.0
+            if pmc:
+                # the recurrence's 2 mul + 1 add per evaluated Gaussian-pixel over everything the kernel executed
+                out["roofline"]["binding"]["useful_frac"] = 3.0 * ev / (pmc["valu_insts"] * 64.0)
         if args.workload == "mixed10k_2048":
             out["secondary"] = secondary_legs(args, env, field)
             if args.sustained > 0:
@@ -635,21 +658,32 @@ def extra_render_legs(args, env, field, out):
     t_assign = (time.perf_counter() - t0) / 3
     out["python_api_list_ms"] = (t_all - t_assign) * 1e3
     u0 = plist[23].u.copy()
-    ll_moved = None
-    t0 = time.perf_counter()
-    for k in range(n):
-        pos = plist[23].u                    # the reference's moves: edit in place, then assign (mcmc_transitions.py:49-51)
-        pos[0] = u0[0] + 1e-6 * ((k % 5) - 2)
-        plist[23].u = pos
-        ll_moved = celeste.celeste_likelihood_multi_image(plist, imgs)
-    out["python_api_list_one_changed_ms"] = (time.perf_counter() - t0) / n * 1e3
-    plist[23].u = u0
-    ll_list2 = celeste.celeste_likelihood_multi_image(plist, imgs)
-    assert ll_moved != ll_list2 and ll_list2 == ll_list, (ll_moved, ll_list2, ll_list)
-    t0 = time.perf_counter()
-    for _ in range(n):
+
+    def list_legs():
+        ll_moved = None
+        t0 = time.perf_counter()
+        for k in range(n):
+            pos = plist[23].u                    # the reference's moves: edit in place, then assign (mcmc_transitions.py:49-51)
+            pos[0] = u0[0] + 1e-6 * ((k % 5) - 2)
+            plist[23].u = pos
+            ll_moved = celeste.celeste_likelihood_multi_image(plist, imgs)
+        one = (time.perf_counter() - t0) / n * 1e3
+        plist[23].u = u0
+        ll_list2 = celeste.celeste_likelihood_multi_image(plist, imgs)
+        assert ll_moved != ll_list2 and ll_list2 == ll_list, (ll_moved, ll_list2, ll_list)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            celeste.celeste_likelihood_multi_image(plist, imgs)
+        return one, (time.perf_counter() - t0) / n * 1e3
+    # the default: every source re-read on every call (the reference's semantics), only the rows that differ uploaded
+    assert celeste.list_cache() == "exact"
+    out["python_api_list_one_changed_ms"], out["python_api_list_unchanged_ms"] = list_legs()
+    try:                                         # the opt-in fast mode: only the objects assigned to since the last call re-read
+        celeste.list_cache("stamps")
         celeste.celeste_likelihood_multi_image(plist, imgs)
-    out["python_api_list_unchanged_ms"] = (time.perf_counter() - t0) / n * 1e3
+        out["python_api_list_stamps_one_changed_ms"], out["python_api_list_stamps_unchanged_ms"] = list_legs()
+    finally:
+        celeste.list_cache("exact")
     views = cel.SrcCatalog.from_params(plist).views()         # a LIST of per-source objects backed by one catalogue
     ll_views = celeste.celeste_likelihood_multi_image(views, imgs)
     views[17].u = views[17].u + 1e-5                          # a write through a view is seen by the next call
@@ -663,8 +697,10 @@ def extra_render_legs(args, env, field, out):
     out["python_api_note"] = ("celeste_likelihood_multi_image(srcs, imgs) end to end, images resident after the first call: "
                               "srcs = SrcCatalog (arrays; python_api_ms) / a plain list of %d SrcParams objects "
                               "(python_api_list_ms: every object assigned to since the last call, the whole list gathered again; "
-                              "python_api_list_one_changed_ms: one source moved between calls -- its row re-read and uploaded; "
-                              "python_api_list_unchanged_ms) / the list SrcCatalog.views() "
+                              "python_api_list_one_changed_ms: one source moved between calls -- EVERY source re-read (the default, list_cache('exact'): "
+                              "the reference's semantics), the one row that differs uploaded, incremental render; "
+                              "python_api_list_unchanged_ms; python_api_list_stamps_*: the opt-in list_cache('stamps'), only objects "
+                              "assigned to since the last call re-read) / the list SrcCatalog.views() "
                               "hands out: per-source objects with SrcParams' attributes, backed by the catalogue's arrays "
                               "(python_api_views_ms)" % len(plist))
     out["python_api_loglik_rel_diff"] = float(abs(ll_api - out["loglik"]) / abs(out["loglik"])) if out["loglik"] else None
@@ -1037,7 +1073,7 @@ def gibbs_cpu_baseline(field, g, gf, orc, n_sources=48):
     S, B = field.S, field.B
     bands = field.bands.copy()
     for b in range(B):
-        bands[b, 36] = field.images.band(b)[36]
+        bands[b, 36] = orc.checked_radius(bands[b], field.images.band(b)[36])
     boxes, offs, data = gf.iset.fetch_samples()
     evals_per_source = max(1, int(round(g.timing["evals"] / max(g.sweeps_timed, 1) / max(float(g.active.sum()), 1.0))))
     rs = np.random.RandomState(5)
@@ -1092,7 +1128,9 @@ def gibbs_report(g, gf, ctx, steps, dt, S, B):
                              "the dispatches, summed per round and averaged over the timed sweeps' rounds; bytes: per evaluation and band "
                              "8 B per photon-holding pixel of a patch scored at its photons (4 B per pixel of the photon rectangle for one "
                              "scored densely) + a 128-B record, counted on the device.  The kernels are fp64-issue-bound like k_render "
-                             "(DESIGN.md 5); the HBM fraction is what the contract asks for"},
+                             "(DESIGN.md 5); the HBM fraction is what the contract asks for; `binding` is the roof they are on",
+                     "binding": _issue_binding(pmc.get("valu_insts"), round_ms, pmc.get("source") or pmc.get("stale"),
+                                               split_valu=pmc.get("split_valu_insts"), split_ms=t_split)},
         "work": {"slice_rounds_per_sweep": g.timing["rounds"] / steps, "loglik_evals_per_sweep": g.timing["evals"] / steps,
                  "sources_updated_per_sweep": float(g.active.sum())},
         "sweep_ms": {"photon_split_and_sky": g.timing["split"] / steps * 1e3, "flux": g.timing["flux"] / steps * 1e3,

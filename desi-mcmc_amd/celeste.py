@@ -11,6 +11,7 @@ Divergences from the reference, all documented in DESIGN.md "Quirks":
   planck  stars given by temperature (`src.t`) need a hook: set `photons_expected_brightness`.
 """
 import collections
+import warnings
 import os
 import itertools
 import operator
@@ -215,6 +216,8 @@ def _source_arrays(srcs, images, counts_fn=expected_photons):
         typ = (a == 1).astype(np.int32)
         return typ, u, counts, np.where((a == 1)[:, None], sh, 0.0)
     if type(srcs) is list and len(srcs) >= _LIST_CACHE_MIN and _LIST_CACHE_MODE[0] != "off":
+        if _LIST_CACHE_MODE[0] == "exact":
+            return _diffed_list_arrays(srcs, images, counts_fn, bidx, calib, kappa)
         return _cached_list_arrays(srcs, images, counts_fn, bidx, calib, kappa)
     return _gather_plain(srcs, images, counts_fn, bidx, calib, kappa)
 
@@ -274,33 +277,42 @@ def _gather_plain(srcs, images, counts_fn, bidx, calib, kappa):
 
 # ---- a LIST of SrcParams evaluated again and again -------------------------------------------------------------------
 # celeste_em.py:25,159, celeste_mcmc.py:130 and every move of util/infer/mcmc_transitions.py:37-152 call
-# celeste_likelihood*(list_of_SrcParams, ...) after changing ONE source.  The arrays gathered from a list are kept (per list
-# object, image group and flux convention); on the next call with the same list -- the same objects in the same places,
-# one C-level identity pass -- only the objects whose modification stamp moved (celeste_src.SrcParams.__setattr__) are read
-# again, and only their rows go to the device (cel_sources_set_rows).  A container changed IN PLACE without an attribute
-# assignment afterwards is not seen: celeste_src.touch(src) (the reference's own moves assign, mcmc_transitions.py:49-51).
-# The audit: every call that trusts the cache re-reads a rotating sixteenth of the list (at least 64 sources: ~0.15 ms of a
-# 10 000-source call) and compares it with the cached rows, so an in-place edit the stamps missed is found within 16 calls and
-# RAISES (the values returned since the edit were stale: silence would be worse than an exception).  list_cache("off") --
-# or CEL_LIST_CACHE=off in the environment -- gathers every list on every call, exactly as the reference re-reads every
-# source (celeste.py:203-219): 3.7 ms more per call at 10 000 sources.
+# celeste_likelihood*(list_of_SrcParams, ...) after changing ONE source.  Three ways to read such a list:
+#
+#   "exact" (the default)  EVERY source is re-read on EVERY call, exactly as the reference does (celeste.py:203-219): whatever
+#       was done to the objects -- an assignment, an edit in place (src.u[0] = x, src.fluxes['r'] = f), a changed calibration
+#       hook -- the call sees it.  The freshly gathered arrays are compared with the ones the device holds (kept per list
+#       object, image group and flux convention) and only the rows that differ go up (cel_sources_set_rows), so a
+#       single-source move still takes the incremental render.  Nothing is ever answered from host-side state.
+#   "stamps" (opt-in, the fast mode)  the arrays are gathered once; afterwards only the objects whose modification stamp moved
+#       (celeste_src.SrcParams.__setattr__) are read again: one C-level identity pass instead of a gather, 3.7 ms less per call
+#       at 10 000 sources.  A container changed IN PLACE without an attribute assignment afterwards moves no stamp and is
+#       NOT seen until celeste_src.touch(src) (the reference's own moves assign, mcmc_transitions.py:49-51); a rotating audit
+#       (a sixteenth of the list re-read per call) meets such an edit within 16 calls, warns, and re-reads the whole list.
+#   "off"  no host-side state at all: gathered and uploaded whole on every call.
+#
+# celeste.list_cache(mode) or CEL_LIST_CACHE=<mode> in the environment.  A SrcCatalog (or its views()) needs none of this.
 _LIST_CACHE_MIN = 64          # shorter lists are gathered every time (cheaper than the bookkeeping)
-_LIST_CACHE_MODE = [os.environ.get("CEL_LIST_CACHE", "stamps")]
+_LIST_CACHE_MODES = ("exact", "stamps", "off")
+_LIST_CACHE_MODE = [os.environ.get("CEL_LIST_CACHE", "exact")]
+if _LIST_CACHE_MODE[0] not in _LIST_CACHE_MODES:
+    raise ValueError("CEL_LIST_CACHE=%r: one of %s" % (_LIST_CACHE_MODE[0], ", ".join(_LIST_CACHE_MODES)))
 _AUDIT_PARTS = 16
 
 
 def list_cache(mode=None):
-    """how a plain LIST of SrcParams passed again and again is read: "stamps" (default) -- gathered once, afterwards only the
-    objects assigned to since (SrcParams.__setattr__ / celeste_src.touch) are re-read, with a rotating audit that raises
-    when it meets an in-place edit nobody stamped; "off" -- every source re-read on every call, as the reference does.
-    -> the mode in force (mode=None only asks)"""
+    """how a plain LIST of SrcParams passed again and again is read: "exact" (default) -- every source re-read on every call,
+    as the reference does; only the rows that differ from the device's copy are uploaded; "stamps" -- gathered once,
+    afterwards only the objects assigned to since (SrcParams.__setattr__ / celeste_src.touch) are re-read, with a rotating
+    audit that warns and re-reads everything when it meets an in-place edit nobody stamped; "off" -- no state kept, whole
+    upload every call.  -> the mode in force (mode=None only asks)"""
     if mode is not None:
-        if mode not in ("stamps", "off"):
-            raise ValueError("list_cache: 'stamps' or 'off'")
-        _LIST_CACHE_MODE[0] = mode
-        if mode == "off":
+        if mode not in _LIST_CACHE_MODES:
+            raise ValueError("list_cache: one of %s" % ", ".join(repr(m) for m in _LIST_CACHE_MODES))
+        if mode != _LIST_CACHE_MODE[0]:
             _LIST_CACHE.clear()
             _ENTRY_OF.clear()
+        _LIST_CACHE_MODE[0] = mode
     return _LIST_CACHE_MODE[0]
 
 _LIST_CACHE = collections.OrderedDict()   # (id(list), image ids, counts_fn) -> _ListEntry; a handful of lists
@@ -330,7 +342,7 @@ def _stamp_column(srcs, S):
 def _cached_list_arrays(srcs, images, counts_fn, bidx, calib, kappa):
     from .celeste_src import clock, stamped_since
     S = len(srcs)
-    key = (id(srcs), tuple(map(id, images)), counts_fn)
+    key = (id(srcs), tuple(map(id, images)), counts_fn, photons_expected_brightness)     # a changed hook is another entry
     imgkey = (tuple(bidx), tuple(calib.tolist()), tuple(kappa.tolist()))
     ent = _LIST_CACHE.get(key)
     if ent is not None and ent.srcs is srcs and len(ent.objs) == S and ent.imgkey == imgkey and all(map(operator.is_, srcs, ent.objs)):
@@ -357,8 +369,7 @@ def _cached_list_arrays(srcs, images, counts_fn, bidx, calib, kappa):
                     ent.log.append((ent.version, rows))
                     del ent.log[:-16]
                 ent.stamps, ent.clock = stamps, now
-        if ent is not None:
-            _audit_rows(ent, srcs, images, counts_fn, bidx, calib, kappa)
+        if ent is not None and _audit_rows(ent, srcs, images, counts_fn, bidx, calib, kappa):
             return ent.typ, ent.radec, ent.counts, ent.shape
     now = clock()
     stamps = _stamp_column(srcs, S)
@@ -396,12 +407,48 @@ def _audit_rows(ent, srcs, images, counts_fn, bidx, calib, kappa):
     if not ok:
         bad = lo + int(np.nonzero(np.any(r != ent.radec[lo:lo + n], axis=1) | np.any(c != ent.counts[lo:lo + n], axis=1) |
                                   np.any(sh != ent.shape[lo:lo + n], axis=1) | (t != ent.typ[lo:lo + n]))[0][0])
-        _LIST_CACHE.clear()
-        _ENTRY_OF.clear()
-        raise RuntimeError("celeste: source %d of this list was changed IN PLACE (src.u[0] = x, src.fluxes['r'] = f) without an "
-                           "attribute assignment afterwards; the values returned since that edit did not see it.  Assign the "
-                           "attribute (src.u = u, as the reference's moves do), call celeste_src.touch(src), or switch the "
-                           "list cache off: celeste.list_cache('off') / CEL_LIST_CACHE=off" % bad)
+        warnings.warn("celeste.list_cache('stamps'): source %d of this list was changed IN PLACE (src.u[0] = x, src.fluxes['r'] = f) "
+                      "without an attribute assignment afterwards, or its counts function is not reproducible; the values returned "
+                      "since that edit did not see it.  The whole list is read again now.  Assign the attribute (src.u = u, as the "
+                      "reference's moves do), call celeste_src.touch(src), or use the default list_cache('exact')" % bad,
+                      RuntimeWarning, stacklevel=4)
+    return ok
+
+
+def _diffed_list_arrays(srcs, images, counts_fn, bidx, calib, kappa):
+    """list_cache("exact"): every source read now (the reference's semantics, celeste.py:203-219); the entry kept per list
+    only remembers what the DEVICE holds, so that the rows that differ -- and only they -- are uploaded"""
+    S = len(srcs)
+    arrs = _gather_plain(srcs, images, counts_fn, bidx, calib, kappa)
+    key = (id(srcs), tuple(map(id, images)), counts_fn, "exact")
+    imgkey = (tuple(bidx), tuple(calib.tolist()), tuple(kappa.tolist()))
+    ent = _LIST_CACHE.get(key)
+    if ent is not None and ent.srcs is srcs and ent.typ.shape[0] == S and ent.imgkey == imgkey:
+        _LIST_CACHE.move_to_end(key)
+        t, r, c, sh = arrs
+        # NaN != NaN: a NaN row is uploaded again every call, which is harmless
+        diff = (t != ent.typ) | np.any(r != ent.radec, axis=1) | np.any(c != ent.counts, axis=1) | np.any(sh != ent.shape, axis=1)
+        rows = np.nonzero(diff)[0]
+        if rows.size <= max(S // 8, 16):
+            if rows.size:
+                ent.typ[rows], ent.radec[rows], ent.counts[rows], ent.shape[rows] = t[rows], r[rows], c[rows], sh[rows]
+                ent.version += 1
+                ent.log.append((ent.version, rows))
+                del ent.log[:-16]
+            return ent.typ, ent.radec, ent.counts, ent.shape
+    old = _LIST_CACHE.pop(key, None)
+    if old is not None:
+        _ENTRY_OF.pop(id(old.typ), None)
+    ent = _ListEntry()
+    ent.srcs, ent.objs, ent.stamps, ent.clock, ent.imgkey = srcs, None, None, None, imgkey
+    ent.typ, ent.radec, ent.counts, ent.shape = arrs
+    ent.version, ent.log, ent.audit, ent.index = 0, [], 0, None
+    _LIST_CACHE[key] = ent
+    _ENTRY_OF[id(ent.typ)] = ent
+    while len(_LIST_CACHE) > _LIST_CACHE_MAX:
+        _, gone = _LIST_CACHE.popitem(last=False)
+        _ENTRY_OF.pop(id(gone.typ), None)
+    return arrs
 
 
 def _device_sources(iset, arrs):
@@ -498,6 +545,17 @@ def gen_src_psf_image(src, image):
     elif src.a == 1:
         return gen_galaxy_psf_image(src, image)
     raise NotImplementedError("not implemented!")
+
+
+# ---- celeste.py:193-199 -----------------------------------------------------------------------
+def gen_psf_src_image_bound(src, img):
+    """radius about the source's pixel position that holds 1 - epsilon of its photons in this image: the band's PSF radius
+    img.R for a star, the 42-component radius of gen_galaxy_psf_image_bound for a galaxy  -- celeste.py:193-199 (the caller
+    pattern of experiments/fields/process_field.py:107-117 forms floor/ceil boxes from it)"""
+    if src.a == 0:
+        return img.R
+    from . import celeste_galaxy_conditionals as gal_funs
+    return gal_funs.gen_galaxy_psf_image_bound(src, img)
 
 
 # ---- celeste.py:72-96 -------------------------------------------------------------------------

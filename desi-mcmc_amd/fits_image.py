@@ -139,6 +139,25 @@ class FitsImage(object):
     def nmgy2counts(self, flux):
         return (flux / self.calib) * self.kappa            # fits_image.py:183-184
 
+    def make_pixel_grid(self):
+        """(H*W, 2) stack of the 1-BASED (x, y) pixel coordinates, x fastest (C order of the H x W frame): fits_image.py:186-194"""
+        y_grid = np.arange(self.nelec.shape[0], dtype=np.float64) + 1
+        x_grid = np.arange(self.nelec.shape[1], dtype=np.float64) + 1
+        xx, yy = np.meshgrid(x_grid, y_grid, indexing='xy')
+        return np.column_stack((xx.ravel(order='C'), yy.ravel(order='C')))
+
+    @property
+    def pixel_grid(self):
+        """the grid the reference builds in its constructor and keeps (fits_image.py:95); here on first read -- 67 MB for a
+        2048^2 frame that nothing on the render path looks at"""
+        if getattr(self, "_pixel_grid", None) is None:
+            self._pixel_grid = self.make_pixel_grid()
+        return self._pixel_grid
+
+    @pixel_grid.setter
+    def pixel_grid(self, value):
+        self._pixel_grid = value
+
     def cd_at_pixel(self, x, y):
         ra0, dec0 = self.pixel2equa(np.array([x, y]))      # fits_image.py:196-216
         step = 10.

@@ -119,6 +119,28 @@ def bounding_radius(w, mu, cov, error, center=(0.0, 0.0), rsq=None):
     return lib().orc_bounding_radius_rsq(wp, mp, cp, C.c_int(len(w)), C.c_double(rsq), ccp)
 
 
+def band_radius(band):
+    """fits_image.py:151-155: FitsImage.R = calc_bounding_radius(weights, means, covars, error=1e-3, center=(0, 0)) of a packed
+    band record (orc_band layout)"""
+    band = np.asarray(band, dtype=np.float64)
+    return bounding_radius(band[3:6], band[6:12].reshape(3, 2), band[12:24].reshape(3, 2, 2), 1e-3, center=(0.0, 0.0))
+
+
+def checked_radius(band, lib_R, rtol=1e-13):
+    """The star radius for a band record handed to the oracle: the ORACLE's own (orc_bounding_radius, pinned to the
+    reference's calc_bounding_radius by golden radius.npz), after asserting that the library under test derived the same
+    number from the same PSF -- so a wrong R in the library cannot move the boxes of library and checker alike."""
+    band = np.asarray(band, dtype=np.float64)
+    if band[36] != 0.0:      # a caller-imposed radius (FitsImage.R assigned by hand): the library must keep it as given
+        if float(lib_R) != band[36]:
+            raise AssertionError("star radius: caller gave %.17g, library holds %.17g" % (band[36], float(lib_R)))
+        return float(band[36])
+    R = band_radius(band)
+    if not abs(float(lib_R) - R) <= rtol * abs(R):
+        raise AssertionError("star radius: library %.17g, oracle %.17g" % (float(lib_R), R))
+    return R
+
+
 def gmm_like_2d(x, ws, mus, sigs):
     x, xp = _d(x)
     ws, wp = _d(ws)

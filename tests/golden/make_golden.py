@@ -25,6 +25,8 @@ mini_field.npz     A9-A11 + Q3 extension: mixed star/galaxy field, 5 bands, 96x8
 config1.npz        config 1: real stamps, catalogue sources, gen_model_image + celeste_likelihood
 source_ll.npz      (f)1 Source.log_likelihood / log_likelihood_isolated (sources.py:134-237)
 estep.npz          (f)4 gen_src_prob_layers reductions (celeste_em.py:38-91)
+src_bound.npz      celeste.gen_psf_src_image_bound (celeste.py:193-199), the boxes of process_field.py:107-117,
+                   FitsImage.make_pixel_grid / pixel_grid (fits_image.py:95,186-194)
 slicesample.npz    config 5: slicesample (util/infer/slicesample.py:89-227) with every draw it made recorded
 real_fields.npz    configs 1 / 4 on EVERY real field the reference ships (data/stamps 11, data/stamp_catalog 63,
                    data/galaxy_stamps 25, data/real 1 = 100 fields, 500 images, 221 catalogue sources): FitsImage
@@ -674,7 +676,37 @@ def gen_real_fields():
     print("real fields: %d fields, %d sources, sum of ll = %.4f" % (len(fields), cat_off[-1], float(np.sum(ll))))
 
 
+def gen_src_bound(imgs):
+    """celeste.gen_psf_src_image_bound (celeste.py:193-199) for stars and galaxies on the real stamps' five images, the
+    floor/ceil boxes its caller forms from it (experiments/fields/process_field.py:107-117), and FitsImage.make_pixel_grid /
+    the pixel_grid attribute (fits_image.py:95, 186-194)."""
+    rs = np.random.RandomState(23)
+    S = 10
+    H, W = imgs[0].nelec.shape
+    pix = np.column_stack([rs.uniform(-5, W + 5, S), rs.uniform(-5, H + 5, S)])
+    is_gal = (np.arange(S) % 2 == 1).astype(np.int64)
+    flux = np.exp(rs.uniform(np.log(1.0), np.log(100.0), size=(S, 5)))
+    shape = np.column_stack([rs.uniform(0.05, 0.95, S), np.exp(rs.uniform(np.log(0.3), np.log(5.0), S)),
+                             rs.uniform(0.0, 180.0, S), rs.uniform(0.2, 0.95, S)])
+    radec = np.array([imgs[2].pixel2equa(p) for p in pix])
+    srcs = [SrcParams(u=radec[s], a=int(is_gal[s]), fluxes=flux[s], theta=shape[s, 0], sigma=shape[s, 1],
+                      phi=shape[s, 2], rho=shape[s, 3]) for s in range(S)]
+    bound = np.array([[ref_cel.gen_psf_src_image_bound(s, img) for s in srcs] for img in imgs])          # (5, S)
+    boxes = []
+    for b, img in enumerate(imgs):                       # process_field.py:107-117, line for line in meaning
+        locs = np.vstack([img.equa2pixel(s.u) for s in srcs])
+        boxes.append(np.column_stack([np.floor(locs[:, 0] - bound[b]), np.ceil(locs[:, 0] + bound[b]),
+                                      np.floor(locs[:, 1] - bound[b]), np.ceil(locs[:, 1] + bound[b])]))
+    grid = imgs[2].make_pixel_grid()
+    assert np.array_equal(grid, imgs[2].pixel_grid)
+    save("src_bound.npz", radec=radec, is_gal=is_gal, flux=flux, shape=shape, bound=bound, boxes=np.array(boxes),
+         pixel_grid=grid, grid_HW=np.array([H, W]))
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["src_bound"]:
+        gen_src_bound(ref_images())
+        sys.exit(0)
     if sys.argv[1:] == ["real_fields"]:
         gen_real_fields()
         sys.exit(0)
@@ -692,4 +724,5 @@ if __name__ == "__main__":
     gen_source_ll()
     gen_estep()
     gen_slicesample()
+    gen_src_bound(imgs)
     gen_real_fields()

@@ -7,6 +7,8 @@ import re
 import subprocess
 import sys
 
+import warnings
+
 import numpy as np
 import pytest
 
@@ -91,6 +93,29 @@ def test_bounding_radius_host_entry(built):
         calc_bounding_radius(rec["weights"][0], rec["means"][0], rec["covars"][0], 1.5)
     boxes = np.array([[0, 10, 0, 10], [5, 15, 5, 15], [20, 30, 20, 30]])
     assert list(get_bounding_boxes_idx(np.array([7, 7]), boxes)) == [0, 1]
+
+
+def test_library_radius_is_the_oracles_on_scaled_and_random_psfs(built):
+    """the star radius of PSFs no golden holds (the scaled PSFs of the sharp-PSF test, the random PSFs of the fuzz tests): the
+    library's host entry against the oracle's restatement, which radius.npz pins to the reference.  The GPU tests hand the
+    checker the oracle's radius and assert this equality per band (orc.checked_radius)."""
+    from desi_mcmc_amd import field, synth
+    from oracle import oracle as orc
+    rs = np.random.RandomState(11)
+    bands = synth.make_bands(96, 128, 5)
+    for scale in (1.0, 0.15, 0.02, 3.0, 40.0):
+        for b in bands:
+            b = b.copy()
+            b[12:24] *= scale
+            b[3:6] = rs.dirichlet([2.0, 2.0, 2.0])
+            b[6:12] += rs.normal(0, 0.3 * np.sqrt(scale), 6)
+            R = field.bounding_radius(b[3:6], b[6:12].reshape(3, 2), b[12:24].reshape(3, 2, 2), 1e-3)
+            assert orc.checked_radius(b, R) == pytest.approx(R, rel=1e-13)
+    b = bands[0].copy()
+    b[36] = 60.0                                    # a caller-imposed radius is kept, not recomputed
+    assert orc.checked_radius(b, 60.0) == 60.0
+    with pytest.raises(AssertionError):
+        orc.checked_radius(bands[0], 1.0001 * orc.band_radius(bands[0]))
 
 
 def test_fitsimage_mirror_host_logic(built):
@@ -342,7 +367,14 @@ def test_list_of_srcparams_is_gathered_once_and_then_row_by_changed_row(built):
     equal a fresh gather: one source assigned, many, the reference's in-place-then-assign idiom, an element replaced,
     two swapped, one appended, one removed, touch() after a purely in-place edit."""
     from desi_mcmc_amd import celeste, celeste_src
+    celeste.list_cache("stamps")                  # the opt-in fast mode; the default ("exact") is tested below
+    try:
+        _stamps_mode_walk(built, celeste, celeste_src)
+    finally:
+        celeste.list_cache("exact")
 
+
+def _stamps_mode_walk(built, celeste, celeste_src):
     class Im(object):
         def __init__(self, band, calib, kappa):
             self.band, self.calib, self.kappa = band, calib, kappa
@@ -409,41 +441,68 @@ def test_list_of_srcparams_is_gathered_once_and_then_row_by_changed_row(built):
 
 
 def test_list_cache_audit_catches_an_unstamped_in_place_edit(built):
-    """An object of a cached list changed IN PLACE without an attribute assignment (src.u[0] = x, src.fluxes['r'] = f) moves
-    no stamp.  The rotating audit (a sixteenth of the list re-read per call) meets it within 16 calls and RAISES -- the
-    values since the edit were stale; celeste.list_cache("off") re-reads every source on every call, as the reference
-    does (celeste.py:203-219), and sees every edit at once."""
+    """An object of a list changed IN PLACE without an attribute assignment (src.u[0] = x, src.fluxes['r'] = f) moves no
+    stamp.  The DEFAULT mode ("exact") re-reads every source on every call, as the reference does (celeste.py:203-219): the
+    FIRST call after the edit returns the edited value, and only that row is marked for upload.  The opt-in "stamps" mode
+    does not see the edit; its rotating audit (a sixteenth of the list re-read per call) meets it within 16 calls, WARNS and
+    re-reads the whole list.  A changed calibration hook is seen at once in either mode."""
     from desi_mcmc_amd import celeste
 
     class Im(object):
         def __init__(self, band, calib, kappa):
             self.band, self.calib, self.kappa = band, calib, kappa
+
+        def nmgy2counts(self, flux):
+            return (flux / self.calib) * self.kappa
     ims = [Im(b, 0.004 + 0.001 * k, 4.0 + 0.2 * k) for k, b in enumerate("gri")]
     rs = np.random.RandomState(2)
     S = 2000
     ps = [built.SrcParams(u=rs.rand(2), a=i % 2, fluxes=dict(zip("ugriz", rs.rand(5) + 1)), theta=.4, sigma=1.5, phi=1. * i, rho=.6)
           for i in range(S)]
-    assert celeste.list_cache() == "stamps"
-    for victim, edit in ((1234, lambda p: p.u.__setitem__(0, 0.5)), (77, lambda p: p.fluxes.__setitem__("r", 9.0))):
-        celeste._source_arrays(ps, ims)
-        for _ in range(20):                                             # clean calls: the audit goes round without a complaint
-            celeste._source_arrays(ps, ims)
-        edit(ps[victim])
-        with pytest.raises(RuntimeError, match="source %d of this list was changed IN PLACE" % victim):
-            for _ in range(celeste._AUDIT_PARTS):
-                celeste._source_arrays(ps, ims)
-        got = celeste._source_arrays(ps, ims)                           # the cache was dropped: a fresh gather
-        want = celeste._gather_plain(ps, ims, celeste.expected_photons, [1, 2, 3], np.array([im.calib for im in ims]),
+
+    def fresh():
+        return celeste._gather_plain(ps, ims, celeste.expected_photons, [1, 2, 3], np.array([im.calib for im in ims]),
                                      np.array([im.kappa for im in ims]))
-        assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    assert celeste.list_cache() == "exact"                              # the default
+    first = celeste._source_arrays(ps, ims)
+    ent = celeste._ENTRY_OF[id(first[0])]
+    assert celeste._source_arrays(ps, ims)[0] is first[0] and ent.version == 0      # nothing changed: nothing to upload
+    for k, (victim, edit) in enumerate(((1234, lambda p: p.u.__setitem__(0, 0.5)), (77, lambda p: p.fluxes.__setitem__("r", 9.0)))):
+        edit(ps[victim])
+        got = celeste._source_arrays(ps, ims)                           # the FIRST call after the edit
+        assert all(np.array_equal(g, w) for g, w in zip(got, fresh()))
+        assert got[0] is first[0] and ent.version == k + 1 and ent.rows_since(k).tolist() == [victim]
+    assert got[1][1234, 0] == 0.5 and got[2][77, 1] == 9.0 / ims[1].calib * ims[1].kappa
+    hook = celeste.photons_expected_brightness
+    try:                                                                # a star given by temperature reads the hook on every call
+        ps[10].a, ps[10].t, ps[10].b = 0, 5000.0, 1.0
+        celeste.photons_expected_brightness = lambda t, b, band: 111.0
+        assert celeste._source_arrays(ps, ims)[2][10, 0] == 111.0
+        celeste.photons_expected_brightness = lambda t, b, band: 222.0
+        assert celeste._source_arrays(ps, ims)[2][10, 0] == 222.0
+        ps[10].t = None
+    finally:
+        celeste.photons_expected_brightness = hook
     try:
+        assert celeste.list_cache("stamps") == "stamps" and not celeste._LIST_CACHE
+        for victim, edit in ((1234, lambda p: p.u.__setitem__(0, 0.25)), (77, lambda p: p.fluxes.__setitem__("r", 7.0))):
+            celeste._source_arrays(ps, ims)
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                for _ in range(20):                                     # clean calls: the audit goes round without a complaint
+                    celeste._source_arrays(ps, ims)
+            edit(ps[victim])
+            with pytest.warns(RuntimeWarning, match="source %d of this list was changed IN PLACE" % victim):
+                for _ in range(celeste._AUDIT_PARTS):
+                    got = celeste._source_arrays(ps, ims)
+            assert all(np.array_equal(g, w) for g, w in zip(got, fresh()))       # the call that warned already returns a fresh gather
         assert celeste.list_cache("off") == "off" and not celeste._LIST_CACHE
         a0 = celeste._source_arrays(ps, ims)
         ps[5].u[1] = 0.875
         a1 = celeste._source_arrays(ps, ims)
         assert a1[1][5, 1] == 0.875 and a0[1] is not a1[1] and not celeste._LIST_CACHE
     finally:
-        celeste.list_cache("stamps")
+        celeste.list_cache("exact")
     with pytest.raises(ValueError):
         celeste.list_cache("sometimes")
 

@@ -120,3 +120,84 @@ print("interop ok")
 ''' % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "interop ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def _src_bound_scene():
+    from conftest import load_golden
+    import desi_mcmc_amd as cel
+    g = load_golden("src_bound.npz")
+    rec = load_golden("bands_253.npz")
+    imgs = [cel.FitsImage.from_record("ugriz"[b], rec, b, rec["nelec"][b]) for b in range(5)]
+    srcs = [cel.SrcParams(u=g["radec"][s], a=int(g["is_gal"][s]), fluxes=g["flux"][s], theta=g["shape"][s, 0],
+                          sigma=g["shape"][s, 1], phi=g["shape"][s, 2], rho=g["shape"][s, 3]) for s in range(len(g["radec"]))]
+    return g, imgs, srcs
+
+
+def test_gen_psf_src_image_bound_and_pixel_grid_golden():
+    """celeste.gen_psf_src_image_bound (celeste.py:193-199) and FitsImage.make_pixel_grid / pixel_grid (fits_image.py:95,
+    186-194) against what the reference's own functions returned on the real stamps (golden src_bound.npz, made by
+    tests/golden/make_golden.py); host arithmetic through cel_bounding_radius: runs without a GPU."""
+    from desi_mcmc_amd import celeste
+    g, imgs, srcs = _src_bound_scene()
+    for b, img in enumerate(imgs):
+        got = np.array([celeste.gen_psf_src_image_bound(s, img) for s in srcs])
+        np.testing.assert_allclose(got, g["bound"][b], rtol=1e-12)
+        assert all(got[s] == img.R for s in range(len(srcs)) if srcs[s].a == 0)
+        # the boxes of experiments/fields/process_field.py:107-117 formed from it
+        locs = np.vstack([img.equa2pixel(s.u) for s in srcs])
+        boxes = np.column_stack([np.floor(locs[:, 0] - got), np.ceil(locs[:, 0] + got),
+                                 np.floor(locs[:, 1] - got), np.ceil(locs[:, 1] + got)])
+        assert np.array_equal(boxes, g["boxes"][b])
+    grid = imgs[2].make_pixel_grid()
+    assert grid.dtype == np.float64 and grid.flags["C_CONTIGUOUS"]
+    assert np.array_equal(grid, g["pixel_grid"]) and np.array_equal(imgs[2].pixel_grid, g["pixel_grid"])
+    H, W = (int(v) for v in g["grid_HW"])
+    assert grid.shape == (H * W, 2) and tuple(grid[0]) == (1.0, 1.0) and tuple(grid[1]) == (2.0, 1.0) and tuple(grid[-1]) == (W, H)
+    assert imgs[2].pixel_grid is imgs[2].pixel_grid                       # kept around, like the reference's attribute
+
+
+@pytest.mark.gpu
+def test_process_field_call_sequence_runs_against_the_mirror():
+    """experiments/fields/process_field.py:84-117 -- the (f)3 caller pattern -- line for line against the mirror: main()'s
+    accumulation of flux-scaled patches per band, then sample_source_photons_single_image's set-up (pixel locations,
+    gen_psf_src_image_bound radii, floor/ceil boxes, gen_src_image_with_fluxes patches).  The accumulated image is
+    gen_model_image minus the sky; every patch lies inside the box its caller draws photons from."""
+    from desi_mcmc_amd import celeste
+    from desi_mcmc_amd.celeste_galaxy_conditionals import gen_galaxy_psf_image
+    from desi_mcmc_amd.util.bound.bounding_box import get_bounding_boxes_idx
+    g, imgs, srcs = _src_bound_scene()
+    BANDS = "ugriz"
+    imgfits = {b: imgs[j] for j, b in enumerate(BANDS)}
+    modelims = {b: np.zeros(imgfits[b].nelec.shape, dtype=float) for b in BANDS}
+    for src_params in srcs:                                                # :86-103
+        for j, band in enumerate(BANDS):
+            if src_params.a == 0:
+                f_s, ylim, xlim = celeste.gen_point_source_psf_image_with_fluxes(src_params, imgfits[band], return_patch=True)
+                if f_s is None:
+                    continue
+                scale = 1.0                                                # the reference multiplies a flux-scaled star patch by the
+            else:                                                          # flux again (:103); kept out of the comparison below
+                f_s, ylim, xlim = gen_galaxy_psf_image(th=[src_params.theta, src_params.sigma, src_params.phi, src_params.rho],
+                                                       u_s=src_params.u, img=imgfits[band])
+                scale = imgfits[band].nmgy2counts(src_params.fluxes[j])
+            modelims[band][int(ylim[0]):int(ylim[1]), int(xlim[0]):int(xlim[1])] += f_s * scale
+    for j, band in enumerate(BANDS):
+        lam = celeste.gen_model_image(srcs, imgfits[band])
+        np.testing.assert_allclose(modelims[band] + imgfits[band].epsilon, lam, rtol=1e-9)
+    img = imgfits["r"]                                                     # :107-120
+    src_locs = np.vstack([img.equa2pixel(s.u) for s in srcs])
+    imgR = np.array([celeste.gen_psf_src_image_bound(s, img) for s in srcs])
+    np.testing.assert_allclose(imgR, g["bound"][2], rtol=1e-12)
+    src_boxes = np.column_stack([np.floor(src_locs[:, 0] - imgR), np.ceil(src_locs[:, 0] + imgR),
+                                 np.floor(src_locs[:, 1] - imgR), np.ceil(src_locs[:, 1] + imgR)])
+    assert np.array_equal(src_boxes, g["boxes"][2])
+    src_imgs = [celeste.gen_src_image_with_fluxes(s, img) for s in srcs]
+    for s, (patch, ylim, xlim) in enumerate(src_imgs):
+        if patch is None:
+            continue
+        assert patch.shape == (int(ylim[1] - ylim[0]), int(xlim[1] - xlim[0]))
+        # a pixel of the patch is one the caller's box test hands to this source (:129-137)
+        y, x = int(ylim[0]), int(xlim[0])
+        assert s in get_bounding_boxes_idx(np.array([x, y]), src_boxes)
+        y, x = int(ylim[1]) - 1, int(xlim[1]) - 1
+        assert s in get_bounding_boxes_idx(np.array([x, y]), src_boxes)

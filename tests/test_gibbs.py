@@ -566,7 +566,7 @@ def test_config5_full_size_sweeps(cel, orc):
     pick = np.random.RandomState(3).choice(S, 200, replace=False)
     for b in range(B):
         band = f.bands[b].copy()
-        band[36] = f.images.band(b)[36]                      # R as the library computed it (pinned by test_fitsimage_radius_matches_reference)
+        band[36] = orc.checked_radius(band, f.images.band(b)[36])                      # R as the library computed it (pinned by test_fitsimage_radius_matches_reference)
         for s in pick:
             p, _, _ = orc.source_patch(band, f.H, f.W, gd.typ[s], gd.u[s], gd.shape[s])
             want = 0.0 if p is None else p.sum()
@@ -870,7 +870,7 @@ def _oracle_terms(orc, f, typ, U, counts, shape, own, boxes, offs, data, threads
     B = f.B
     bands = [f.bands[b].copy() for b in range(B)]
     for b in range(B):
-        bands[b][36] = f.images.band(b)[36]              # R as the library computed it (pinned to the reference's elsewhere)
+        bands[b][36] = orc.checked_radius(bands[b], f.images.band(b)[36])              # R as the library computed it (pinned to the reference's elsewhere)
 
     def one(p):
         t, nph = np.zeros(4), 0.0

@@ -364,14 +364,14 @@ def test_real_field_set_dealt_to_the_ranks(cel, ctx):
 # seeded synthetic fields against the CPU oracle
 # ------------------------------------------------------------------------------------------
 def oracle_bands(field):
-    """The field's band records for the oracle, with the star radius R the LIBRARY computed (cel_bounding_radius on the band's
-    PSF) copied in -- the synthetic records leave R = 0 = "compute it".  Handing the library's R to the checker is sound
-    because R itself is pinned separately: test_fitsimage_radius_matches_reference compares the same host function with the
-    reference's FitsImage.R on the real stamps (golden bands_253.npz), and tests/test_oracle.py pins the oracle's own
-    orc_bounding_radius to the reference's calc_bounding_radius (golden radius.npz)."""
+    """The field's band records for the oracle.  The synthetic records leave the star radius R = 0 = "compute it": the checker
+    gets the ORACLE's radius (orc_bounding_radius on the band's PSF, pinned to the reference's calc_bounding_radius by golden
+    radius.npz), and orc.checked_radius first asserts that the library derived the same number (1e-13) -- in every oracle test,
+    the scaled-PSF and fuzz cases included, so a wrong R cannot move the boxes of library and checker alike."""
+    from oracle import oracle as orc
     b = field.bands.copy()
     for i in range(b.shape[0]):
-        b[i, 36] = field.images.band(i)[36]      # the radius the library computed
+        b[i, 36] = orc.checked_radius(b[i], field.images.band(i)[36])      # the oracle's own radius; the library's must equal it
     return b
 
 
@@ -440,7 +440,7 @@ def test_edge_cases_empty_ragged_offimage(cel, ctx, orc):
     sset = cel.SourceSet(ctx, 1, 2).set(np.zeros(1, np.int32), radec, np.full((1, 2), 3e4), np.tile([0.5, 2.0, 30.0, 0.5], (1, 1)))
     ll, llb = iset.render(sset, loglik=True)
     ob = bands.copy()
-    ob[:, 36] = [iset.band(0)[36], iset.band(1)[36]]
+    ob[:, 36] = [orc.checked_radius(ob[b], iset.band(b)[36]) for b in range(2)]
     o_lam, o_ll, _ = orc.render_field(ob, H, W, np.zeros(1, np.int32), radec, np.full((1, 2), 3e4),
                                       np.tile([0.5, 2.0, 30.0, 0.5], (1, 1)), nelec)
     lam = iset.model_images()
@@ -462,7 +462,7 @@ def test_edge_cases_empty_ragged_offimage(cel, ctx, orc):
     sset = cel.SourceSet(ctx, 8, 2).set(typ, radec, counts, shape)
     ll, llb = iset.render(sset, loglik=True)
     ob = bands.copy()
-    ob[:, 36] = [iset.band(0)[36], iset.band(1)[36]]
+    ob[:, 36] = [orc.checked_radius(ob[b], iset.band(b)[36]) for b in range(2)]
     o_lam, o_ll, _ = orc.render_field(ob, H, W, typ, radec, counts, shape, nelec)
     np.testing.assert_allclose(iset.model_images(), o_lam, rtol=RT_LAM)
     np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
@@ -488,7 +488,7 @@ def test_sharp_psf_forces_direct_fallback_and_short_segments(cel, ctx, orc):
         iset = cel.ImageSet(ctx, b, H, W, nelec=nelec)
         sset = cel.SourceSet(ctx, 3, 1).set(typ, radec, counts, shape)
         ll, llb = iset.render(sset, loglik=True)
-        b[0, 36] = iset.band(0)[36]
+        b[0, 36] = orc.checked_radius(b[0], iset.band(0)[36])
         o_lam, o_ll, _ = orc.render_field(b, H, W, typ, radec, counts, shape, nelec)
         np.testing.assert_allclose(iset.model_images(), o_lam, rtol=RT_LAM)
         np.testing.assert_allclose(llb, o_ll, rtol=RT_LL)
@@ -916,7 +916,7 @@ def test_tile_parts_agree_and_each_is_reproducible(cel, ctx, orc, frac_gal):
     finally:
         ctx.set_option(L.CEL_OPT_TILE_PARTS, 0)
     ob = bands.copy()
-    ob[:, 36] = [iset.band(b)[36] for b in range(B)]
+    ob[:, 36] = [orc.checked_radius(ob[b], iset.band(b)[36]) for b in range(B)]
     o_lam, o_ll, _ = orc.render_field(ob, H, W, src["type"], src["radec"], src["counts"], src["shape"], nelec)
     for parts in (1, 2, 4):
         lam, llb, wlam, llw = got[parts]
@@ -950,7 +950,7 @@ def test_estep_statistics_and_model_classes(cel, orc):
     counts = g["flux"] / g["calib"][None, :] * g["kappa"][None, :]
     from desi_mcmc_amd import field
     ob = field.pack_bands(g)
-    ob[:, 36] = [im.R for im in imgs]
+    ob[:, 36] = [orc.checked_radius(ob[b], im.R) for b, im in enumerate(imgs)]
     oxt, oms, onz = orc.estep_stats(ob, H, W, g["is_gal"], g["radec"], counts, g["shape"], g["nelec"])
     np.testing.assert_allclose(X, oxt, rtol=1e-10)
     np.testing.assert_allclose(F, np.minimum(1.0, oms), rtol=1e-10)
@@ -1023,7 +1023,7 @@ def test_crowded_field_exercises_list_chunking_and_regrowth(cel, ctx, orc, tail)
         assert np.array_equal(llb, llb2) and np.array_equal(lam, iset.model_images())
         if layout == 1:
             ob = bands.copy()
-            ob[:, 36] = [iset.band(0)[36], iset.band(1)[36]]
+            ob[:, 36] = [orc.checked_radius(ob[b], iset.band(b)[36]) for b in range(2)]
             o_lam, o_ll, o_st = orc.render_field(ob, H, W, src["type"], src["radec"], src["counts"], src["shape"], nelec)
             assert st["n_srcpix"] == o_st["n_srcpix"]
             lam1, llb1 = lam, llb
@@ -1162,7 +1162,7 @@ def test_photon_split_conservation_moments_quirks(cel, ctx, orc):
             assert np.array_equal(noise, n2)
             assert any(not np.array_equal(a, b) for ra, rb in zip(patches, p3) for a, b in zip(ra, rb) if a is not None)
             ob = bands.copy()
-            ob[:, 36] = [iset.band(b)[36] for b in range(5)]
+            ob[:, 36] = [orc.checked_radius(ob[b], iset.band(b)[36]) for b in range(5)]
     pa, ba, na = results[1]
     pb, bb, nb = results[0]
     assert np.array_equal(ba, bb) and np.array_equal(na, nb)                     # same draws whatever the tiling
@@ -1477,7 +1477,7 @@ def test_patch_loglik_adversarial_patches_vs_oracle(cel, ctx, orc, kernel, tail)
     iset = cel.ImageSet(ctx, bands, H, W, nelec=nelec)
     sset = cel.SourceSet(ctx, 4, 2).set(typ, radec, counts, shape)
     ob = bands.copy()
-    ob[:, 36] = [iset.band(0)[36], iset.band(1)[36]]
+    ob[:, 36] = [orc.checked_radius(ob[b], iset.band(b)[36]) for b in range(2)]
     cases = [
         np.array([[130, 171, 181, 222], [120, 190, 170, 233]]),     # around sources 0/1/3: 41x41 and 70x63
         np.array([[60, 260, 100, 300], [149, 152, 199, 202]]),      # 200 x 200 (chunks both ways) and 3 x 3
@@ -1551,7 +1551,7 @@ def test_fuzz_random_fields_vs_oracle(cel, ctx, orc, seed):
     finally:
         ctx.set_tail_log("default")
     ob = bands.copy()
-    ob[:, 36] = [iset.band(b)[36] for b in range(B)]
+    ob[:, 36] = [orc.checked_radius(ob[b], iset.band(b)[36]) for b in range(B)]
     o_lam, o_ll, o_st = orc.render_field(ob, H, W, typ, radec, counts, shape, nelec)
     np.testing.assert_allclose(lam_got, o_lam, rtol=RT_LAM_STRICT)
     # a band's log-likelihood is a sum of terms of both signs: the tolerance is relative to the sum of their magnitudes
@@ -1621,7 +1621,7 @@ def test_fuzz_random_fields_vs_oracle_default_threshold(cel, ctx, orc, seed):
     ll, llb = iset.render(sset, loglik=True)
     lam = iset.model_images()
     ob = bands.copy()
-    ob[:, 36] = [iset.band(b)[36] for b in range(B)]
+    ob[:, 36] = [orc.checked_radius(ob[b], iset.band(b)[36]) for b in range(B)]
     o_lam, o_ll, _ = orc.render_field(ob, H, W, typ, radec, counts, shape, nelec)
     err = float(np.max(np.abs(lam / o_lam - 1.0)))
     assert err <= 42 * S * np.exp(-24.0) + 1e-12, (err, S)          # the rule's guarantee
@@ -1664,7 +1664,7 @@ def test_integration_md_ctypes_binding(cel, orc):
     rec = np.zeros(37)
     for b in range(B):
         check(L.cel_images_get_band(img, b, rec.ctypes.data_as(dp)))
-        ob[b, 36] = rec[36]
+        ob[b, 36] = orc.checked_radius(ob[b], rec[36])
     o_lam, o_ll, _ = orc.render_field(ob, H, W, typ, radec, counts, shape, nelec)
     np.testing.assert_allclose(lam, o_lam, rtol=RT_LAM)
     np.testing.assert_allclose(ll_band, o_ll, rtol=RT_LL)
@@ -1898,7 +1898,7 @@ def test_fuzz_star_fields_vs_oracle(cel, ctx, orc, seed):
     iset.render(ss)
     ob = f_bands.copy()
     for b in range(5):
-        ob[b, 36] = iset.band(b)[36]
+        ob[b, 36] = orc.checked_radius(ob[b], iset.band(b)[36])
     nelec = rs.poisson(iset.model_images()).astype(np.float64)
     iset.set_nelec(nelec)
     ll, llb = iset.render(ss, loglik=True)
@@ -1955,7 +1955,7 @@ def test_star_tile_kernel_vs_oracle_and_general_kernel(cel, ctx, orc, seed):
         iset.render(ss)
         ob = f_bands.copy()
         for b in range(5):
-            ob[b, 36] = iset.band(b)[36]
+            ob[b, 36] = orc.checked_radius(ob[b], iset.band(b)[36])
         nelec = rs.poisson(iset.model_images()).astype(np.float64)
         iset.set_nelec(nelec)
         ll0, llb0, ns0, ng0 = run(0)
@@ -2188,7 +2188,7 @@ def test_fuzz_patch_loglik_vs_oracle(cel, ctx, orc, seed):
     iset = cel.ImageSet(ctx, bands, H, W, nelec=nelec)
     sset = cel.SourceSet(ctx, P, B).set(typ, radec, counts, shape)
     ob = bands.copy()
-    ob[:, 36] = [iset.band(b)[36] for b in range(B)]
+    ob[:, 36] = [orc.checked_radius(ob[b], iset.band(b)[36]) for b in range(B)]
     for case in range(3):
         # one rectangle per band, placed near a random source, of a random size (up to several chunks)
         boxes = np.zeros((B, 4), dtype=np.int64)

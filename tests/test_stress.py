@@ -32,8 +32,12 @@ def test_incremental_render_under_random_call_sequences_full_size():
     run("incremental_stress.py", 600, 5, "big")
 
 
-def test_list_cache_under_random_caller_behaviour():
-    out = run("list_cache_stress.py", 2500, 4, "big")
+@pytest.mark.parametrize("mode", ["exact", "stamps"])
+def test_list_cache_under_random_caller_behaviour(mode):
+    """the default list mode (every source re-read per call; unannounced in-place edits among the caller's moves) and the opt-in
+    stamps mode, each against the values of fresh copies on image sets of their own"""
+    out = run("list_cache_stress.py", 1500, 4, "big", mode)
+    assert "list_cache %r" % mode in out
     assert " 0 of dirty tiles only" not in out          # the row uploads did reach the dirty-tile render
 
 

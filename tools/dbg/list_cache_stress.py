@@ -1,7 +1,8 @@
 """random sequences of what a caller does to a LIST of SrcParams between likelihood calls -- assignments, in-place edits followed by
 an assignment or touch(), objects replaced, lists re-ordered, shortened, extended, two lists and two image groups in turn -- with
 celeste_likelihood_multi_image / gen_model_image after each: the value must be, bit for bit, what the same list gives with the list
-cache off (every source re-read, whole upload, every tile rendered).   python tools/dbg/list_cache_stress.py [STEPS] [seed]"""
+cache off (every source re-read, whole upload, every tile rendered).   python tools/dbg/list_cache_stress.py [STEPS] [seed] [big] [stamps]
+(the default mode, "exact", also gets in-place edits that nobody announces)"""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
@@ -13,6 +14,8 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 ctx = cel.default_context(0)
 celeste.set_device(0)
 rs = np.random.RandomState(seed)
+mode = "stamps" if "stamps" in sys.argv else "exact"      # the list mode under test (celeste.list_cache): the default re-reads every source
+celeste.list_cache(mode)
 big = "big" in sys.argv                   # a frame of 5 120 tiles: the one-wave-per-tile kernel, whose dirty-tile path the row uploads reach
 fa = synth.SyntheticField(ctx, 2500, 5, 1024, 2048, frac_gal=0.5, seed=5) if big else synth.SyntheticField(ctx, 600, 5, 500, 420, frac_gal=0.5, seed=5)
 imgs_a = synth.fits_images(fa)
@@ -33,13 +36,18 @@ log = []
 
 
 def mutate(L):
-    op = rs.choice(["assign_u", "assign_u", "assign_u", "inplace_then_assign", "inplace_touch", "flux", "shape", "type", "replace", "swap", "pop", "append", "many", "noop_assign"])
+    op = rs.choice(["assign_u", "assign_u", "assign_u", "inplace_then_assign", "inplace_touch", "flux", "shape", "type", "replace", "swap", "pop", "append", "many", "noop_assign"] +
+                   (["inplace_only", "inplace_only", "inplace_flux_only"] if mode == "exact" else []))
     i = int(rs.randint(len(L)))
     p = L[i]
     if op == "assign_u":
         p.u = p.u + rs.normal(0, 2e-5, 2)
     elif op == "inplace_then_assign":
         p.u[0] += 1e-5; p.u = p.u
+    elif op == "inplace_only":                       # nobody tells the library: the default mode must see it all the same
+        p.u[int(rs.randint(2))] += 1e-5 * rs.normal()
+    elif op == "inplace_flux_only":
+        p.fluxes[int(rs.randint(5))] *= 1.01
     elif op == "inplace_touch":
         p.u[1] -= 1e-5; celeste_src.touch(p)
     elif op == "flux":
@@ -100,4 +108,4 @@ for step in range(STEPS):
         log.append("%s(list %d, %d images)" % (what, L is lists[1], len(imgs)))
     if step % 500 == 499:
         print("step %d: %d evaluations" % (step + 1, n_eval), flush=True)
-print("ok: %d steps, %d evaluations equal to the cache-off values; likelihood renders: %d of dirty tiles only, %d of every tile" % (STEPS, n_eval, incremental[0], incremental[1]))
+print("ok: list_cache %r, %d steps, %d evaluations equal to the cache-off values; likelihood renders: %d of dirty tiles only, %d of every tile" % (mode, STEPS, n_eval, incremental[0], incremental[1]))
