@@ -180,6 +180,8 @@ def dry_run(args):
     rank, world, local = dist.init_from_env(backend=os.environ.get("CEL_BENCH_BACKEND", "gloo"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # the same first act as the real job: how many ranks the collective reaches, who sits on which device
+    call = dist.roll_call(args.gpus, local, allow_shared_devices=True)
     red = dist.LoglikReducer(5, depth=2)
     red.submit(np.full(5, float(rank + 1)))
     got = red.drain()[-1]
@@ -187,10 +189,29 @@ def dry_run(args):
     dist.barrier()
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": world, "allreduce_check": float(got[0]),
-                          "expected": world * (world + 1) / 2.0, "fields_of_rank0": shard}))
+                          "expected": world * (world + 1) / 2.0, "fields_of_rank0": shard,
+                          "ranks_seen_by_collective": call["ranks_seen_by_collective"], "device_uuid": call["device_uuid"],
+                          # rank 0's job in the N-rank weak-scaling run IS the --gpus 1 headline: same function, same field
+                          "rank0_job": job_of_rank(args, 0, world), "n1_job": job_of_rank(args, 0, 1)}))
     if world > 1:
         import torch.distributed as td
         td.destroy_process_group()
+
+
+def field_seed(rank, strong):
+    """weak scaling: one field per rank, same population, another seed per rank (rank 0's is the 1-GPU headline's field);
+    strong: every rank builds the SAME field"""
+    return 42 + (0 if strong else 1000 * rank)
+
+
+def job_of_rank(args, rank, world):
+    """what rank `rank` of a `world`-rank job runs: the function, the workload and the field it builds.  At any N the weak job's
+    rank 0 is the `--gpus 1` job (tests/test_dist_gloo.py asserts it on the dry run): the N = 1 point of the scaling curve is the
+    headline, not another code path"""
+    kind = "gibbs" if args.workload == "gibbs10k" else ("fields" if args.workload.startswith("fields") else "render")
+    strong = (args.scaling == "strong") and world > 1
+    return {"function": "run_" + kind, "workload": args.workload, "field_seed": field_seed(rank, strong),
+            "scaling": "strong" if strong else "weak"}
 
 
 # ---- shared pieces -----------------------------------------------------------------------------------
@@ -408,7 +429,7 @@ def run_render(args, env):
     # weak: one field per rank (same population, different seed).  strong: every rank builds the SAME
     # field (the catalogue is small and replicated) and keeps only its row strip of the pixels.
     strong = (args.scaling == "strong") and world > 1
-    field = synth.SyntheticField.from_config(ctx, args.workload, seed=42 + (0 if strong else 1000 * rank))
+    field = synth.SyntheticField.from_config(ctx, args.workload, seed=field_seed(rank, strong))
     full_stats = None
     if strong:
         field.images.render(field.sources, loglik=False)
@@ -500,7 +521,8 @@ def run_render(args, env):
                                        2: "heaviest first by the binning pass's estimate"}[args.tile_order],
                    "parallelism": ("1 field cut into %d row strips, 1 per GPU" if strong else "1 field per GPU, %d GPU(s)") % world
                                   + ", 1 all-reduce of %d doubles per step (overlapped with the next step's render)" % B,
-                   "ranks": world, "collective_backend": env["backend"]},
+                   "ranks": world, "collective_backend": env["backend"],
+                   "ranks_seen_by_collective": env["roll_call"]["ranks_seen_by_collective"], "device_uuid": env["roll_call"]["device_uuid"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic"] if pmc else None,
                      "traffic_source": pmc["source"] if pmc else pmc_note,
@@ -1046,7 +1068,8 @@ def run_fields(args, env):
                    "parallelism": "fields dealt round-robin to %d GPU(s), 1 all-reduce of %d doubles per step; on a GPU "
                                   "the fields run on %d streams (a context and a host thread each)" % (world, B, n_str),
                    "streams_per_gpu": n_str,
-                   "ranks": world, "collective_backend": env["backend"]},
+                   "ranks": world, "collective_backend": env["backend"],
+                   "ranks_seen_by_collective": env["roll_call"]["ranks_seen_by_collective"], "device_uuid": env["roll_call"]["device_uuid"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": "k_render", "kernel_ms": t_render, "launches": n_render,
                      "algorithmic_bytes_per_launch": alg_bytes},
@@ -1225,7 +1248,8 @@ def run_gibbs(args, env):
                                    "of 11 doubles per source per sweep; the chain is the 1-GPU chain bit for bit" % world) if strong else
                                   ("%d independent chain(s), 1 per GPU, over the same field; 1 all-reduce of the chains' "
                                    "log-likelihood per sweep" % world),
-                   "ranks": world, "collective_backend": env["backend"]},
+                   "ranks": world, "collective_backend": env["backend"],
+                   "ranks_seen_by_collective": env["roll_call"]["ranks_seen_by_collective"], "device_uuid": env["roll_call"]["device_uuid"]},
         "loglik_before": ll0, "loglik_trace_tail": trace[-3:]}
     out.update(rep)
     if world == 1 and args.cpu_sample > 0:
@@ -1334,8 +1358,14 @@ def main():
     if world > 1:
         import torch.distributed as td
         backend = {"nccl": "rccl (torch.distributed nccl)"}.get(td.get_backend(), td.get_backend())
+    # first-run insurance: the collective must reach exactly --gpus ranks, each on a device of its own; anything else exits non-zero
+    # on every rank before a number is printed (CEL_BENCH_BACKEND=gloo rehearsals may share GPUs)
+    try:
+        call = dist.roll_call(args.gpus, local, allow_shared_devices=os.environ.get("CEL_BENCH_BACKEND") == "gloo")
+    except RuntimeError as e:
+        raise SystemExit("bench.py: %s" % e)
     env = dict(torch=torch, cel=cel, dist=dist, synth=synth, _lib=_lib, rank=rank, world=world, local=local, ctx=ctx,
-               backend=backend)
+               backend=backend, roll_call=call)
     if args.of:
         if world != 1 or args.scaling != "strong":
             raise SystemExit("--of N plays the ranks of a strong-scaling job on ONE GPU: use it with --scaling strong and without --gpus")

@@ -394,6 +394,46 @@ class LoglikReducer(object):
         return out
 
 
+def device_identity(local):
+    """what tells two GPUs apart on one node: the HIP device's UUID (else its PCI address); "cpu:<pid>" without a GPU"""
+    import torch
+    if not torch.cuda.is_available():
+        return "cpu:%d" % os.getpid()
+    p = torch.cuda.get_device_properties(local)
+    uuid = getattr(p, "uuid", None)
+    if uuid is not None:
+        return str(uuid)
+    return "pci:%s:%s:%s" % (getattr(p, "pci_domain_id", "?"), getattr(p, "pci_bus_id", "?"), getattr(p, "pci_device_id", "?"))
+
+
+def roll_call(expected, local=0, allow_shared_devices=False):
+    """First thing an N-rank job does with its process group: an all-reduce of ones (how many ranks the COLLECTIVE reaches -- not
+    what the environment claims) and an all-gather of every rank's device identity.  Raises RuntimeError -- on every rank alike,
+    so the launcher exits non-zero -- when the collective sees another number of ranks than `expected`, or when two ranks sit
+    on the same device (unless allow_shared_devices: the gloo rehearsals on a box with fewer GPUs than ranks).
+    -> dict(ranks_seen_by_collective, device_uuid=[per rank], backend).  Without a process group: one rank, its own device."""
+    import torch
+    import torch.distributed as td
+    me = device_identity(local)
+    if not (td.is_available() and td.is_initialized()):
+        seen, ids, backend = 1, [me], "none"
+    else:
+        backend = td.get_backend()
+        one = torch.ones(1, dtype=torch.float64)
+        if backend == "nccl":
+            one = one.cuda(local)
+        td.all_reduce(one, op=td.ReduceOp.SUM)
+        seen = int(round(float(one.item())))
+        ids = [None] * td.get_world_size()
+        td.all_gather_object(ids, me)
+    out = {"ranks_seen_by_collective": seen, "device_uuid": ids, "backend": backend}
+    if seen != expected or len(ids) != expected:
+        raise RuntimeError("roll call: the collective reached %d rank(s) (%d identities), the job was started for %d" % (seen, len(ids), expected))
+    if len(set(ids)) != len(ids) and not allow_shared_devices:
+        raise RuntimeError("roll call: two ranks share a device: %s" % ids)
+    return out
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

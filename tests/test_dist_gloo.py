@@ -284,6 +284,41 @@ def test_bench_self_launch_spawns_n_ranks_gloo_dry_run():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["ranks"] == 2
     assert out["allreduce_check"] == out["expected"] == 3.0
+    # the roll call: the collective itself counted two ranks, each reported where it sits
+    assert out["ranks_seen_by_collective"] == 2 and len(out["device_uuid"]) == 2 and len(set(out["device_uuid"])) == 2
+    # the N = 1 point of the weak-scaling curve is the headline: rank 0 of the 2-rank job runs what `--gpus 1` runs
+    assert out["rank0_job"] == out["n1_job"] == {"function": "run_render", "workload": "mixed10k_2048", "field_seed": 42, "scaling": "weak"}
+
+
+def test_roll_call_refuses_a_short_group_and_shared_devices(tmp_path):
+    """dist.roll_call in a 2-rank gloo group: the right count passes; a job started for 3 ranks whose collective reaches 2, and two
+    ranks on one device, raise on every rank (bench.py turns that into a non-zero exit before any number is printed)"""
+    import torch.multiprocessing as mp
+    mp.spawn(_roll_call_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(str(tmp_path))) == ["ok_0", "ok_1"]
+
+
+def _roll_call_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from desi_mcmc_amd import dist
+    dist.init_from_env(backend="gloo")
+    out = dist.roll_call(2, 0)
+    assert out["ranks_seen_by_collective"] == 2 and len(set(out["device_uuid"])) == 2 and out["backend"] == "gloo"
+    with pytest.raises(RuntimeError, match="reached 2 rank"):
+        dist.roll_call(3, 0)
+    real = dist.device_identity
+    dist.device_identity = lambda local: "GPU-same"
+    try:
+        with pytest.raises(RuntimeError, match="share a device"):
+            dist.roll_call(2, 0)
+        assert dist.roll_call(2, 0, allow_shared_devices=True)["device_uuid"] == ["GPU-same", "GPU-same"]
+    finally:
+        dist.device_identity = real
+    open(os.path.join(out_dir, "ok_%d" % rank), "w").close()
+    dist.barrier()
+    import torch.distributed as td
+    td.destroy_process_group()
 
 
 def test_bench_gpus_n_fails_loudly_with_fewer_devices():

@@ -2118,6 +2118,15 @@ import numpy as np, torch, torch.distributed as td
 from desi_mcmc_amd import dist
 torch.cuda.set_device(0)
 td.init_process_group(backend="nccl", rank=0, world_size=1)
+# bench.py's first-run insurance over RCCL: the collective counts its ranks, every rank names its device
+call = dist.roll_call(1, 0)
+assert call["ranks_seen_by_collective"] == 1 and call["backend"] == "nccl" and len(call["device_uuid"]) == 1 and not call["device_uuid"][0].startswith("cpu"), call
+try:
+    dist.roll_call(2, 0)
+    raise SystemExit("roll_call(2) passed in a one-rank group")
+except RuntimeError as e:
+    assert "reached 1 rank" in str(e)
+print("roll call over rccl:", call)
 x = np.array([1.5, -2.0, 3.25, 4.0, 1e9])
 assert np.array_equal(dist.allreduce_loglik(x, device=0, force=True), x)
 assert np.array_equal(dist.allreduce_loglik(x, device=0, deterministic=True, force=True), x)
