@@ -868,7 +868,8 @@ def measured_row_cost(ctx, _lib, images, sources, align):
     ntx, nty = (W + 31) // 32, (H + 63) // 64                   # the 32 x 64 layout's tiles, [band][tile row][tile column]
     if dur.shape[0] != B * ntx * nty:
         return None
-    return dist.strip_cost_from_tiles(dur, B, nty, ntx, 64, align)[: (H + align - 1) // align]
+    # (row i of the timing table is TILE i: k_render_hw<true> records by tile index, not by launch position)
+    return dist.strip_cost_from_tiles(dur, B, nty, ntx, 64, align, H=H)
 
 
 def run_projection(args, env, field=None, emit=True):

@@ -1357,7 +1357,9 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
                 im->lambda_gen = src->gen;
                 im->lambda_uid = src->uid;
                 im->lambda_T = c->render_T;
-                im->lambda_parts = parts_used;
+                // a render by the DIAG instantiation (tile timing, ablation bits) vouches for nothing: with an ablation bit set its
+                // pixels and partials are documented as wrong, and the incremental path would take them as a base
+                im->lambda_parts = diag ? 0 : parts_used;
                 // (a render WITHOUT the log-likelihood vouches for no partials: those in the buffer may be of another sky
                 // level or drop threshold although the catalogue's generation is the same -- found by tools/dbg/incremental_stress.py)
                 im->partials_gen = (flags & CEL_RENDER_LOGLIK) ? src->gen : 0;

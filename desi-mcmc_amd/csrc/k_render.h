@@ -585,9 +585,9 @@ k_render(RenderArgs a) {
         if (lane == 0) a.partials[tile] = part;
     }
     if (a.timing && lane == 0) {   // diagnostic build of the launch only (CEL_OPT_TILE_TIMING)
-        a.timing[3 * (size_t)blockIdx.x + 0] = t_start;
-        a.timing[3 * (size_t)blockIdx.x + 1] = wall_clock64();
-        a.timing[3 * (size_t)blockIdx.x + 2] = ((unsigned long long)tile << 32) | (unsigned)cnt;
+        a.timing[3 * (size_t)tile + 0] = t_start;
+        a.timing[3 * (size_t)tile + 1] = wall_clock64();
+        a.timing[3 * (size_t)tile + 2] = ((unsigned long long)tile << 32) | (unsigned)cnt;
     }
 }
 

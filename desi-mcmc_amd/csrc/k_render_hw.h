@@ -701,12 +701,12 @@ k_render_hw(RenderArgs a) {
     hw_epilogue<false, DIAG>(a, acc, reinterpret_cast<double *>(&T), bd, tile, b, xi, Y0, lane, nullptr);
     if (a.cost && lane == 0) a.cost[tile] = (int)min((wall_clock64() - t_start) * (unsigned long long)peff, 0x3fffffffull) + 1;
     if (timing && lane == 0) {
-        timing[3 * (size_t)blockIdx.x + 0] = t_start;
-        timing[3 * (size_t)blockIdx.x + 1] = wall_clock64();
+        timing[3 * (size_t)tile + 0] = t_start;
+        timing[3 * (size_t)tile + 1] = wall_clock64();
         // work counters of this tile (diagnostic): sources | pairs of groups << 12 | kept component-rows << 32
-        timing[3 * (size_t)blockIdx.x + 2] = (unsigned long long)(unsigned)cnt | ((unsigned long long)dbg_pairs << 12) |
+        timing[3 * (size_t)tile + 2] = (unsigned long long)(unsigned)cnt | ((unsigned long long)dbg_pairs << 12) |
                                                ((unsigned long long)(dbg_comprows + dbg_halfrows) << 32);
         if ((a.flags >> 8) & 128)   // diagnostic (tools/row_waste.py): what the kept components need one by one
-            timing[3 * (size_t)blockIdx.x + 2] = (unsigned long long)dbg_pairrows | ((unsigned long long)(unsigned)(dbg_area / 32.f) << 32);
+            timing[3 * (size_t)tile + 2] = (unsigned long long)dbg_pairrows | ((unsigned long long)(unsigned)(dbg_area / 32.f) << 32);
     }
 }

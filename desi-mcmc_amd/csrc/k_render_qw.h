@@ -223,9 +223,9 @@ k_render_qw(RenderArgs a) {
     }
     if (a.cost && lane == 0) a.cost[tile] = (int)min(wall_clock64() - t_start, 0x3fffffffull) + 1;
     if (a.timing && lane == 0) {
-        a.timing[3 * (size_t)blockIdx.x + 0] = t_start;
-        a.timing[3 * (size_t)blockIdx.x + 1] = wall_clock64();
-        a.timing[3 * (size_t)blockIdx.x + 2] = (unsigned long long)(unsigned)cnt | ((unsigned long long)dbg_pairs << 12) |
+        a.timing[3 * (size_t)tile + 0] = t_start;
+        a.timing[3 * (size_t)tile + 1] = wall_clock64();
+        a.timing[3 * (size_t)tile + 2] = (unsigned long long)(unsigned)cnt | ((unsigned long long)dbg_pairs << 12) |
                                                ((unsigned long long)dbg_comprows << 32);
     }
 }

@@ -55,13 +55,15 @@ def strip_edges(H, world, row_cost=None, align=TILE_ROWS):
     return [min(e * align, H) for e in edges]
 
 
-def strip_cost_from_tiles(tile_cost, B, nty, ntx, tile_rows, align=TILE_ROWS):
+def strip_cost_from_tiles(tile_cost, B, nty, ntx, tile_rows, align=TILE_ROWS, H=None):
     """per-`align`-row cost of the frame from per-tile costs laid out [band][tile row][tile column] (the render's
-    measured tile durations, ImageSet.tile_timing, or the binning pass's estimates): a tile row's cost spread over the
-    bands of `align` rows it covers"""
+    measured tile durations -- ImageSet.tile_timing, whose row i is TILE i whatever the launch order -- or the binning pass's
+    estimates): a tile row's cost spread over the bands of `align` rows it covers.  With H, exactly the ceil(H / align) bands
+    strip_edges asks for (a frame whose height is no multiple of tile_rows ends in a partial tile row)."""
     c = np.asarray(tile_cost, dtype=np.float64).reshape(B, nty, ntx).sum(axis=(0, 2))
     per = max(tile_rows // align, 1)
-    return np.repeat(c / per, per)
+    out = np.repeat(c / per, per)
+    return out if H is None else out[: (int(H) + align - 1) // align]
 
 
 def agree_on_edges(edges, src=0):
@@ -206,6 +208,11 @@ class StripDeal(SourceDeal):
         edges = [int(e) for e in edges]
         if len(edges) != world + 1 or edges[0] != 0 or edges[-1] != int(H) or any(b <= a for a, b in zip(edges, edges[1:])):
             raise ValueError("StripDeal: edges must be %d increasing rows from 0 to %d" % (world + 1, H))
+        if any(e % TILE_ROWS for e in edges[:-1]):
+            # the halo below is rounded to whole tiles RELATIVE to the edges: an edge off the tile grid would put the window,
+            # and with it every pixel's tile, off the grid the split's and the render's tiles are cut on
+            raise ValueError("StripDeal: strip edges must be multiples of %d rows (dist.strip_edges gives such edges): %s"
+                             % (TILE_ROWS, edges))
         ends = np.array(edges[1:])
         owner = np.minimum(np.searchsorted(ends, np.clip(np.floor(rows), 0, H - 1), side="right"), world - 1)
         SourceDeal.__init__(self, rows.shape[0], world, rank, device=device, owner=owner, solo=solo)

@@ -208,8 +208,13 @@ class ImageSet(object):
         L.check(L.lib().cel_images_set_window(self._h, int(y0), int(full_H)))
 
     def set_noise_rows(self, y0, y1):
-        """rows [y0, y1) of this set (window-relative) that photon_split's noise sums count (a strip inside its halo)"""
+        """rows [y0, y1) of this set (window-relative) that the set OWNS (a strip inside its halo): photon_split's noise sums count
+        them, and render(loglik=True) adds the Poisson terms of their tiles only.  For a log-likelihood the rows must begin and
+        end on RENDER-tile rows -- 64 in the default 32x64 layout, so dist.StripDeal(align=64) / strip_edges(align=64), not the
+        32-row TILE_ROWS the split alone needs; cel_render_field refuses other rows (CEL_ERR_INVALID) rather than add a partial
+        tile.  A set with owned rows never takes the one-launch small-star path."""
         L.check(L.lib().cel_images_set_noise_rows(self._h, int(y0), int(y1)))
+        self._noise_rows = (int(y0), int(y1))
 
     def set_epsilon(self, band, eps):
         L.check(L.lib().cel_images_set_epsilon(self._h, int(band), float(eps)))
@@ -247,7 +252,8 @@ class ImageSet(object):
     def render(self, sources, loglik=False, store=True):
         """gen_model_image for all bands (+ fused celeste_likelihood).
         -> (ll_total, ll_band[B]) when loglik else None.  Model images stay on the device;
-        fetch with .model_images()."""
+        fetch with .model_images().  On a set with owned rows (set_noise_rows) the log-likelihood is that of the owned rows'
+        tiles, and those rows must lie on render-tile rows (see set_noise_rows)."""
         flags = (L.CEL_RENDER_LOGLIK if loglik else 0) | (0 if store else L.CEL_RENDER_NO_STORE)
         if loglik:
             llb = np.zeros(self.B)

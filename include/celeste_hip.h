@@ -268,9 +268,10 @@ int cel_render_field(cel_images *img, cel_sources *src, int flags, double *ll_ba
 /* work counters of the last cel_render_field: n_srcpix = sum of box areas (source-pixel
  * evaluations), n_gauss = sum of K*area, n_tile_entries = length of the tile lists */
 int cel_field_stats(cel_images *img, double *n_srcpix, double *n_gauss, double *n_tile_entries);
-/* diagnostic (CEL_OPT_TILE_TIMING): per launched render block i, out[3i] = start, out[3i+1] = end
- * (100 MHz wall clock ticks), out[3i+2] = (tile index << 32) | list length.  out == NULL: only
- * *n_tiles is returned.  Never enabled in a timed run. */
+/* diagnostic (CEL_OPT_TILE_TIMING): per render TILE i in [band][tile row][tile column] order -- whatever position the tile
+ * order gave its block in the launch -- out[3i] = start, out[3i+1] = end (100 MHz wall clock ticks), out[3i+2] = packed work
+ * counters (32x64 / 16x128 layouts: list length | pairs of groups << 12 | kept component-rows << 32; 64x32 layout:
+ * (tile index << 32) | list length).  out == NULL: only *n_tiles is returned.  Never enabled in a timed run. */
 /* the totals image the last cel_photon_split on the recurrence kernels drew from (every pixel's rate under the split's
  * strict boxes), B*H*W doubles to host memory: what the tests compare between the two ways of forming it (CEL_OPT_SPLIT_REUSE) */
 int cel_debug_split_rates(cel_images *img, double *out);

@@ -697,6 +697,52 @@ def test_row_strips_tile_the_frame(cel, ctx, world, frac_gal, tail):
         _row_strips_body(cel, ctx, f, H, W, world, frac_gal, 1e-12 if frac_gal == 0.0 else RT_LAM)
 
 
+def test_measured_tile_costs_land_on_their_tiles_with_the_tile_order_on(cel, ctx):
+    """cel_debug_tile_timing's row i is TILE i, whatever launch position the heaviest-first order (CEL_OPT_TILE_ORDER = 1, in force
+    on frames of more than 2 048 tiles) gave its block: a frame of 2 560 tiles whose tile row 3 holds 500 galaxies on top of a
+    sparse star background.  The per-row cost dist.strip_cost_from_tiles forms from the measured durations -- what `bench.py
+    --scaling strong --strip-cut measured` cuts the strips from -- peaks on that row, the counters name its list lengths, and the
+    cut evens out the cost (round 5 recorded by LAUNCH position: the per-row cost was scrambled and every measured cut came out
+    equal)."""
+    from desi_mcmc_amd import _lib, dist, synth
+    B, H, W = 5, 512, 2048
+    bands = synth.make_bands(H, W, B)
+    rs = np.random.RandomState(3)
+    S_bg, S_row = 400, 500
+    pix = np.vstack([np.column_stack([rs.uniform(0, W, S_bg), rs.uniform(0, H, S_bg)]),
+                     np.column_stack([rs.uniform(0, W, S_row), rs.uniform(200, 248, S_row)])])      # tile row 3 = rows 192..255
+    typ = np.concatenate([np.zeros(S_bg, np.int32), np.ones(S_row, np.int32)])
+    S = S_bg + S_row
+    shape = np.column_stack([rs.uniform(0.2, 0.8, S), rs.uniform(0.5, 1.0, S), rs.uniform(0, 180, S), rs.uniform(0.4, 0.9, S)])
+    counts = np.exp(rs.uniform(np.log(5e3), np.log(5e4), size=(S, B)))
+    iset = cel.ImageSet(ctx, bands, H, W)
+    sset = cel.SourceSet(ctx, S, B).set(typ, synth.pixel2equa(bands[0], pix), counts, shape)
+    ntx, nty = W // 32, H // 64
+    assert B * ntx * nty > 2048 and ctx.get_option(_lib.CEL_OPT_TILE_ORDER) == 1
+    for _ in range(3):                                   # the order of a render is the durations of the one before
+        iset.render(sset, loglik=False)
+    lam = iset.model_images()
+    ctx.set_option(_lib.CEL_OPT_TILE_TIMING, 1)
+    try:
+        iset.render(sset, loglik=False)
+        tt = iset.tile_timing()
+    finally:
+        ctx.set_option(_lib.CEL_OPT_TILE_TIMING, 0)
+    assert np.array_equal(iset.model_images(), lam)       # (the timing instantiation keeps the arithmetic)
+    assert tt.shape == (B * ntx * nty, 3)
+    cnt = (tt[:, 2] & np.uint64(0xfff)).astype(np.int64).reshape(B, nty, ntx)
+    # the list lengths the counters carry are those of the tiles they are filed under: row 3 holds the galaxies in every band
+    per_row = cnt.sum(axis=(0, 2))
+    assert per_row.argmax() == 3 and per_row[3] > 4 * np.delete(per_row, [2, 3, 4]).max(), per_row
+    dur = (tt[:, 1] - tt[:, 0]).astype(np.float64)
+    cost = dist.strip_cost_from_tiles(dur, B, nty, ntx, 64, 64, H=H)
+    assert cost.shape == (nty,) and cost.argmax() == 3 and cost[3] > 2 * np.delete(cost, [2, 3, 4]).max(), cost
+    edges = dist.strip_edges(H, 4, cost, align=64)
+    assert edges != dist.strip_edges(H, 4, align=64) and 192 in edges and 256 in edges, edges       # the heavy row is a strip of its own
+    iset.render(sset, loglik=False)                       # and a DIAG render vouches for nothing: this one is complete
+    assert np.array_equal(iset.model_images(), lam)
+
+
 def _row_strips_body(cel, ctx, f, H, W, world, frac_gal, rt):
     from desi_mcmc_amd import dist
     ctx.profile(True)
