@@ -690,7 +690,7 @@ def extra_render_legs(args, env, field, out):
             plist[23].u = pos
             ll_moved = celeste.celeste_likelihood_multi_image(plist, imgs)
         one = (time.perf_counter() - t0) / n * 1e3
-        plist[23].u = u0
+        plist[23].u = u0.copy()              # (a copy: the next leg edits the source's array in place again)
         ll_list2 = celeste.celeste_likelihood_multi_image(plist, imgs)
         assert ll_moved != ll_list2 and ll_list2 == ll_list, (ll_moved, ll_list2, ll_list)
         t0 = time.perf_counter()

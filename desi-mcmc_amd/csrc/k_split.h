@@ -76,7 +76,10 @@ __device__ inline double philox_double(Philox &g) {
     return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
 }
 
-// Stirling-series tail used by BTPE's final acceptance test
+// Stirling-series tail used by BTPE's final acceptance test.  The leading constant is randomkit's 13680
+// (deps/randomkit/distributions.c:362-365, the sampler the reference's split calls); Kachitvichyanukul & Schmeiser print
+// 13860 = 166320/12.  Kept as the reference's dependency has it: the term is a 1e-3 relative change of a 1/(12 x)
+// correction inside an accept/reject bound, far below anything the pmf tests resolve.
 __device__ inline double btpe_st(double x) {
     double x2 = x * x;
     return (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / x2) / x2) / x2) / x2) / x / 166320.0;
@@ -683,6 +686,12 @@ k_photon_split_hw(SplitArgs a) {
 #ifdef SPLIT_LC_IN_REGISTERS
     const LaneConst lc = lane_consts(lane, bd);
 #endif
+#ifdef CEL_ABLATE
+    // work counters of the diagnostic build (CEL_OPT_DEBUG bits 8..): returned in place of the noise sums, summed over the tiles
+    //   8 queued draws | 16 sampler trips of 64 | 32 (source, half-tile) pairs walked | 64 draws by BTPE | 128 queued draws that
+    //   left a photon | 256 first-pass steps (row pairs) | 512 pairs with a non-empty queue
+    double dbg_count = 0.0;
+#endif
     const int nent = (Y0 < a.H) ? (int)min((int64_t)cnt, a.capacity > off ? a.capacity - off : (int64_t)0) : 0;
     int idx64 = (lane < nent) ? a.lists[off + lane] : 0;
     int s_next = __builtin_amdgcn_readlane(idx64, 0);
@@ -765,6 +774,15 @@ k_photon_split_hw(SplitArgs a) {
             nq += __popcll(sm);
         }
         __syncthreads();
+#ifdef CEL_ABLATE
+        if (lane == 0) {
+            if (a.debug & 8) dbg_count += (double)nq;
+            if (a.debug & 16) dbg_count += (double)((nq + 63) >> 6);
+            if (a.debug & 32) dbg_count += 1.0;
+            if (a.debug & 256) dbg_count += (double)(((rb + 1) >> 1) - (ra >> 1));
+            if ((a.debug & 512) && nq > 0) dbg_count += 1.0;
+        }
+#endif
         for (int q0 = 0; q0 < nq; q0 += 64) {
             if (q0 + lane < nq) {
                 const int li = queue[q0 + lane];
@@ -780,6 +798,10 @@ k_photon_split_hw(SplitArgs a) {
                 left[li] = (TL)(n - (int)z);
                 rate[li] = tot - F;
                 patch0[(int64_t)row * nx + xq] = (TS)z;
+#ifdef CEL_ABLATE
+                if ((a.debug & 64) && fmin(pr, 1.0 - pr) * (double)n > BINV_MAX_NP) dbg_count += 1.0;
+                if ((a.debug & 128) && z > 0) dbg_count += 1.0;
+#endif
                 if (z > 0) {
                     zlo = min(zlo, row); zhi = max(zhi, row); xlo = min(xlo, xq); xhi = max(xhi, xq);
                     zsum += (double)z;
@@ -831,6 +853,9 @@ k_photon_split_hw(SplitArgs a) {
         const double v = ((covered >> r) & 1u) ? (double)left[r * 64 + lane] : (in ? raw[r] : 0.0);
         noise += counted ? v : 0.0;
     }
+#ifdef CEL_ABLATE
+    if (a.debug & ~7) noise = dbg_count;
+#endif
     noise = wave_sum(noise);
     if (lane == 0) a.partials[2 * tile + sub] = noise;
 }

@@ -27,4 +27,10 @@ for name, bits in (("full", 0), ("no draws at all (every pixel fast, no uniform)
     ms, n = ctx.profile_get("split")
     ctx.profile(False)
     print("%-48s k_photon_split_hw %.3f ms" % (name, ms))
+# work counters of the same build (returned in place of the noise sums)
+for name, bits in (("queued draws (pixels that failed the first test)", 8), ("sampler trips of 64 lanes", 16), ("(source, half-tile) pairs walked", 32),
+                   ("pairs with a non-empty queue", 512), ("draws by BTPE", 64), ("queued draws that left a photon", 128), ("first-pass steps (row pairs)", 256)):
+    ctx.set_option(_lib.CEL_OPT_DEBUG, bits)
+    tot = f.images.photon_split_resident(f.sources, seed=3).sum()
+    print("%-52s %.4e" % (name, tot))
 ctx.set_option(_lib.CEL_OPT_DEBUG, 0)
