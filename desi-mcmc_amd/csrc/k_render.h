@@ -23,6 +23,14 @@ struct CompTab {
     int gL[4], gr0[4], gr1[4];
 };
 
+// fp32 reciprocal / square root / reciprocal square root as ONE instruction each (v_rcp_f32, v_sqrt_f32, v_rsq_f32: 1 ulp).
+// Every use below either refines the value in fp64 (Newton steps) or rounds outwards by far more than an ulp.  The
+// correctly rounded forms (__frcp_rn, __fsqrt_rn: what rounds 1-5 called) expand to the IEEE division / square-root sequences
+// -- 11 and ~9 instructions: a dozen of them per (source, tile) set-up were 8 % of k_render_hw's instruction stream.
+__device__ __forceinline__ float rcp_f32(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sqrt_f32(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float rsq_f32(float x) { return __builtin_amdgcn_rsqf(x); }
+
 struct Comp {   // one component in registers
     double A, mx, my, qa, qb, qc, ixx, iyy;   // ixx = 1/Sigma_xx, iyy = 1/Sigma_yy (marginals)
 };
@@ -54,8 +62,8 @@ __device__ inline Comp make_comp(int k, int type, double px, double py, double s
     c.my = py + bd->muy[kk];
     // marginal precisions feed only the conservative drop test: fp32 reciprocals, shrunk by
     // 1e-6 so that rounding can only make the test keep more, never less
-    c.ixx = (double)(__frcp_rn((float)cxx) * 0.999999f);
-    c.iyy = (double)(__frcp_rn((float)cyy) * 0.999999f);
+    c.ixx = (double)(rcp_f32((float)cxx) * 0.999999f);
+    c.iyy = (double)(rcp_f32((float)cyy) * 0.999999f);
     return c;
 }
 
@@ -115,10 +123,10 @@ __device__ inline int rec_fetch(const SrcRec *__restrict__ recs, int s, int lane
 // fp64 division followed by a correctly rounded square root, whose last bit nothing here needs.
 // d is a covariance determinant: positive, far inside fp32's range.
 __device__ inline void rcp_rsqrt(double d, double &inv, double &rsq) {
-    double y = (double)__frcp_rn((float)d);
+    double y = (double)rcp_f32((float)d);
     y = fma(y, fma(-d, y, 1.0), y);
     inv = fma(y, fma(-d, y, 1.0), y);
-    double z = (double)__frsqrt_rn((float)d);
+    double z = (double)rsq_f32((float)d);
     z = z * fma(-0.5 * d * z, z, 1.5);
     rsq = z * fma(-0.5 * d * z, z, 1.5);
 }
@@ -144,8 +152,8 @@ __device__ inline Comp make_comp_lc(const LaneConst &lc, const RecU &r) {
     c.A = r.scale * wt * (0.5 / PI_D) * rsq;
     c.mx = r.px + mux;
     c.my = r.py + muy;
-    c.ixx = (double)(__frcp_rn((float)cxx) * 0.999999f);
-    c.iyy = (double)(__frcp_rn((float)cyy) * 0.999999f);
+    c.ixx = (double)(rcp_f32((float)cxx) * 0.999999f);
+    c.iyy = (double)(rcp_f32((float)cyy) * 0.999999f);
     return c;
 }
 
@@ -197,7 +205,7 @@ __device__ __forceinline__ double wave_sum_lane63(double v) {
 // result is shrunk by 1e-5 so that the drop test built on it can only err towards keeping.
 __device__ inline double quad_min_rect(double a, double b, double c, double x1, double x2, double y1, double y2) {
     if (x1 <= 0.0 && x2 >= 0.0 && y1 <= 0.0 && y2 >= 0.0) return 0.0;
-    const double rc = (double)__frcp_rn((float)c), ra = (double)__frcp_rn((float)a);
+    const double rc = (double)rcp_f32((float)c), ra = (double)rcp_f32((float)a);
     double best = INFINITY;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -220,11 +228,11 @@ __device__ inline double quad_min_rect(double a, double b, double c, double x1, 
 __device__ inline void quad_rows_on_columns(double a, double b, double c, double R, double x1, double x2,
                                             float &ylo, float &yhi) {
     const double det = a * c - b * b;
-    const double xs = b * (double)__fsqrt_rn((float)R * __frcp_rn((float)(det * a)));
+    const double xs = b * (double)sqrt_f32((float)R * rcp_f32((float)(det * a)));
     const double xt = fmin(fmax(-xs, x1), x2), xb = fmin(fmax(xs, x1), x2);
-    const float rc = __frcp_rn((float)c);
-    const float st = __fsqrt_rn(fmaxf((float)(c * R - det * xt * xt), 0.0f));
-    const float sb = __fsqrt_rn(fmaxf((float)(c * R - det * xb * xb), 0.0f));
+    const float rc = rcp_f32((float)c);
+    const float st = sqrt_f32(fmaxf((float)(c * R - det * xt * xt), 0.0f));
+    const float sb = sqrt_f32(fmaxf((float)(c * R - det * xb * xb), 0.0f));
     yhi = ((float)(-b * xt) + st) * rc;
     ylo = ((float)(-b * xb) - sb) * rc;
 }
@@ -327,8 +335,8 @@ __device__ inline double eval_direct(const CompTab &T, int k0, int k1, double x,
 __device__ inline int seg_len(double qc, double T) {
     // largest L with (L sqrt(qc/2) + sqrt(T))^2 <= REC_EMAX.  fp32 is ample for a row count;
     // the 0.999 keeps the rounding on the safe (shorter) side.  T <= 300 => u > 0.
-    float u = 26.0768f - __fsqrt_rn((float)T);                 // sqrt(680) = 26.0768
-    float L = u * __frsqrt_rn(0.5f * (float)qc) * 0.999f;
+    float u = 26.0768f - sqrt_f32((float)T);                 // sqrt(680) = 26.0768
+    float L = u * rsq_f32(0.5f * (float)qc) * 0.999f;
     return (int)fminf(L, 4096.0f);
 }
 
@@ -501,7 +509,7 @@ k_render(RenderArgs a) {
                 double qmin = quad_min_rect(c.qa, c.qb, c.qc, xa - c.mx, xb - c.mx, ya - c.my, yb - c.my);
                 keep = (0.5 * qmin <= Tk);
                 // rows on which the component can matter at all: |dy| <= sqrt(2 Tk Sigma_yy)
-                float half = __fsqrt_rn(2.0f * (float)fmax(Tk, 0.0) / (float)c.iyy) + 1.0f;
+                float half = sqrt_f32(2.0f * (float)fmax(Tk, 0.0) / (float)c.iyy) + 1.0f;
                 rlo = max(ra, (int)floorf((float)(c.my - (double)Y0) - half));
                 rhi = min(rb, (int)ceilf((float)(c.my - (double)Y0) + half) + 1);
                 keep = keep && (rhi > rlo);

@@ -597,7 +597,7 @@ k_render_hw(RenderArgs a) {
             float cw = 0.f;
             if (keep) {
                 double Tk2 = Tdrop + (double)__logf((float)(fabs(c.A) / eps_sky));
-                float hx = __fsqrt_rn(2.0f * (float)fmax(Tk2, 0.0) / (float)c.ixx) + 1.0f;
+                float hx = sqrt_f32(2.0f * (float)fmax(Tk2, 0.0) / (float)c.ixx) + 1.0f;
                 float lo = fmaxf((float)xa, (float)c.mx - hx), hi = fminf((float)xb + 1.f, (float)c.mx + hx);
                 cw = fmaxf(hi - lo, 0.f);
             }

@@ -76,19 +76,15 @@ __device__ inline double philox_double(Philox &g) {
     return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
 }
 
-// Stirling-series tail used by BTPE's final acceptance test.  The leading constant is randomkit's 13680
+// Stirling-series tail used by BTPE's final acceptance test (btpe_st_r below).  The leading constant is randomkit's 13680
 // (deps/randomkit/distributions.c:362-365, the sampler the reference's split calls); Kachitvichyanukul & Schmeiser print
 // 13860 = 166320/12.  Kept as the reference's dependency has it: the term is a 1e-3 relative change of a 1/(12 x)
 // correction inside an accept/reject bound, far below anything the pmf tests resolve.
-__device__ inline double btpe_st(double x) {
-    double x2 = x * x;
-    return (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 / x2) / x2) / x2) / x2) / x / 166320.0;
-}
 
-// 1/x to ~4e-15 relative for x of fp32 range: fp32 reciprocal + one Newton step (4 instructions
-// against ~15 for an IEEE fp64 division).  Used where a probability or a pmf ratio is formed.
+// 1/x to ~4e-15 relative for x of fp32 range: v_rcp_f32 (1 ulp) + one Newton step in fp64 (5 instructions with the two
+// conversions, against ~15 for an IEEE fp64 division).  Used where a probability or a pmf ratio is formed.
 __device__ inline double fast_rcp(double x) {
-    double y = (double)__frcp_rn((float)x);
+    double y = (double)rcp_f32((float)x);
     return fma(y, fma(-x, y, 1.0), y);
 }
 
@@ -122,20 +118,32 @@ __device__ inline long long binom_inversion(long long n, double r, double U /* t
     return (long long)X;
 }
 
-// Binomial(n, r) for r <= 1/2, n r > 30: BTPE (triangle / parallelogram / exponential tails)
-__device__ inline long long binom_btpe(long long n, double r, Philox &g) {
+// Binomial(n, r) for r <= 1/2, n r > 30: BTPE (triangle / parallelogram / exponential tails).
+// Round 6: no IEEE fp64 division and no library log in it -- quotients by fast_rcp (4e-15 relative: fp32 reciprocal + a Newton
+// step, 4 instructions against ~15), logarithms by the table log of k_render.h (the sampler's LDS table, to the last bits); the
+// square root that sizes the triangle stays exact (the envelope's constants assume that p1).  These touch the algorithm at accept/reject
+// boundaries only, 1e-14 wide; the pmf tests (chi^2 against the exact pmf, moments) are unchanged.  A trip of 64 queued draws
+// holding one BTPE lane costs every lane this code: ~1 500 instructions before, ~600 now (tools/ablate_split.py).
+__device__ inline double btpe_st_r(double x, double rx /* ~1/x */) {
+    const double r2 = rx * rx;
+    return (13680.0 - (462.0 - (132.0 - (99.0 - 140.0 * r2) * r2) * r2) * r2) * rx * (1.0 / 166320.0);
+}
+__device__ inline long long binom_btpe(long long n, double r, Philox &g, const double *__restrict__ lt) {
     const double q = 1.0 - r, nd = (double)n;
     const double nrq = nd * r * q;
     const double fm = nd * r + r;
     const long long m = (long long)floor(fm);
+    const double md = (double)m;
     const double p1 = floor(2.195 * sqrt(nrq) - 4.6 * q) + 0.5;
-    const double xm = (double)m + 0.5, xl = xm - p1, xr = xm + p1;
-    const double c = 0.134 + 20.5 / (15.3 + (double)m);
-    double a = (fm - xl) / (fm - xl * r);
-    const double laml = a * (1.0 + a / 2.0);
-    a = (xr - fm) / (xr * q);
-    const double lamr = a * (1.0 + a / 2.0);
-    const double p2 = p1 * (1.0 + 2.0 * c), p3 = p2 + c / laml, p4 = p3 + c / lamr;
+    const double xm = md + 0.5, xl = xm - p1, xr = xm + p1;
+    const double c = 0.134 + 20.5 * fast_rcp(15.3 + md);
+    double a = (fm - xl) * fast_rcp(fm - xl * r);
+    const double laml = a * (1.0 + a * 0.5);
+    a = (xr - fm) * fast_rcp(xr * q);
+    const double lamr = a * (1.0 + a * 0.5);
+    const double rc = fast_rcp(c), rp1 = fast_rcp(p1), rlaml = fast_rcp(laml), rlamr = fast_rcp(lamr), rnrq = fast_rcp(nrq);
+    const double p2 = p1 * (1.0 + 2.0 * c), p3 = p2 + c * rlaml, p4 = p3 + c * rlamr;
+    const double s = r * fast_rcp(q), aa = s * (nd + 1.0);
     long long y;
     for (int guard = 0; guard < 100000; guard++) {
         double u = philox_double(g) * p4, v = philox_double(g);
@@ -144,38 +152,42 @@ __device__ inline long long binom_btpe(long long n, double r, Philox &g) {
             return y;
         }
         if (u <= p2) {                                   // parallelograms
-            double x = xl + (u - p1) / c;
-            v = v * c + 1.0 - fabs((double)m - x + 0.5) / p1;
+            double x = xl + (u - p1) * rc;
+            v = v * c + 1.0 - fabs(md - x + 0.5) * rp1;
             if (v > 1.0) continue;
             y = (long long)floor(x);
         } else if (u <= p3) {                            // left exponential tail
-            y = (long long)floor(xl + log(v) / laml);
+            y = (long long)floor(xl + log_tab(v, lt) * rlaml);
             if (y < 0) continue;
             v = v * (u - p2) * laml;
         } else {                                         // right exponential tail
-            y = (long long)floor(xr - log(v) / lamr);
+            y = (long long)floor(xr - log_tab(v, lt) * rlamr);
             if (y > n) continue;
             v = v * (u - p3) * lamr;
         }
-        const double k = fabs((double)(y - m));
-        if (k <= 20.0 || k >= nrq / 2.0 - 1.0) {
-            // evaluate f(y)/f(m) by the recurrence
-            const double s = r / q, aa = s * (nd + 1.0);
-            double F = 1.0;
-            if (m < y) { for (long long i = m + 1; i <= y; i++) F *= (aa / (double)i - s); }
-            else if (m > y) { for (long long i = y + 1; i <= m; i++) F /= (aa / (double)i - s); }
-            if (v > F) continue;
+        const double yd = (double)y;
+        const double k = fabs(yd - md);
+        if (k <= 20.0 || k >= nrq * 0.5 - 1.0) {
+            // evaluate f(y)/f(m) by the recurrence: the product of (aa / i - s) over the integers between m and y, numerator
+            // and denominator kept apart so that the loop holds no reciprocal
+            double num = 1.0, den = 1.0;
+            if (m < y) { for (long long i = m + 1; i <= y; i++) { const double di = (double)i; num *= (aa - s * di); den *= di; } if (v * den > num) continue; }
+            else if (m > y) { for (long long i = y + 1; i <= m; i++) { const double di = (double)i; num *= (aa - s * di); den *= di; } if (v * num > den) continue; }
+            else if (v > 1.0) continue;
             return y;
         }
         // squeezes, then the Stirling bound
-        const double rho = (k / nrq) * ((k * (k / 3.0 + 0.625) + 0.16666666666666666) / nrq + 0.5);
-        const double t = -k * k / (2.0 * nrq);
-        const double A = log(v);
+        const double knrq = k * rnrq;
+        const double rho = knrq * ((k * (k * (1.0 / 3.0) + 0.625) + 0.16666666666666666) * rnrq + 0.5);
+        const double t = -0.5 * k * knrq;
+        const double A = log_tab(v, lt);
         if (A < t - rho) return y;
         if (A > t + rho) continue;
-        const double x1 = (double)y + 1.0, f1 = (double)m + 1.0, z = nd + 1.0 - (double)m, w = nd - (double)y + 1.0;
-        const double bound = xm * log(f1 / x1) + (nd - (double)m + 0.5) * log(z / w) +
-                             (double)(y - m) * log(w * r / (x1 * q)) + btpe_st(f1) + btpe_st(z) + btpe_st(x1) + btpe_st(w);
+        const double x1 = yd + 1.0, f1 = md + 1.0, z = nd + 1.0 - md, w = nd - yd + 1.0;
+        const double rx1 = fast_rcp(x1), rf1 = fast_rcp(f1), rz = fast_rcp(z), rw = fast_rcp(w);
+        const double bound = xm * log_tab(f1 * rx1, lt) + (nd - md + 0.5) * log_tab(z * rw, lt) +
+                             (yd - md) * log_tab(w * s * rx1, lt) +
+                             btpe_st_r(f1, rf1) + btpe_st_r(z, rz) + btpe_st_r(x1, rx1) + btpe_st_r(w, rw);
         if (A > bound) continue;
         return y;
     }
@@ -198,7 +210,7 @@ __device__ inline long long binomial_draw(long long n, double p, double a, Philo
         const double u = philox_double(g);
         y = binom_inversion(n, r, a + u * (1.0 - a), g, et, lt);
     } else {
-        y = binom_btpe(n, r, g);
+        y = binom_btpe(n, r, g, lt);
     }
     return flip ? n - y : y;
 }
@@ -207,21 +219,26 @@ __device__ inline long long binomial_draw(long long n, double p, Philox &g, cons
     return binomial_draw(n, p, 0.0, g, et, lt);
 }
 
-// ---- the split's first decision on a shared 32-bit word --------------------------------------------------------------
+// ---- the split's first decision on a shared 16-bit word -----------------------------------------------------------------
 // Most of a split's binomials are 0 and are decided by the sampler's first test, U <= 1 - n p (a pixel in a source's tail):
-// that test needs no 53-bit uniform of its own.  Let V be the top 32 bits of U: if V + 1 <= floor((1 - n p) 2^32) =: tf the
-// test holds whatever the other bits are.  So ONE Philox block, keyed by (seed; band, column, the pixel's row with bits 1
-// and 2 cleared; source), serves the four pixels y, y + 2, y + 4, y + 6 of a column -- the four rows a lane of
-// k_photon_split_hw takes in consecutive steps -- word (y >> 1) & 3 each; a pixel that does not pass (V >= tf) goes to the
-// sampler proper with its own stream (seed; band, pixel; source), whose first uniform is drawn from [tf 2^-32, 1): the
-// law of U given V >= tf.  Together: P(first test holds) = tf 2^-32 + (1 - n p - tf 2^-32) = 1 - n p, exactly the
-// sampler's; a quarter of the Philox blocks (the first uniforms were 1.9 ms of the 6.9 ms kernel, tools/ablate_split.py).
+// that test needs no 53-bit uniform of its own.  Let V be the top 16 bits of U: if V + 1 <= floor((1 - n p) 2^16) =: tf the
+// test holds whatever the other bits are.  So ONE Philox block (128 bits), keyed by (seed; band, column, the pixel's row with
+// bits 1, 2 and 3 cleared; source), serves the EIGHT pixels y, y + 2, ..., y + 14 of a column -- the eight rows a lane of
+// k_photon_split_hw takes in consecutive steps -- half-word (y >> 1) & 7 each (round 4: 32-bit words, four rows per block;
+// round 6: half the blocks).  A pixel that does not pass (V >= tf) goes to the sampler proper with its own stream (seed; band,
+// pixel; source), whose first uniform is drawn from [tf 2^-16, 1): the law of U given V >= tf.  Together: P(first test
+// holds) = tf 2^-16 + (1 - n p - tf 2^-16) = 1 - n p, exactly the sampler's; the coarser word only sends 2^-16 more of the
+// pixels to the sampler (6 000 of 4e8 at config 3).
 #define SPLIT_GROUP_BIT (1ull << 63)      // keys of the shared blocks: never a pixel's own stream (pixel indices stay below 2^63)
-__device__ inline double split_tf(long long n, double pr) {         // floor((1 - n p) 2^32): V < tf passes; <= 0: nobody does
-    return floor((1.0 - (double)n * pr) * 4294967296.0);
+#define SPLIT_GROUP_MASK ((int64_t)14)    // the row bits a group shares
+#define SPLIT_WORD_SCALE 65536.0
+__device__ inline double split_tf(long long n, double pr) {         // floor((1 - n p) 2^16): V < tf passes; <= 0: nobody does
+    return floor((1.0 - (double)n * pr) * SPLIT_WORD_SCALE);
 }
-__device__ inline unsigned philox_word(const Philox &g, int w) {
-    return (w == 0) ? g.out[0] : (w == 1) ? g.out[1] : (w == 2) ? g.out[2] : g.out[3];
+__device__ inline unsigned philox_word(const Philox &g, int w /* 0..7 */) {
+    // (shifts, not a selection among the four words: the compiler turns a chain of selects on an index into a table in scratch)
+    const unsigned long long lo = ((unsigned long long)g.out[1] << 32) | g.out[0], hi = ((unsigned long long)g.out[3] << 32) | g.out[2];
+    return (unsigned)(((w & 4) ? hi : lo) >> ((w & 3) * 16)) & 0xffffu;
 }
 // the whole draw for one (pixel, source): what k_photon_split_hw does in two passes
 __device__ inline long long split_draw(long long n, double pr, unsigned long long seed, unsigned long long group_key, int word,
@@ -234,7 +251,7 @@ __device__ inline long long split_draw(long long n, double pr, unsigned long lon
         Philox h = philox_init(seed, group_key | SPLIT_GROUP_BIT, s);
         philox_block(h);
         if ((double)philox_word(h, word) < tf) return 0;
-        a = fmax(tf, 0.0) * (1.0 / 4294967296.0);
+        a = fmax(tf, 0.0) * (1.0 / SPLIT_WORD_SCALE);
     }
     Philox g = philox_init(seed, pixel_key, s);
     return binomial_draw(n, pr, a, g, et, lt);
@@ -576,8 +593,8 @@ k_photon_split(SplitArgs a) {
                     if (n > 0) {
                         const int64_t yf = (int64_t)a.win_y0 + y;            // full-frame row
                         const int64_t kb = (int64_t)b * a.full_H * a.W;
-                        z = split_draw((long long)n, F * fast_rcp(tot), a.seed, (unsigned long long)(kb + (yf & ~(int64_t)6) * a.W + xi),
-                                       (int)((yf >> 1) & 3), (unsigned long long)(kb + yf * a.W + xi), (unsigned)s, et, lt);   // curr_prob / sum_probs (:147)
+                        z = split_draw((long long)n, F * fast_rcp(tot), a.seed, (unsigned long long)(kb + (yf & ~SPLIT_GROUP_MASK) * a.W + xi),
+                                       (int)((yf >> 1) & 7), (unsigned long long)(kb + yf * a.W + xi), (unsigned)s, et, lt);   // curr_prob / sum_probs (:147)
                     }
                     left[li] = n - (int)z;
                     rate[li] = tot - F;                                   // sum_probs -= curr_prob (:152)
@@ -742,16 +759,16 @@ k_photon_split_hw(SplitArgs a) {
         for (int r = ra >> 1; 2 * r < rb; r++) {
             const int row = 2 * r + half;
             const int li = r * 64 + lane;
-            // the shared block of this lane's four consecutive rows: one per four steps, every lane at the same step
+            // the shared block of this lane's eight consecutive rows: one per eight steps, every lane at the same step
             // (windows start on even rows), whether or not it has a pixel here
             const int64_t yf = (int64_t)a.win_y0 + Y0 + row;
-            const int64_t grp = yf & ~(int64_t)6;
+            const int64_t grp = yf & ~SPLIT_GROUP_MASK;
             if (grp != grp_have && !(SPLIT_ABLATE(a) & 1)) {
                 hg = philox_init(a.seed, (unsigned long long)(kband + grp * a.W + (xi < a.W ? xi : 0)) | SPLIT_GROUP_BIT, (unsigned)s);
                 philox_block(hg);
                 grp_have = grp;
             }
-            const unsigned vword = philox_word(hg, (int)((yf >> 1) & 3));
+            const unsigned vword = philox_word(hg, (int)((yf >> 1) & 7));
             bool slow = false;
             if (on && row >= ra && row < rb) {
                 const double F = one[li];
@@ -793,7 +810,7 @@ k_photon_split_hw(SplitArgs a) {
                 const double tot = rate[li];
                 Philox g = philox_init(a.seed, (unsigned long long)(key0 + (int64_t)(Y0 + row) * a.W + xq), (unsigned)s);
                 const double pr = F * fast_rcp(tot);
-                const double afirst = (pr <= 0.5) ? fmax(split_tf((long long)n, pr), 0.0) * (1.0 / 4294967296.0) : 0.0;   // pass 1 saw V >= tf
+                const double afirst = (pr <= 0.5) ? fmax(split_tf((long long)n, pr), 0.0) * (1.0 / SPLIT_WORD_SCALE) : 0.0;   // pass 1 saw V >= tf
                 const long long z = (SPLIT_ABLATE(a) & 2) ? 1 : binomial_draw((long long)n, pr, afirst, g, et, lt);
                 left[li] = (TL)(n - (int)z);
                 rate[li] = tot - F;
