@@ -1292,6 +1292,9 @@ def main():
     ap.add_argument("--split", default="replicated", choices=["replicated", "strips"],
                     help="gibbs10k --scaling strong: every rank runs the whole photon split (the chain is the 1-GPU chain bit for "
                          "bit), or the split is partitioned by row strips like the sources (SURVEY 8e)")
+    ap.add_argument("--slice-fuse", type=int, default=None,
+                    help="gibbs10k: CEL_OPT_SLICE_FUSE (N = a slice round of at most N likelihood blocks is ONE launch: the block that finishes a chain's last job "
+                         "steps the chain; 1 = every round, 0 = never: three launches per round; default: the library's)")
     ap.add_argument("--shapes", action="store_true", help="gibbs10k: every sweep also resamples the galaxies' shapes")
     ap.add_argument("--of", type=int, default=0,
                     help="with --scaling strong on ONE GPU (no --gpus): play the ranks of an N-rank job one at a time, each "
@@ -1355,6 +1358,8 @@ def main():
     ctx.set_option(_lib.CEL_OPT_TILE_ORDER, args.tile_order)
     ctx.set_option(_lib.CEL_OPT_PHOTON_LISTS, args.photon_lists)
     ctx.set_option(_lib.CEL_OPT_STAR_TILES, args.star_tiles)
+    if args.slice_fuse is not None:
+        ctx.set_option(_lib.CEL_OPT_SLICE_FUSE, args.slice_fuse)
     backend = "none"
     if world > 1:
         import torch.distributed as td

@@ -17,7 +17,7 @@ CEL_HOST, CEL_DEVICE = 0, 1
 CEL_RENDER_LOGLIK, CEL_RENDER_NO_STORE = 1, 2
 CEL_OPT_KERNEL, CEL_OPT_TAIL_LOG, CEL_OPT_PROFILE, CEL_OPT_TILE_ORDER, CEL_OPT_TILE_ROWS = 1, 2, 3, 4, 5
 CEL_OPT_TILE_TIMING, CEL_OPT_TILE_LAYOUT, CEL_OPT_DEBUG, CEL_OPT_PHOTON_LISTS, CEL_OPT_STAR_TILES, CEL_OPT_SPLIT_REUSE = 6, 7, 8, 9, 10, 11
-CEL_OPT_TAIL_LOG_SOURCE, CEL_OPT_TILE_PARTS, CEL_OPT_INCREMENTAL, CEL_OPT_SPLIT_FULL_BOX = 12, 13, 14, 15
+CEL_OPT_TAIL_LOG_SOURCE, CEL_OPT_TILE_PARTS, CEL_OPT_INCREMENTAL, CEL_OPT_SPLIT_FULL_BOX, CEL_OPT_SLICE_FUSE = 12, 13, 14, 15, 16
 #: CEL_OPT_TAIL_LOG presets.  32 (the default): a skipped component is below eps * e^-32 on its tile, model pixels
 #: agree with the reference to ~1e-13, which is what the parity tests assert (1e-10).  20: the documented fast
 #: preset for callers that need only north_star's 1e-6 -- a skipped component is below eps * 2e-9, the sum of

@@ -108,6 +108,9 @@ struct Prof {
     unsigned seen[CEL_K_COUNT] = {0};   // launches of each kernel since the reset (level 3 times every fourth)
 };
 
+#ifndef SLICE_FUSE_DEFAULT
+#define SLICE_FUSE_DEFAULT 0       // CEL_OPT_SLICE_FUSE: off.  Built and measured in round 6 (cel_slice_locations): no gain at any threshold
+#endif
 struct cel_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -123,6 +126,7 @@ struct cel_ctx {
     double render_T = env_tail_ok() ? atof(getenv("CEL_TAIL_LOG")) : 24.0;
     int live = 0;               // image sets and source sets of this context that have not been destroyed (cel_ctx_destroy refuses)
     int split_full = 0;         // CEL_OPT_SPLIT_FULL_BOX
+    int slice_fuse = SLICE_FUSE_DEFAULT;   // CEL_OPT_SLICE_FUSE
     int incremental = (getenv("CEL_INCREMENTAL") && atoi(getenv("CEL_INCREMENTAL")) == 0) ? 0 : 1;       // CEL_OPT_INCREMENTAL
     int tile_parts = (getenv("CEL_TILE_PARTS") && (atoi(getenv("CEL_TILE_PARTS")) == 1 || atoi(getenv("CEL_TILE_PARTS")) == 2 || atoi(getenv("CEL_TILE_PARTS")) == 4))
                          ? atoi(getenv("CEL_TILE_PARTS")) : 0;       // CEL_OPT_TILE_PARTS (the env var: the initial value, for A/B runs)
@@ -540,6 +544,10 @@ int cel_ctx_set_option(cel_ctx *c, int key, double v) {
         if (v != 0.0 && v != 1.0) return fail(CEL_ERR_INVALID, "CEL_OPT_SPLIT_FULL_BOX must be 0 or 1");
         c->split_full = (int)v;
         return CEL_OK;
+    case CEL_OPT_SLICE_FUSE:
+        if (!(v >= 0.0 && v <= 1e9) || v != floor(v)) return fail(CEL_ERR_INVALID, "CEL_OPT_SLICE_FUSE must be 0, 1 or a block count");
+        c->slice_fuse = (int)v;
+        return CEL_OK;
     case CEL_OPT_TILE_PARTS:
         if (v != 0.0 && v != 1.0 && v != 2.0 && v != 4.0) return fail(CEL_ERR_INVALID, "CEL_OPT_TILE_PARTS must be 0 (by the frame's size), 1, 2 or 4");
         c->tile_parts = (int)v;
@@ -599,6 +607,7 @@ int cel_ctx_get_option(cel_ctx *c, int key, double *v) {
     case CEL_OPT_TILE_PARTS: *v = c->tile_parts; return CEL_OK;
     case CEL_OPT_INCREMENTAL: *v = c->incremental; return CEL_OK;
     case CEL_OPT_SPLIT_FULL_BOX: *v = c->split_full; return CEL_OK;
+    case CEL_OPT_SLICE_FUSE: *v = c->slice_fuse; return CEL_OK;
     case CEL_OPT_PROFILE: *v = (double)c->profile; return CEL_OK;
     case CEL_OPT_TILE_ORDER: *v = (double)c->tile_order; return CEL_OK;
     case CEL_OPT_TILE_ROWS: *v = c->tile_rows; return CEL_OK;
@@ -1659,7 +1668,7 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
                     hipLaunchKernelGGL(k_patch_ll_nz, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
                                        (const int *)d_owner, (const int4 *)d_box, (const int4 *)d_nz, (const int *)im->d_nzmode,
                                        (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_out, (const int *)nullptr,
-                                       (const int *)nullptr);
+                                       (const int *)nullptr, (const SliceFuse *)nullptr);
             } else
                 hipLaunchKernelGGL((k_patch_ll_hw<0, double>), dim3((unsigned)(P * B * nparts)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
                                    d_owner, d_box, d_off, (const double *)d_data, im->d_nelec, im->H, im->W, d_nz, c->tail_T, d_out,
@@ -1827,8 +1836,8 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     // blocks per (chain, band) job in rounds with at most SLICE_SPLIT_JOBS jobs left (measured at config 3: 4 blocks
     // below 2048 jobs 29.4 ms per location step, below 8192 jobs 29.0; 8 blocks 29.4; without 30.3)
     const int SLICE_SPLIT = PLL_PARTS, SLICE_SPLIT_JOBS = 8192;
-    const size_t per_chain = 2 * 8 + 10 * 8 + 4 * 4 + 4 + (size_t)B * 8 * SLICE_SPLIT + 4 + (size_t)B * 4 * 6 * SLICE_SPLIT;
-    const size_t need = per_chain * (size_t)S + 128;
+    const size_t per_chain = 2 * 8 + 10 * 8 + 4 * 4 + 4 + (size_t)B * 8 * SLICE_SPLIT + 4 + (size_t)B * 4 * 6 * SLICE_SPLIT + 3 * 4;
+    const size_t need = per_chain * (size_t)S + 128 + 2 * sizeof(SliceFuse) + 16;
     if (need > im->slice_cap) {
         HIP_TRY(hipStreamSynchronize(st));
         if (im->d_slice) (void)hipFree(im->d_slice);
@@ -1870,8 +1879,14 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     int *d_work_nz = (int *)p; p += 4 * S * B * SLICE_SPLIT;
     int *d_jobs_nz = (int *)p; p += 4 * S * B * SLICE_SPLIT;
     int *d_live_nz = (int *)p; p += 4 * S * B * SLICE_SPLIT;
+    // the fused rounds (SliceFuse, k_slice_state.h): per chain its ticket counter and the blocks the full / the live lists hold for it
+    int *d_tick = (int *)p; p += 4 * S;
+    int *d_need_full = (int *)p; p += 4 * S;
+    int *d_need_live = (int *)p; p += 4 * S;
     int *d_flags = (int *)p;            // [0] chains still running, [1] error bits, [2] likelihood evaluations so far, [3] rounds with work,
-                                        // [4] / [5] live dense / photon-list jobs of the batch, [6..7] byte counter, [8] / [9] dense / photon-list jobs
+                                        // [4] / [5] live dense / photon-list jobs of the batch, [6..7] byte counter, [8] / [9] dense / photon-list jobs;
+                                        // a call that may fuse rounds: [6] chains still running (k_slice_live_jobs, per batch: a fused round keeps no
+                                        // count), [11] / [12] evaluations / rounds with work (k_slice_bytes, at the end)
     // the proposal set: this catalogue with the locations rewritten every round
     HIP_TRY(hipMemcpyAsync(prop->d_type, src->d_type, sizeof(int) * S, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(prop->d_counts, src->d_counts, sizeof(double) * B * S, hipMemcpyDeviceToDevice, st));
@@ -1882,7 +1897,8 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         HIP_TRY(hipMemcpyAsync(d_ids, chain_ids, sizeof(int) * S, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(int) * 11, st));      // [0..3] and [10]: see k_slice.h; the rest is set where it is used
+    HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(int) * 13, st));      // [0..3] and [10]: see k_slice.h; the rest is set where it is used
+    HIP_TRY(hipMemsetAsync(d_tick, 0, sizeof(int) * 2 * S, st));    // the tickets and the full lists' block counts
     const unsigned g256 = (unsigned)((S + 255) / 256);
     hipLaunchKernelGGL(k_slice_init, dim3(g256), dim3(256), 0, st, ss, S, src->d_radec, chain_ids ? d_ids : (const int *)nullptr,
                        im->d_soff, B, (unsigned long long)seed, sigma, d_owner);
@@ -1895,7 +1911,8 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     if (c->variant != 0) {
         const int nent = (int)(S * B * SLICE_SPLIT);
         hipLaunchKernelGGL(k_job_work, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, st, src->d_type, im->d_snz, S, B, d_work,
-                           (const int *)(use_nz ? im->d_nzmode : nullptr), (const int *)im->d_nnz, use_nz ? d_work_nz : (int *)nullptr);
+                           (const int *)(use_nz ? im->d_nzmode : nullptr), (const int *)im->d_nnz, use_nz ? d_work_nz : (int *)nullptr,
+                           use_nz ? d_need_full : (int *)nullptr);
         // members compacted by the whole GPU, then ordered heaviest first by one block (the live-list arrays are free now)
         HIP_TRY(hipMemsetAsync(d_flags + 8, 0, sizeof(int) * 2, st));
         hipLaunchKernelGGL(k_list_members, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, st, d_work, nent, d_live, d_live_nz, d_flags + 8);
@@ -1910,6 +1927,17 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         HIP_TRY(hipStreamSynchronize(st));
         n_dense = h_cnt[0]; n_nz = use_nz ? h_cnt[1] : 0;
     }
+    // One launch per round: every patch of the call is scored at its photons (no dense job: the usual case, and config 5's), so
+    // the block that finishes a chain's last job of a round steps the chain itself (SliceFuse).  With dense jobs in the call the
+    // chains are stepped by k_slice_step as before (the dense kernel carries no ticket).  CEL_OPT_SLICE_FUSE = 0: never fused.
+    // MEASURED, AND OFF BY DEFAULT (round 6, kernel traces of ten sweeps per setting, the same chains: the location step's span
+    // on the device 12.67 ms unfused; fused in rounds of at most 4 096 blocks 12.65, 12 288: 12.70, 32 768: 12.9, every round:
+    // 13.25).  A ticket is a returning atomic every block waits for before it leaves (~2 us of a wave slot) and the stepping block
+    // holds its slot ~7 us longer: on a full round (50 000 blocks on 4 096 slots) 45 us more kernel time against the 27 us of the
+    // step launch and its two gaps; in the late rounds the step's latency moves from a launch of its own to the end of the
+    // likelihood launch and the round gains under 10 us.  c->slice_fuse = N: rounds of at most N blocks are fused (1: every round).
+    const bool fuse_ok = use_nz && c->slice_fuse && n_dense == 0 && n_nz > 0;
+    bool fused = false;                               // of the batch being queued
     int64_t rounds = 0, evals = 0, queued = 0, live = S;
     if (chain_ids) {                    // chains with a negative id are another rank's: they never run here
         live = 0;
@@ -1938,6 +1966,17 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
     pa.recs = im->d_recs; pa.boxes = im->d_boxes; pa.kind = im->d_kind; pa.status = im->d_status; pa.nobox = 1;
     if ((rc = ensure_recs(im, S * B > 0 ? S * B : 1))) return rc;   // (before the pointers are taken)
     pa.recs = im->d_recs; pa.boxes = im->d_boxes; pa.kind = im->d_kind; pa.status = im->d_status;
+    // the fused rounds' arguments, in device memory: [0] for the full lists, [1] for the live lists (they differ in `need`)
+    SliceFuse *d_fz = reinterpret_cast<SliceFuse *>(((uintptr_t)(d_flags + 13) + 15) & ~(uintptr_t)15);
+    if (fuse_ok) {
+        SliceFuse fz[2];
+        memset(fz, 0, sizeof(fz));
+        for (int k = 0; k < 2; k++) {
+            fz[k].tick = d_tick; fz[k].need = k ? d_need_live : d_need_full; fz[k].st = ss; fz[k].ll_pb = d_ll; fz[k].nparts = SLICE_SPLIT;
+            fz[k].B = B; fz[k].sigma = sigma; fz[k].flags = d_flags; fz[k].prop_radec = prop->d_radec; fz[k].owner = d_owner; fz[k].pa = pa;
+        }
+        HIP_TRY(hipMemcpyAsync(d_fz, fz, sizeof(fz), hipMemcpyHostToDevice, st));      // (pageable: staged before the call returns)
+    }
     if (!c->slice_ev[0]) {
         HIP_TRY(hipEventCreateWithFlags(&c->slice_ev[0], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->slice_ev[1], hipEventDisableTiming));
@@ -1956,6 +1995,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
             const int64_t cap_blocks = S * B * SLICE_SPLIT;
             const int64_t gd = use_live ? std::min<int64_t>(live_dense * grow, cap_blocks) : n_dense;
             const int64_t gn = !use_nz ? 0 : (use_live ? std::min<int64_t>(live_nz * grow, cap_blocks) : n_nz);
+            fused = fuse_ok && (c->slice_fuse == 1 || gn <= (int64_t)c->slice_fuse);
             for (int k = 0; k < nb; k++) {
                 // the first round's points; every later round's were named by the step kernel of the round before
                 if (queued == 0) hipLaunchKernelGGL(k_slice_propose, dim3(g256), dim3(256), 0, st, ss, S, prop->d_radec, d_owner, d_flags);
@@ -1977,12 +2017,14 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
                     }
                     if (gn > 0) {
                         int pi = prof_slot(c, CEL_K_PATCH_LL);
+                        const SliceFuse *fq = fused ? d_fz + (use_live ? 1 : 0) : nullptr;
                         LAUNCH_EV(k_patch_ll_nz, dim3((unsigned)gn), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
                                   (const int *)d_owner, (const int4 *)im->d_sbox, (const int4 *)im->d_snz, (const int *)im->d_nzmode,
                                   (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_ll,
-                                  (const int *)(use_live ? d_live_nz : d_jobs_nz), (const int *)(use_live ? d_flags + 5 : nullptr));
+                                  (const int *)(use_live ? d_live_nz : d_jobs_nz), (const int *)(use_live ? d_flags + 5 : nullptr), fq);
                     }
                 }
+                if (!fused)
                 hipLaunchKernelGGL(k_slice_step, dim3((unsigned)((S + 63) / 64)), dim3(64 * B), 0, st, ss, S, B, ostr, d_ll, sigma, d_flags, (int)queued, prop->d_radec, d_owner, pa);
                 queued++;
             }
@@ -1990,10 +2032,11 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
             deal_of[slot] = 0;
             if (c->variant != 0) {          // the running chains' blocks, for the next batch; few chains left: every job dealt
                 deal_of[slot] = (live * B <= SLICE_SPLIT_JOBS) ? 1 : 0;
-                HIP_TRY(hipMemsetAsync(d_flags + 4, 0, sizeof(int) * 2, st));
+                HIP_TRY(hipMemsetAsync(d_flags + 4, 0, sizeof(int) * (fuse_ok ? 3 : 2), st));
+                if (fuse_ok) HIP_TRY(hipMemsetAsync(d_need_live, 0, sizeof(int) * S, st));
                 hipLaunchKernelGGL(k_slice_live_jobs, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, ss, S, B, d_live, d_flags + 4,
                                    (const int *)(use_nz ? im->d_nzmode : nullptr), d_live_nz, d_flags + 5, (const int *)im->d_nnz,
-                                   (const int4 *)im->d_snz, deal_of[slot]);
+                                   (const int4 *)im->d_snz, deal_of[slot], fuse_ok ? d_need_live : (int *)nullptr, fuse_ok ? d_flags + 6 : (int *)nullptr);
             }
             HIP_TRY(hipMemcpyAsync(h_flag_slot[slot], d_flags, sizeof(int) * 11, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipEventRecord(c->slice_ev[slot], st));
@@ -2006,15 +2049,14 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         HIP_TRY(hipEventSynchronize(c->slice_ev[slot]));
         rb++;
         const int *hf = h_flag_slot[slot];
-        const int running = hf[last_par[slot] ? 10 : 0], err = hf[1];      // the batch's last round's slot
+        const int running = fuse_ok ? hf[6] : hf[last_par[slot] ? 10 : 0], err = hf[1];    // the batch's last round's slot; a call that may fuse: k_slice_live_jobs' count
         live = running;
         if (c->variant != 0) { live_dense = hf[4]; live_nz = hf[5]; deal_read = deal_of[slot]; }
         if (err & 3) {
             (void)hipStreamSynchronize(st);                      // the batch still in flight works on this call's buffers
             return fail(CEL_ERR_INVALID, (err & 1) ? "Slice sampler got a NaN" : "Slice sampler shrank to zero!");
         }
-        evals = hf[2];
-        rounds = hf[3];
+        if (!fuse_ok) { evals = hf[2]; rounds = hf[3]; }
         if (running == 0) finished = true;                       // whatever is still queued scores nothing
         else if (queued >= max_rounds && rb == qb)
             return fail(CEL_ERR_INVALID, "cel_slice_locations: %d rounds without every chain finishing", max_rounds);
@@ -2032,11 +2074,13 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         // per shrink step), each walking its photon rectangles
         HIP_TRY(hipMemsetAsync(d_bytes, 0, sizeof(unsigned long long), st));
         hipLaunchKernelGGL(k_slice_bytes, dim3(g256), dim3(256), 0, st, ss, S, B, (const int4 *)im->d_snz, d_bytes,
-                           (const int *)(use_nz ? im->d_nzmode : nullptr), (const int64_t *)im->d_nzoff);
+                           (const int *)(use_nz ? im->d_nzmode : nullptr), (const int64_t *)im->d_nzoff, fuse_ok ? d_flags + 11 : (int *)nullptr);
         HIP_TRY(hipMemcpyAsync(h_flag_slot[0] + 6, d_bytes, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        if (fuse_ok) HIP_TRY(hipMemcpyAsync(h_flag_slot[1], d_flags + 11, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
     if (stats) {
+        if (fuse_ok) { evals = h_flag_slot[1][0]; rounds = h_flag_slot[1][1]; }    // what the per-round counts of the unfused rounds add up to
         stats[0] = rounds; stats[1] = evals;
         stats[2] = (int64_t)(*reinterpret_cast<unsigned long long *>(h_flag_slot[0] + 6));
         stats[3] = queued;
@@ -2171,7 +2215,7 @@ int cel_slice_sample(cel_images *im, cel_sources *src, int param, const int32_t 
                     int pi = prof_slot(c, CEL_K_PATCH_LL);
                     LAUNCH_EV(k_patch_ll_nz, dim3((unsigned)n_nz), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, P, im->d_recs,
                               (const int *)d_owner, (const int4 *)im->d_sbox, (const int4 *)im->d_snz, (const int *)im->d_nzmode,
-                              (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_ll, (const int *)d_list_nz, (const int *)nullptr);
+                              (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_ll, (const int *)d_list_nz, (const int *)nullptr, (const SliceFuse *)nullptr);
                 }
             }
             hipLaunchKernelGGL(k_sg_consume, dim3(g256), dim3(256), 0, st, g, rs, S, B, ostr, (const double *)d_ll, d_flags);

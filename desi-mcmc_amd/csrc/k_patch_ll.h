@@ -23,6 +23,7 @@
 //                  drop rule relative to the source itself (mode 0) or to the sky (mode 1), then
 //                  reduced against the patch data with the table log.
 #pragma once
+#include "k_slice_state.h"
 #include "hw_source.h"
 
 // TZ: the patch data's element type -- double for patches a caller hands over, int for the device-resident photon
@@ -454,7 +455,11 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
               const int *__restrict__ nzmode, const int64_t *__restrict__ nzoff, const NzEntry *__restrict__ nzlist,
               double *__restrict__ out /* PLL_PARTS doubles per job */,
               const int *__restrict__ job_order /* per BLOCK: job << 3 | part << 1 | split, or nullptr: block = job, whole */,
-              const int *__restrict__ job_count) {
+              const int *__restrict__ job_count,
+              const SliceFuse *__restrict__ fzp /* != nullptr (the location sampler's fused rounds): the block that finishes a chain's
+                              last job of the round steps the chain (k_slice_state.h).  A pointer, not the 200-byte struct: as a
+                              kernel argument its fields sat in scalar registers through the photon loop (40 SGPR spills, the
+                              kernel 11 % slower whether a round was fused or not) */) {
     __shared__ double et[256];                 // 2^(j/256): the photon kernel's exponentials take a cubic on it (exp_tab256_p3)
     __shared__ double ltq[128];
     __shared__ double cq[8 * K_GAL];
@@ -547,8 +552,9 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
         use_gal = (K == K_GAL) && (__ballot(lane < K && !gal_ok) == 0ull);
     }
     if (done) {
-        if (split) { if (lane == 0) outp[part] = (part == 0) ? mass_only : 0.0; }
-        else if (lane < PLL_PARTS) outp[lane] = (lane == 0) ? mass_only : 0.0;
+        if (split) { if (lane == 0) sl_put(outp + part, (part == 0) ? mass_only : 0.0, fzp != nullptr); }
+        else if (lane < PLL_PARTS) sl_put(outp + lane, (lane == 0) ? mass_only : 0.0, fzp != nullptr);
+        if (fzp) sl_fused_step(*fzp, p, lane);
         return;
     }
     __syncthreads();
@@ -584,8 +590,9 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
         s = __shfl(s, 0);
         if (lane == k) mine = s;
     }
-    if (split) { if (lane == part) outp[part] = mine; }
-    else if (lane < PLL_PARTS) outp[lane] = mine;
+    if (split) { if (lane == part) sl_put(outp + part, mine, fzp != nullptr); }
+    else if (lane < PLL_PARTS) sl_put(outp + lane, mine, fzp != nullptr);
+    if (fzp) sl_fused_step(*fzp, p, lane);
 }
 
 // work estimate of every (chain, band) job of the device slice sampler: components x pixels of the
@@ -599,7 +606,8 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
 __global__ void __launch_bounds__(256)
 k_job_work(const int *__restrict__ type, const int4 *__restrict__ nzbox, int64_t S, int B, int *__restrict__ work /* S*B*PLL_PARTS */,
            const int *__restrict__ nzmode = nullptr, const int *__restrict__ nnz = nullptr,
-           int *__restrict__ work_nz = nullptr /* with nzmode: the blocks of the jobs scored at their photons */) {
+           int *__restrict__ work_nz = nullptr /* with nzmode: the blocks of the jobs scored at their photons */,
+           int *__restrict__ need = nullptr /* per chain, zeroed by the caller: the blocks the two lists hold for it (SliceFuse) */) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S * B * PLL_PARTS) return;
     const int64_t job = i / PLL_PARTS;
@@ -623,6 +631,7 @@ k_job_work(const int *__restrict__ type, const int4 *__restrict__ nzbox, int64_t
             if (deal_n || part == 0) wn = (int)(min(deal_n ? ws / PLL_PARTS : ws, (long long)0x1fffffff) << 1) | (deal_n ? 1 : 0);
         }
         work_nz[i] = wn;
+        if (need && (w >= 0 || wn >= 0)) atomicAdd(&need[job / B], 1);
     }
 }
 

@@ -12,34 +12,7 @@
 // drawn in the reference's order), so a chain takes the same trajectory on either engine.
 #pragma once
 #include "device_common.h"
-
-#define SL_LEVEL 0
-#define SL_SHRINK 4
-#define SL_FINAL 7
-
-struct SliceState {            // SoA over chains
-    unsigned long long *key, *count;
-    double *x;                 // current location (ra, dec), 2 per chain
-    double *x0;                // location the current direction started from, 2 per chain
-    double *lower, *upper, *log_u, *llh_s, *new_z, *new_llh;
-    int *phase, *kdir, *first; // first = axis of the chain's first direction (0 or 1)
-    int *steps;                // shrink steps taken (diagnostic)
-};
-
-__device__ inline unsigned long long sl_mix(unsigned long long x) {
-    x += 0x9E3779B97F4A7C15ull;
-    unsigned long long z = x;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
-__device__ inline double sl_uniform(const SliceState &st, int64_t s) {
-    const unsigned long long c = st.count[s];
-    st.count[s] = c + 1ull;
-    const unsigned long long z = sl_mix(st.key[s] + c * 0x9E3779B97F4A7C15ull);
-    return ((double)(z >> 11) + 0.5) * (1.0 / 9007199254740992.0);
-}
+#include "k_slice_state.h"
 
 // ---- Gamma variates on per-element counter-based streams -----------------------------------------------------------------
 // celeste_mcmc.gamma_by_stream on the device: the flux conditionals' Gamma(a_0 + photons) draws of Source.resample_fluxes
@@ -83,18 +56,6 @@ k_gamma_streams(int64_t n, const double *__restrict__ a, unsigned long long seed
     out[i] = res;
 }
 
-// slicesample.py:142-146: the interval about the current point and the random part of the level
-__device__ inline void sl_start_direction(const SliceState &st, int64_t s, double sigma) {
-#pragma clang fp contract(off)
-    st.x0[2 * s] = st.x[2 * s];
-    st.x0[2 * s + 1] = st.x[2 * s + 1];
-    const double up = sigma * sl_uniform(st, s);
-    st.upper[s] = up;
-    st.lower[s] = up - sigma;
-    st.log_u[s] = log(sl_uniform(st, s));
-    st.phase[s] = SL_LEVEL;
-}
-
 __global__ void __launch_bounds__(256)
 k_slice_init(SliceState st, int64_t S, const double *__restrict__ radec, const int *__restrict__ chain_ids,
              const int64_t *__restrict__ soff, int B, unsigned long long seed, double sigma, int *__restrict__ owner) {
@@ -117,24 +78,6 @@ k_slice_init(SliceState st, int64_t S, const double *__restrict__ radec, const i
     if (has_patch) sl_start_direction(st, s, sigma);
     else st.phase[s] = SL_FINAL;
     owner[s] = has_patch ? (int)s : -1;
-}
-
-// the point an unfinished chain needs next -> the proposal set's radec; owner[s] = -1 retires a chain
-__device__ __forceinline__ void sl_propose_chain(const SliceState &st, int64_t s, double *__restrict__ prop_radec, int *__restrict__ owner) {
-#pragma clang fp contract(off)
-    const int ph = st.phase[s];
-    if (ph == SL_FINAL) { owner[s] = -1; return; }
-    double z = 0.0;
-    if (ph == SL_SHRINK) {
-        z = (st.upper[s] - st.lower[s]) * sl_uniform(st, s) + st.lower[s];      // slicesample.py:172
-        st.new_z[s] = z;
-        st.steps[s] += 1;
-    }
-    const int axis = st.kdir[s] == 0 ? st.first[s] : 1 - st.first[s];
-    const double d0 = axis == 0 ? 1.0 : 0.0, d1 = axis == 1 ? 1.0 : 0.0;
-    prop_radec[2 * s] = st.x0[2 * s] + z * d0;
-    prop_radec[2 * s + 1] = st.x0[2 * s + 1] + z * d1;
-    owner[s] = (int)s;
 }
 
 // Flags of a call (ints): [0] / [10] chains still running after the last even / odd round, [1] error bits, [2] likelihood
@@ -176,52 +119,7 @@ k_slice_step(SliceState st, int64_t S, int B, int nparts /* blocks per (chain, b
         *prev = 0;                                               // round + 1 adds here
     }
     bool active = false, scored = false;
-    if (s < S) {
-        const int ph = st.phase[s];
-        if (ph != SL_FINAL) {
-            scored = true;
-            double v = 0.0;
-            for (int b = 0; b < B; b++) {
-                const double *q = ll_pb + (s * B + b) * nparts;
-                double x = q[0];
-                for (int k = 1; k < nparts; k++) x += q[k];
-                v += x;
-            }
-            if (ph == SL_LEVEL) {
-                st.llh_s[s] = st.log_u[s] + v;                                   // slicesample.py:146
-                st.phase[s] = SL_SHRINK;
-            } else {
-                if (v != v) atomicOr(err, 1);                                    // "Slice sampler got a NaN"
-                const double z = st.new_z[s];
-                if (v > st.llh_s[s]) {                                           // accepted (:177; no doubling, nothing to test)
-                    st.new_llh[s] = v;
-                    const int axis = st.kdir[s] == 0 ? st.first[s] : 1 - st.first[s];
-                    const double d0 = axis == 0 ? 1.0 : 0.0, d1 = axis == 1 ? 1.0 : 0.0;
-                    st.x[2 * s] = st.x0[2 * s] + z * d0;                        // :203
-                    st.x[2 * s + 1] = st.x0[2 * s + 1] + z * d1;
-                    const int k = st.kdir[s] + 1;
-                    st.kdir[s] = k;
-                    if (k >= 2) st.phase[s] = SL_FINAL;
-                    else {
-                        // the second axis starts where the first ended: its level needs the log-likelihood
-                        // of a point that has just been scored (the reference evaluates it again and gets
-                        // the same number), so the chain goes straight to shrinking
-                        sl_start_direction(st, s, sigma);
-                        st.llh_s[s] = st.log_u[s] + v;
-                        st.phase[s] = SL_SHRINK;
-                    }
-                } else if (z < 0.0) {
-                    st.lower[s] = z;
-                } else if (z > 0.0) {
-                    st.upper[s] = z;
-                } else {
-                    atomicOr(err, 2);                                            // "Slice sampler shrank to zero!"
-                    st.phase[s] = SL_FINAL;
-                }
-            }
-            active = st.phase[s] != SL_FINAL;
-        }
-    }
+    if (s < S) scored = sl_consume_chain(st, s, B, nparts, ll_pb, sigma, err, active);
     const unsigned long long m = __ballot(active), me = __ballot(scored);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_active, __popcll(m));
     if ((threadIdx.x & 63) == 0 && me) atomicAdd(err + 1, __popcll(me));         // evaluations so far (int: < 2^31 per call)
@@ -249,9 +147,15 @@ k_slice_step(SliceState st, int64_t S, int B, int nparts /* blocks per (chain, b
 __global__ void __launch_bounds__(256)
 k_slice_live_jobs(SliceState st, int64_t S, int B, int *__restrict__ list, int *__restrict__ count,
                   const int *__restrict__ nzmode, int *__restrict__ list_nz, int *__restrict__ count_nz,
-                  const int *__restrict__ nnz, const int4 *__restrict__ nzbox, int deal_all) {
+                  const int *__restrict__ nnz, const int4 *__restrict__ nzbox, int deal_all,
+                  int *__restrict__ need = nullptr /* per chain, zeroed by the caller: the blocks these lists hold for it (SliceFuse) */,
+                  int *__restrict__ running = nullptr /* zeroed by the caller: chains still running (the fused rounds keep no per-round count) */) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool alive = i < S * B && st.phase[i / B] != SL_FINAL;
+    if (running) {
+        const unsigned long long rm = __ballot(alive && (i % B) == 0);
+        if ((threadIdx.x & 63) == 0 && rm) atomicAdd(running, __popcll(rm));
+    }
     bool nz = false, deal = deal_all != 0;
     if (alive) {
         nz = nzmode && nzmode[i];
@@ -267,6 +171,7 @@ k_slice_live_jobs(SliceState st, int64_t S, int B, int *__restrict__ list, int *
     const int at_d = wave_reserve(count, (alive && !nz) ? per : 0);
     const int at_n = nzmode ? wave_reserve(count_nz, (alive && nz) ? per : 0) : 0;
     if (!alive) return;
+    if (need) atomicAdd(&need[i / B], per);
     int *dst = nz ? list_nz : list;
     const int at = nz ? at_n : at_d;
     for (int part = 0; part < per; part++) dst[at + part] = (int)(i << 3) | (part << 1) | (deal ? 1 : 0);
@@ -277,9 +182,15 @@ k_slice_live_jobs(SliceState st, int64_t S, int B, int *__restrict__ list, int *
 // the rectangle that holds the source's photons (k_patch_nzbox)
 __global__ void __launch_bounds__(256)
 k_slice_bytes(SliceState st, int64_t S, int B, const int4 *__restrict__ nzbox, unsigned long long *__restrict__ bytes,
-              const int *__restrict__ nzmode, const int64_t *__restrict__ nzoff) {
+              const int *__restrict__ nzmode, const int64_t *__restrict__ nzoff,
+              int *__restrict__ evals_rounds = nullptr /* [0] += evaluations of the call, [1] = max over chains = rounds with work (the fused rounds count neither as they go) */) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long v = 0ull;
+    if (evals_rounds) {
+        int ev = (s < S && st.new_llh[s] == st.new_llh[s]) ? 1 + st.steps[s] : 0, mx = ev;
+        for (int o = 32; o > 0; o >>= 1) { ev += __shfl_xor(ev, o); mx = max(mx, __shfl_xor(mx, o)); }
+        if ((threadIdx.x & 63) == 0 && ev) { atomicAdd(evals_rounds, ev); atomicMax(evals_rounds + 1, mx); }
+    }
     if (s < S && st.new_llh[s] == st.new_llh[s]) {          // NaN: the chain never ran
         unsigned long long per = 0ull;
         for (int b = 0; b < B; b++) {

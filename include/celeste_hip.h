@@ -89,6 +89,11 @@ enum {
                                ModelGibbs(conditional="exact") need (DESIGN Q20: with the reference's rule a big galaxy's first box
                                row and column -- up to 10^-4 of its photons -- are modelled but never attributed).  The stamp-mass
                                short cut of CEL_OPT_SPLIT_REUSE = 2 is not taken then */
+    CEL_OPT_SLICE_FUSE = 16, /* 0 (default): a round of cel_slice_locations is three launches (likelihoods, chain step).  N > 1: a round
+                                of at most N likelihood blocks is ONE launch when every patch of the call is scored at its photons --
+                                the block that finishes a chain's last job of the round consumes the chain's log-likelihoods, names
+                                its next point and writes that point's records; 1: every round.  The chains are the same bit for
+                                bit either way.  Measured in round 6: no gain at any N, hence off */
     CEL_OPT_TILE_PARTS = 13, /* how many one-wave blocks share a render tile of the general 32 x 64 kernel.  0 (default) = by
                                the frame's size: 4 for at most 512 tiles, 2 for at most 3 072, else 1 -- a frame of few tiles
                                (one rank's row strip of a field cut 8 ways, a 51 x 51 real field) finishes when its heaviest

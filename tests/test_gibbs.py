@@ -487,6 +487,48 @@ def test_slice_locations_error_paths(cel):
     assert st["rounds"] >= 4 and st["evals"] >= 4 * 20 and np.all(np.isfinite(llh))
 
 
+@pytest.mark.parametrize("S,H,W", [(60, 192, 224), (700, 512, 640)])
+def test_fused_slice_rounds_are_the_three_launch_rounds_bit_for_bit(cel, S, H, W):
+    """CEL_OPT_SLICE_FUSE (round 6; an option, off by default: measured without gain): a round of cel_slice_locations as ONE launch -- the likelihood block that finishes a chain's
+    last job of the round steps the chain -- against the round of three launches (likelihoods, k_slice_step): every chain ends at
+    the same place with the same log-likelihood, to the last bit, after the same number of rounds and evaluations; repeated runs
+    of the fused form agree with themselves (whichever block draws a chain's last ticket); chains of another rank (negative ids)
+    stay put; a call with densely scored patches (CEL_OPT_PHOTON_LISTS = 2) is not fused and still agrees.  The larger field
+    has rounds of full lists, of live lists and of live lists with every job dealt."""
+    from desi_mcmc_amd import synth, _lib
+    ctx = cel.default_context(0)
+    f = synth.SyntheticField(ctx, S, 5, H, W, frac_gal=0.5, seed=6)
+    u0 = f.src["radec"].copy()
+
+    def run(fuse, ids=None, lists=0):
+        ctx.set_option(_lib.CEL_OPT_SLICE_FUSE, fuse)
+        ctx.set_option(_lib.CEL_OPT_PHOTON_LISTS, lists)
+        try:
+            f.sources.set(f.src["type"], u0, f.src["counts"], f.src["shape"])
+            f.images.render(f.sources, loglik=True)
+            f.images.photon_split_resident(f.sources, seed=11)
+            return f.images.slice_locations(f.sources, 1e-3, seed=5, chain_ids=ids)
+        finally:
+            ctx.set_option(_lib.CEL_OPT_SLICE_FUSE, default)
+            ctx.set_option(_lib.CEL_OPT_PHOTON_LISTS, 0)
+    default = ctx.get_option(_lib.CEL_OPT_SLICE_FUSE)      # N: rounds of at most N likelihood blocks are fused (1: every round; 0, the default: none)
+    assert default == 0
+    u_ref, l_ref, st_ref = run(0)
+    for fuse in (1, 1, 1, 4096, 64):                      # every round fused (three times); fused from a middle / a late round on
+        u, l, st = run(fuse)
+        assert np.array_equal(u, u_ref) and np.array_equal(l, l_ref, equal_nan=True)
+        assert st["rounds"] == st_ref["rounds"] and st["evals"] == st_ref["evals"] and st["evals"] >= 4 * S
+    assert not np.array_equal(u_ref, u0)
+    ids = np.where(np.arange(S) % 3 == 1, -1, np.arange(S)).astype(np.int32)           # a third of the chains are another rank's
+    u_a, l_a, st_a = run(0, ids)
+    u_b, l_b, st_b = run(1, ids)
+    assert np.array_equal(u_a, u_b) and np.array_equal(l_a, l_b, equal_nan=True) and st_a["evals"] == st_b["evals"]
+    assert np.array_equal(u_b[ids < 0], u0[ids < 0]) and np.array_equal(u_b[ids >= 0], u_ref[ids >= 0])
+    u_d, l_d, st_d = run(1, None, 2)                      # every patch densely: the fused form does not apply, the call still runs
+    assert st_d["rounds"] == st_ref["rounds"]
+    np.testing.assert_allclose(l_d, l_ref, rtol=1e-9)
+
+
 def test_conditional_loglik_does_not_depend_on_how_its_jobs_are_dealt(cel):
     """a proposal's value is bit for bit the same in a small call (every (proposal, band) job dealt to four
     blocks by chunk) and inside a call of 2 000 proposals (one block per job): the kernel sums a job's chunks in

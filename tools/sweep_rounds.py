@@ -22,3 +22,16 @@ for i, (s, e, _) in enumerate(nz):
     nxt = nz[i + 1][0] if i + 1 < len(nz) else max(r[1] for r in last if r[0] < e + 200000 and r[0] >= s)
     busy = sum(min(r[1], nxt) - r[0] for r in last if s <= r[0] < nxt)
     print("%4d  %8.3f  %6.1f  %8.1f  %8.1f" % (i, (s - t0) / 1e6, (e - s) / 1e3, (nxt - s) / 1e3, busy / 1e3))
+
+# every sweep of the trace: the location step's span on the device (first likelihood launch -> the end of the last kernel before
+# the trace render) and its likelihood-kernel time
+splits = [i for i, r in enumerate(rows) if "k_photon_split_hw" in r[2]] + [len(rows)]
+print("per sweep: rounds, location span ms (first k_patch_ll_nz start -> last k_patch_ll_nz / k_slice_step end), nz kernel ms")
+for a, b in zip(splits[:-1], splits[1:]):
+    sw = rows[a:b]
+    nzs = [r for r in sw if r[2].startswith("k_patch_ll_nz")]
+    if not nzs:
+        continue
+    tail = [r for r in sw if r[2].startswith("k_patch_ll_nz") or r[2].startswith("k_slice_step")]
+    print("   %3d rounds  span %8.3f ms   nz %8.3f ms   launches of k_slice_step %d" % (len(nzs), (max(r[1] for r in tail) - nzs[0][0]) / 1e6,
+          sum(e - s for s, e, _ in nzs) / 1e6, sum(1 for r in sw if r[2].startswith("k_slice_step"))))
