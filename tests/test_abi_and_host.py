@@ -440,6 +440,71 @@ def _stamps_mode_walk(built, celeste, celeste_src):
     assert len(celeste._LIST_CACHE) <= celeste._LIST_CACHE_MAX
 
 
+def test_native_gather_reads_what_the_numpy_passes_read(built):
+    """csrc_host/srcgather.c (one C pass over the objects' slots) against celeste._gather_plain's numpy passes: the same bits for
+    every flux convention and container the fast path takes (ndarray / dict fluxes, python and numpy scalars, untyped rows), and
+    a clean hand-over to the general path -- same values, same exceptions -- for everything it does not (a temperature star, a
+    float32 or list location, a numpy-integer type, a subclass, fluxes of another length, a missing flux)."""
+    from desi_mcmc_amd import celeste
+
+    class Im(object):
+        def __init__(self, band, calib, kappa):
+            self.band, self.calib, self.kappa = band, calib, kappa
+
+        def nmgy2counts(self, flux):
+            return (flux / self.calib) * self.kappa
+    ims = [Im(b, 0.004 + 0.001 * k, 4.0 + 0.2 * k) for k, b in enumerate("zgu")]
+    bidx = [4, 1, 0]
+    calib, kappa = np.array([im.calib for im in ims]), np.array([im.kappa for im in ims])
+    rs = np.random.RandomState(7)
+    assert celeste._native_gather(), "the host helper is built by __graft_entry__.build()"
+
+    def make(i):
+        fl = rs.rand(5) * 10 + 1
+        return built.SrcParams(u=rs.rand(2), a=[0, 1, None, True, np.int64(1)][i % 5], fluxes=dict(zip("ugriz", fl)) if i % 2 else fl,
+                               theta=.4 if i % 3 else np.float64(.3), sigma=1.5, phi=7 * i, rho=.6)      # (phi: a python int)
+
+    def both(ps, fn=celeste.expected_photons):
+        out = []
+        for native in (None, False):
+            celeste._NATIVE[0] = native
+            try:
+                out.append(celeste._gather_plain(ps, ims, fn, bidx, calib, kappa))
+            except Exception as e:                       # noqa: BLE001 -- compared below
+                out.append(e)
+            finally:
+                celeste._NATIVE[0] = None
+        a, b = out
+        if isinstance(b, Exception):
+            assert type(a) is type(b) and str(a) == str(b), (a, b)
+        else:
+            assert all(x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b))
+        return b
+    ps = [make(i) for i in range(300)]
+    both(ps)
+    both(ps, fn="flux_dict convention")
+    # the hand-overs: one odd object anywhere in the list
+    class Sub(built.SrcParams):
+        __slots__ = ()
+    odd = [built.SrcParams(u=rs.rand(2).astype(np.float32), a=0, fluxes=rs.rand(5)),                   # float32 location
+           built.SrcParams(u=list(rs.rand(2)), a=0, fluxes=rs.rand(5)),                                # a list
+           built.SrcParams(u=rs.rand(2), a=0, fluxes=rs.rand(5), t=5000.0, b=1.0),                     # a temperature star: the hook
+           built.SrcParams(u=rs.rand(2), a=1, fluxes=rs.rand(5), theta=.5, sigma=None, phi=1., rho=.5),  # a shape that is no number (NaN, by numpy's rule)
+           built.SrcParams(u=rs.rand(2), a=None, fluxes=None),                                         # no flux at all
+           built.SrcParams(u=rs.rand(2), a=0, fluxes={"u": 1.0, "g": 2.0}),                            # a band missing
+           built.SrcParams(u=rs.rand(4)[::2], a=0, fluxes=rs.rand(5)),                                 # a strided view
+           Sub(u=rs.rand(2), a=0, fluxes=rs.rand(5))]
+    for o in odd:
+        both(ps[:40] + [o] + ps[40:80])
+    hook = celeste.photons_expected_brightness
+    try:
+        celeste.photons_expected_brightness = lambda t, b, band: 123.0
+        got = both(ps[:10] + [odd[2]])
+        assert np.all(got[2][10] == 123.0)
+    finally:
+        celeste.photons_expected_brightness = hook
+
+
 def test_list_cache_audit_catches_an_unstamped_in_place_edit(built):
     """An object of a list changed IN PLACE without an attribute assignment (src.u[0] = x, src.fluxes['r'] = f) moves no
     stamp.  The DEFAULT mode ("exact") re-reads every source on every call, as the reference does (celeste.py:203-219): the
