@@ -1665,7 +1665,7 @@ int cel_patch_loglik_multi(cel_images *im, cel_sources *src, const int32_t *owne
                                    d_owner, d_box, d_off, i_data, im->d_nelec, im->H, im->W, d_nz, c->tail_T, d_out,
                                    (const int *)nullptr, nsplit, (const int *)nullptr, (const int *)(nzl ? im->d_nzmode : nullptr), 0, nparts);
                 if (nzl)                    // ... and the proposals whose patch is scored at its photons (the others return at once)
-                    hipLaunchKernelGGL(k_patch_ll_nz, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
+                    hipLaunchKernelGGL(k_patch_ll_nz<false>, dim3((unsigned)(P * B)), dim3(64), 0, c->stream, im->d_bands, B, P, im->d_recs,
                                        (const int *)d_owner, (const int4 *)d_box, (const int4 *)d_nz, (const int *)im->d_nzmode,
                                        (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_out, (const int *)nullptr,
                                        (const int *)nullptr, (const SliceFuse *)nullptr);
@@ -2018,10 +2018,16 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
                     if (gn > 0) {
                         int pi = prof_slot(c, CEL_K_PATCH_LL);
                         const SliceFuse *fq = fused ? d_fz + (use_live ? 1 : 0) : nullptr;
-                        LAUNCH_EV(k_patch_ll_nz, dim3((unsigned)gn), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
-                                  (const int *)d_owner, (const int4 *)im->d_sbox, (const int4 *)im->d_snz, (const int *)im->d_nzmode,
-                                  (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_ll,
-                                  (const int *)(use_live ? d_live_nz : d_jobs_nz), (const int *)(use_live ? d_flags + 5 : nullptr), fq);
+                        if (fq)
+                            LAUNCH_EV(k_patch_ll_nz<true>, dim3((unsigned)gn), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
+                                      (const int *)d_owner, (const int4 *)im->d_sbox, (const int4 *)im->d_snz, (const int *)im->d_nzmode,
+                                      (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_ll,
+                                      (const int *)(use_live ? d_live_nz : d_jobs_nz), (const int *)(use_live ? d_flags + 5 : nullptr), fq);
+                        else
+                            LAUNCH_EV(k_patch_ll_nz<false>, dim3((unsigned)gn), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, S, im->d_recs,
+                                      (const int *)d_owner, (const int4 *)im->d_sbox, (const int4 *)im->d_snz, (const int *)im->d_nzmode,
+                                      (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_ll,
+                                      (const int *)(use_live ? d_live_nz : d_jobs_nz), (const int *)(use_live ? d_flags + 5 : nullptr), fq);
                     }
                 }
                 if (!fused)
@@ -2213,7 +2219,7 @@ int cel_slice_sample(cel_images *im, cel_sources *src, int param, const int32_t 
                 }
                 if (n_nz > 0) {
                     int pi = prof_slot(c, CEL_K_PATCH_LL);
-                    LAUNCH_EV(k_patch_ll_nz, dim3((unsigned)n_nz), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, P, im->d_recs,
+                    LAUNCH_EV(k_patch_ll_nz<false>, dim3((unsigned)n_nz), dim3(64), st, EV0(c, pi), EV1(c, pi), im->d_bands, B, P, im->d_recs,
                               (const int *)d_owner, (const int4 *)im->d_sbox, (const int4 *)im->d_snz, (const int *)im->d_nzmode,
                               (const int64_t *)im->d_nzoff, (const NzEntry *)im->d_nzlist, d_ll, (const int *)d_list_nz, (const int *)nullptr, (const SliceFuse *)nullptr);
                 }

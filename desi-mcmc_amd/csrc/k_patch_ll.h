@@ -449,6 +449,10 @@ __device__ __forceinline__ double nz_trip_gal(const NzEntry *__restrict__ L, int
 // SIMD instead of two hide the job's chain of dependent loads (job -> owner -> record -> list).
 #define NZ_TRIP 256          // photons per trip of the main loop (four per lane)
 #define NZ_SPLIT_PHOTONS 2048   // a list longer than this is worth dealing to PLL_PARTS blocks (k_job_work, k_slice_live_jobs)
+// FUSE = true: the instantiation of the fused slice rounds (CEL_OPT_SLICE_FUSE, an opt-in experiment: k_slice_state.h).  It is
+// a kernel of its own because the code behind `if (fzp)` cost the plain kernel 1.3 % (10.96 -> 11.10 ms per sweep, same box, same
+// chains) although the branch was never taken.
+template <bool FUSE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec *__restrict__ recs,
               const int *__restrict__ owner, const int4 *__restrict__ pbox, const int4 *__restrict__ nzbox,
@@ -456,10 +460,9 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
               double *__restrict__ out /* PLL_PARTS doubles per job */,
               const int *__restrict__ job_order /* per BLOCK: job << 3 | part << 1 | split, or nullptr: block = job, whole */,
               const int *__restrict__ job_count,
-              const SliceFuse *__restrict__ fzp /* != nullptr (the location sampler's fused rounds): the block that finishes a chain's
-                              last job of the round steps the chain (k_slice_state.h).  A pointer, not the 200-byte struct: as a
-                              kernel argument its fields sat in scalar registers through the photon loop (40 SGPR spills, the
-                              kernel 11 % slower whether a round was fused or not) */) {
+              const SliceFuse *__restrict__ fzp /* FUSE: the block that finishes a chain's last job of the round steps the chain
+                              (k_slice_state.h).  A pointer, not the 200-byte struct: as a kernel argument its fields sat in scalar
+                              registers through the photon loop (40 SGPR spills, the kernel 11 % slower) */) {
     __shared__ double et[256];                 // 2^(j/256): the photon kernel's exponentials take a cubic on it (exp_tab256_p3)
     __shared__ double ltq[128];
     __shared__ double cq[8 * K_GAL];
@@ -552,9 +555,9 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
         use_gal = (K == K_GAL) && (__ballot(lane < K && !gal_ok) == 0ull);
     }
     if (done) {
-        if (split) { if (lane == 0) sl_put(outp + part, (part == 0) ? mass_only : 0.0, fzp != nullptr); }
-        else if (lane < PLL_PARTS) sl_put(outp + lane, (lane == 0) ? mass_only : 0.0, fzp != nullptr);
-        if (fzp) sl_fused_step(*fzp, p, lane);
+        if (split) { if (lane == 0) sl_put(outp + part, (part == 0) ? mass_only : 0.0, FUSE); }
+        else if (lane < PLL_PARTS) sl_put(outp + lane, (lane == 0) ? mass_only : 0.0, FUSE);
+        if (FUSE) sl_fused_step(*fzp, p, lane);
         return;
     }
     __syncthreads();
@@ -590,9 +593,9 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
         s = __shfl(s, 0);
         if (lane == k) mine = s;
     }
-    if (split) { if (lane == part) sl_put(outp + part, mine, fzp != nullptr); }
-    else if (lane < PLL_PARTS) sl_put(outp + lane, mine, fzp != nullptr);
-    if (fzp) sl_fused_step(*fzp, p, lane);
+    if (split) { if (lane == part) sl_put(outp + part, mine, FUSE); }
+    else if (lane < PLL_PARTS) sl_put(outp + lane, mine, FUSE);
+    if (FUSE) sl_fused_step(*fzp, p, lane);
 }
 
 // work estimate of every (chain, band) job of the device slice sampler: components x pixels of the

@@ -582,7 +582,7 @@ def test_hot_kernels_keep_their_resource_budget(built):
     finally:
         sys.path.pop(0)
     k = resource_usage.collect()
-    hot = ("k_render_hw<false, 1>", "k_render_hw<false, 2>", "k_render_stars<2, false>", "k_small_stars", "k_patch_ll_nz", "k_patch_ll_hw<0, int>",
+    hot = ("k_render_hw<false, 1>", "k_render_hw<false, 2>", "k_render_stars<2, false>", "k_small_stars", "k_patch_ll_nz<false>", "k_patch_ll_hw<0, int>",
            "k_photon_split_hw<int, unsigned short>")
     for name in hot:
         assert name in k, (name, sorted(k))
