@@ -526,19 +526,22 @@ k_patch_ll_nz(const BandDev *__restrict__ bands, int B, int64_t P, const SrcRec 
             cq[8 * lane + 7] = 0.0;
             if (K == K_GAL) {
                 // the pair (W, P_k) diagonalised: W = L L^T, C = L^-1 P_k L^-T, one Jacobi rotation of C (nz_trip_gal)
-                const double l11 = sqrt(rec.w00), l21 = rec.w01 / l11, d22 = rec.w11 - l21 * l21, l22 = sqrt(d22);
-                const double ia = 1.0 / l11, ic = 1.0 / l22, ib = -l21 * ia * ic;
+                // (round 6: reciprocals and reciprocal roots by fp32 seed + two Newton steps -- rounding -- where the operand is a
+                // variance-like number; the one quotient whose denominator can be anything, tau, stays an IEEE division.  Four
+                // square roots and six divisions were a sixth of a job's ~600 set-up instructions.)
+                const double ia = rsqrt64(rec.w00), l21 = rec.w01 * ia, d22 = rec.w11 - l21 * l21;
+                const double ic = rsqrt64(d22), ib = -l21 * ia * ic;
                 const double C11 = ia * ia * lc.g_cxx, C12 = ia * (ib * lc.g_cxx + ic * lc.g_cxy);
                 const double C22 = ib * ib * lc.g_cxx + 2.0 * ib * ic * lc.g_cxy + ic * ic * lc.g_cyy;
                 double cs = 1.0, sn = 0.0, lam1 = C11, lam2 = C22;
                 if (C12 != 0.0) {
                     const double tau = (C22 - C11) / (2.0 * C12);
-                    const double t = copysign(1.0, tau) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    cs = 1.0 / sqrt(1.0 + t * t); sn = t * cs;
+                    const double t = copysign(1.0, tau) / (fabs(tau) + sqrt(1.0 + tau * tau));      // (tau may be anything: IEEE)
+                    cs = rsqrt64(1.0 + t * t); sn = t * cs;                                        // |t| <= 1
                     lam1 = C11 - t * C12; lam2 = C22 + t * C12;
                 }
                 const double d1 = lc.g_var + lam1, d2 = lc.g_var + lam2;
-                const double gs1 = -0.5 * EXP_SCALE256 / d1, gs2 = -0.5 * EXP_SCALE256 / d2;
+                const double gs1 = -0.5 * EXP_SCALE256 * rcp64(d1), gs2 = -0.5 * EXP_SCALE256 * rcp64(d2);
                 const double al1 = cs * ia - sn * ib, be1 = -sn * ic, al2 = sn * ia + cs * ib, be2 = cs * ic;
                 const double g0 = -(al1 * ux + be1 * uy), g3 = -(al2 * ux + be2 * uy);
                 gq[32 + 4 * lane + 0] = gs1; gq[32 + 4 * lane + 1] = gs2; gq[32 + 4 * lane + 2] = c.A;

@@ -131,6 +131,18 @@ __device__ inline void rcp_rsqrt(double d, double &inv, double &rsq) {
     rsq = z * fma(-0.5 * d * z, z, 1.5);
 }
 
+// 1/d and 1/sqrt(d) alone, the same way (d positive and of moderate size: variances, determinants, 1 + t^2)
+__device__ inline double rcp64(double d) {
+    double y = (double)rcp_f32((float)d);
+    y = fma(y, fma(-d, y, 1.0), y);
+    return fma(y, fma(-d, y, 1.0), y);
+}
+__device__ inline double rsqrt64(double d) {
+    double z = (double)rsq_f32((float)d);
+    z = z * fma(-0.5 * d * z, z, 1.5);
+    return z * fma(-0.5 * d * z, z, 1.5);
+}
+
 __device__ inline Comp make_comp_lc(const LaneConst &lc, const RecU &r) {
     double cxx, cxy, cyy, wt, mux, muy;
     if (r.type == 1) {
