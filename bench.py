@@ -49,17 +49,17 @@ FP64_LANE_OPS_PEAK = 3.93e13 # the same in lane-instructions per second (an fma 
 FLOP_PER_GAUSS = 35.0        # SURVEY 8d accounting: 10 arithmetic + exp counted as 25
 
 # Per-launch PMC figures of the dominant kernel.  Counters cannot be read from inside this process (rocprofv3
-# runs in its own passes: tools/profile_r05.sh), so they are READ AT RUN TIME from the committed summaries of
+# runs in its own passes: tools/profile_r06.sh), so they are READ AT RUN TIME from the committed summaries of
 # exactly this command -- and only when the summary was taken with the library that is loaded now (its sha256 is
 # stored in the profile): after any kernel change without a re-profile the fields print null instead of going stale.
 #   traffic = 2 * FETCH_SIZE + WRITE_SIZE (gfx950 correction, re-calibrated with tools/calib_traffic.hip)
 #   valu    = SQ_INSTS_VALU (wave-instructions), busy = waves per SIMD * SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES
 PMC_PROFILES = {   # (workload, kernel, tail_log, layout) -> committed summary
-    ("mixed10k_2048", "recurrence", 24.0, 1): "profiles/r05_final_pmc.json",
-    ("stars10k_2048", "recurrence", 24.0, 1): "profiles/r05_stars_pmc.json",
-    ("stars1k_512", "recurrence", 24.0, 1): "profiles/r05_stars1k_pmc.json",
+    ("mixed10k_2048", "recurrence", 24.0, 1): "profiles/r06_final_pmc.json",
+    ("stars10k_2048", "recurrence", 24.0, 1): "profiles/r06_stars_pmc.json",
+    ("stars1k_512", "recurrence", 24.0, 1): "profiles/r06_stars1k_pmc.json",
 }
-GIBBS_PMC_PROFILE = "profiles/r05_aux_pmc.json"     # bench.py --workload gibbs10k under the counters
+GIBBS_PMC_PROFILE = "profiles/r06_aux_pmc.json"     # bench.py --workload gibbs10k under the counters
 
 
 def library_sha256():
@@ -80,7 +80,7 @@ def load_pmc(key, kernel="k_render"):
     prof = json.load(open(path))
     have, want = prof.get("library_sha256"), library_sha256()
     if have != want:
-        return {"stale": "%s was taken with library sha256 %s..., loaded is %s...: re-run tools/profile_r05.sh"
+        return {"stale": "%s was taken with library sha256 %s..., loaded is %s...: re-run tools/profile_r06.sh"
                          % (rel, str(have)[:12], want[:12])}
     ks = [k for k in prof["kernels"] if kernel in k or "k_small_stars" in k]
     if not ks:
@@ -103,7 +103,7 @@ def load_gibbs_pmc():
     prof = json.load(open(path))
     have, want = prof.get("library_sha256"), library_sha256()
     if have != want:
-        return {"stale": "%s was taken with library sha256 %s..., loaded is %s...: re-run tools/profile_r05.sh"
+        return {"stale": "%s was taken with library sha256 %s..., loaded is %s...: re-run tools/profile_r06.sh"
                          % (GIBBS_PMC_PROFILE, str(have)[:12], want[:12])}
     ks = [k for k in prof["kernels"] if "k_patch_ll_nz" in k or "k_patch_ll_hw<0" in k]
     if not ks:
