@@ -48,6 +48,7 @@
 #include <atomic>
 #include <new>
 #include <vector>
+#include <type_traits>
 
 #include "../../include/celeste_hip.h"
 

@@ -660,6 +660,9 @@ k_photon_split_hw(SplitArgs a) {
     unsigned short *queue = reinterpret_cast<unsigned short *>(&T);
     double *lt = reinterpret_cast<double *>(reinterpret_cast<char *>(&T) + sizeof(unsigned short) * SP_TH * HW_TW);
     __shared__ double et[64];
+    // the band's three PSF components as a STAR needs them (round 6): inverse covariance in the table exponential's units,
+    // amplitude per unit count, centre offsets, and exp(-4 qc): the ratio of a stride-two column recurrence's ratios
+    __shared__ double sc[8 * K_PSF];
     const int lane = threadIdx.x;
     const int half = lane >> 5, col = lane & 31;
     const int sub = blockIdx.x & 1;
@@ -718,6 +721,33 @@ k_photon_split_hw(SplitArgs a) {
     //   left a photon | 256 first-pass steps (row pairs) | 512 pairs with a non-empty queue
     double dbg_count = 0.0;
 #endif
+    // ---- a star takes no component table (round 6) ----------------------------------------------------------------------
+    // Half of a field's sources are stars, and a star's three components are the band's PSF shifted to the star: nothing to
+    // invert, nothing to drop, no slots to sort.  Yet every (star, half-tile) pair went through hw_build -- ~600 instructions
+    // and two barriers -- before its walk.  Here a lane seeds the three components at its own column and first row and walks ITS
+    // pixels (row = 2 r + half: every other row, so the recurrence runs with stride two: g(y + 2) = g(y) R(y), R(y + 2) =
+    // R(y) e^(-4 qc)) inside the first-test loop itself: the value arrives in a register, the scratch tile is written only for
+    // the pixels that go to the sampler.  Legal when no exponent on a star's box leaves the range one segment is safe on (the
+    // check of the field kernel's star pass, star_setup); a sharper PSF takes the general path.  Nothing is dropped, so a star's
+    // pixel carries all three components (the general path skips those below eps e^-T): 1e-14 apart.
+    bool star_bad = false;
+    if (lane < K_PSF) {
+        const double cxx = bd->cxx[lane], cxy = bd->cxy[lane], cyy = bd->cyy[lane];
+        double inv, rsq;
+        rcp_rsqrt(cxx * cyy - cxy * cxy, inv, rsq);
+        const double qa = cyy * inv, qb = -cxy * inv, qc = cxx * inv;
+        sc[8 * lane + 0] = qa * EXP_SCALE; sc[8 * lane + 1] = qb * EXP_SCALE; sc[8 * lane + 2] = qc * EXP_SCALE;
+        sc[8 * lane + 3] = bd->w[lane] * (0.5 / PI_D) * rsq;
+        sc[8 * lane + 4] = bd->mux[lane]; sc[8 * lane + 5] = bd->muy[lane];
+        sc[8 * lane + 6] = exp_tab64(-4.0 * qc * EXP_SCALE, et);
+        sc[8 * lane + 7] = 0.0;
+        const double rb_ = bd->R + 2.0;
+        star_bad = !(0.5 * quad_max_rect_hw(qa, qb, qc, -rb_ - bd->mux[lane], rb_ - bd->mux[lane], -rb_ - bd->muy[lane], rb_ - bd->muy[lane]) <= STAR_EMAX);
+    }
+    const bool star_ok = (__ballot(star_bad) == 0ull) && !(SPLIT_ABLATE(a) & (4 | 1024));
+    lt[lane] = c_log_ic[lane];              // (a star leaves the table's storage alone: the sampler's log table must be there from the start)
+    lt[64 + lane] = c_log_lc[lane];
+    __syncthreads();
     const int nent = (Y0 < a.H) ? (int)min((int64_t)cnt, a.capacity > off ? a.capacity - off : (int64_t)0) : 0;
     int idx64 = (lane < nent) ? a.lists[off + lane] : 0;
     int s_next = __builtin_amdgcn_readlane(idx64, 0);
@@ -741,16 +771,7 @@ k_photon_split_hw(SplitArgs a) {
         const int xa = max(sx0, X0), xb = min(rec.x1, X0 + HW_TW) - 1;
         if (ra >= rb || xa > xb) continue;          // touches the tile's other half only (wave-uniform)
         const bool on = (xi >= xa) && (xi <= xb);
-        bool direct;
-#ifndef SPLIT_LC_IN_REGISTERS
-        asm volatile("" ::: "memory");      // (keeps the compiler from hoisting the loads out of the loop again)
-        const LaneConst lc = lane_consts(lane, bd);
-#endif
-        const int Kk = hw_build(T, lc, rec, lane, dropmode, a.tail_T, log_sky, Y0, xa, xb, ra, rb, direct, nullptr, et);
-        if (!(SPLIT_ABLATE(a) & 4)) hw_walk(T, et, Kk, x, Y0, ra, rb, on, direct, one, lane);
-        __syncthreads();
-        lt[lane] = c_log_ic[lane];          // the component table is dead until the next source: queue + log table
-        lt[64 + lane] = c_log_lc[lane];
+        const bool star_fast = star_ok && rec.type == 0;
         // Two passes over the source's pixels on this half-tile.  Most draws are decided by ONE
         // uniform (U <= 1 - n p gives 0: a pixel in the source's tail); the few that are not would
         // each hold their whole wave in the sampler's loops.  Pass 1 settles the easy pixels and
@@ -762,42 +783,87 @@ k_photon_split_hw(SplitArgs a) {
         const int nx = rec.x1 - rec.x0;
         TS *patch0 = static_cast<TS *>(a.samp) + poff + (int64_t)(Y0 - rec.y0) * nx - rec.x0;   // + row * nx + x
         int nq = 0;
-        int64_t grp_have = -1;              // the row group (full-frame row, bits 1 and 2 cleared) whose block this lane holds
-        Philox hg;
-        hg.out[0] = hg.out[1] = hg.out[2] = hg.out[3] = 0u;
-        for (int r = ra >> 1; 2 * r < rb; r++) {
-            const int row = 2 * r + half;
-            const int li = r * 64 + lane;
-            // the shared block of this lane's eight consecutive rows: one per eight steps, every lane at the same step
-            // (windows start on even rows), whether or not it has a pixel here
-            const int64_t yf = (int64_t)a.win_y0 + Y0 + row;
-            const int64_t grp = yf & ~SPLIT_GROUP_MASK;
-            if (grp != grp_have && !(SPLIT_ABLATE(a) & 1)) {
-                hg = philox_init(a.seed, (unsigned long long)(kband + grp * a.W + (xi < a.W ? xi : 0)) | SPLIT_GROUP_BIT, (unsigned)s);
-                philox_block(hg);
-                grp_have = grp;
-            }
-            const unsigned vword = philox_word(hg, (int)((yf >> 1) & 7));
-            bool slow = false;
-            if (on && row >= ra && row < rb) {
-                const double F = one[li];
-                const int n = (int)left[li];
-                const double tot = rate[li];
-                fsum += F;
-                covered |= 1u << r;
-                if (n > 0 && !(SPLIT_ABLATE(a) & 1)) {
-                    const double pr = F * fast_rcp(tot);                  // curr_prob / sum_probs (:147)
-                    if (pr > 0.0) slow = !(pr <= 0.5 && (double)vword < split_tf((long long)n, pr));     // the first test, on the shared word
+        // pass 1, in two instantiations (a generic lambda: the star form's six recurrence registers must not be live through the
+        // general form's walk -- as plain locals of this loop they cost the general path six spilled registers and 0.2 ms)
+        auto pass1 = [&](auto star_tag) {
+            constexpr bool STAR = decltype(star_tag)::value;
+            double sg0 = 0.0, sg1 = 0.0, sg2 = 0.0, sr0 = 1.0, sr1 = 1.0, sr2 = 1.0, sq0 = 1.0, sq1 = 1.0, sq2 = 1.0;
+            if (STAR) {
+                sq0 = sc[6]; sq1 = sc[14]; sq2 = sc[22];      // e^(-4 qc): registers of the star form only
+                // seeds at this lane's column and first row of the loop below (row 2 (ra >> 1) + half: possibly one above the box)
+                const double y0 = (double)(Y0 + 2 * (ra >> 1) + half);
+#define SPLIT_STAR_SEED(K, G, R)                                                                           \
+                {                                                                                          \
+                    const double *cs_ = sc + 8 * (K);                                                      \
+                    const double dx = x - (rec.px + cs_[4]), dy = y0 - (rec.py + cs_[5]);                  \
+                    const double hx = cs_[1] * dx + cs_[2] * dy;                                           \
+                    G = (cs_[3] * rec.scale) * exp_tab64(-0.5 * (cs_[0] * dx * dx + (cs_[1] * dx + hx) * dy), et); \
+                    R = exp_tab64(-2.0 * (hx + cs_[2]), et);                                               \
                 }
-                if (!slow) {
-                    one[li] = 0.0;                    // the scratch tile is clean again for the next source
-                    rate[li] = tot - F;               // sum_probs -= curr_prob (:152)
-                    patch0[(int64_t)row * nx + xi] = (TS)0;
-                }
+                SPLIT_STAR_SEED(0, sg0, sr0)
+                SPLIT_STAR_SEED(1, sg1, sr1)
+                SPLIT_STAR_SEED(2, sg2, sr2)
+#undef SPLIT_STAR_SEED
             }
-            const unsigned long long sm = __ballot(slow);
-            if (slow) queue[nq + __builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0))] = (unsigned short)li;
-            nq += __popcll(sm);
+            int64_t grp_have = -1;              // the row group (full-frame row, bits 1, 2 and 3 cleared) whose block this lane holds
+            Philox hg;
+            hg.out[0] = hg.out[1] = hg.out[2] = hg.out[3] = 0u;
+            for (int r = ra >> 1; 2 * r < rb; r++) {
+                const int row = 2 * r + half;
+                const int li = r * 64 + lane;
+                // the shared block of this lane's eight consecutive rows: one per eight steps, every lane at the same step
+                // (windows start on even rows), whether or not it has a pixel here
+                const int64_t yf = (int64_t)a.win_y0 + Y0 + row;
+                const int64_t grp = yf & ~SPLIT_GROUP_MASK;
+                if (grp != grp_have && !(SPLIT_ABLATE(a) & 1)) {
+                    hg = philox_init(a.seed, (unsigned long long)(kband + grp * a.W + (xi < a.W ? xi : 0)) | SPLIT_GROUP_BIT, (unsigned)s);
+                    philox_block(hg);
+                    grp_have = grp;
+                }
+                const unsigned vword = philox_word(hg, (int)((yf >> 1) & 7));
+                bool slow = false;
+                double Fstar = 0.0;
+                if (STAR) {             // this lane's pixel of the step, then one stride-two step of the three recurrences
+#pragma clang fp contract(off)
+                    Fstar = (sg0 + sg1) + sg2;
+                    sg0 *= sr0; sg1 *= sr1; sg2 *= sr2;
+                    sr0 *= sq0; sr1 *= sq1; sr2 *= sq2;
+                }
+                if (on && row >= ra && row < rb) {
+                    const double F = STAR ? Fstar : one[li];
+                    const int n = (int)left[li];
+                    const double tot = rate[li];
+                    fsum += F;
+                    covered |= 1u << r;
+                    if (n > 0 && !(SPLIT_ABLATE(a) & 1)) {
+                        const double pr = F * fast_rcp(tot);                  // curr_prob / sum_probs (:147)
+                        if (pr > 0.0) slow = !(pr <= 0.5 && (double)vword < split_tf((long long)n, pr));     // the first test, on the shared word
+                    }
+                    if (!slow) {
+                        if (!STAR) one[li] = 0.0;         // the scratch tile is clean again for the next source
+                        rate[li] = tot - F;               // sum_probs -= curr_prob (:152)
+                        patch0[(int64_t)row * nx + xi] = (TS)0;
+                    } else if (STAR) one[li] = F;         // the sampler's pass reads the value there (and clears it)
+                }
+                const unsigned long long sm = __ballot(slow);
+                if (slow) queue[nq + __builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0))] = (unsigned short)li;
+                nq += __popcll(sm);
+            }
+        };
+        if (star_fast) {
+            pass1(std::true_type{});
+        } else {
+            bool direct;
+#ifndef SPLIT_LC_IN_REGISTERS
+            asm volatile("" ::: "memory");      // (keeps the compiler from hoisting the loads out of the loop again)
+            const LaneConst lc = lane_consts(lane, bd);
+#endif
+            const int Kk = hw_build(T, lc, rec, lane, dropmode, a.tail_T, log_sky, Y0, xa, xb, ra, rb, direct, nullptr, et);
+            if (!(SPLIT_ABLATE(a) & 4)) hw_walk(T, et, Kk, x, Y0, ra, rb, on, direct, one, lane);
+            __syncthreads();
+            lt[lane] = c_log_ic[lane];          // the component table is dead until the next source: queue + log table
+            lt[64 + lane] = c_log_lc[lane];
+            pass1(std::false_type{});
         }
         __syncthreads();
 #ifdef CEL_ABLATE

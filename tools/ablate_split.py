@@ -16,7 +16,7 @@ ap.add_argument("--steps", type=int, default=5)
 args = ap.parse_args()
 ctx = cel.Context(0)
 f = synth.SyntheticField.from_config(ctx, args.workload)
-for name, bits in (("full", 0), ("no draws at all (every pixel fast, no uniform)", 1), ("sampler replaced by z = 1", 2), ("no stamp walk", 4),
+for name, bits in (("full", 0), ("full, stars through the component table (the round-5 path)", 1024), ("no draws at all (every pixel fast, no uniform)", 1), ("sampler replaced by z = 1", 2), ("no stamp walk", 4),
                    ("no walk, no draws", 5)):
     ctx.set_option(_lib.CEL_OPT_DEBUG, bits)
     for _ in range(2):
@@ -26,7 +26,7 @@ for name, bits in (("full", 0), ("no draws at all (every pixel fast, no uniform)
         f.images.photon_split_resident(f.sources, seed=3)
     ms, n = ctx.profile_get("split")
     ctx.profile(False)
-    print("%-48s k_photon_split_hw %.3f ms" % (name, ms))
+    print("%-60s k_photon_split_hw %.3f ms" % (name, ms))
 # work counters of the same build (returned in place of the noise sums)
 for name, bits in (("queued draws (pixels that failed the first test)", 8), ("sampler trips of 64 lanes", 16), ("(source, half-tile) pairs walked", 32),
                    ("pairs with a non-empty queue", 512), ("draws by BTPE", 64), ("queued draws that left a photon", 128), ("first-pass steps (row pairs)", 256)):
