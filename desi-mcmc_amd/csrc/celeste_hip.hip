@@ -1899,7 +1899,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         HIP_TRY(hipStreamSynchronize(st));
     }
     HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(int) * 13, st));      // [0..3] and [10]: see k_slice.h; the rest is set where it is used
-    HIP_TRY(hipMemsetAsync(d_tick, 0, sizeof(int) * 2 * S, st));    // the tickets and the full lists' block counts
+    if (c->slice_fuse) HIP_TRY(hipMemsetAsync(d_tick, 0, sizeof(int) * 2 * S, st));    // the tickets and the full lists' block counts
     const unsigned g256 = (unsigned)((S + 255) / 256);
     hipLaunchKernelGGL(k_slice_init, dim3(g256), dim3(256), 0, st, ss, S, src->d_radec, chain_ids ? d_ids : (const int *)nullptr,
                        im->d_soff, B, (unsigned long long)seed, sigma, d_owner);
@@ -1913,7 +1913,7 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
         const int nent = (int)(S * B * SLICE_SPLIT);
         hipLaunchKernelGGL(k_job_work, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, st, src->d_type, im->d_snz, S, B, d_work,
                            (const int *)(use_nz ? im->d_nzmode : nullptr), (const int *)im->d_nnz, use_nz ? d_work_nz : (int *)nullptr,
-                           use_nz ? d_need_full : (int *)nullptr);
+                           (use_nz && c->slice_fuse) ? d_need_full : (int *)nullptr);
         // members compacted by the whole GPU, then ordered heaviest first by one block (the live-list arrays are free now)
         HIP_TRY(hipMemsetAsync(d_flags + 8, 0, sizeof(int) * 2, st));
         hipLaunchKernelGGL(k_list_members, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, st, d_work, nent, d_live, d_live_nz, d_flags + 8);
@@ -2032,15 +2032,18 @@ int cel_slice_locations(cel_images *im, cel_sources *src, const int32_t *chain_i
                     }
                 }
                 if (!fused)
-                hipLaunchKernelGGL(k_slice_step, dim3((unsigned)((S + 63) / 64)), dim3(64 * B), 0, st, ss, S, B, ostr, d_ll, sigma, d_flags, (int)queued, prop->d_radec, d_owner, pa);
+                hipLaunchKernelGGL(k_slice_step, dim3((unsigned)((S + 63) / 64)), dim3(64 * B), 0, st, ss, S, B, ostr, d_ll, sigma, d_flags, (int)queued, prop->d_radec, d_owner,
+                                   (k == nb - 1 && c->variant != 0 && !fuse_ok) ? 1 : 0, pa);
                 queued++;
             }
             const int slot = qb & 1;
             deal_of[slot] = 0;
             if (c->variant != 0) {          // the running chains' blocks, for the next batch; few chains left: every job dealt
                 deal_of[slot] = (live * B <= SLICE_SPLIT_JOBS) ? 1 : 0;
-                HIP_TRY(hipMemsetAsync(d_flags + 4, 0, sizeof(int) * (fuse_ok ? 3 : 2), st));
-                if (fuse_ok) HIP_TRY(hipMemsetAsync(d_need_live, 0, sizeof(int) * S, st));
+                if (fuse_ok) {                   // (otherwise the batch's last k_slice_step cleared the two counts)
+                    HIP_TRY(hipMemsetAsync(d_flags + 4, 0, sizeof(int) * 3, st));
+                    HIP_TRY(hipMemsetAsync(d_need_live, 0, sizeof(int) * S, st));
+                }
                 hipLaunchKernelGGL(k_slice_live_jobs, dim3((unsigned)((S * B + 255) / 256)), dim3(256), 0, st, ss, S, B, d_live, d_flags + 4,
                                    (const int *)(use_nz ? im->d_nzmode : nullptr), d_live_nz, d_flags + 5, (const int *)im->d_nnz,
                                    (const int4 *)im->d_snz, deal_of[slot], fuse_ok ? d_need_live : (int *)nullptr, fuse_ok ? d_flags + 6 : (int *)nullptr);

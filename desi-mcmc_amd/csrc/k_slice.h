@@ -104,6 +104,8 @@ __global__ void __launch_bounds__(1024)
 k_slice_step(SliceState st, int64_t S, int B, int nparts /* blocks per (chain, band) job: their partial sums are added first, in order */,
              const double *__restrict__ ll_pb, double sigma, int *__restrict__ flags, int round,
              double *__restrict__ prop_radec, int *__restrict__ owner,
+             int zero_live /* the last round of a batch: flags[4], flags[5] -- the live lists' lengths, which this batch's likelihood launches
+                              have read -- are cleared for k_slice_live_jobs, instead of a fill launch of their own (13 per sweep) */,
              PrepArgs pa /* pa.recs != nullptr: the named point's records (k_prep's own arithmetic, prep_one) are written here too --
                             the round's k_prep launch, 7 us of kernel and as much of queue, is gone */) {
 #pragma clang fp contract(off)
@@ -113,6 +115,7 @@ k_slice_step(SliceState st, int64_t S, int B, int nparts /* blocks per (chain, b
     const int64_t s = chain_thread ? (int64_t)blockIdx.x * 64 + threadIdx.x : S;        // (the other waves: no chain)
     int *const n_active = flags + ((round & 1) ? 10 : 0);
     int *const err = flags + 1;
+    if (s == 0 && zero_live) { flags[4] = 0; flags[5] = 0; }
     if (s == 0 && round > 0) {
         int *const prev = flags + ((round & 1) ? 0 : 10);        // complete: round - 1's kernel has finished
         if (*prev > 0) flags[3] += 1;

@@ -1130,10 +1130,11 @@ def test_stamp_masses_read_off_the_split(cel, orc):
 
 @pytest.mark.parametrize("y0,hw", [(37, 150), (64, 128), (91, 165)])
 def test_split_draws_do_not_depend_on_the_window(cel, y0, hw):
-    """A pixel's draws are keyed by its FULL-FRAME coordinates -- the first test's shared Philox word by (column, the row with
-    bits 1 and 2 cleared), the sampler's stream by the pixel -- so an image set that holds rows [y0, y0 + hw) of the frame
+    """A pixel's draws are keyed by its FULL-FRAME coordinates -- the first test's shared Philox half-word by (column, the row with
+    bits 1, 2 and 3 cleared), the sampler's stream by the pixel -- so an image set that holds rows [y0, y0 + hw) of the frame
     (cel_images_set_window: a rank's strip) splits its pixels exactly as the full frame's set does, wherever the window starts
-    (odd rows, rows that are no multiple of a tile: the lanes' four-row groups then straddle the kernel's steps)."""
+    (odd rows, rows that are no multiple of a tile: the lanes' eight-row groups then straddle the kernel's steps; a star's
+    stride-two recurrence starts on another row)."""
     from desi_mcmc_amd import synth
     import desi_mcmc_amd as celmod
     ctx = cel.default_context(0)
