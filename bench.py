@@ -807,7 +807,7 @@ def secondary_legs(args, env, field):
     if args.projection:
         import copy
         pa = copy.copy(args)
-        pa.of, pa.as_rank, pa.workload, pa.steps, pa.warmup, pa.strip_cut = 8, None, "mixed10k_2048", 60, 10, "measured"
+        pa.of, pa.as_rank, pa.workload, pa.steps, pa.warmup, pa.strip_cut = 8, None, "mixed10k_2048", 60, 10, "equal"
         pr = run_projection(pa, env, field=field, emit=False)
         pg = copy.copy(pa)
         pg.workload, pg.steps, pg.split = "gibbs10k", 5, "strips"
@@ -1300,9 +1300,13 @@ def main():
                     help="with --scaling strong on ONE GPU (no --gpus): play the ranks of an N-rank job one at a time, each "
                          "building its strip / window exactly as in the N-rank job and timing its full step -> projected_strong")
     ap.add_argument("--as-rank", type=int, default=None, help="with --of N: only this rank (default: all N in turn)")
-    ap.add_argument("--strip-cut", default="measured", choices=["measured", "equal"],
-                    help="--scaling strong: strip edges that even out the whole-frame render's measured tile durations "
-                         "(cel_debug_tile_timing; rank 0 measures, every rank cuts alike) or equal tile rows")
+    ap.add_argument("--strip-cut", default="equal", choices=["measured", "equal"],
+                    help="--scaling strong: equal tile rows (default), or strip edges that even out the whole-frame render's measured "
+                         "tile durations (cel_debug_tile_timing; rank 0 measures, every rank cuts alike).  Round 6: with the durations "
+                         "filed under their tiles (round 5 filed them by launch position and every 'measured' cut came out equal) the "
+                         "measured cut of the benchmark field is WORSE, 0.32 against 0.29 ms for the slowest of 8 ranks: a strip is "
+                         "4 tile rows, one row is a quarter of it, and a tile's duration in a full launch (heaviest first: the light "
+                         "tiles run last on a half-empty chip) understates the light rows")
     ap.add_argument("--legs", default="all", choices=["all", "none"],
                     help="render workloads at N=1: 'all' (default) adds the untimed-by-the-contract extras after the timed region "
                          "(evaluated-Gaussian count, fast tail preset, source-upload step, Python-API call); 'none' runs the "

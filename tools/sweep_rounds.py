@@ -12,7 +12,7 @@ rows.sort()
 # the last sweep: from the last k_photon_split_hw on
 i_split = max(i for i, r in enumerate(rows) if "k_photon_split_hw" in r[2])
 last = rows[i_split:]
-nz = [r for r in last if r[2].startswith("k_patch_ll_nz")]
+nz = [r for r in last if "k_patch_ll_nz" in r[2]]
 print("last sweep: %d slice rounds; k_patch_ll_nz total %.2f ms; first round starts %.2f ms after the split's start, last ends %.2f ms after"
       % (len(nz), sum(e - s for s, e, _ in nz) / 1e6, (nz[0][0] - last[0][0]) / 1e6, (nz[-1][1] - last[0][0]) / 1e6))
 t0 = nz[0][0]
@@ -29,9 +29,9 @@ splits = [i for i, r in enumerate(rows) if "k_photon_split_hw" in r[2]] + [len(r
 print("per sweep: rounds, location span ms (first k_patch_ll_nz start -> last k_patch_ll_nz / k_slice_step end), nz kernel ms")
 for a, b in zip(splits[:-1], splits[1:]):
     sw = rows[a:b]
-    nzs = [r for r in sw if r[2].startswith("k_patch_ll_nz")]
+    nzs = [r for r in sw if "k_patch_ll_nz" in r[2]]
     if not nzs:
         continue
-    tail = [r for r in sw if r[2].startswith("k_patch_ll_nz") or r[2].startswith("k_slice_step")]
+    tail = [r for r in sw if "k_patch_ll_nz" in r[2] or "k_slice_step" in r[2]]
     print("   %3d rounds  span %8.3f ms   nz %8.3f ms   launches of k_slice_step %d" % (len(nzs), (max(r[1] for r in tail) - nzs[0][0]) / 1e6,
-          sum(e - s for s, e, _ in nzs) / 1e6, sum(1 for r in sw if r[2].startswith("k_slice_step"))))
+          sum(e - s for s, e, _ in nzs) / 1e6, sum(1 for r in sw if "k_slice_step" in r[2])))
