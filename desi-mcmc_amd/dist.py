@@ -402,15 +402,21 @@ class LoglikReducer(object):
 
 
 def device_identity(local):
-    """what tells two GPUs apart on one node: the HIP device's UUID (else its PCI address); "cpu:<pid>" without a GPU"""
+    """what tells two GPUs apart on one node: the HIP device's UUID and PCI address as far as torch exposes them; "cpu:<pid>"
+    without a GPU; "unknown:<pid>" when the runtime exposes neither (never equal between two ranks: the roll call cannot prove
+    a shared device then, and must not invent one)"""
     import torch
     if not torch.cuda.is_available():
         return "cpu:%d" % os.getpid()
     p = torch.cuda.get_device_properties(local)
+    parts = []
     uuid = getattr(p, "uuid", None)
-    if uuid is not None:
-        return str(uuid)
-    return "pci:%s:%s:%s" % (getattr(p, "pci_domain_id", "?"), getattr(p, "pci_bus_id", "?"), getattr(p, "pci_device_id", "?"))
+    if uuid is not None and str(uuid).replace("0", "").replace("-", "").strip():        # (an all-zero UUID says nothing)
+        parts.append(str(uuid))
+    pci = [getattr(p, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    if any(v is not None for v in pci):
+        parts.append("pci:%s:%s:%s" % tuple("?" if v is None else v for v in pci))
+    return "/".join(parts) if parts else "unknown:%d" % os.getpid()
 
 
 def roll_call(expected, local=0, allow_shared_devices=False):
