@@ -21,7 +21,14 @@ step (RCCL).  Other render workloads: stars1k_512 (configs[1]), stars10k_2048, s
     all-reduced every sweep.
 
 `python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run child)
-before touching the GPU, and refuses to run on fewer than N GPUs.
+before touching the GPU, and refuses to run on fewer than N GPUs.  Every run opens with a roll call
+(dist.roll_call): the collective counts its ranks and gathers their device identities; another count
+than --gpus, or two ranks on one device, exits non-zero before a number is printed.
+
+The JSON line's `roofline` keeps the contract's fields (bound "hbm", algorithmic bytes over the dominant
+kernel's live-measured duration, PMC traffic from the committed counter passes of this library) and nests
+`roofline.binding`: the roof that actually binds these kernels -- fp64 vector issue -- with achieved,
+peak, frac, the useful (recurrence) share and VALU busy.
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--kernel direct|recurrence]
 """
