@@ -64,6 +64,8 @@ SYMBOLS = [
     ("cel_render_field", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_double_p, c_double_p]),
     ("cel_field_stats", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     ("cel_gamma_streams", C.c_int, [C.c_void_p, C.c_int64, c_double_p, C.c_uint64, c_double_p]),
+    ("cel_flux_conditionals", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, c_int32_p, c_double_p, c_double_p,
+                                        c_double_p, c_int32_p]),
     ("cel_debug_split_rates", C.c_int, [C.c_void_p, c_double_p]),
     ("cel_debug_tile_timing", C.c_int, [C.c_void_p, C.c_void_p, c_int64_p]),
     ("cel_debug_last_render", C.c_int, [C.c_void_p, c_int64_p]),

@@ -133,6 +133,19 @@ class GibbsField(object):
         self.prop = None
         self.sub = None             # this rank's sources of a dealt chain (resample_fluxes)
         self.has_patch = None
+        self._sums = None           # photons per (source, image) of the current split: fetched when somebody reads `sums`
+
+    @property
+    def sums(self):
+        """photons per (source, image) of the resident split, read back on first use (the device flux step never reads them:
+        400 KB per sweep that stay where they are)"""
+        if self._sums is None:
+            self._sums = self.iset.sample_sums()
+        return self._sums
+
+    @sums.setter
+    def sums(self, value):
+        self._sums = value
 
 
 def strip_gibbs_field(ctx, bands, nelec, rows, boxes, status, world, rank, band_index=None, slack=48, device=None, edges=None,
@@ -276,6 +289,9 @@ class ModelGibbs(object):
         # the same sampler (gamma_by_stream: the same streams and decisions, values equal to rounding)
         import os
         self.host_gamma = os.environ.get("CEL_HOST_GAMMA") == "1"
+        # the flux step as ONE device call (cel_flux_conditionals) where it applies; CEL_HOST_FLUX=1 / device_flux = False: the
+        # host form (sums and masses read back, variates drawn on the device, fluxes formed in numpy): the same bits
+        self.device_flux = os.environ.get("CEL_HOST_FLUX") != "1"
 
     # -- helpers ---------------------------------------------------------------------------------
     SLICE_INTENDED = dict(step_out=False, sigma=1e-3)
@@ -378,7 +394,7 @@ class ModelGibbs(object):
                 # (one collective for both; every rank raises if any rank's window cuts a box)
                 bx, stt = f.iset.source_boxes(f.sset)
                 noise = self.deal.check_boxes(bx, stt, extra=noise)
-            f.sums = f.iset.sample_sums()                              # photons per (source, image)
+            f.sums = None                                              # photons per (source, image): read back on first use
             f.has_patch = f.iset.sample_box_areas() > 0
             any_patch |= f.has_patch.any(axis=1)
             if self.conditional == "exact":
@@ -401,9 +417,32 @@ class ModelGibbs(object):
                     f.images[b].epsilon = float(f.epsilon[b])
 
     # -- Source.resample_fluxes: sources.py:321-349 --------------------------------------------------
+    def _device_flux_applies(self):
+        """the whole flux step on the device (cel_flux_conditionals): one field whose resident split belongs to the catalogue on
+        the device, every source this process's own, the default conditional and the device's Gamma streams, scalar priors"""
+        f = self.fields[0]
+        return (self.device_flux and len(self.fields) == 1 and (self.deal is None or self.deal.world == 1) and not self.host_gamma and
+                self.conditional != "exact" and np.isscalar(self.flux_a_0) and np.isscalar(self.flux_b_0) and
+                getattr(f, "sset", None) is not None and getattr(f, "_uploaded", None) is not None and f.sset.S == self.S and
+                hasattr(f.iset, "flux_conditionals"))
+
     def resample_fluxes(self):
         import time
         t0 = time.perf_counter()
+        if self._device_flux_applies():
+            # Round 6: sums, masses, Gamma variates and the new counts never leave the device (the host form below read the
+            # photon sums and the masses back, sent the Gamma shapes up, read the variates back and uploaded the whole catalogue
+            # again before the location step: 0.45 ms of copies per sweep).  The values are the host form's bit for bit
+            # (tests/test_gibbs.py::test_device_flux_step_is_the_host_flux_step).
+            f = self.fields[0]
+            new, act = f.iset.flux_conditionals(f.sset, self.step_seed("flux"), self.flux_a_0, self.flux_b_0, f.band_index, f.calib, f.kappa)
+            if not np.array_equal(act, self.active):
+                raise RuntimeError("cel_flux_conditionals: the device's patches are not those of the split this chain made")
+            self.fluxes = np.where(self.active[:, None], new, self.fluxes)
+            # the device's catalogue holds the new counts already: what _sources compares with is brought up to date, not uploaded
+            f._uploaded = (f._uploaded[0], f._uploaded[1], self.counts(f), f._uploaded[3])
+            self.timing["flux"] += time.perf_counter() - t0
+            return self.fluxes
         band_counts = np.zeros((self.S, 5))
         for f in self.fields:
             for b in range(f.iset.B):

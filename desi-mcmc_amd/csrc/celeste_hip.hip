@@ -1765,8 +1765,9 @@ int cel_stamp_mass_begin(cel_images *im, cel_sources *src) {
     return CEL_OK;
 }
 
-int cel_stamp_mass_end(cel_images *im, double *mass) {
-    if (!im || !mass) return fail(CEL_ERR_INVALID, "cel_stamp_mass_end: null argument");
+// the second half of cel_stamp_mass without the copy: the leftovers' kernel queued, im->d_mass complete in stream order; *n_out
+// = values (0: nothing pending was there to finish)
+static int mass_finish(cel_images *im, int64_t *n_out) {
     if (im->mass_pending < 0) return fail(CEL_ERR_INVALID, "cel_stamp_mass_end without a cel_stamp_mass_begin");
     cel_ctx *c = im->ctx;
     HIP_TRY(hipSetDevice(c->device));
@@ -1774,6 +1775,7 @@ int cel_stamp_mass_end(cel_images *im, double *mass) {
     im->mass_pending = -1;
     const int64_t S_todo = im->mass_todo_S;
     im->mass_todo_S = -1;
+    *n_out = n;
     if (n == 0) return CEL_OK;
     if (S_todo >= 0) {                  // the short cut's leftovers (cel_stamp_mass_begin)
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1792,7 +1794,66 @@ int cel_stamp_mass_end(cel_images *im, double *mass) {
             HIP_TRY(hipGetLastError());
         }
     }
-    return copy_out(mass, im->d_mass, sizeof(double) * n, CEL_HOST, c->stream);
+    return CEL_OK;
+}
+
+int cel_stamp_mass_end(cel_images *im, double *mass) {
+    if (!im || !mass) return fail(CEL_ERR_INVALID, "cel_stamp_mass_end: null argument");
+    int64_t n = 0;
+    int rc = mass_finish(im, &n);
+    if (rc || n == 0) return rc;
+    return copy_out(mass, im->d_mass, sizeof(double) * n, CEL_HOST, im->ctx->stream);
+}
+
+// Source.resample_fluxes for the whole catalogue on the device (k_flux_step): the stamp masses (cel_stamp_mass's own path, short
+// cut and leftovers), the Gamma variates and the new fluxes without a host round trip; the catalogue's expected counts are
+// rewritten in place.  One D2H of S * 5 doubles + S ints at the end.
+int cel_flux_conditionals(cel_images *im, cel_sources *src, uint64_t seed, double a0, double b0, const int32_t *band_letter,
+                          const double *calib, const double *kappa, double *flux_new, int32_t *active) {
+    if (!im || !src || !band_letter || !calib || !kappa || !flux_new || !active) return fail(CEL_ERR_INVALID, "cel_flux_conditionals: null argument");
+    if (src->B != im->B || src->ctx != im->ctx) return fail(CEL_ERR_INVALID, "sources do not match images");
+    if (im->samp_S <= 0 || im->samp_S != src->S || !im->ssum_valid)
+        return fail(CEL_ERR_INVALID, "cel_flux_conditionals needs a resident photon split of these %lld sources (have %lld)",
+                    (long long)src->S, (long long)im->samp_S);
+    if (!(a0 > 0.0) || !(b0 > 0.0) || !(a0 < 1e300) || !(b0 < 1e300)) return fail(CEL_ERR_INVALID, "cel_flux_conditionals: a0 and b0 must be positive and finite");
+    cel_ctx *c = im->ctx;
+    const int B = im->B;
+    const int64_t S = src->S;
+    for (int b = 0; b < B; b++) {
+        if (band_letter[b] < 0 || band_letter[b] > 4) return fail(CEL_ERR_INVALID, "cel_flux_conditionals: band letter %d of image %d outside ugriz", band_letter[b], b);
+        if (!(calib[b] > 0.0) || !(kappa[b] > 0.0)) return fail(CEL_ERR_INVALID, "cel_flux_conditionals: calib and kappa must be positive");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = cel_stamp_mass_begin(im, src);
+    if (rc) return rc;
+    int64_t n = 0;
+    if ((rc = mass_finish(im, &n))) return rc;
+    // the per-image constants ride in one small upload: letter[B] | ratio[B] | calib[B] | kappa[B], then the outputs
+    char *d = nullptr;
+    const size_t cbytes = (size_t)MAX_BANDS * (sizeof(int) + 3 * sizeof(double));
+    if ((rc = scratch_get(c, 6, cbytes + sizeof(double) * 5 * S + sizeof(int) * S + 64, (void **)&d))) return rc;
+    struct { int letter[MAX_BANDS]; double ratio[MAX_BANDS], calib[MAX_BANDS], kappa[MAX_BANDS]; } hc;
+    memset(&hc, 0, sizeof(hc));
+    for (int b = 0; b < B; b++) { hc.letter[b] = band_letter[b]; hc.ratio[b] = kappa[b] / calib[b]; hc.calib[b] = calib[b]; hc.kappa[b] = kappa[b]; }
+    static_assert(sizeof(hc) == MAX_BANDS * (sizeof(int) + 3 * sizeof(double)), "packed");
+    HIP_TRY(hipMemcpyAsync(d, &hc, sizeof(hc), hipMemcpyHostToDevice, c->stream));      // (pageable: staged before the call returns)
+    const int *d_letter = reinterpret_cast<const int *>(d);
+    const double *d_ratio = reinterpret_cast<const double *>(d + sizeof(int) * MAX_BANDS);
+    double *d_flux = reinterpret_cast<double *>(d + cbytes);
+    int *d_act = reinterpret_cast<int *>(d + cbytes + sizeof(double) * 5 * S);
+    if (S > 0) {
+        hipLaunchKernelGGL(k_flux_step, dim3((unsigned)((S * 5 + 255) / 256)), dim3(256), 0, c->stream, S, B, (const double *)im->d_ssum,
+                           (const double *)im->d_mass, (const int64_t *)im->d_soff, d_letter, d_ratio, d_ratio + MAX_BANDS, d_ratio + 2 * MAX_BANDS,
+                           a0, b0, (unsigned long long)seed, src->d_counts, d_flux, d_act);
+        HIP_TRY(hipGetLastError());
+        // the catalogue on the device has new counts: a new generation (no row stamps: everything may have changed)
+        src->gen = src->full_gen = ++g_source_gen;
+        src->row_gen.clear();
+        HIP_TRY(hipMemcpyAsync(flux_new, d_flux, sizeof(double) * 5 * S, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(active, d_act, sizeof(int) * S, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return CEL_OK;
 }
 
 // celeste_mcmc.gamma_by_stream on the device (k_gamma_streams): n standard Gamma(a[i]) variates, element i from its own

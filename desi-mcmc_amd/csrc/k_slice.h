@@ -21,15 +21,12 @@
 // element's draw does not depend on which others are drawn beside it, by which rank, or in what order.  Marsaglia & Tsang
 // (2000) with the squeeze test, the same decisions in the same order as the numpy version; the values agree with it to
 // rounding (cos and log are the device's).  50 000 elements: ~10 us; on the host the draws took 1.7 ms on a good day.
-__global__ void __launch_bounds__(256)
-k_gamma_streams(int64_t n, const double *__restrict__ a, unsigned long long seed, double *__restrict__ out) {
+// one standard Gamma(a) variate of element i's streams (what k_gamma_streams writes to out[i])
+__device__ inline double gamma_stream_draw(double ai, unsigned long long seed, int64_t i) {
 #pragma clang fp contract(off)
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     const unsigned long long key = sl_mix(seed ^ ((unsigned long long)i * 0xD1342543DE82EF95ull));
     const unsigned long long nkey = sl_mix(key ^ 0xA0761D6478BD642Full);
     unsigned long long cnt = 0ull, ncnt = 0ull;
-    const double ai = a[i];
     const bool boost = ai < 1.0;
     const double aa = boost ? ai + 1.0 : ai;
     const double d = aa - 1.0 / 3.0;
@@ -53,7 +50,57 @@ k_gamma_streams(int64_t n, const double *__restrict__ a, unsigned long long seed
         const double u = ((double)(sl_mix(key + cnt * 0x9E3779B97F4A7C15ull) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
         res *= pow(u, 1.0 / ai);
     }
-    out[i] = res;
+    return res;
+}
+
+__global__ void __launch_bounds__(256)
+k_gamma_streams(int64_t n, const double *__restrict__ a, unsigned long long seed, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = gamma_stream_draw(a[i], seed, i);
+}
+
+// ---- the flux conditionals of a whole catalogue on the device (round 6) -------------------------------------------------------
+// Source.resample_fluxes (CelestePy/sources.py:321-349) for every source and band letter at once: element (s, L) of the (S, 5)
+// flux table gets  Gamma(a0 + photons of s in the images of letter L) / (b0 + sum over those images of mass * kappa / calib),
+// the Gamma variate from element s * 5 + L's own streams (gamma_stream_draw), every operation in the order the host form
+// (celeste_mcmc.ModelGibbs.resample_fluxes) takes it -- the values are the host's bit for bit.  The photons (the resident
+// split's sums), the stamp masses (cel_stamp_mass's buffer) and the patch layout are on the device already; the new expected
+// counts go straight into the catalogue's device array.  A source without any patch (`active` 0) is left alone, as the
+// reference leaves it (sources.py:243).
+__global__ void __launch_bounds__(256)
+k_flux_step(int64_t S, int B, const double *__restrict__ sums /* [S][B] */, const double *__restrict__ mass /* [S][B] */,
+            const int64_t *__restrict__ soff /* [S*B + 1]: a patch exists where soff grows */, const int *__restrict__ letter /* [B]: 0..4 */,
+            const double *__restrict__ ratio /* [B]: kappa / calib, as the host divides them */, const double *__restrict__ calib,
+            const double *__restrict__ kappa, double a0, double b0, unsigned long long seed,
+            double *__restrict__ counts /* [S][B]: the catalogue's expected photons, rewritten for active sources */,
+            double *__restrict__ flux_new /* [S][5] */, int *__restrict__ active /* [S] */) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * 5) return;
+    const int64_t s = i / 5;
+    const int L = (int)(i - s * 5);
+    bool act = false;
+    double cnt = 0.0, psf = 0.0;
+    for (int b = 0; b < B; b++) {
+        const int64_t j = s * B + b;
+        const bool has = soff[j + 1] > soff[j];
+        act = act || has;
+        if (letter[b] == L) {
+            cnt += sums[j];                                   // band_counts[:, L] += sums[:, b]
+            const double m = mass[j] * (has ? 1.0 : 0.0);     // mass = m * has_patch
+            psf += m * ratio[b];                              // psf_sums[:, L] += mass[:, b] * (kappa[b] / calib[b])
+        }
+    }
+    const double a_n = a0 + cnt;
+    const double g = gamma_stream_draw(a_n, seed, i);
+    const double fnew = g * (1.0 / (b0 + psf));
+    flux_new[i] = fnew;
+    if (L == 0) active[s] = act ? 1 : 0;
+    if (act) {
+        for (int b = 0; b < B; b++)
+            if (letter[b] == L) counts[s * B + b] = fnew / calib[b] * kappa[b];       // ModelGibbs.counts: fl / calib * kappa
+    }
 }
 
 __global__ void __launch_bounds__(256)

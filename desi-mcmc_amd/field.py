@@ -468,6 +468,22 @@ class ImageSet(object):
         L.check(L.lib().cel_stamp_mass_end(self._h, L.dptr(out)))
         return out
 
+    def flux_conditionals(self, sources, seed, a0, b0, band_letter, calib, kappa):
+        """Source.resample_fluxes for the whole catalogue on the device (cel_flux_conditionals): needs the resident split of
+        `sources`; the catalogue's expected counts are rewritten on the device for the sources that have a patch.
+        -> (flux_new[S,5], active[S] bool)"""
+        S = sources.S
+        letter = np.ascontiguousarray(band_letter, dtype=np.int32)
+        cal, kap = L.f64(calib), L.f64(kappa)
+        if letter.shape != (self.B,) or cal.shape != (self.B,) or kap.shape != (self.B,):
+            raise ValueError("band_letter, calib and kappa must have one entry per image")
+        new = np.zeros((S, 5))
+        act = np.zeros(S, dtype=np.int32)
+        L.check(L.lib().cel_flux_conditionals(self._h, sources._h, C.c_uint64(int(seed) & (2 ** 64 - 1)), float(a0), float(b0),
+                                              letter.ctypes.data_as(L.c_int32_p), L.dptr(cal), L.dptr(kap), L.dptr(new),
+                                              act.ctypes.data_as(L.c_int32_p)))
+        return new, act.astype(bool)
+
     def estep_stats(self, sources):
         """E-step reductions (celeste_em.py:38-91) -> (xtilde[S,B], mass[S,B], noise[B])."""
         S = sources.S

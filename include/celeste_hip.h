@@ -355,6 +355,16 @@ int cel_stamp_mass_ready(cel_images *img, cel_sources *src, int *ready);
  * CEL_ERR_INVALID when the source records or the photon split were rebuilt in between. */
 int cel_stamp_mass_begin(cel_images *img, cel_sources *src);
 int cel_stamp_mass_end(cel_images *img, double *mass);
+/* Source.resample_fluxes (CelestePy/sources.py:321-349) for every source of a catalogue whose resident photon split is on the
+ * device, without a host round trip (round 6): element (s, L) of flux_new[S][5] (L = band letter u g r i z) =
+ *     Gamma(a0 + photons of s in the images of letter L) / (b0 + sum over those images of mass(s, image) * kappa / calib),
+ * the Gamma variate from element s * 5 + L's own streams (cel_gamma_streams' sampler), the masses cel_stamp_mass's (short cut
+ * and leftovers alike), every operation in the order celeste_mcmc.ModelGibbs.resample_fluxes takes on the host: the same bits.
+ * band_letter[b] in 0..4 names image b's letter; calib / kappa per image.  active[s] = 1 when the source has a sample patch in
+ * some image: only those sources' expected counts (flux / calib * kappa) are rewritten in the catalogue's device array -- the
+ * caller keeps the old flux of the others, as the reference leaves a source without a patch alone (sources.py:243). */
+int cel_flux_conditionals(cel_images *img, cel_sources *src, uint64_t seed, double a0, double b0, const int32_t *band_letter,
+                          const double *calib, const double *kappa, double *flux_new, int32_t *active);
 
 /* Source.resample_location (CelestePy/sources.py:308-319) for EVERY source of `src` at once: slicesample
  * (CelestePy/util/infer/slicesample.py:89-227) with the options of that call -- component-wise, no stepping

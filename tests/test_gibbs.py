@@ -144,6 +144,54 @@ def test_model_gibbs_conserves_photons_and_draws_the_gamma_conditionals(cel):
     assert g.timing["rounds"] > 0 and g.timing["evals"] >= 4 * g.timing["rounds"] // 4
 
 
+@pytest.mark.parametrize("letters", [[0, 1, 2, 3, 4], [2, 2, 4]])
+def test_device_flux_step_is_the_host_flux_step(cel, letters):
+    """cel_flux_conditionals (round 6: sums, stamp masses, Gamma variates and the new expected counts never leave the device)
+    against the host form of Source.resample_fluxes (sources.py:321-349: sums and masses read back, fluxes formed in numpy):
+    two chains from the same seed, one per form, stay equal BIT FOR BIT through whole sweeps -- fluxes, locations, the trace --
+    with very faint sources (the mass short cut's leftovers take the mass kernel proper), a source off the frame (no patch:
+    left alone) and, in the second case, two images of one band letter and letters without an image (drawn from the prior)."""
+    from desi_mcmc_amd import celeste_mcmc, synth
+    ctx = cel.default_context(0)
+    B = len(letters)
+    S = 260
+    f0 = synth.SyntheticField(ctx, S, B, 288, 320, frac_gal=0.5, seed=17)
+    flux5 = np.zeros((S, 5))
+    for b, L in enumerate(letters):
+        flux5[:, L] = f0.src["flux"][:, b]
+    flux5[flux5 == 0] = 3.0
+    flux5[5] *= 1e-4                                     # far below eps / 1024: not vouched for by the split's mass sums
+    flux5[6] *= 1e-3
+    u = f0.src["radec"].copy()
+    u[9] = synth.pixel2equa(f0.bands[0], np.array([[5000.0, 40.0]]))[0]         # off the frame: no patch anywhere
+    chains = []
+    for device_flux in (True, False):
+        imgs = cel.ImageSet(ctx, f0.bands, f0.H, f0.W, nelec=f0.nelec)
+        gf = celeste_mcmc.GibbsField(imgs, letters, f0.bands[:, 2], f0.bands[:, 1], f0.H * f0.W)
+        g = celeste_mcmc.ModelGibbs([gf], f0.src["type"], u, flux5, f0.src["shape"], seed=5, slice_args=dict(step_out=False, sigma=0.001))
+        g.device_flux = device_flux
+        chains.append((g, gf))
+    (ga, fa), (gb, fb) = chains
+    assert ga.device_flux and not gb.device_flux
+    for sweep in range(3):
+        for g in (ga, gb):
+            g.resample_photons()
+        assert ga._device_flux_applies() and not gb._device_flux_applies()
+        assert np.array_equal(fa.sums, fb.sums) and np.array_equal(ga.active, gb.active) and not ga.active[9]
+        fl_a, fl_b = ga.resample_fluxes().copy(), gb.resample_fluxes().copy()
+        assert np.array_equal(fl_a, fl_b), (sweep, np.nonzero(fl_a != fl_b))
+        assert np.array_equal(fl_a[9], flux5[9])                                   # the source without a patch kept its fluxes
+        # the device's catalogue holds the new counts: the location step that follows needs no upload and gives the same chains
+        ua, ub = ga.resample_locations().copy(), gb.resample_locations().copy()
+        assert np.array_equal(ua, ub)
+        for g in (ga, gb):
+            g.merge_ranks(); g.sweeps += 1
+        assert ga.log_likelihood() == gb.log_likelihood()
+    unused = [L for L in range(5) if L not in letters]
+    if unused:                                          # a letter without an image: Gamma(a0) / b0 from its own stream, in both forms
+        assert np.all(fl_a[ga.active][:, unused] > 0)
+
+
 def test_short_chain_recovers_a_bright_star(cel):
     """the posterior of the bright star's position: mean within 4 Fisher sigma of the truth, spread
     of the order of the Fisher sigma; fluxes within 5 sigma of their Poisson error"""
