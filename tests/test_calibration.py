@@ -208,11 +208,13 @@ def test_a_broken_sweep_fails_the_calibration(monkeypatch):
     ctx = cel.default_context(0)
     real_end = field.ImageSet.stamp_mass_end
     monkeypatch.setattr(field.ImageSet, "stamp_mass_end", lambda self: real_end(self) * 1.03)
-    ru, rf = pooled_ranks(cel, ctx, "device", 12)
+    monkeypatch.setenv("CEL_HOST_FLUX", "1")          # (the flux step's host form is where the masses can be tampered with from here;
+    ru, rf = pooled_ranks(cel, ctx, "device", 12)     #  the device form is pinned to it bit for bit, tests/test_gibbs.py)
     p_flux = chi2_pvalue(rf, K_DRAWS)[1]
     print("masses off by 3 %%: p(flux) = %.3g" % p_flux)
     assert p_flux < 1e-8
     monkeypatch.setattr(field.ImageSet, "stamp_mass_end", real_end)
+    monkeypatch.delenv("CEL_HOST_FLUX")
     real = celeste_mcmc.step_seed
     monkeypatch.setattr(celeste_mcmc, "step_seed", lambda seed, step, sweep, k=0: real(seed, step, 0, k))
     ru, rf = pooled_ranks(cel, ctx, "device", 12)
