@@ -1380,7 +1380,13 @@ def main():
     try:
         call = dist.roll_call(args.gpus, local, allow_shared_devices=os.environ.get("CEL_BENCH_BACKEND") == "gloo")
     except RuntimeError as e:
-        raise SystemExit("bench.py: %s" % e)
+        if str(e).startswith("roll call:"):           # the two things it exists to refuse: a short group, a shared device
+            raise SystemExit("bench.py: %s" % e)
+        call = {"ranks_seen_by_collective": None, "device_uuid": None, "backend": backend, "error": "%s: %s" % (type(e).__name__, e)}
+        sys.stderr.write("bench.py: roll call could not run (%s); continuing without it\n" % call["error"])
+    except Exception as e:                            # noqa: BLE001 -- insurance must not be what breaks the first multi-GPU run
+        call = {"ranks_seen_by_collective": None, "device_uuid": None, "backend": backend, "error": "%s: %s" % (type(e).__name__, e)}
+        sys.stderr.write("bench.py: roll call could not run (%s); continuing without it\n" % call["error"])
     env = dict(torch=torch, cel=cel, dist=dist, synth=synth, _lib=_lib, rank=rank, world=world, local=local, ctx=ctx,
                backend=backend, roll_call=call)
     if args.of:
