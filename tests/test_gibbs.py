@@ -192,6 +192,32 @@ def test_device_flux_step_is_the_host_flux_step(cel, letters):
         assert np.all(fl_a[ga.active][:, unused] > 0)
 
 
+def test_flux_conditionals_error_paths(cel):
+    """cel_flux_conditionals refuses what it cannot do: no resident split, another catalogue than the split's, a band letter outside
+    ugriz, non-positive priors or calibration"""
+    from desi_mcmc_amd import synth
+    ctx = cel.default_context(0)
+    f = synth.SyntheticField(ctx, 30, 5, 128, 160, frac_gal=0.5, seed=4)
+    letters, cal, kap = [0, 1, 2, 3, 4], f.bands[:, 2], f.bands[:, 1]
+    with pytest.raises(ValueError, match="resident photon split"):
+        f.images.flux_conditionals(f.sources, 1, 5.0, 0.005, letters, cal, kap)
+    f.images.photon_split_resident(f.sources, seed=3)
+    other = cel.SourceSet(ctx, 7, 5).set(f.src["type"][:7], f.src["radec"][:7], f.src["counts"][:7], f.src["shape"][:7])
+    with pytest.raises(ValueError, match="resident photon split"):
+        f.images.flux_conditionals(other, 1, 5.0, 0.005, letters, cal, kap)
+    for bad in (dict(letters=[0, 1, 2, 3, 5]), dict(a0=0.0), dict(b0=-1.0), dict(cal=cal * 0.0)):
+        with pytest.raises(ValueError):
+            f.images.flux_conditionals(f.sources, 1, bad.get("a0", 5.0), bad.get("b0", 0.005), bad.get("letters", letters), bad.get("cal", cal), kap)
+    with pytest.raises(ValueError):
+        f.images.flux_conditionals(f.sources, 1, 5.0, 0.005, letters[:3], cal, kap)
+    new, act = f.images.flux_conditionals(f.sources, 1, 5.0, 0.005, letters, cal, kap)
+    assert new.shape == (30, 5) and act.shape == (30,) and act.dtype == bool and np.all(new > 0) and act.any()
+    # same seed, same split: the same Gamma draws (the masses now come from the mass kernel proper -- the catalogue's generation
+    # moved with its counts, so the split's own sums no longer vouch -- which agrees with them to 1e-10)
+    again, _ = f.images.flux_conditionals(f.sources, 1, 5.0, 0.005, letters, cal, kap)
+    np.testing.assert_allclose(again, new, rtol=1e-9)
+
+
 def test_short_chain_recovers_a_bright_star(cel):
     """the posterior of the bright star's position: mean within 4 Fisher sigma of the truth, spread
     of the order of the Fisher sigma; fluxes within 5 sigma of their Poisson error"""
