@@ -21,6 +21,9 @@ struct CompTab {
     // shortest safe segment and the union of the row ranges, reduced with LDS min/max while the
     // table is written, so that the walk reads three values instead of looping over 12 entries
     int gL[4], gr0[4], gr1[4];
+    // ... and the union of the row ranges of the pair's SMALLER half of the slots (the nested walk, rec_group_nested in
+    // k_render_hw.h: slots are ordered by decreasing row count, so the later slots of a pair need fewer rows than its union)
+    int gs0[4], gs1[4];
 };
 
 // fp32 reciprocal / square root / reciprocal square root as ONE instruction each (v_rcp_f32, v_sqrt_f32, v_rsq_f32: 1 ulp).

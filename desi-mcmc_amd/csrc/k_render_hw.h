@@ -97,6 +97,82 @@ __device__ inline void rec_group_hw(const CompTab &T, const double *__restrict__
     }
 }
 
+// ---- the nested walk (round 6) ------------------------------------------------------------------------------------------------
+// A pair of groups walked the UNION of its 12 components' row ranges with all 12 -- 24 % more component-rows than the components
+// need one by one (tools/row_waste.py).  The slots are ordered by decreasing row count, so the pair's later slots need a
+// shorter stretch of rows than its first ones: the pair's first 2 NB slots (NB per half) are walked over the whole union
+// [ga, gb) as before, the remaining ones (NS per half) only over THEIR union [sa, sb), seeded at its first row -- three
+// phases of one recurrence, the middle one with NB + NS components per lane, the outer ones with NB.  A component is still
+// added on every row of its own range: what is left out lies below the drop level by the range's construction.  One segment
+// only (the caller checks gb - ga <= L).  Slots of a half: big p0 + half * NB + i, small p0 + 2 NB + half * NS + i.
+template <int N, int NT>
+__device__ __forceinline__ void rec_walk_n(double (&g)[NT], double (&r)[NT], const double (&q)[NT], int row, int rend, bool advance,
+                                           double *__restrict__ acc_col) {
+    for (; row + 1 < rend; row += 2) {
+#pragma clang fp contract(off)
+        double s0 = g[0], s1, g1[N], r1[N];
+#pragma unroll
+        for (int i = 1; i < N; i++) s0 += g[i];
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            g1[i] = g[i] * r[i];
+            r1[i] = r[i] * q[i];
+        }
+        s1 = g1[0];
+#pragma unroll
+        for (int i = 1; i < N; i++) s1 += g1[i];
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            g[i] = g1[i] * r1[i];
+            r[i] = r1[i] * q[i];
+        }
+        lds_add(&acc_col[row * HW_TW], s0);
+        lds_add(&acc_col[(row + 1) * HW_TW], s1);
+    }
+    if (row < rend) {
+#pragma clang fp contract(off)
+        double s0 = g[0];
+#pragma unroll
+        for (int i = 1; i < N; i++) s0 += g[i];
+        lds_add(&acc_col[row * HW_TW], s0);
+        if (advance) {                       // the next phase goes on from the row behind this one
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                g[i] = g[i] * r[i];
+                r[i] = r[i] * q[i];
+            }
+        }
+    }
+}
+
+template <int NB, int NS>
+__device__ inline void rec_group_nested(const CompTab &T, const double *__restrict__ et, int kb, int ks, double x, int Y0,
+                                        int ga, int gb, int sa, int sb, bool on, double *__restrict__ acc_col) {
+    constexpr int NT = NB + NS;
+    double g[NT], r[NT], q[NT];
+    const double aon = on ? 1.0 : 0.0;
+    auto seed = [&](int i, int k, double y0) {
+        double dx = x - T.mx[k], dy = y0 - T.my[k];
+        double qb = T.qb[k], qc = T.qc[k];
+        double hx = qb * dx + qc * dy;
+        double e = -0.5 * (T.qa[k] * dx * dx + (qb * dx + hx) * dy);
+        double er = fmin(fmax(-(hx + 0.5 * qc), -REC_EMAX * EXP_SCALE), REC_EMAX * EXP_SCALE);
+        g[i] = (T.A[k] * aon) * exp_tab64(e, et);
+        r[i] = exp_tab64(er, et);
+        q[i] = T.eq[k];
+    };
+#pragma unroll
+    for (int i = 0; i < NB; i++) seed(i, kb + i, (double)(Y0 + ga));
+    rec_walk_n<NB, NT>(g, r, q, ga, sa, true, acc_col);
+#pragma unroll
+    for (int i = 0; i < NS; i++) seed(NB + i, ks + i, (double)(Y0 + sa));
+    rec_walk_n<NT, NT>(g, r, q, sa, sb, true, acc_col);
+    rec_walk_n<NB, NT>(g, r, q, sb, gb, false, acc_col);
+}
+
+// components per half in the pair's first (larger) set when a half holds gA: 3 of 5 or 6, 2 of 4; fewer than 4: no second set
+__host__ __device__ inline int nested_big(int gA) { return gA >= 5 ? 3 : (gA == 4 ? 2 : gA); }
+
 // Table slot of a kept component: by decreasing number of tile rows it can matter on, in eight
 // classes of eight rows (inside a class: component order).  The 12 components of a pair of groups walk
 // the UNION of their row ranges, so similar ranges belong together: 2.55e8 -> 2.2e8 walked
@@ -606,7 +682,7 @@ k_render_hw(RenderArgs a) {
             dbg_pairrows += (unsigned)ir; dbg_area += ar;
         }
         __syncthreads();   // previous source's table reads are done
-        if (lane < 4) { T.gL[lane] = 4096; T.gr0[lane] = HW_TH; T.gr1[lane] = 0; }
+        if (lane < 4) { T.gL[lane] = 4096; T.gr0[lane] = HW_TH; T.gr1[lane] = 0; T.gs0[lane] = HW_TH; T.gs1[lane] = 0; }
         const int slot = slot_by_rows(keep, rlo, rhi);
         if (keep) {
             const int p = slot;
@@ -618,6 +694,12 @@ k_render_hw(RenderArgs a) {
             atomicMin(&T.gL[gi], Lk);
             atomicMin(&T.gr0[gi], rlo);
             atomicMax(&T.gr1[gi], rhi);
+            // the pair's second set: the slots behind its first 2 NB (rec_group_nested)
+            const int Rp = min(2 * REC_G, Kk - gi * (2 * REC_G));
+            if (p - gi * (2 * REC_G) >= 2 * nested_big((Rp + 1) / 2)) {
+                atomicMin(&T.gs0[gi], rlo);
+                atomicMax(&T.gs1[gi], rhi);
+            }
         }
         if (lane < HW_PAD) {   // zero components behind the table (amplitude 0, ratio 1)
             int p = Kk + lane;
@@ -644,8 +726,32 @@ k_render_hw(RenderArgs a) {
             const int L = __builtin_amdgcn_readfirstlane(T.gL[gi]);
             const int ga = __builtin_amdgcn_readfirstlane(T.gr0[gi]);
             const int gb = __builtin_amdgcn_readfirstlane(T.gr1[gi]);
-            if (timing) { dbg_comprows += (unsigned)(gb - ga) * (unsigned)R; dbg_pairs += 1; }
             const int k0 = half ? p0 + gA : p0;
+            // the nested walk: a pair of at least 7 components in one segment
+            const int nb = nested_big(gA);
+            const bool nested = (gA >= 4) && (gb - ga <= L);
+            int sa = 0, sb = 0;
+            if (nested) {
+                sa = __builtin_amdgcn_readfirstlane(T.gs0[gi]);
+                sb = __builtin_amdgcn_readfirstlane(T.gs1[gi]);
+                sa = min(max(sa, ga), gb);
+                sb = max(min(sb, gb), sa);
+            }
+            if (timing) {
+                dbg_comprows += nested ? (unsigned)(gb - ga) * (unsigned)(2 * nb) + (unsigned)(sb - sa) * (unsigned)(R - 2 * nb)
+                                       : (unsigned)(gb - ga) * (unsigned)R;
+                dbg_pairs += 1;
+            }
+            if (nested) {
+                double *colp = acc + col;
+                const int kb = p0 + half * nb, ks = p0 + 2 * nb + half * (gA - nb);
+                switch (gA) {
+                case 6: rec_group_nested<3, 3>(T, et, kb, ks, x, Y0, ga, gb, sa, sb, on, colp); break;
+                case 5: rec_group_nested<3, 2>(T, et, kb, ks, x, Y0, ga, gb, sa, sb, on, colp); break;
+                default: rec_group_nested<2, 2>(T, et, kb, ks, x, Y0, ga, gb, sa, sb, on, colp); break;
+                }
+                continue;
+            }
             if (L < 4) {
                 // pathologically sharp component: evaluate this pair of groups directly
                 const int k1 = half ? p0 + R : p0 + gA;

@@ -99,6 +99,27 @@ for s in gal:
                     tot["pairs"] += 1
                     tot["pair_rows"] += rows
                     tot["pair_cost"] += gA * 37 + rows * (3 * gA - 1 + 2)
+                    # phased walk: the pair's larger half of the slots on the whole union, the smaller half on ITS union only
+                    nb = (R + 1) // 2
+                    big, small = m[:nb], m[nb:]
+                    rs_ = (rhi[small].max() - rlo[small].min()) if len(small) else 0
+                    tot["walk_now"] = tot.get("walk_now", 0.0) + rows * R
+                    tot["walk_phased"] = tot.get("walk_phased", 0.0) + rows * len(big) + rs_ * len(small)
+                    tot["walk_own"] = tot.get("walk_own", 0.0) + float((rhi[m] - rlo[m]).sum())
+                    # the best of the splits 2 / 3 / 4 big slots per half (pairs of 12 only; the others as above)
+                    best = rows * len(big) + rs_ * len(small)
+                    if R == 12:
+                        for nbh in (1, 2, 4, 5):
+                            sm = m[2 * nbh:]
+                            c_ = rows * 2 * nbh + (rhi[sm].max() - rlo[sm].min()) * len(sm)
+                            best = min(best, c_)
+                    tot["walk_best"] = tot.get("walk_best", 0.0) + best
+                    # three nested sets: thirds
+                    n3 = (R + 2) // 3
+                    a, bq, c = m[:n3], m[n3:2 * n3], m[2 * n3:]
+                    rb_ = (rhi[np.concatenate([bq, c])].max() - rlo[np.concatenate([bq, c])].min()) if len(bq) + len(c) else 0
+                    rc_ = (rhi[c].max() - rlo[c].min()) if len(c) else 0
+                    tot["walk_thirds"] = tot.get("walk_thirds", 0.0) + rows * len(a) + rb_ * len(bq) + rc_ * len(c)
                 # tasks: balanced groups of <= 6
                 ng = (Kk + G - 1) // G
                 Gs = (Kk + ng - 1) // ng
@@ -129,5 +150,9 @@ print("now  : pairs %d (%.2f per entry)  pair-rows %.3e  own component-rows %.3e
       (tot["pairs"], tot["pairs"] / tot["entries"], tot["pair_rows"], tot["comprows"], tot["pair_cost"]))
 print("tasks: trips %d (%.2f per entry)  trip-rows %.3e  tasks %d (%.1f per trip)  cost %.3e" %
       (tot["trips"], tot["trips"] / tot["entries"], tot["trip_rows"], tot["tasks"], tot["tasks"] / max(tot["trips"], 1), tot["trip_cost"]))
+print("walk component-rows: now %.3e  own %.3e (%.3f)  two nested sets %.3e (%.3f)  three %.3e (%.3f)" %
+      (tot["walk_now"], tot["walk_own"], tot["walk_own"] / tot["walk_now"], tot["walk_phased"], tot["walk_phased"] / tot["walk_now"],
+       tot["walk_thirds"], tot["walk_thirds"] / tot["walk_now"]))
+print("best split per pair of 12 (1, 2, 3, 4 or 5 big slots per half): %.3e (%.3f)" % (tot["walk_best"], tot["walk_best"] / tot["walk_now"]))
 print("ratio tasks / now: steps %.3f  rows %.3f  cost %.3f" % (tot["trips"] / tot["pairs"], tot["trip_rows"] / tot["pair_rows"],
                                                               tot["trip_cost"] / tot["pair_cost"]))
