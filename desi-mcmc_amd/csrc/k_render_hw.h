@@ -658,8 +658,10 @@ k_render_hw(RenderArgs a) {
                 float ylo, yhi;
                 quad_rows_on_columns(c.qa, c.qb, c.qc, 2.0 * fmax(Tk, 0.0), xa - c.mx, xb - c.mx, ylo, yhi);
                 const float cy = (float)(c.my - (double)Y0);
-                rlo = max(ra, (int)floorf(cy + ylo - 0.02f));
-                rhi = min(rb, (int)ceilf(cy + yhi + 0.02f) + 1);
+                // (the integer rows inside [cy + ylo, cy + yhi], a fiftieth of a row of margin for the fp32 ends: rounds 1-5 took
+                // floor and ceil + 1, a row more at either end of every component that ends inside the tile)
+                rlo = max(ra, (int)ceilf(cy + ylo - 0.02f));
+                rhi = min(rb, (int)floorf(cy + yhi + 0.02f) + 1);
                 keep = keep && (rhi > rlo);
             } else {
                 keep = true;

@@ -20,6 +20,7 @@ from oracle import oracle as orc  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--every", type=int, default=20)
 ap.add_argument("--T", type=float, default=24.0)
+ap.add_argument("--tight", action="store_true", help="row ranges by ceil / floor + 1 instead of floor / ceil + 1")
 ap.add_argument("--chords", action="store_true", help="tasks walk the union chord of their group's ellipses at their column")
 args = ap.parse_args()
 S, B, H, W, fg = synth.CONFIGS["mixed10k_2048"]
@@ -73,8 +74,12 @@ for s in gal:
                 ok = disc >= 0
                 hh = np.sqrt(np.maximum(disc, 0.0) / qc[None, :])
                 cy = means[None, :, 1] - (qb / qc)[None, :] * xs
-                lo = np.where(ok, np.floor(cy - hh), 1e9)
-                hi = np.where(ok, np.ceil(cy + hh) + 1, -1e9)
+                if args.tight:
+                    lo = np.where(ok, np.ceil(cy - hh - 0.02), 1e9)
+                    hi = np.where(ok, np.floor(cy + hh + 0.02) + 1, -1e9)
+                else:
+                    lo = np.where(ok, np.floor(cy - hh), 1e9)
+                    hi = np.where(ok, np.ceil(cy + hh) + 1, -1e9)
                 clo = np.maximum(lo, ya)
                 chi = np.minimum(hi, yb + 1)                    # per (column, component) chord, clipped to the box rows on this tile
                 rlo = clo.min(axis=0)
