@@ -82,8 +82,13 @@ k_bin_coarse(const int4 *__restrict__ boxes, int64_t S, int nsx, int nsy, int *_
 // reserves each tile's list segment, pass 1 fills it; with n <= BIN_CH (the usual case) the
 // candidates are read from global memory once; every box test reads LDS.
 #define BIN_CH 1024
-#define FINE_WAVES 16  // waves per block: a block is latency-bound (one per CU), so its tiles are spread over many waves
-#define BIN_TPW 2      // max tiles per wave: (256/64) * (256/32) / FINE_WAVES
+// waves per block.  Round 6, from stamps inside the kernel (a -DBIN_STAMPS build): a 16-wave block takes 17 us (scan 3.1, second
+// scan 5.6, counting pass 2.4, cursor atomic 2.2-3.3, filling pass 2.6-3.3) and only ONE fits a CU (78 VGPRs: 24 waves), so the
+// 320 blocks of configs[2] ran in two rounds: 38 us.  Three 8-wave blocks fit: one round of slower blocks, 33 us.
+#ifndef FINE_WAVES
+#define FINE_WAVES 8
+#endif
+#define BIN_TPW (32 / FINE_WAVES)      // max tiles per wave: (256/64) * (256/32) / FINE_WAVES
 
 // FUSED: the block finds its candidates itself -- its 16 waves scan the band's S boxes (each wave a
 // contiguous slice, so the compacted list stays ordered) straight into the LDS staging arrays -- and

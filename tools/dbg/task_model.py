@@ -21,6 +21,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--every", type=int, default=20)
 ap.add_argument("--T", type=float, default=24.0)
 ap.add_argument("--tight", action="store_true", help="row ranges by ceil / floor + 1 instead of floor / ceil + 1")
+ap.add_argument("--classes", type=int, default=8, help="row-count classes of the slot order (0: exact order by rows)")
 ap.add_argument("--chords", action="store_true", help="tasks walk the union chord of their group's ellipses at their column")
 args = ap.parse_args()
 S, B, H, W, fg = synth.CONFIGS["mixed10k_2048"]
@@ -87,11 +88,17 @@ for s in gal:
                 keep &= rhi > rlo
                 if not keep.any():
                     tot["entries"] += 1
+                    tot["empty"] = tot.get("empty", 0) + 1
                     continue
+                tot.setdefault("kk", []).append(int(keep.sum()))
                 tot["entries"] += 1
                 idx = np.nonzero(keep)[0]
                 nrows = (rhi - rlo)[idx]
-                cls = 7 - np.minimum((nrows - 1) // 8, 7)
+                if args.classes == 0:
+                    cls = -nrows
+                else:
+                    w_ = 64 // args.classes
+                    cls = (args.classes - 1) - np.minimum((nrows - 1) // w_, args.classes - 1)
                 order = idx[np.argsort(cls, kind="stable")]
                 Kk = len(order)
                 tot["comprows"] += float(nrows.sum())
@@ -159,5 +166,8 @@ print("walk component-rows: now %.3e  own %.3e (%.3f)  two nested sets %.3e (%.3
       (tot["walk_now"], tot["walk_own"], tot["walk_own"] / tot["walk_now"], tot["walk_phased"], tot["walk_phased"] / tot["walk_now"],
        tot["walk_thirds"], tot["walk_thirds"] / tot["walk_now"]))
 print("best split per pair of 12 (1, 2, 3, 4 or 5 big slots per half): %.3e (%.3f)" % (tot["walk_best"], tot["walk_best"] / tot["walk_now"]))
+kk = np.array(tot["kk"])
+print("entries without a kept component: %d of %d (%.1f %%); kept components per entry with any: mean %.1f, <= 6: %.1f %%, <= 12: %.1f %%" %
+      (tot.get("empty", 0), tot["entries"], 100.0 * tot.get("empty", 0) / tot["entries"], kk.mean(), 100.0 * (kk <= 6).mean(), 100.0 * (kk <= 12).mean()))
 print("ratio tasks / now: steps %.3f  rows %.3f  cost %.3f" % (tot["trips"] / tot["pairs"], tot["trip_rows"] / tot["pair_rows"],
                                                               tot["trip_cost"] / tot["pair_cost"]))
