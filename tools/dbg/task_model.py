@@ -109,6 +109,9 @@ for s in gal:
                     gA = (R + 1) // 2
                     rows = rhi[m].max() - rlo[m].min()
                     tot["pairs"] += 1
+                    if xb - xa + 1 <= 16:
+                        tot["narrow_rows"] = tot.get("narrow_rows", 0.0) + rows
+                        tot["narrow_pairs"] = tot.get("narrow_pairs", 0) + 1
                     tot["pair_rows"] += rows
                     tot["pair_cost"] += gA * 37 + rows * (3 * gA - 1 + 2)
                     # phased walk: the pair's larger half of the slots on the whole union, the smaller half on ITS union only
@@ -166,6 +169,8 @@ print("walk component-rows: now %.3e  own %.3e (%.3f)  two nested sets %.3e (%.3
       (tot["walk_now"], tot["walk_own"], tot["walk_own"] / tot["walk_now"], tot["walk_phased"], tot["walk_phased"] / tot["walk_now"],
        tot["walk_thirds"], tot["walk_thirds"] / tot["walk_now"]))
 print("best split per pair of 12 (1, 2, 3, 4 or 5 big slots per half): %.3e (%.3f)" % (tot["walk_best"], tot["walk_best"] / tot["walk_now"]))
+print("pairs on entries whose box covers <= 16 of the tile's columns: %d of %d (%.1f %%), their rows %.1f %%" %
+      (tot.get("narrow_pairs", 0), tot["pairs"], 100.0 * tot.get("narrow_pairs", 0) / tot["pairs"], 100.0 * tot.get("narrow_rows", 0) / tot["pair_rows"]))
 kk = np.array(tot["kk"])
 print("entries without a kept component: %d of %d (%.1f %%); kept components per entry with any: mean %.1f, <= 6: %.1f %%, <= 12: %.1f %%" %
       (tot.get("empty", 0), tot["entries"], 100.0 * tot.get("empty", 0) / tot["entries"], kk.mean(), 100.0 * (kk <= 6).mean(), 100.0 * (kk <= 12).mean()))
