@@ -23,6 +23,19 @@
 
 #define HW_TW 32
 #define HW_TH 64
+// The blocks of these kernels are ONE wave, and the LDS operations of one wave execute in the order they were issued: a table
+// written by some lanes is what the other lanes read afterwards without anyone waiting.  Between a source's table writes and
+// reads the compiler only has to keep the order (no instruction; __syncthreads() there made the wave wait for every LDS operation
+// in flight -- the previous pair's last ds_add_f64 among them -- twice per (source, tile) entry).
+#ifdef HW_SYNC_BARRIER
+#define HW_WAVE_SYNC() __syncthreads()
+#else
+#define HW_WAVE_SYNC()                                              \
+    do {                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      \
+        __builtin_amdgcn_wave_barrier();                            \
+    } while (0)
+#endif
 #define HW_PAD 12   // zero components behind the compacted table: a half's group may read past the end
 #ifndef HW_PART_ENTRIES
 #define HW_PART_ENTRIES 12   // k_render_hw<, PARTS>: list entries per working part of a tile
@@ -683,7 +696,7 @@ k_render_hw(RenderArgs a) {
             for (int o = 32; o; o >>= 1) { ir += __shfl_xor(ir, o); ar += __shfl_xor(ar, o); }
             dbg_pairrows += (unsigned)ir; dbg_area += ar;
         }
-        __syncthreads();   // previous source's table reads are done
+        HW_WAVE_SYNC();    // previous source's table reads are done
         if (lane < 4) { T.gL[lane] = 4096; T.gr0[lane] = HW_TH; T.gr1[lane] = 0; T.gs0[lane] = HW_TH; T.gs1[lane] = 0; }
         const int slot = slot_by_rows(keep, rlo, rhi);
         if (keep) {
@@ -709,7 +722,7 @@ k_render_hw(RenderArgs a) {
             T.qa[p] = 0.0; T.qb[p] = 0.0; T.qc[p] = 0.0;
             T.eq[p] = 1.0;
         }
-        __syncthreads();
+        HW_WAVE_SYNC();
         if (a.variant == 0) {
             // direct evaluator: the halves split the kept components
             const int kh = (Kk + 1) / 2;
