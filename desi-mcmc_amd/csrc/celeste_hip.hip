@@ -134,6 +134,7 @@ struct cel_ctx {
     int profile = 0;          // CEL_OPT_PROFILE: 0 off, 1 every kernel, 2 the evaluating kernels only
     int star_tiles = (getenv("CEL_STAR_TILES") && atoi(getenv("CEL_STAR_TILES")) >= 0 && atoi(getenv("CEL_STAR_TILES")) <= 3)
                          ? atoi(getenv("CEL_STAR_TILES")) : 1;       // CEL_OPT_STAR_TILES (the env var: the initial value, for test runs)
+    int n_cu = 256;           // compute units of the device (set at creation): the binning pass sizes its blocks by it
     int tile_order = 1;       // 0 = launch k_render tiles in index order, 1 = heaviest first by the last render's measured tile durations (estimate when none), 2 = heaviest first by the estimate only
     int tile_rows = 32;       // rows per render tile (32 or 64), read when an image set is created
     bool tile_timing = false; // diagnostic: k_render stamps each tile's start/end wall clock
@@ -455,6 +456,10 @@ int cel_ctx_create(int device, void *stream, cel_ctx **out) {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete c; return fail(CEL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         c->own_stream = true;
+    }
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
     }
     hipError_t e = hipHostMalloc((void **)&c->pinned, sizeof(double) * (MAX_BANDS + 16), hipHostMallocDefault);
     if (e != hipSuccess) { delete c; return fail(CEL_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
@@ -1257,13 +1262,27 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         } else if (im->bin_two_level) {
             LAUNCH_EV(k_bin_coarse, dim3(NS), dim3(64 * COARSE_WAVES), st, EV0(c, pi), (hipEvent_t) nullptr, im->d_boxes, S, im->nsx, im->nsy,
                       im->d_sup_cnt, im->d_sup_off, im->d_cursor + 2, im->d_clist, im->clist_cap, (int *)(im->d_cursor + 3));
-            LAUNCH_EV(k_bin_fine_blk<false>, dim3(NS), dim3(64 * FINE_WAVES), st, (hipEvent_t) nullptr, bin_ev1,
+            // (16-wave blocks while every super-tile gets a CU of its own, 8-wave blocks -- three to a CU -- beyond that: k_bin2.h)
+            if (NS > c->n_cu)
+                LAUNCH_EV((k_bin_fine_blk<false, 8>), dim3(NS), dim3(64 * 8), st, (hipEvent_t) nullptr, bin_ev1,
+                          im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
+                          im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
+                          im->d_tile_nstar, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
+                          (int *)(im->d_cursor + 1), (int *)(im->d_cursor + 3));
+            else
+                LAUNCH_EV((k_bin_fine_blk<false, 16>), dim3(NS), dim3(64 * 16), st, (hipEvent_t) nullptr, bin_ev1,
+                          im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
+                          im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
+                          im->d_tile_nstar, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
+                          (int *)(im->d_cursor + 1), (int *)(im->d_cursor + 3));
+        } else if (NS > c->n_cu) {
+            LAUNCH_EV((k_bin_fine_blk<true, 8>), dim3(NS), dim3(64 * 8), st, EV0(c, pi), bin_ev1,
                       im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
                       im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
                       im->d_tile_nstar, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,
                       (int *)(im->d_cursor + 1), (int *)(im->d_cursor + 3));
         } else {
-            LAUNCH_EV(k_bin_fine_blk<true>, dim3(NS), dim3(64 * FINE_WAVES), st, EV0(c, pi), bin_ev1,
+            LAUNCH_EV((k_bin_fine_blk<true, 16>), dim3(NS), dim3(64 * 16), st, EV0(c, pi), bin_ev1,
                       im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,
                       im->nsx, im->nsy, im->d_sup_cnt, im->d_sup_off, im->d_clist, im->clist_cap, im->d_tile_cnt,
                       im->d_tile_nstar, im->d_tile_work, im->d_tile_off, im->d_cursor, im->d_lists, im->lists_cap,

@@ -85,23 +85,22 @@ k_bin_coarse(const int4 *__restrict__ boxes, int64_t S, int nsx, int nsy, int *_
 // waves per block.  Round 6, from stamps inside the kernel (a -DBIN_STAMPS build): a 16-wave block takes 17 us (scan 3.1, second
 // scan 5.6, counting pass 2.4, cursor atomic 2.2-3.3, filling pass 2.6-3.3) and only ONE fits a CU (78 VGPRs: 24 waves), so the
 // 320 blocks of configs[2] ran in two rounds: 38 us.  Three 8-wave blocks fit: one round of slower blocks, 33 us.
-#ifndef FINE_WAVES
-#define FINE_WAVES 8
-#endif
-#define BIN_TPW (32 / FINE_WAVES)      // max tiles per wave: (256/64) * (256/32) / FINE_WAVES
+// ... so the host takes 8-wave blocks when the frame has more super-tiles than the device has CUs and 16-wave blocks
+// otherwise (a rank's strip of an 8-way cut is 40 super-tiles: 19 us with 16 waves against 26 with 8).
 
 // FUSED: the block finds its candidates itself -- its 16 waves scan the band's S boxes (each wave a
 // contiguous slice, so the compacted list stays ordered) straight into the LDS staging arrays -- and
 // k_bin_coarse, its list in global memory and a launch drop out of the step.  Possible while a
 // super-tile has at most BIN_CH candidates (265 at config 3); a block that finds more raises bit 1 of
 // the coarse overflow flag and the host goes back to the two-level form for these images.
-template <bool FUSED>
+template <bool FUSED, int FINE_WAVES /* waves per block: 8 or 16 */>
 __global__ void __launch_bounds__(64 * FINE_WAVES)
 k_bin_fine_blk(const int4 *__restrict__ boxes, const int *__restrict__ kind, int64_t S, int ntx, int nty, int TH,
                int TW, int nsx, int nsy, const int *__restrict__ sup_cnt, const int64_t *__restrict__ sup_off,
                const int *__restrict__ clist, int64_t ccap, int *__restrict__ tile_cnt, int *__restrict__ tile_nstar,
                int *__restrict__ tile_work, int64_t *__restrict__ tile_off, unsigned long long *cursor,
                int *__restrict__ lists, int64_t capacity, int *overflow, int *coarse_overflow) {
+    constexpr int BIN_TPW = 32 / FINE_WAVES;      // max tiles per wave: (256/64) * (256/32) / FINE_WAVES
     __shared__ int4 sbox[BIN_CH];
     __shared__ int skind[BIN_CH];
     __shared__ int sid[BIN_CH];
