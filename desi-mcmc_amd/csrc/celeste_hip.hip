@@ -1262,7 +1262,7 @@ static int render_impl(cel_images *im, cel_sources *src, int flags, double *ll_b
         } else if (im->bin_two_level) {
             LAUNCH_EV(k_bin_coarse, dim3(NS), dim3(64 * COARSE_WAVES), st, EV0(c, pi), (hipEvent_t) nullptr, im->d_boxes, S, im->nsx, im->nsy,
                       im->d_sup_cnt, im->d_sup_off, im->d_cursor + 2, im->d_clist, im->clist_cap, (int *)(im->d_cursor + 3));
-            // (16-wave blocks while every super-tile gets a CU of its own, 8-wave blocks -- three to a CU -- beyond that: k_bin2.h)
+            // (16-wave blocks while every super-tile gets a CU of its own, 8-wave blocks -- two to a CU -- beyond that: k_bin2.h)
             if (NS > c->n_cu)
                 LAUNCH_EV((k_bin_fine_blk<false, 8>), dim3(NS), dim3(64 * 8), st, (hipEvent_t) nullptr, bin_ev1,
                           im->d_boxes, im->d_kind, S, im->ntx, im->nty, im->TH, im->TW,

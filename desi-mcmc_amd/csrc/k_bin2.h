@@ -84,7 +84,7 @@ k_bin_coarse(const int4 *__restrict__ boxes, int64_t S, int nsx, int nsy, int *_
 #define BIN_CH 1024
 // waves per block.  Round 6, from stamps inside the kernel (a -DBIN_STAMPS build): a 16-wave block takes 17 us (scan 3.1, second
 // scan 5.6, counting pass 2.4, cursor atomic 2.2-3.3, filling pass 2.6-3.3) and only ONE fits a CU (78 VGPRs: 24 waves), so the
-// 320 blocks of configs[2] ran in two rounds: 38 us.  Three 8-wave blocks fit: one round of slower blocks, 33 us.
+// 320 blocks of configs[2] ran in two rounds: 38 us.  Two 8-wave blocks fit (110 VGPRs: 16 waves per CU): one round of slower blocks, 33 us.
 // ... so the host takes 8-wave blocks when the frame has more super-tiles than the device has CUs and 16-wave blocks
 // otherwise (a rank's strip of an 8-way cut is 40 super-tiles: 19 us with 16 waves against 26 with 8).
 
