@@ -22,6 +22,7 @@ ap.add_argument("--every", type=int, default=20)
 ap.add_argument("--T", type=float, default=24.0)
 ap.add_argument("--tight", action="store_true", help="row ranges by ceil / floor + 1 instead of floor / ceil + 1")
 ap.add_argument("--classes", type=int, default=8, help="row-count classes of the slot order (0: exact order by rows)")
+ap.add_argument("--order", default="class", help="slot order inside a class: class (component order) | rlo | mid")
 ap.add_argument("--chords", action="store_true", help="tasks walk the union chord of their group's ellipses at their column")
 args = ap.parse_args()
 S, B, H, W, fg = synth.CONFIGS["mixed10k_2048"]
@@ -99,7 +100,12 @@ for s in gal:
                 else:
                     w_ = 64 // args.classes
                     cls = (args.classes - 1) - np.minimum((nrows - 1) // w_, args.classes - 1)
-                order = idx[np.argsort(cls, kind="stable")]
+                if args.order == "rlo":
+                    order = idx[np.lexsort((rlo[idx], cls))]
+                elif args.order == "mid":
+                    order = idx[np.lexsort(((rlo + rhi)[idx], cls))]
+                else:
+                    order = idx[np.argsort(cls, kind="stable")]
                 Kk = len(order)
                 tot["comprows"] += float(nrows.sum())
                 # now: pairs of 12
