@@ -538,6 +538,31 @@ def test_full_size_properties(cel, ctx, big_field):
     assert st["n_srcpix"] > 1e8 and st["n_gauss"] > st["n_srcpix"]
 
 
+def test_render_work_counters_of_the_benchmark_field(cel, ctx, big_field):
+    """The work k_render_hw does on BASELINE configs[2] is a function of the data and the walk's rules, not of timing: the tile
+    entries, the pairs of groups and the kept component-rows its counters report (CEL_OPT_TILE_TIMING, third word) are the same in
+    every run, and stay where round 6 left them -- 1.555e8 component-rows of 32 columns at the shipping threshold (1.765e8 before
+    the nested walk and the exact rows; the CPU model of tools/dbg/task_model.py).  A change that makes the kernel walk more rows
+    again fails here, without a stopwatch."""
+    f = big_field
+    L = cel._lib
+    ctx.set_option(L.CEL_OPT_TILE_TIMING, 1)
+    try:
+        got = []
+        for _ in range(2):
+            f.images.render(f.sources, loglik=True)
+            tt = f.images.tile_timing()
+            w = tt[:, 2]
+            got.append((int(np.sum(w & np.uint64(0xfff))), int(np.sum((w >> np.uint64(12)) & np.uint64(0xfffff))), int(np.sum(w >> np.uint64(32)))))
+    finally:
+        ctx.set_option(L.CEL_OPT_TILE_TIMING, 0)
+    assert got[0] == got[1]
+    entries, pairs, comprows = got[0]
+    assert entries == int(f.images.stats()["n_tile_entries"]) == 412326
+    assert 6.1e5 < pairs < 6.3e5
+    assert comprows < 1.60e8, comprows
+
+
 def test_full_size_spot_check_vs_oracle(cel, ctx, orc, big_field):
     """a 256 x 192 window of the 2048^2 field against the oracle: only sources near the window"""
     f = big_field
